@@ -1,0 +1,186 @@
+"""Generate ``tests/golden/*`` from the IMPORTED reference (authoring container only).
+
+    python -m oracle.make_golden
+
+Runs the reference modules (imported from /root/reference through ``oracle/shim.py``) on seeded inputs
+with the synthetic weights of ``oracle/weights.py`` and stores inputs + expected outputs as small
+safetensors fixtures.  The fixtures are data (tensors and key/shape manifests); no reference source is
+copied.  ``tests/test_oracle_golden.py`` then pins the oracle restatement against them.
+"""
+import json
+import os
+
+import torch
+from safetensors.torch import save_file
+
+from . import shim
+from .weights import (random_state_dict, unet_param_shapes, vae_decoder_param_shapes, checksum)
+from .unet_ref import UNetCfg
+
+GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+TINY_A = dict(in_dim=4, dim=32, context_dim=1024, out_dim=4, dim_mult=[1, 2], num_heads=8, head_dim=32,
+              num_res_blocks=1, attn_scales=[1.0, 0.5])
+TINY_B = dict(in_dim=4, dim=64, context_dim=1024, out_dim=4, dim_mult=[1, 2, 2], num_heads=4, head_dim=64,
+              num_res_blocks=2, attn_scales=[1.0, 0.5])
+
+
+def build_ref_unet(ns, c: dict):
+    U = ns.unet_t2v.UNetSD_T2VBase
+    m = U(in_dim=c["in_dim"], dim=c["dim"], y_dim=c["context_dim"], context_dim=c["context_dim"],
+          out_dim=c["out_dim"], dim_mult=c["dim_mult"], num_heads=c["num_heads"], head_dim=c["head_dim"],
+          num_res_blocks=c["num_res_blocks"], attn_scales=c["attn_scales"], dropout=0.1,
+          temporal_attention=True, use_checkpoint=False, use_camera_condition=True,
+          use_fps_condition=False, use_lgm_refine=False)
+    return m.eval()
+
+
+def unet_case(ns, name, c, seed, F_, H, W, L):
+    cfg = UNetCfg(**c)
+    shapes = unet_param_shapes(cfg)
+    ref = build_ref_unet(ns, c)
+    ref_sd = ref.state_dict()
+    assert list(ref_sd.keys()) == list(shapes.keys()), "manifest order mismatch"
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), (k, v.shape, shapes[k])
+    sd = random_state_dict(shapes, seed)
+    ref.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(seed + 1)
+    B = 2
+    x = torch.randn(B, 4, F_, H, W, generator=g)
+    t = torch.tensor([501, 21])
+    y = torch.randn(B, L, c["context_dim"], generator=g)
+    cam = torch.randn(B, F_, 16, generator=g)
+    taps = {}
+
+    def hook(key):
+        def fn(mod, inp, out):
+            taps[key] = (out[0] if isinstance(out, tuple) else out).detach().clone()
+        return fn
+
+    # the reference iterates ModuleLists manually (no module forward), so hook the LAST leaf of each block
+    handles = []
+    for i, blk in enumerate(ref.input_blocks):
+        last = blk[-1] if isinstance(blk, torch.nn.ModuleList) else blk
+        handles.append(last.register_forward_hook(hook(f"in{i}")))
+    handles.append(ref.middle_block[-1].register_forward_hook(hook("mid")))
+    for i, blk in enumerate(ref.output_blocks):
+        handles.append(blk[-1].register_forward_hook(hook(f"out{i}")))
+    with torch.no_grad():
+        eps = ref(x, t, y=y, camera_data=cam)
+    for h in handles:
+        h.remove()
+    out = {"x": x, "t": t, "y": y, "camera_data": cam, "eps": eps.contiguous(),
+           "weights_checksum": torch.tensor([checksum(sd)], dtype=torch.float64)}
+    for k, v in taps.items():
+        if v.dim() == 5:  # TemporalTransformer returns b c f h w -> store as (b f) c h w like the others
+            b_, c_, f_, h_, w_ = v.shape
+            v = v.permute(0, 2, 1, 3, 4).reshape(b_ * f_, c_, h_, w_)
+        out[f"tap.{k}"] = v.contiguous()
+    save_file(out, os.path.join(GOLD, f"{name}.safetensors"),
+              metadata={"cfg": json.dumps(c), "seed": str(seed)})
+    print(name, "eps", tuple(eps.shape), float(eps.abs().mean()), "taps", len(taps))
+    return ref, sd
+
+
+def ddim_case(ns, ref, c):
+    """BASELINE config-1 analogue: 4 views, 2 DDIM steps, CFG 9, fp32 CPU eager."""
+    D = ns.ddim.DiffusionDDIM
+    dif = D(schedule="linear_sd", schedule_param=dict(num_timesteps=1000, init_beta=0.00085, last_beta=0.012,
+                                                       zero_terminal_snr=False),
+            mean_type="eps", loss_type="mse", var_type="fixed_small", rescale_timesteps=False,
+            noise_strength=0.0)
+    g = torch.Generator().manual_seed(11)
+    noise = torch.randn(1, 4, 4, 8, 8, generator=g)
+    y = torch.randn(1, 5, c["context_dim"], generator=g)
+    y0 = torch.randn(1, 5, c["context_dim"], generator=g)
+    cam = torch.randn(1, 4, 16, generator=g)
+    kw = [dict(y=y, camera_data=cam), dict(y=y0, camera_data=cam)]
+    out = {}
+    for n in (2, 5):
+        xt = dif.ddim_sample_loop(noise=noise.clone(), model=ref, model_kwargs=kw, guide_scale=9.0,
+                                  ddim_timesteps=n, eta=0.0)
+        out[f"x0_steps{n}"] = xt.contiguous()
+    out.update({"noise": noise, "y": y, "y_uncond": y0, "camera_data": cam})
+    save_file(out, os.path.join(GOLD, "ddim_tiny.safetensors"))
+    print("ddim", {k: float(v.abs().mean()) for k, v in out.items() if k.startswith("x0")})
+
+
+def schedule_case(ns):
+    D = ns.ddim.DiffusionDDIM
+    out = {}
+    for tag, kw in (("linear_sd", dict(schedule="linear_sd",
+                                       schedule_param=dict(num_timesteps=1000, init_beta=0.00085,
+                                                           last_beta=0.012, zero_terminal_snr=False))),
+                    ("cosine_ztsnr", dict(schedule="cosine",
+                                          schedule_param=dict(num_timesteps=1000, cosine_s=0.008,
+                                                              zero_terminal_snr=True)))):
+        d = D(mean_type="eps", var_type="fixed_small", **kw)
+        for name in ("betas", "alphas_cumprod", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+                     "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod"):
+            out[f"{tag}.{name}"] = getattr(d, name).clone()
+    for n in (2, 20, 50):
+        out[f"steps{n}"] = (1 + torch.arange(0, 1000, 1000 // n)).clamp(0, 999).flip(0)
+    save_file(out, os.path.join(GOLD, "schedules.safetensors"))
+    print("schedules ac[0], ac[999] =", float(out["linear_sd.alphas_cumprod"][0]),
+          float(out["linear_sd.alphas_cumprod"][999]))
+
+
+def vae_case(ns):
+    A = ns.autoencoder.AutoencoderKL
+    dd = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=32,
+              ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    vae = A(ddconfig=dd, embed_dim=4).eval()
+    shapes = vae_decoder_param_shapes(ch=32)
+    ref_sd = {k: v for k, v in vae.state_dict().items()
+              if k.startswith("decoder.") or k.startswith("post_quant_conv.")}
+    assert set(ref_sd.keys()) == set(shapes.keys()), set(ref_sd.keys()) ^ set(shapes.keys())
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), k
+    sd = random_state_dict(shapes, 77)
+    vae.load_state_dict(sd, strict=False)
+    g = torch.Generator().manual_seed(78)
+    z = torch.randn(2, 4, 8, 8, generator=g)
+    with torch.no_grad():
+        img = vae.decode(z)
+    save_file({"z": z, "img": img.contiguous(),
+               "weights_checksum": torch.tensor([checksum(sd)], dtype=torch.float64)},
+              os.path.join(GOLD, "vae_tiny.safetensors"))
+    print("vae", tuple(img.shape), float(img.abs().mean()))
+
+
+def manifest_case(ns):
+    """Full-size key/shape manifests (G7): text, no tensors."""
+    full = dict(in_dim=4, dim=320, context_dim=1024, out_dim=4, dim_mult=[1, 2, 4, 4], num_heads=8, head_dim=64,
+                num_res_blocks=2, attn_scales=[1.0, 0.5, 0.25])
+    with torch.device("meta"):
+        ref = build_ref_unet(ns, full)
+    man = {k: list(v.shape) for k, v in ref.state_dict().items()}
+    n_params = sum(p.numel() for p in ref.parameters())
+    with open(os.path.join(GOLD, "manifest_unet_t2v_full.json"), "w") as f:
+        json.dump({"n_params": n_params, "n_keys": len(man), "keys": man}, f, indent=0)
+    print("manifest", len(man), n_params)
+    A = ns.autoencoder.AutoencoderKL
+    dd = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128,
+              ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    with torch.device("meta"):
+        vae = A(ddconfig=dd, embed_dim=4)
+    man = {k: list(v.shape) for k, v in vae.state_dict().items()}
+    with open(os.path.join(GOLD, "manifest_vae_full.json"), "w") as f:
+        json.dump({"n_keys": len(man), "keys": man}, f, indent=0)
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    ns = shim.load_reference()
+    torch.manual_seed(0)
+    schedule_case(ns)
+    ref_a, _ = unet_case(ns, "unet_tiny_a", TINY_A, seed=1234, F_=4, H=8, W=8, L=7)
+    ddim_case(ns, ref_a, TINY_A)
+    unet_case(ns, "unet_tiny_b", TINY_B, seed=4321, F_=3, H=8, W=12, L=5)
+    vae_case(ns)
+    manifest_case(ns)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,154 @@
+"""Import shim for the *reference* (TEST INFRASTRUCTURE ONLY — never imported by the product path).
+
+This file contains no reference code.  It pre-seeds ``sys.modules`` with stand-ins for the
+third-party packages the reference imports but this image lacks (xformers, open_clip, fairscale,
+rotary_embedding_torch, easydict, tyro, kiui, pynvml), registers bare package objects for
+``tools`` / ``tools.modules`` / ``tools.modules.unet`` / ``tools.modules.diffusions`` so the
+reference's package ``__init__`` files (which pull in cv2-based datasets) never run, and puts
+``/root/reference`` on ``sys.path``.
+
+It is used in exactly two places, both in the authoring container only (``/root/reference`` does not
+exist on the GPU box):
+  * ``oracle/make_golden.py`` — generates ``tests/golden/*.safetensors`` from the imported reference;
+  * ``tests/test_oracle_vs_reference.py`` — skipped automatically when ``/root/reference`` is absent.
+
+The xformers stand-in maps ``memory_efficient_attention`` to exact softmax attention
+(``F.scaled_dot_product_attention``): FMHA is exact attention up to rounding, SURVEY §8c.
+"""
+import os
+import sys
+import types
+import importlib.machinery
+
+REF_ROOT = os.environ.get("VMV_REFERENCE_ROOT", "/root/reference")
+
+
+def reference_available() -> bool:
+    return os.path.isdir(os.path.join(REF_ROOT, "tools", "modules", "unet"))
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def _pkg(name, path):
+    m = types.ModuleType(name)
+    m.__path__ = [path]
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None, is_package=True)
+    m.__spec__.submodule_search_locations = [path]
+    sys.modules[name] = m
+    return m
+
+
+class _AttrDict(dict):
+    """easydict.EasyDict stand-in: attribute access + recursive wrapping."""
+
+    def __init__(self, d=None, **kw):
+        super().__init__()
+        d = dict(d or {})
+        d.update(kw)
+        for k, v in d.items():
+            self[k] = v
+
+    @classmethod
+    def _wrap(cls, v):
+        if isinstance(v, dict) and not isinstance(v, cls):
+            return cls(v)
+        if isinstance(v, (list, tuple)):
+            return type(v)(cls._wrap(u) for u in v)
+        return v
+
+    def __setitem__(self, k, v):
+        super().__setitem__(k, self._wrap(v))
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def update(self, *a, **kw):
+        for k, v in dict(*a, **kw).items():
+            self[k] = v
+
+
+_installed = False
+
+
+def install():
+    """Idempotently install the stubs and make ``/root/reference`` importable."""
+    global _installed
+    if _installed:
+        return
+    if not reference_available():
+        raise RuntimeError(f"reference not found at {REF_ROOT}")
+    import torch
+    import torch.nn.functional as F
+
+    sys.dont_write_bytecode = True
+
+    def memory_efficient_attention(q, k, v, attn_bias=None, op=None, p=0.0, scale=None):
+        causal = attn_bias is not None
+        if q.dim() == 3:  # [B, M, K]
+            return F.scaled_dot_product_attention(q, k, v, is_causal=causal, scale=scale)
+        # [B, M, H, K] layout
+        o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2),
+                                           is_causal=causal, scale=scale)
+        return o.transpose(1, 2)
+
+    class LowerTriangularMask:  # noqa: D401 - marker only
+        pass
+
+    ops = _mod("xformers.ops", memory_efficient_attention=memory_efficient_attention,
+               LowerTriangularMask=LowerTriangularMask, unbind=torch.unbind)
+    xf = _mod("xformers", ops=ops)
+    xf.__path__ = []
+    _mod("open_clip")
+
+    class RotaryEmbedding(torch.nn.Module):
+        def __init__(self, *a, **kw):
+            super().__init__()
+
+        def rotate_queries_or_keys(self, x, *a, **kw):
+            return x
+
+    _mod("rotary_embedding_torch", RotaryEmbedding=RotaryEmbedding)
+    fs = _mod("fairscale")
+    fs.__path__ = []
+    fsnn = _mod("fairscale.nn")
+    fsnn.__path__ = []
+    _mod("fairscale.nn.checkpoint", checkpoint_wrapper=lambda m, *a, **kw: m)
+    _mod("easydict", EasyDict=_AttrDict)
+    _mod("tyro")
+    _mod("kiui")
+    _mod("pynvml")
+
+    if REF_ROOT not in sys.path:
+        sys.path.insert(0, REF_ROOT)
+    _pkg("tools", os.path.join(REF_ROOT, "tools"))
+    _pkg("tools.modules", os.path.join(REF_ROOT, "tools", "modules"))
+    _pkg("tools.modules.unet", os.path.join(REF_ROOT, "tools", "modules", "unet"))
+    _pkg("tools.modules.diffusions", os.path.join(REF_ROOT, "tools", "modules", "diffusions"))
+    _installed = True
+
+
+def load_reference():
+    """Return a namespace with the reference classes on the hot path."""
+    install()
+    import importlib
+
+    ns = types.SimpleNamespace()
+    ns.util = importlib.import_module("tools.modules.unet.util")
+    ns.unet_t2v = importlib.import_module("tools.modules.unet.unet_t2v")
+    ns.ddim = importlib.import_module("tools.modules.diffusions.diffusion_ddim")
+    ns.schedules = importlib.import_module("tools.modules.diffusions.schedules")
+    ns.autoencoder = importlib.import_module("tools.modules.autoencoder")
+    return ns
