@@ -1,0 +1,218 @@
+/* vmv.h — C ABI of libvmv_hip.so: the MI355X (gfx950) kernels behind VideoMV's DDIM denoising hot path.
+ *
+ * The reference (alibaba/VideoMV) has NO native code of its own: its hot path bottoms out in PyTorch ops that
+ * dispatch to cuDNN / cuBLAS / xformers.  Each entry point below therefore replaces a
+ * family of those leaf calls; the reference call sites are cited per function (paths relative to the
+ * reference root).  The Python host (videomv_amd/) binds these with ctypes — see INTEGRATION.md.
+ *
+ * Contract for every launcher:
+ *   - plain pointers + sizes only; all pointers are caller-owned DEVICE memory; nothing is allocated or freed;
+ *   - no synchronisation, no global state: work is enqueued on `stream` (a hipStream_t passed as void*),
+ *     so calls are hipGraph-capturable and thread-safe across streams;
+ *   - returns 0 on success, a negative VMV_E* code for argument violations (reported, never asserted), or the
+ *     positive hipError_t of a failed launch.
+ * Activations are channels-last "rows": a [rows, C] bf16 matrix whose row index enumerates (batch, frame, y, x)
+ * (see DESIGN.md §3); weights are bf16 [N][K] (output-channel major, reduction contiguous).
+ */
+#ifndef VMV_H
+#define VMV_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VMV_OK            0
+#define VMV_EINVAL       -1   /* bad dimension / flag combination */
+#define VMV_EALIGN       -2   /* pointer or leading dimension not 16-byte aligned */
+#define VMV_ENULL        -3   /* required pointer is NULL */
+#define VMV_ERANGE       -4   /* size outside what the kernel supports */
+
+#define VMV_ABI_VERSION   1
+int vmv_abi_version(void);
+/* sizeof() of the argument blocks, so a foreign-language binding can verify its struct layout:
+ * which = VMV_OP_* (GN_STATS/GN_APPLY share a block), 100 = VmvDdimParams, 101 = VmvGemmSeg, 102 = VmvSeqMap */
+int vmv_sizeof(int which);
+/* human-readable text for a code returned by any launcher (VMV_E* or hipError_t) */
+const char* vmv_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Implicit-GEMM: out[M,N] = epilogue( sum_s  gather_s(A_s)[M,K_s] * W[:, koff_s : koff_s+K_s]^T )
+ * One kernel covers (reference call sites):
+ *   nn.Linear / Conv1d(k=1) / 1x1 conv ............ util.py:223-227,337,351,546,573,688,1016,1032
+ *   Conv2d 3x3 s1 p1, s2 p1, nearest-x2 + 3x3 ..... util.py:651,677,749,595-606; unet_t2v.py:169,264
+ *   Conv3d (3,1,1) zero-padded over frames ......... util.py:1360-1375
+ *   VAE decoder convs .............................. autoencoder.py:582-687
+ * A "segment" is one (source tensor, tap) pair; the K loop walks the segments in order, so im2col, the
+ * channel-concat of decoder ResBlocks (torch.cat at unet_t2v.py:361) and the fused 1x1 skip connection
+ * (util.py:720) never materialise.
+ * ---------------------------------------------------------------------------------------------------- */
+#define VMV_MAX_SEGS 24
+#define VMV_SEG_LINEAR   0   /* source row = m */
+#define VMV_SEG_SPATIAL  1   /* m -> (n, oy, ox); source pixel (oy*stride+d0, ox*stride+d1) in the (up-sampled) image */
+#define VMV_SEG_TEMPORAL 2   /* m -> (b, f, p); source row m + d0*P if 0 <= f+d0 < F else zero */
+
+typedef struct {
+    const void* src;     /* bf16 rows; row stride `ld` elements                                  */
+    int32_t ld;          /* elements; multiple of 8                                              */
+    int32_t k;           /* channels taken from each source row (multiple of 8)                   */
+    int32_t mode;        /* VMV_SEG_*                                                            */
+    int32_t d0, d1;      /* tap offsets (dy,dx) or (dt,-)                                        */
+    int32_t _pad;
+} VmvGemmSeg;
+
+#define VMV_EPI_NONE   0
+#define VMV_EPI_GEGLU  1   /* N counts x|gate pairs interleaved in 16-column blocks; writes N/2 columns: x*gelu_erf(gate) */
+#define VMV_ACT_NONE   0
+#define VMV_ACT_SILU   1
+
+typedef struct {
+    int32_t M, N;            /* output rows / weight rows (N multiple of 4)                         */
+    int32_t nseg;
+    int32_t ktot;            /* = sum of seg.k = row stride of W                                   */
+    VmvGemmSeg seg[VMV_MAX_SEGS];
+    const void* W;           /* bf16 [N][ktot]                                                     */
+    const float* bias;       /* [N] or NULL                                                        */
+    const float* rowvec;     /* optional [M / rowvec_div][rowvec_ld] fp32 added per row group (time embedding) */
+    int32_t rowvec_div, rowvec_ld;
+    const void* residual;    /* optional bf16 [M][ldr] added last                                  */
+    int32_t ldr;
+    int32_t epilogue;        /* VMV_EPI_*                                                          */
+    int32_t act;             /* VMV_ACT_* applied after bias/rowvec, before residual               */
+    int32_t out_fp32;        /* 0: bf16 output, 1: fp32 output                                     */
+    void* out;               /* [M][ldo]                                                           */
+    int32_t ldo;
+    /* geometry for SPATIAL segments */
+    int32_t OH, OW, IH, IW, stride, ups;
+    /* geometry for TEMPORAL segments */
+    int32_t F, P;
+    /* split-K: ksplit > 1 needs workspace of ksplit*M*N floats; 0/1 = off */
+    int32_t ksplit;
+    float* workspace;
+    int32_t tile;            /* 0 = auto; else VMV_TILE_* to force a configuration                 */
+    int32_t _pad;
+} VmvGemmParams;
+
+#define VMV_TILE_AUTO     0
+#define VMV_TILE_128x128  1
+#define VMV_TILE_128x160  2
+#define VMV_TILE_128x64   3
+#define VMV_TILE_64x64    4
+
+int vmv_gemm_bf16(const VmvGemmParams* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * GroupNorm(32 groups) over row blocks + optional SiLU (torch group_norm + silu: util.py:329,649,673,1014,
+ * 1358-1373; unet_t2v.py:262; autoencoder.py Normalize).  A "stat group" is `rows_per_stat` consecutive rows:
+ * H*W rows for the per-frame 4-D norms, F*H*W rows for the 5-D norms whose statistics span all frames
+ * (SURVEY F9).  Two launches: partial sums (deterministic, no atomics), then normalise(+SiLU).
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const void* x;         /* bf16 [rows][ld]   (second source x1 optional: channels [C0, C0+C1) )  */
+    const void* x1;
+    int32_t ld, ld1;
+    int32_t C0, C1;        /* C = C0 + C1, C % 32 == 0, (C/32) % 2 == 0, C0 % 8 == 0               */
+    int32_t rows, rows_per_stat;
+    int32_t chunk_rows;    /* rows per partial-sum block (rows_per_stat % chunk_rows may be != 0)   */
+    float* partial;        /* workspace [nstat][nchunk][32][2] floats                              */
+    const float* gamma;    /* [C] */
+    const float* beta;     /* [C] */
+    float eps;
+    int32_t silu;          /* 1: y = silu(gn(x)) */
+    void* y;               /* bf16 [rows][ldy] */
+    int32_t ldy;
+} VmvGroupNormParams;
+
+int vmv_groupnorm_stats(const VmvGroupNormParams* p, void* stream);
+int vmv_groupnorm_apply(const VmvGroupNormParams* p, void* stream);
+
+/* LayerNorm over the channel axis of [rows][C] bf16 (nn.LayerNorm, eps 1e-5: util.py:528-530) */
+typedef struct {
+    const void* x; int32_t ldx;
+    void* y; int32_t ldy;
+    const float* gamma; const float* beta;
+    int32_t rows, C;       /* C % 8 == 0, C <= 2048 */
+    float eps;
+    int32_t _pad;
+} VmvLayerNormParams;
+int vmv_layernorm(const VmvLayerNormParams* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Softmax attention, head_dim 64, no mask/bias, scale given (xformers memory_efficient_attention at
+ * util.py:253,258).  One kernel for the three uses, selected by the index maps:
+ *   spatial self  : problems (b f, head), Nq = Nk = H*W
+ *   spatial cross : same queries, Nk = 77 text tokens shared by all frames of a batch item (kv_div = F)
+ *   temporal      : problems (b, pixel, head), Nq = Nk = F, rows strided by H*W   
+ * Row address of sequence position i of problem `o`, head h:
+ *     base + (o / inner) * s_outer + (o % inner) * s_inner + i * s_row + h * 64      (elements)
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int64_t s_outer, s_inner, s_row;
+    int32_t inner; int32_t _pad;
+} VmvSeqMap;
+
+typedef struct {
+    const void* q; const void* k; const void* v; void* o;   /* bf16 */
+    VmvSeqMap qm, km, vm, om;
+    int32_t n_outer;       /* number of q problems per head */
+    int32_t kv_div;        /* kv problem index = o / kv_div */
+    int32_t heads;
+    int32_t Nq, Nk;
+    float scale;
+} VmvAttnParams;
+int vmv_attention_bf16(const VmvAttnParams* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Sampler glue kernels (DiffusionDDIM.p_mean_variance / ddim_sample: diffusion_ddim.py:157-160,192-195,233-243;
+ * layout moves of unet_t2v.py:348,368; embeddings unet_t2v.py:326-335).
+ * ---------------------------------------------------------------------------------------------------- */
+/* latent [nb_src][C][F][H][W] fp32 -> rows [nrep*nb_src*F*H*W][Cpad] bf16 (channels zero-padded to Cpad, the
+ * whole volume written nrep times: the cond / uncond CFG branches see the same x_t) */
+int vmv_latent_to_rows(const float* x, void* rows, int nb_src, int C, int F, int H, int W, int Cpad, int nrep,
+                       void* stream);
+/* rows [n*HW][ld] (bf16 or fp32) -> image/latent [n][C][H][W] fp32 (C <= ld) */
+int vmv_rows_to_nchw(const void* rows, int rows_fp32, int ld, float* out, int n, int C, int HW, void* stream);
+
+typedef struct {
+    const float* eps_rows;   /* fp32 [2][F*H*W][ld]: branch 0 = conditional, 1 = unconditional        */
+    int32_t ld;
+    int32_t C, F, HW;
+    float guide_scale;
+    float c_recip, c_recipm1;      /* sqrt(1/abar_t), sqrt(1/abar_t - 1)   (eps-prediction)            */
+    float c_sqrt_ac, c_sqrt_1mac;  /* sqrt(abar_t), sqrt(1-abar_t)         (v-prediction)              */
+    float a_prev;                  /* abar_{t-stride}                                                  */
+    int32_t v_pred;                /* 0: eps-prediction, 1: v-prediction                               */
+    float* xt;                     /* fp32 [C][F][HW] updated in place to x_{t-1}                      */
+    float* x0_out;                 /* optional fp32 [C][F][HW] predicted x0                            */
+} VmvDdimParams;
+int vmv_cfg_ddim_step(const VmvDdimParams* p, void* stream);
+
+/* e[r][c] = silu(temb[(r / rows_per_t)][c] + (cam ? cam[r % cam_rows][c] : 0)) -> bf16 [rows][C] */
+int vmv_emb_combine_silu(const float* temb, const float* cam, void* out, int rows, int C, int rows_per_t,
+                         int cam_rows, void* stream);
+/* sinusoidal timestep embedding (cos || sin), out fp32->bf16 [n][dim]  (util.py:177-189) */
+int vmv_sinusoidal(const float* t, void* out_bf16, int n, int dim, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Plan: a recorded sequence of the launches above, replayed with one call (host-side launch overhead of
+ * >1000 kernels per forward would otherwise dominate).
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct VmvPlan VmvPlan;
+#define VMV_OP_GEMM        1
+#define VMV_OP_GN_STATS    2
+#define VMV_OP_GN_APPLY    3
+#define VMV_OP_LAYERNORM   4
+#define VMV_OP_ATTENTION   5
+VmvPlan* vmv_plan_create(void);
+void     vmv_plan_destroy(VmvPlan* plan);
+int      vmv_plan_add(VmvPlan* plan, int op, const void* params, size_t nbytes);
+int      vmv_plan_size(const VmvPlan* plan);
+int      vmv_plan_run(const VmvPlan* plan, void* stream);
+/* run ops [first, last) only — used by tests and profiling */
+int      vmv_plan_run_range(const VmvPlan* plan, int first, int last, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VMV_H */

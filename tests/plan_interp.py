@@ -1,0 +1,208 @@
+"""TEST INFRASTRUCTURE: a CPU interpreter of the C-ABI argument blocks (include/vmv.h), written from the header's
+contract in plain torch.  It lets the `not gpu` suite execute a recorded UNet plan on host memory and compare it
+with the oracle, so that the host logic (segment lists, weight packing, index maps, buffer reuse) is verified
+without a GPU.  It is never imported by the product package and says nothing about the HIP kernels themselves —
+those are checked on the GPU against torch references and against the oracle.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from videomv_amd import _lib as L
+
+
+def _view(ptr, n, kind):
+    """Torch view of n elements at raw host address ptr. kind: 'bf16' | 'f32'."""
+    if kind == "bf16":
+        arr = np.ctypeslib.as_array((C.c_uint16 * n).from_address(ptr))
+        return torch.from_numpy(arr.view(np.int16)).view(torch.bfloat16)
+    arr = np.ctypeslib.as_array((C.c_float * n).from_address(ptr))
+    return torch.from_numpy(arr)
+
+
+def _rows(ptr, nrows, ld, kind="bf16"):
+    return _view(ptr, nrows * ld, kind).view(nrows, ld)
+
+
+def gemm(p: L.GemmParams):
+    M, N = p.M, p.N
+    m = torch.arange(M)
+    cols = []
+    for s in range(p.nseg):
+        sg = p.seg[s]
+        if sg.mode == L.SEG_LINEAR:
+            src_row = m.clone()
+            valid = torch.ones(M, dtype=torch.bool)
+        elif sg.mode == L.SEG_SPATIAL:
+            hw = p.OH * p.OW
+            n = m // hw
+            rem = m % hw
+            oy, ox = rem // p.OW, rem % p.OW
+            iy = oy * p.stride + sg.d0
+            ix = ox * p.stride + sg.d1
+            VH, VW = p.IH << p.ups, p.IW << p.ups
+            valid = (iy >= 0) & (iy < VH) & (ix >= 0) & (ix < VW)
+            src_row = n * p.IH * p.IW + (iy.clamp(0, VH - 1) >> p.ups) * p.IW + (ix.clamp(0, VW - 1) >> p.ups)
+        else:
+            f = (m // p.P) % p.F
+            valid = (f + sg.d0 >= 0) & (f + sg.d0 < p.F)
+            src_row = (m + sg.d0 * p.P).clamp(0, M - 1)
+        nsrc = int(src_row.max()) + 1
+        src = _rows(sg.src, nsrc, sg.ld)[:, : sg.k].float()
+        a = src[src_row]
+        a[~valid] = 0
+        cols.append(a)
+    A = torch.cat(cols, dim=1)
+    W = _rows(p.W, N, p.ktot).float()
+    acc = A @ W.t()
+    if p.bias:
+        acc = acc + _view(p.bias, N, "f32")
+    if p.epilogue == L.EPI_GEGLU:
+        acc = acc.view(M, N // 32, 2, 16)
+        x, g = acc[:, :, 0], acc[:, :, 1]
+        acc = (x * torch.nn.functional.gelu(g)).reshape(M, N // 2)
+    No = acc.shape[1]
+    if p.rowvec:
+        ngroups = (M + p.rowvec_div - 1) // p.rowvec_div
+        rv = _rows(p.rowvec, ngroups, p.rowvec_ld, "f32")[:, :No]
+        acc = acc + rv[m // p.rowvec_div]
+    if p.act == L.ACT_SILU:
+        acc = torch.nn.functional.silu(acc)
+    if p.residual:
+        acc = acc + _rows(p.residual, M, p.ldr)[:, :No].float()
+    out = _rows(p.out, M, p.ldo, "f32" if p.out_fp32 else "bf16")
+    out[:, :No] = acc if p.out_fp32 else acc.to(torch.bfloat16)
+
+
+def groupnorm(p: L.GroupNormParams):
+    Cc = p.C0 + p.C1
+    x = _rows(p.x, p.rows, p.ld)[:, : p.C0].float()
+    if p.C1:
+        x = torch.cat([x, _rows(p.x1, p.rows, p.ld1)[:, : p.C1].float()], dim=1)
+    nstat = p.rows // p.rows_per_stat
+    xg = x.view(nstat, p.rows_per_stat, 32, Cc // 32)
+    mean = xg.mean(dim=(1, 3), keepdim=True)
+    var = xg.var(dim=(1, 3), unbiased=False, keepdim=True)
+    y = ((xg - mean) * torch.rsqrt(var + p.eps)).view(p.rows, Cc)
+    y = y * _view(p.gamma, Cc, "f32") + _view(p.beta, Cc, "f32")
+    if p.silu:
+        y = torch.nn.functional.silu(y)
+    _rows(p.y, p.rows, p.ldy)[:, :Cc] = y.to(torch.bfloat16)
+
+
+def layernorm(p: L.LayerNormParams):
+    x = _rows(p.x, p.rows, p.ldx)[:, : p.C].float()
+    y = torch.nn.functional.layer_norm(x, (p.C,), _view(p.gamma, p.C, "f32"), _view(p.beta, p.C, "f32"), p.eps)
+    _rows(p.y, p.rows, p.ldy)[:, : p.C] = y.to(torch.bfloat16)
+
+
+def _seq_rows(ptr, mp, o, h, n):
+    base = (o // mp.inner) * mp.s_outer + (o % mp.inner) * mp.s_inner + h * 64
+    flat = _view(ptr, int(base + (n - 1) * mp.s_row + 64), "bf16")
+    idx = base + torch.arange(n)[:, None] * mp.s_row + torch.arange(64)[None, :]
+    return flat, idx
+
+
+def attention(p: L.AttnParams):
+    for o in range(p.n_outer):
+        for h in range(p.heads):
+            qf, qi = _seq_rows(p.q, p.qm, o, h, p.Nq)
+            kf, ki = _seq_rows(p.k, p.km, o // p.kv_div, h, p.Nk)
+            vf, vi = _seq_rows(p.v, p.vm, o // p.kv_div, h, p.Nk)
+            q, k, v = qf[qi].float(), kf[ki].float(), vf[vi].float()
+            s = torch.softmax(q @ k.t() * p.scale, dim=-1)
+            out = (s @ v).to(torch.bfloat16)
+            of, oi = _seq_rows(p.o, p.om, o, h, p.Nq)
+            of[oi.reshape(-1)] = out.reshape(-1)
+
+
+def run_recorded(recorded):
+    for op, params in recorded:
+        if op == L.OP_GEMM:
+            gemm(params)
+        elif op == L.OP_GN_STATS:
+            pass                      # folded into GN_APPLY below
+        elif op == L.OP_GN_APPLY:
+            groupnorm(params)
+        elif op == L.OP_LAYERNORM:
+            layernorm(params)
+        elif op == L.OP_ATTENTION:
+            attention(params)
+        else:
+            raise ValueError(op)
+
+
+# ---- direct glue kernels (same contracts as videomv_amd/ops.py's launchers)
+def latent_to_rows(x, rows, Cpad, nrep):
+    nb, Cc, F_, H, W = x.shape
+    r = x.permute(0, 2, 3, 4, 1).reshape(nb * F_ * H * W, Cc)
+    full = torch.zeros(nb * F_ * H * W, Cpad)
+    full[:, :Cc] = r
+    rows.copy_(full.repeat(nrep, 1).to(torch.bfloat16))
+
+
+def rows_to_nchw(rows, ld, out):
+    n, Cc, H, W = out.shape
+    out.copy_(rows.view(n, H * W, ld)[:, :, :Cc].float().permute(0, 2, 1).reshape(n, Cc, H, W))
+
+
+def emb_combine_silu(temb, cam, out, rows, Cc, rows_per_t, cam_rows):
+    r = torch.arange(rows)
+    v = temb[r // rows_per_t]
+    if cam is not None:
+        v = v + cam[r % cam_rows]
+    out.copy_(torch.nn.functional.silu(v).to(torch.bfloat16))
+
+
+def sinusoidal(t, out, n, dim):
+    half = dim // 2
+    freq = torch.pow(10000, -torch.arange(half).float() / half)
+    s = torch.outer(t.float(), freq)
+    out.copy_(torch.cat([torch.cos(s), torch.sin(s)], dim=1).to(torch.bfloat16))
+
+
+def cfg_ddim_step(eps_rows, ld, xt, guide_scale, c_recip, c_recipm1, c_sqrt_ac, c_sqrt_1mac, a_prev, v_pred=False,
+                  x0_out=None):
+    _, Cc, F_, H, W = xt.shape
+    FHW = F_ * H * W
+    e = eps_rows.view(2, FHW, ld)[:, :, :Cc]
+    y, u = e[0].t().reshape(1, Cc, F_, H, W), e[1].t().reshape(1, Cc, F_, H, W)
+    out = u + guide_scale * (y - u)
+    f = torch.float32
+    x0 = (torch.tensor(c_sqrt_ac, dtype=f) * xt - torch.tensor(c_sqrt_1mac, dtype=f) * out) if v_pred else \
+        (torch.tensor(c_recip, dtype=f) * xt - torch.tensor(c_recipm1, dtype=f) * out)
+    eps = (torch.tensor(c_recip, dtype=f) * xt - x0) / torch.tensor(c_recipm1, dtype=f)
+    ap = torch.tensor(a_prev, dtype=f)
+    xt.copy_(torch.sqrt(ap) * x0 + torch.sqrt(1 - ap) * eps)
+    if x0_out is not None:
+        x0_out.copy_(x0)
+
+
+def install(monkeypatch):
+    """Route every launch of videomv_amd.ops to this interpreter (CPU tensors)."""
+    from videomv_amd import ops
+
+    def _go(self, op, params, fn, label):
+        if self.record:
+            self.labels.append(label)
+            self.recorded.append((op, params))
+            self.nops += 1
+        else:
+            run_recorded([(op, params)])
+
+    def run(self, first=0, last=None):
+        run_recorded(self.recorded[first:last])
+
+    def init(self, record=False):
+        self.lib = L.load()      # symbols only; nothing is launched
+        self.record = record
+        self.plan = None
+        self.keep, self.nops, self.labels, self.recorded = [], 0, [], []
+
+    monkeypatch.setattr(ops.Stream, "__init__", init)
+    monkeypatch.setattr(ops.Stream, "_go", _go)
+    monkeypatch.setattr(ops.Stream, "run", run)
+    for name in ("latent_to_rows", "rows_to_nchw", "emb_combine_silu", "sinusoidal", "cfg_ddim_step"):
+        monkeypatch.setattr(ops, name, globals()[name])

@@ -1,0 +1,131 @@
+"""ctypes binding of ``libvmv_hip.so`` (the C ABI declared in ``include/vmv.h``).
+
+The structures below mirror the header field-for-field.  Loading fails loudly (``RuntimeError``) when the
+shared library is missing: there is NO CPU / PyTorch fallback for the hot path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvmv_hip.so")
+
+VMV_MAX_SEGS = 24
+SEG_LINEAR, SEG_SPATIAL, SEG_TEMPORAL = 0, 1, 2
+EPI_NONE, EPI_GEGLU = 0, 1
+ACT_NONE, ACT_SILU = 0, 1
+TILE_AUTO, TILE_128x128, TILE_128x160, TILE_128x64, TILE_64x64 = 0, 1, 2, 3, 4
+OP_GEMM, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTENTION = 1, 2, 3, 4, 5
+
+
+class GemmSeg(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("ld", C.c_int32), ("k", C.c_int32), ("mode", C.c_int32),
+                ("d0", C.c_int32), ("d1", C.c_int32), ("_pad", C.c_int32)]
+
+
+class GemmParams(C.Structure):
+    _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("nseg", C.c_int32), ("ktot", C.c_int32),
+                ("seg", GemmSeg * VMV_MAX_SEGS),
+                ("W", C.c_void_p), ("bias", C.c_void_p), ("rowvec", C.c_void_p),
+                ("rowvec_div", C.c_int32), ("rowvec_ld", C.c_int32),
+                ("residual", C.c_void_p), ("ldr", C.c_int32),
+                ("epilogue", C.c_int32), ("act", C.c_int32), ("out_fp32", C.c_int32),
+                ("out", C.c_void_p), ("ldo", C.c_int32),
+                ("OH", C.c_int32), ("OW", C.c_int32), ("IH", C.c_int32), ("IW", C.c_int32),
+                ("stride", C.c_int32), ("ups", C.c_int32),
+                ("F", C.c_int32), ("P", C.c_int32),
+                ("ksplit", C.c_int32), ("workspace", C.c_void_p),
+                ("tile", C.c_int32), ("_pad", C.c_int32)]
+
+
+class GroupNormParams(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("x1", C.c_void_p), ("ld", C.c_int32), ("ld1", C.c_int32),
+                ("C0", C.c_int32), ("C1", C.c_int32), ("rows", C.c_int32), ("rows_per_stat", C.c_int32),
+                ("chunk_rows", C.c_int32), ("partial", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("eps", C.c_float), ("silu", C.c_int32), ("y", C.c_void_p), ("ldy", C.c_int32)]
+
+
+class LayerNormParams(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("ldx", C.c_int32), ("y", C.c_void_p), ("ldy", C.c_int32),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("rows", C.c_int32), ("C", C.c_int32),
+                ("eps", C.c_float), ("_pad", C.c_int32)]
+
+
+class SeqMap(C.Structure):
+    _fields_ = [("s_outer", C.c_int64), ("s_inner", C.c_int64), ("s_row", C.c_int64),
+                ("inner", C.c_int32), ("_pad", C.c_int32)]
+
+
+class AttnParams(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p),
+                ("qm", SeqMap), ("km", SeqMap), ("vm", SeqMap), ("om", SeqMap),
+                ("n_outer", C.c_int32), ("kv_div", C.c_int32), ("heads", C.c_int32),
+                ("Nq", C.c_int32), ("Nk", C.c_int32), ("scale", C.c_float)]
+
+
+class DdimParams(C.Structure):
+    _fields_ = [("eps_rows", C.c_void_p), ("ld", C.c_int32), ("C", C.c_int32), ("F", C.c_int32), ("HW", C.c_int32),
+                ("guide_scale", C.c_float), ("c_recip", C.c_float), ("c_recipm1", C.c_float),
+                ("c_sqrt_ac", C.c_float), ("c_sqrt_1mac", C.c_float), ("a_prev", C.c_float),
+                ("v_pred", C.c_int32), ("xt", C.c_void_p), ("x0_out", C.c_void_p)]
+
+
+# every symbol include/vmv.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "vmv_abi_version": (C.c_int, []),
+    "vmv_sizeof": (C.c_int, [C.c_int]),
+    "vmv_error_string": (C.c_char_p, [C.c_int]),
+    "vmv_gemm_bf16": (C.c_int, [C.POINTER(GemmParams), _P]),
+    "vmv_groupnorm_stats": (C.c_int, [C.POINTER(GroupNormParams), _P]),
+    "vmv_groupnorm_apply": (C.c_int, [C.POINTER(GroupNormParams), _P]),
+    "vmv_layernorm": (C.c_int, [C.POINTER(LayerNormParams), _P]),
+    "vmv_attention_bf16": (C.c_int, [C.POINTER(AttnParams), _P]),
+    "vmv_latent_to_rows": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "vmv_rows_to_nchw": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "vmv_cfg_ddim_step": (C.c_int, [C.POINTER(DdimParams), _P]),
+    "vmv_emb_combine_silu": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "vmv_sinusoidal": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "vmv_plan_create": (_P, []),
+    "vmv_plan_destroy": (None, [_P]),
+    "vmv_plan_add": (C.c_int, [_P, C.c_int, _P, C.c_size_t]),
+    "vmv_plan_size": (C.c_int, [_P]),
+    "vmv_plan_run": (C.c_int, [_P, _P]),
+    "vmv_plan_run_range": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and type the shared library.  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; "
+            f"g.build()' or make -C videomv_amd/csrc).  There is no CPU fallback for the hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI drifted
+        fn.restype = res
+        fn.argtypes = args
+    if lib.vmv_abi_version() != 1:
+        raise RuntimeError("libvmv_hip.so ABI version mismatch")
+    for which, st in ((OP_GEMM, GemmParams), (OP_GN_STATS, GroupNormParams), (OP_LAYERNORM, LayerNormParams),
+                      (OP_ATTENTION, AttnParams), (100, DdimParams), (101, GemmSeg), (102, SeqMap)):
+        if lib.vmv_sizeof(which) != C.sizeof(st):
+            raise RuntimeError(f"struct layout drift for {st.__name__}: C {lib.vmv_sizeof(which)} vs ctypes "
+                               f"{C.sizeof(st)}")
+    _lib = lib
+    return lib
+
+
+class VmvError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().vmv_error_string(rc)
+        raise VmvError(f"{what}: rc={rc} ({msg.decode() if msg else '?'})")

@@ -1,0 +1,238 @@
+// attention.hip — softmax(Q K^T * scale) V for head_dim 64 on gfx950, bf16 in/out, fp32 softmax + accumulate.
+// One flash-style kernel serves the UNet's three attention shapes through index maps (include/vmv.h):
+// spatial self (N = H*W), spatial cross (Nk = 77 text tokens) and per-pixel temporal (N = 24 frames).
+//
+// Formulation (everything transposed so that softmax statistics are lane-local):
+//   S^T = K Q^T  : MFMA A = K fragment (rows = keys), B = Q fragment (cols = queries)
+//                  -> lane (u = lane&15, g = lane>>4) holds S[q = u][4 keys] per 16-key tile
+//   O^T = V^T P^T: MFMA A = V^T fragment (rows = d),  B = P^T fragment (cols = queries)
+//                  -> lane holds O[q = u][d = 16*dt + 4*g + r]: the same q as its softmax state, so the
+//                     running max / sum / rescale never cross lanes, and the output store is 8 bytes per lane.
+// The K rows of each 16-key MFMA tile are loaded in a permuted order (tile t, row u -> key 32*(t>>1) + 8*(u>>2)
+// + 4*(t&1) + (u&3)) so that the exponentiated S^T registers of tiles (2kk, 2kk+1) ARE the P^T B-operand for
+// keys 32kk + 8g + 0..7 — no shuffles and no LDS round trip between the two GEMMs.
+// K tiles are staged in LDS row-major [key][64] and V tiles transposed [d][key] (both XOR-swizzled so that the
+// 16-byte fragment reads and the staging writes are bank-conflict free).
+//   WPP = 4: the 4 waves of a block share one (problem, 128-query tile) and one K/V stage;
+//   WPP = 1: every wave owns a whole short problem (Nq <= 32, e.g. the 24-frame temporal attention) with a
+//            private 16-KB stage.
+#include "common.h"
+
+namespace {
+
+VMV_DEV long seq_base(const VmvSeqMap& m, int o) {
+    return (long)(o / m.inner) * m.s_outer + (long)(o % m.inner) * m.s_inner;
+}
+VMV_DEV int k_swz(int key) { return (((key >> 3) & 3) << 1) | ((key >> 1) & 1); }
+
+constexpr float NEG_BIG = -1.0e30f;
+
+template <int WPP>
+__global__ __launch_bounds__(256) void attn_kernel(const VmvAttnParams p, const int nproblems) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int u = lane & 15, g = lane >> 4;
+
+    // ---- which problem / query rows does this wave own?
+    int o, h, q0;
+    bool wvalid = true;
+    if constexpr (WPP == 4) {
+        o = blockIdx.z; h = blockIdx.y; q0 = (blockIdx.x * 4 + wave) * 32;
+    } else {
+        const int pidx = blockIdx.x * 4 + wave;
+        wvalid = pidx < nproblems;
+        const int pi = wvalid ? pidx : 0;
+        h = pi % p.heads; o = pi / p.heads; q0 = 0;
+    }
+    const uint16_t* qp = reinterpret_cast<const uint16_t*>(p.q) + seq_base(p.qm, o) + h * 64;
+    const uint16_t* kp = reinterpret_cast<const uint16_t*>(p.k) + seq_base(p.km, o / p.kv_div) + h * 64;
+    const uint16_t* vp = reinterpret_cast<const uint16_t*>(p.v) + seq_base(p.vm, o / p.kv_div) + h * 64;
+    uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + seq_base(p.om, o) + h * 64;
+
+    // ---- staging group
+    constexpr int NT = (WPP == 4) ? 256 : 64;
+    const int stid = (WPP == 4) ? tid : lane;
+    unsigned char* region = smem_raw + ((WPP == 4) ? 0 : wave * 16384);
+    u32x4_t* const Ks = reinterpret_cast<u32x4_t*>(region);            // [64 keys][8 slots] 16-B units
+    uint16_t* const Vt = reinterpret_cast<uint16_t*>(region + 8192);   // [64 d][64 keys] bf16
+
+    // ---- Q fragments (B operand): row q0 + 16*qt + u, k-slot kk*32 + 8*g
+    bf16x8_t qf[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = q0 + qt * 16 + u;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (wvalid && q < p.Nq) v = *reinterpret_cast<const u32x4_t*>(qp + (long)q * p.qm.s_row + kk * 32 + g * 8);
+            qf[qt][kk] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    }
+
+    f32x4_t oacc[2][4];
+    float m_run[2], l_run[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        m_run[qt] = NEG_BIG; l_run[qt] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oacc[qt][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    const float sc = p.scale * 1.44269504088896341f;   // exp2 domain
+
+    const int ntile = (p.Nk + 63) >> 6;
+    for (int kt = 0; kt < ntile; ++kt) {
+        const int key0 = kt * 64;
+        __syncthreads();   // previous tile's fragment reads are done
+        // ---- stage K (row-major, swizzled) and V (transposed, swizzled)
+        for (int idx = stid; idx < 512; idx += NT) {
+            const int row = idx >> 3, slot = idx & 7;
+            const int key = key0 + row;
+            u32x4_t kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+            if (wvalid && key < p.Nk) {
+                kv = *reinterpret_cast<const u32x4_t*>(kp + (long)key * p.km.s_row + slot * 8);
+                vv = *reinterpret_cast<const u32x4_t*>(vp + (long)key * p.vm.s_row + slot * 8);
+            }
+            Ks[row * 8 + (slot ^ k_swz(row))] = kv;
+            const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = slot * 8 + j;
+                const int fk = ((slot ^ (((slot & 1) << 2) | (j >> 1))) & 7) << 3;   // = 8*(((d>>3)^(d>>1))&7)
+                const uint16_t val = (j & 1) ? (uint16_t)(w[j >> 1] >> 16) : (uint16_t)(w[j >> 1] & 0xffffu);
+                Vt[d * 64 + (row ^ fk)] = val;
+            }
+        }
+        __syncthreads();
+
+        // ---- S^T tiles
+        f32x4_t s[2][4];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) s[qt][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int krow = 32 * (t >> 1) + 8 * (u >> 2) + 4 * (t & 1) + (u & 3);
+            const int ksw = k_swz(krow);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, Ks[krow * 8 + ((kk * 4 + g) ^ ksw)]);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                    s[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][kk], s[qt][t], 0, 0, 0);
+            }
+        }
+        // ---- online softmax (per lane: query u, 16 keys of this tile)
+        bf16x8_t pf[2][2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float mx = NEG_BIG;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int kb = key0 + 32 * (t >> 1) + 8 * g + 4 * (t & 1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float val = (kb + r < p.Nk) ? s[qt][t][r] * sc : NEG_BIG;
+                    s[qt][t][r] = val;
+                    mx = fmaxf(mx, val);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qt], mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+            m_run[qt] = m_new;
+            float psum = 0.f;
+            float pv[4][4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(s[qt][t][r] - m_new);
+                    pv[t][r] = e;
+                    psum += e;
+                }
+            }
+            l_run[qt] = l_run[qt] * alpha + psum;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) oacc[qt][dt] *= alpha;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                u32x4_t w;
+                w.x = pack_bf16x2(pv[2 * kk][0], pv[2 * kk][1]);
+                w.y = pack_bf16x2(pv[2 * kk][2], pv[2 * kk][3]);
+                w.z = pack_bf16x2(pv[2 * kk + 1][0], pv[2 * kk + 1][1]);
+                w.w = pack_bf16x2(pv[2 * kk + 1][2], pv[2 * kk + 1][3]);
+                pf[qt][kk] = __builtin_bit_cast(bf16x8_t, w);
+            }
+        }
+        // ---- O^T += V^T P^T
+        const u32x4_t* Vt16 = reinterpret_cast<const u32x4_t*>(Vt);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const int d = dt * 16 + u;
+            const int fsl = ((d >> 3) ^ (d >> 1)) & 7;   // 8-key block swizzle of row d
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, Vt16[d * 8 + ((kk * 4 + g) ^ fsl)]);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+                    oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][kk], oacc[qt][dt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- normalise and store: lane owns O[q = q0 + 16 qt + u][d = 16 dt + 4 g + 0..3]
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float l = l_run[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const int q = q0 + qt * 16 + u;
+        if (wvalid && q < p.Nq) {
+            uint16_t* orow = op + (long)q * p.om.s_row + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const f32x4_t a = oacc[qt][dt] * inv;
+                u32x2_t w;
+                w.x = pack_bf16x2(a.x, a.y); w.y = pack_bf16x2(a.z, a.w);
+                *reinterpret_cast<u32x2_t*>(orow + dt * 16) = w;
+            }
+        }
+    }
+}
+
+int map_ok(const VmvSeqMap& m) {
+    return m.inner > 0 && !(m.s_outer & 7) && !(m.s_inner & 7) && !(m.s_row & 3);
+}
+
+}  // namespace
+
+extern "C" int vmv_attention_bf16(const VmvAttnParams* pp, void* stream) {
+    if (!pp) return VMV_ENULL;
+    const VmvAttnParams& p = *pp;
+    if (!p.q || !p.k || !p.v || !p.o) return VMV_ENULL;
+    if (p.n_outer <= 0 || p.heads <= 0 || p.Nq <= 0 || p.Nk <= 0 || p.kv_div <= 0) return VMV_EINVAL;
+    if (!map_ok(p.qm) || !map_ok(p.km) || !map_ok(p.vm) || !map_ok(p.om)) return VMV_EALIGN;
+    if ((p.qm.s_row & 7) || (p.km.s_row & 7) || (p.vm.s_row & 7)) return VMV_EALIGN;
+    if (!vmv_aligned16(p.q) || !vmv_aligned16(p.k) || !vmv_aligned16(p.v) || (((uintptr_t)p.o) & 7)) return VMV_EALIGN;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (p.Nq <= 32) {
+        const int nproblems = p.n_outer * p.heads;
+        static bool attr1 = false;
+        if (!attr1) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<1>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+            if (e != hipSuccess) return (int)e;
+            attr1 = true;
+        }
+        hipLaunchKernelGGL((attn_kernel<1>), dim3((nproblems + 3) / 4), dim3(256), 65536, st, p, nproblems);
+    } else {
+        if (p.n_outer > 65535 || p.heads > 65535) return VMV_ERANGE;
+        hipLaunchKernelGGL((attn_kernel<4>), dim3((p.Nq + 127) / 128, p.heads, p.n_outer), dim3(256), 16384, st, p, 0);
+    }
+    return vmv_launch_status();
+}

@@ -1,0 +1,53 @@
+// common.h — shared device helpers for the gfx950 kernels (wave64, bf16 storage / fp32 math).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vmv.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+#define VMV_DEV __device__ __forceinline__
+
+// bf16 <-> fp32 (round-to-nearest-even; NaN not expected on this path)
+VMV_DEV float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+VMV_DEV float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+VMV_DEV uint32_t f32_to_bf16_bits(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+VMV_DEV uint32_t pack_bf16x2(float lo, float hi) {
+    return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+}
+VMV_DEV float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+VMV_DEV void unpack8(const u32x4_t& v, float* f) {
+    f[0] = bf16_lo(v.x); f[1] = bf16_hi(v.x);
+    f[2] = bf16_lo(v.y); f[3] = bf16_hi(v.y);
+    f[4] = bf16_lo(v.z); f[5] = bf16_hi(v.z);
+    f[6] = bf16_lo(v.w); f[7] = bf16_hi(v.w);
+}
+VMV_DEV u32x4_t pack8(const float* f) {
+    u32x4_t v;
+    v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
+    v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
+    return v;
+}
+
+VMV_DEV float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+VMV_DEV float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+VMV_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+static inline int vmv_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+static inline int vmv_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? VMV_OK : (int)e;
+}

@@ -1,0 +1,366 @@
+// gemm.hip — bf16 MFMA implicit-GEMM for gfx950 (MI355X): linear / 1x1 / 3x3 (s1, s2, nearest-x2) / temporal
+// (3,1,1) convolutions with a fused epilogue.  See include/vmv.h for the contract and DESIGN.md §4.1.
+//
+// Mapping to the hardware
+//   * block = 256 threads = 4 waves (2 x 2); wave tile = (16*WM) activation rows x (16*WN) output channels,
+//     built from v_mfma_f32_16x16x32_bf16.  The MFMA "A" operand is the WEIGHT fragment and the "B" operand
+//     the ACTIVATION fragment, i.e. we compute out^T: every lane then owns 4 consecutive output channels of
+//     one activation row, so the epilogue loads/stores 8-byte (bf16x4) / 16-byte (fp32x4) vectors.
+//   * K is walked in 64-channel chunks over a list of (source, tap) segments; both operand tiles are staged
+//     global -> registers -> LDS (the activation gather needs zero-fill predication, so LDS-DMA is not used),
+//     double buffered with ONE barrier per chunk: loads for chunk t+1 are issued before the MFMAs of chunk t
+//     and written to the other LDS buffer after them.
+//   * LDS tiles are [rows][64] bf16 (128-B rows) with the 16-B slot index XOR-swizzled by (row>>1)&7 so that
+//     ds_read_b128 fragment reads and ds_write_b128 staging writes are bank-conflict free.
+//   * blockIdx -> tile is XCD-aware (8 XCDs, private L2): each XCD gets a contiguous range of tiles and walks
+//     the N tiles of one M tile first, so the activation tile is re-used out of that XCD's L2.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 64;
+
+struct RowInfo {
+    int m;       // global row (or -1 when out of range)
+    int nb;      // spatial: image base row (n * IH * IW)
+    int oy, ox;  // spatial: output pixel
+    int fr;      // temporal: frame index
+};
+
+template <int WM, int WN>
+struct GemmCfg {
+    static constexpr int BM = 32 * WM;
+    static constexpr int BN = 32 * WN;
+    static constexpr int LDS_BYTES = 2 * (BM + BN) * BK * 2;
+};
+
+VMV_DEV int seg_row_offset(const VmvGemmParams& p, const VmvGemmSeg& sg, const RowInfo& r) {
+    // element offset of the source row feeding output row r for this segment, or -1 (zero row)
+    if (r.m < 0) return -1;
+    if (sg.mode == VMV_SEG_LINEAR) return r.m * sg.ld;
+    if (sg.mode == VMV_SEG_SPATIAL) {
+        const int iy = r.oy * p.stride + sg.d0;
+        const int ix = r.ox * p.stride + sg.d1;
+        const int VH = p.IH << p.ups, VW = p.IW << p.ups;
+        if (iy < 0 || iy >= VH || ix < 0 || ix >= VW) return -1;
+        return (r.nb + (iy >> p.ups) * p.IW + (ix >> p.ups)) * sg.ld;
+    }
+    // temporal
+    const int f = r.fr + sg.d0;
+    if (f < 0 || f >= p.F) return -1;
+    return (r.m + sg.d0 * p.P) * sg.ld;
+}
+
+// Epilogue for 4 consecutive output channels [n, n+4) of row m.  v = accumulators (x half for GEGLU),
+// g = gate accumulators (GEGLU only).  `n` indexes W rows (pre-GEGLU numbering).
+VMV_DEV void epilogue_store(const VmvGemmParams& p, int m, int n, f32x4_t v, f32x4_t g) {
+    if (m >= p.M || n >= p.N) return;
+    if (p.bias) {
+        const f32x4_t b = *reinterpret_cast<const f32x4_t*>(p.bias + n);
+        v += b;
+        if (p.epilogue == VMV_EPI_GEGLU) g += *reinterpret_cast<const f32x4_t*>(p.bias + n + 16);
+    }
+    int no = n;
+    if (p.epilogue == VMV_EPI_GEGLU) {
+        v.x *= gelu_erf_f(g.x); v.y *= gelu_erf_f(g.y); v.z *= gelu_erf_f(g.z); v.w *= gelu_erf_f(g.w);
+        no = (n >> 5) * 16 + (n & 15);
+    }
+    if (p.rowvec) {
+        const f32x4_t rv = *reinterpret_cast<const f32x4_t*>(p.rowvec + (size_t)(m / p.rowvec_div) * p.rowvec_ld + no);
+        v += rv;
+    }
+    if (p.act == VMV_ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+    if (p.residual) {
+        const u32x2_t r = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const uint16_t*>(p.residual) + (size_t)m * p.ldr + no);
+        v.x += bf16_lo(r.x); v.y += bf16_hi(r.x); v.z += bf16_lo(r.y); v.w += bf16_hi(r.y);
+    }
+    if (p.out_fp32) {
+        *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + no) = v;
+    } else {
+        u32x2_t o;
+        o.x = pack_bf16x2(v.x, v.y); o.y = pack_bf16x2(v.z, v.w);
+        *reinterpret_cast<u32x2_t*>(reinterpret_cast<uint16_t*>(p.out) + (size_t)m * p.ldo + no) = o;
+    }
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_kernel(const VmvGemmParams p, const int tiles_m, const int tiles_n,
+                                                   const int total_steps, const int steps_per_split) {
+    using Cfg = GemmCfg<WM, WN>;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4_t* const lds = reinterpret_cast<u32x4_t*>(smem_raw);
+    // layout (in 16-B units): A buf0 [BM*8] | A buf1 | W buf0 [BN*8] | W buf1
+    constexpr int A_U = BM * 8, W_U = BN * 8;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+
+    // ---- XCD-aware tile mapping (bijective for any block count)
+    const int nblk = tiles_m * tiles_n;
+    int logical;
+    {
+        const int bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = logical % tiles_n;
+    const int tile_m = logical / tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int split = blockIdx.y;
+    const int step_begin = split * steps_per_split;
+    const int step_end = min(total_steps, step_begin + steps_per_split);
+
+    // ---- staging assignment: thread -> (row srow + 32*i, 16-B slot sslot)
+    const int srow = tid >> 3, sslot = tid & 7;
+    const int sw_slot = sslot ^ ((srow >> 1) & 7);
+
+    RowInfo rinfo[WM];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int m = m0 + srow + 32 * i;
+        RowInfo r;
+        r.m = (m < p.M) ? m : -1;
+        r.nb = 0; r.oy = 0; r.ox = 0; r.fr = 0;
+        if (p.OH > 0) {
+            const int hw = p.OH * p.OW;
+            const int n = m / hw, rem = m - n * hw;
+            r.nb = n * p.IH * p.IW;
+            r.oy = rem / p.OW;
+            r.ox = rem - r.oy * p.OW;
+        }
+        if (p.P > 0) r.fr = (m / p.P) % p.F;
+        rinfo[i] = r;
+    }
+    const uint16_t* wrow[WN];
+    bool wvalid[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int n = n0 + srow + 32 * j;
+        wvalid[j] = n < p.N;
+        wrow[j] = reinterpret_cast<const uint16_t*>(p.W) + (size_t)(wvalid[j] ? n : 0) * p.ktot + sslot * 8;
+    }
+
+    // ---- K-walk state (segment s, chunk offset kc inside it, cumulative weight offset koff)
+    int s = 0, kc = 0, koff = 0;
+    {
+        int skip = step_begin;
+        while (s < p.nseg) {
+            const int nch = (p.seg[s].k + BK - 1) / BK;
+            if (skip < nch) { kc = skip * BK; break; }
+            skip -= nch; koff += p.seg[s].k; ++s;
+        }
+    }
+    int aoff[WM];
+    auto enter_segment = [&]() {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) aoff[i] = seg_row_offset(p, p.seg[s], rinfo[i]);
+    };
+    if (s < p.nseg) enter_segment();
+
+    u32x4_t ra[WM], rw[WN];
+    auto load_chunk = [&]() {
+        const VmvGemmSeg& sg = p.seg[s];
+        const int kk = kc + sslot * 8;
+        const bool kvalid = kk < sg.k;
+        const uint16_t* src = reinterpret_cast<const uint16_t*>(sg.src) + kk;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (kvalid && aoff[i] >= 0) v = *reinterpret_cast<const u32x4_t*>(src + aoff[i]);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (kvalid && wvalid[j]) v = *reinterpret_cast<const u32x4_t*>(wrow[j] + koff + kc);
+            rw[j] = v;
+        }
+    };
+    auto advance = [&]() {
+        kc += BK;
+        if (kc >= p.seg[s].k) {
+            koff += p.seg[s].k; ++s; kc = 0;
+            if (s < p.nseg) enter_segment();
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        u32x4_t* a = lds + buf * A_U;
+        u32x4_t* w = lds + 2 * A_U + buf * W_U;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a[(srow + 32 * i) * 8 + sw_slot] = ra[i];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) w[(srow + 32 * j) * 8 + sw_slot] = rw[j];
+    };
+
+    f32x4_t acc[WN][WM];
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int i = 0; i < WM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15;           // row inside a 16-row fragment
+    const int fgrp = lane >> 4;           // k-group 0..3 (8 bf16 each)
+    const int fswz = (frow >> 1) & 7;
+
+    const int nsteps = step_end - step_begin;
+    if (nsteps > 0) {
+        load_chunk();
+        advance();
+        store_chunk(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < nsteps; ++t) {
+        const bool more = (t + 1) < nsteps;
+        if (more) { load_chunk(); advance(); }
+        const u32x4_t* a = lds + cur * A_U + (wave_m * 16 * WM + frow) * 8;
+        const u32x4_t* w = lds + 2 * A_U + cur * W_U + (wave_n * 16 * WN + frow) * 8;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int slot = (kk * 4 + fgrp) ^ fswz;
+            bf16x8_t af[WM], wf[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) af[i] = __builtin_bit_cast(bf16x8_t, a[i * 16 * 8 + slot]);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) wf[j] = __builtin_bit_cast(bf16x8_t, w[j * 16 * 8 + slot]);
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+        }
+        if (more) store_chunk(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: lane owns row m = .. + (lane&15), channels n = .. + 4*(lane>>4) + {0..3}
+    const int mbase = m0 + wave_m * 16 * WM + frow;
+    const int nbase = n0 + wave_n * 16 * WN + 4 * fgrp;
+    if (p.ksplit > 1) {
+        float* ws = p.workspace + (size_t)split * p.M * p.N;
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                const int m = mbase + 16 * i, n = nbase + 16 * j;
+                if (m < p.M && n < p.N) *reinterpret_cast<f32x4_t*>(ws + (size_t)m * p.N + n) = acc[j][i];
+            }
+        return;
+    }
+    if (p.epilogue == VMV_EPI_GEGLU) {
+        if constexpr ((WN & 1) == 0) {
+#pragma unroll
+            for (int j = 0; j < WN; j += 2)
+#pragma unroll
+                for (int i = 0; i < WM; ++i) epilogue_store(p, mbase + 16 * i, nbase + 16 * j, acc[j][i], acc[j + 1][i]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int i = 0; i < WM; ++i) epilogue_store(p, mbase + 16 * i, nbase + 16 * j, acc[j][i], acc[j][i]);
+    }
+}
+
+// split-K second pass: sum the fp32 slabs in a fixed order (deterministic) and run the epilogue.
+__global__ __launch_bounds__(256) void gemm_splitk_reduce(const VmvGemmParams p) {
+    const int geglu = p.epilogue == VMV_EPI_GEGLU;
+    const int nq = geglu ? (p.N / 32) * 4 : p.N / 4;       // work items per row
+    const long total = (long)p.M * nq;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / nq);
+        const int qi = (int)(idx - (long)m * nq);
+        const int n = geglu ? (qi >> 2) * 32 + (qi & 3) * 4 : qi * 4;
+        f32x4_t v = {0.f, 0.f, 0.f, 0.f}, g = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < p.ksplit; ++s) {
+            const float* ws = p.workspace + ((size_t)s * p.M + m) * p.N + n;
+            v += *reinterpret_cast<const f32x4_t*>(ws);
+            if (geglu) g += *reinterpret_cast<const f32x4_t*>(ws + 16);
+        }
+        epilogue_store(p, m, n, v, g);
+    }
+}
+
+template <int WM, int WN>
+int launch_cfg(const VmvGemmParams& p, int total_steps, hipStream_t st) {
+    using Cfg = GemmCfg<WM, WN>;
+    const int tiles_m = (p.M + Cfg::BM - 1) / Cfg::BM;
+    const int tiles_n = (p.N + Cfg::BN - 1) / Cfg::BN;
+    const int ks = p.ksplit > 1 ? p.ksplit : 1;
+    const int sps = (total_steps + ks - 1) / ks;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<WM, WN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid(tiles_m * tiles_n, ks, 1);
+    hipLaunchKernelGGL((gemm_kernel<WM, WN>), grid, dim3(256), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n, total_steps, sps);
+    int rc = vmv_launch_status();
+    if (rc != VMV_OK) return rc;
+    if (ks > 1) {
+        const long items = (long)p.M * (p.N / 4);
+        int blocks = (int)((items + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(gemm_splitk_reduce, dim3(blocks), dim3(256), 0, st, p);
+        rc = vmv_launch_status();
+    }
+    return rc;
+}
+
+int pick_tile(const VmvGemmParams& p) {
+    if (p.tile != VMV_TILE_AUTO) return p.tile;
+    const int geglu = p.epilogue == VMV_EPI_GEGLU;
+    auto padded = [&](int bn) { return ((p.N + bn - 1) / bn) * bn; };
+    int best = VMV_TILE_128x128, best_pad = padded(128);
+    if (!geglu && padded(160) <= best_pad) { best = VMV_TILE_128x160; best_pad = padded(160); }
+    if (padded(64) < best_pad) { best = VMV_TILE_128x64; best_pad = padded(64); }
+    if (p.M <= 64 && best == VMV_TILE_128x64) best = VMV_TILE_64x64;
+    return best;
+}
+
+}  // namespace
+
+extern "C" int vmv_gemm_bf16(const VmvGemmParams* pp, void* stream) {
+    if (!pp) return VMV_ENULL;
+    const VmvGemmParams& p = *pp;
+    if (!p.W || !p.out) return VMV_ENULL;
+    if (p.M <= 0 || p.N <= 0 || (p.N & 3) || p.nseg <= 0 || p.nseg > VMV_MAX_SEGS) return VMV_EINVAL;
+    if (!vmv_aligned16(p.W) || !vmv_aligned16(p.out) || (p.ktot & 7)) return VMV_EALIGN;
+    if (p.bias && !vmv_aligned16(p.bias)) return VMV_EALIGN;
+    if (p.ldo & 3) return VMV_EALIGN;
+    int ksum = 0, total_steps = 0, maxld = p.ldo;
+    for (int s = 0; s < p.nseg; ++s) {
+        const VmvGemmSeg& sg = p.seg[s];
+        if (!sg.src) return VMV_ENULL;
+        if (!vmv_aligned16(sg.src) || (sg.ld & 7) || (sg.k & 7) || sg.k <= 0) return VMV_EALIGN;
+        if (sg.mode == VMV_SEG_SPATIAL && (p.OH <= 0 || p.OW <= 0 || p.IH <= 0 || p.IW <= 0 || p.stride <= 0)) return VMV_EINVAL;
+        if (sg.mode == VMV_SEG_TEMPORAL && (p.F <= 0 || p.P <= 0)) return VMV_EINVAL;
+        if (sg.mode < 0 || sg.mode > 2) return VMV_EINVAL;
+        ksum += sg.k;
+        if (sg.ld > maxld) maxld = sg.ld;
+        total_steps += (sg.k + BK - 1) / BK;
+    }
+    if (ksum != p.ktot) return VMV_EINVAL;
+    if (p.epilogue == VMV_EPI_GEGLU && (p.N & 31)) return VMV_EINVAL;
+    if (p.rowvec && (p.rowvec_div <= 0 || (p.rowvec_ld & 3) || !vmv_aligned16(p.rowvec))) return VMV_EINVAL;
+    if (p.residual && ((p.ldr & 3) || (((uintptr_t)p.residual) & 7))) return VMV_EALIGN;
+    if (p.ksplit > 1 && (!p.workspace || !vmv_aligned16(p.workspace))) return VMV_ENULL;
+    if ((long)p.M * (long)maxld >= (1L << 31) || (long)p.N * (long)p.ktot >= (1L << 31)) return VMV_ERANGE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    switch (pick_tile(p)) {
+        case VMV_TILE_128x128: return launch_cfg<4, 4>(p, total_steps, st);
+        case VMV_TILE_128x160:
+            if (p.epilogue == VMV_EPI_GEGLU) return VMV_EINVAL;
+            return launch_cfg<4, 5>(p, total_steps, st);
+        case VMV_TILE_128x64: return launch_cfg<4, 2>(p, total_steps, st);
+        case VMV_TILE_64x64: return launch_cfg<2, 2>(p, total_steps, st);
+        default: return VMV_EINVAL;
+    }
+}

@@ -1,0 +1,240 @@
+// norm.hip — GroupNorm(32) statistics / apply(+SiLU) and LayerNorm over channels-last bf16 rows (gfx950).
+// All three are HBM-bound streaming kernels: 16-byte vector loads/stores (8 bf16 per lane), fp32 math,
+// wave-shuffle + LDS reductions, and NO atomics (partial sums are written per chunk and reduced in a fixed
+// order, so results are bitwise reproducible run to run).
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ GN stats
+// grid = (nchunk, nstat).  Block (256 threads) owns `chunk_rows` rows of one stat group and ALL channels.
+// Thread -> fixed column slot (8 channels) so sums stay in registers; lanes that share a column are combined
+// through an LDS [lane_rows][C] array in fixed order; then 32 threads produce the per-group (sum, sumsq).
+__global__ __launch_bounds__(256) void gn_stats_kernel(const VmvGroupNormParams p, const int nchunk) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];
+    const int C = p.C0 + p.C1;
+    const int CS = C >> 3;                       // 16-byte column slots per row
+    const int TPR = CS < 256 ? CS : 256;         // threads per row
+    const int RPP = 256 / TPR;                   // rows per pass
+    const int tid = threadIdx.x;
+    const int rl = tid / TPR;                    // row lane
+    const int cl = tid - rl * TPR;               // column lane
+    const bool active = rl < RPP;
+    const int stat = blockIdx.y, chunk = blockIdx.x;
+    const long row0 = (long)stat * p.rows_per_stat + (long)chunk * p.chunk_rows;
+    long row_end = row0 + p.chunk_rows;
+    const long stat_end = (long)(stat + 1) * p.rows_per_stat;
+    if (row_end > stat_end) row_end = stat_end;
+    float* lsum = sh;                            // [RPP][C]
+    float* lsq = sh + RPP * C;
+    const uint16_t* x0 = reinterpret_cast<const uint16_t*>(p.x);
+    const uint16_t* x1 = reinterpret_cast<const uint16_t*>(p.x1);
+    for (int cs = cl; cs < CS; cs += TPR) {
+        float s[8], q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+        if (active) {
+            const int c = cs * 8;
+            const bool first = c < p.C0;
+            const uint16_t* base = first ? (x0 + c) : (x1 + (c - p.C0));
+            const long ld = first ? p.ld : p.ld1;
+            for (long r = row0 + rl; r < row_end; r += RPP) {
+                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(base + r * ld);
+                float f[8];
+                unpack8(v, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { lsum[rl * C + cs * 8 + e] = s[e]; lsq[rl * C + cs * 8 + e] = q[e]; }
+        }
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const int cpg = C >> 5;
+        float s = 0.f, q = 0.f;
+        for (int r = 0; r < RPP; ++r)
+            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { s += lsum[r * C + c]; q += lsq[r * C + c]; }
+        float* out = p.partial + (((long)stat * nchunk + chunk) * 32 + tid) * 2;
+        out[0] = s; out[1] = q;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ GN apply
+// grid = (nblk, nstat).  Every block first folds the partial sums of its stat group (fixed order) into
+// mean / rstd for the 32 groups and expands them to per-channel scale/shift tables in LDS, then streams its
+// rows: y = [silu](x * scale[c] + shift[c]).
+__global__ __launch_bounds__(256) void gn_apply_kernel(const VmvGroupNormParams p, const int nchunk,
+                                                       const int apply_rows) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];
+    const int C = p.C0 + p.C1;
+    const int CS = C >> 3;
+    const int cpg = C >> 5;
+    const int tid = threadIdx.x;
+    const int stat = blockIdx.y;
+    float* scale = sh;        // [C]
+    float* shift = sh + C;    // [C]
+    float* s_mean = sh + 2 * C;   // [32]  (all LDS in the one dynamic region: keeps the base 16-B aligned)
+    float* s_rstd = s_mean + 32;  // [32]
+    if (tid < 32) {
+        float s = 0.f, q = 0.f;
+        const float* pp = p.partial + ((long)stat * nchunk * 32 + tid) * 2;
+        for (int c = 0; c < nchunk; ++c) { s += pp[(long)c * 64]; q += pp[(long)c * 64 + 1]; }
+        const float n = (float)p.rows_per_stat * (float)cpg;
+        const float mean = s / n;
+        float var = q / n - mean * mean;
+        var = var < 0.f ? 0.f : var;
+        s_mean[tid] = mean;
+        s_rstd[tid] = rsqrtf(var + p.eps);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const int g = c / cpg;
+        const float sc = s_rstd[g] * p.gamma[c];
+        scale[c] = sc;
+        shift[c] = p.beta[c] - s_mean[g] * sc;
+    }
+    __syncthreads();
+    const long row0 = (long)stat * p.rows_per_stat + (long)blockIdx.x * apply_rows;
+    long row_end = row0 + apply_rows;
+    const long stat_end = (long)(stat + 1) * p.rows_per_stat;
+    if (row_end > stat_end) row_end = stat_end;
+    const int nitem = (int)(row_end - row0) * CS;
+    const uint16_t* x0 = reinterpret_cast<const uint16_t*>(p.x);
+    const uint16_t* x1 = reinterpret_cast<const uint16_t*>(p.x1);
+    uint16_t* y = reinterpret_cast<uint16_t*>(p.y);
+    for (int it = tid; it < nitem; it += 256) {
+        const int rr = it / CS;
+        const int cs = it - rr * CS;
+        const long r = row0 + rr;
+        const int c = cs * 8;
+        const u32x4_t v = (c < p.C0) ? *reinterpret_cast<const u32x4_t*>(x0 + r * p.ld + c)
+                                     : *reinterpret_cast<const u32x4_t*>(x1 + r * p.ld1 + (c - p.C0));
+        float f[8];
+        unpack8(v, f);
+        const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(scale + c);
+        const f32x4_t a1 = *reinterpret_cast<const f32x4_t*>(scale + c + 4);
+        const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(shift + c);
+        const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(shift + c + 4);
+        f[0] = f[0] * a0.x + b0.x; f[1] = f[1] * a0.y + b0.y; f[2] = f[2] * a0.z + b0.z; f[3] = f[3] * a0.w + b0.w;
+        f[4] = f[4] * a1.x + b1.x; f[5] = f[5] * a1.y + b1.y; f[6] = f[6] * a1.z + b1.z; f[7] = f[7] * a1.w + b1.w;
+        if (p.silu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e]);
+        }
+        *reinterpret_cast<u32x4_t*>(y + r * p.ldy + c) = pack8(f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+// One wave per row (4 rows per block); the row lives in registers (<= 4 x 8 values per lane), two-pass
+// mean / variance for accuracy, then a single write.
+constexpr int LN_MAX_IT = 4;   // C <= 4 * 64 * 8 = 2048
+__global__ __launch_bounds__(256) void layernorm_kernel(const VmvLayerNormParams p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const int CS = p.C >> 3;
+    const uint16_t* x = reinterpret_cast<const uint16_t*>(p.x) + row * p.ldx;
+    float f[LN_MAX_IT][8];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < LN_MAX_IT; ++it) {
+        const int cs = lane + it * 64;
+        if (cs < CS) {
+            unpack8(*reinterpret_cast<const u32x4_t*>(x + cs * 8), f[it]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += f[it][e];
+        }
+    }
+    const float mean = wave_sum(s) / (float)p.C;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < LN_MAX_IT; ++it) {
+        const int cs = lane + it * 64;
+        if (cs < CS) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = f[it][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)p.C + p.eps);
+    uint16_t* y = reinterpret_cast<uint16_t*>(p.y) + row * p.ldy;
+#pragma unroll
+    for (int it = 0; it < LN_MAX_IT; ++it) {
+        const int cs = lane + it * 64;
+        if (cs < CS) {
+            const int c = cs * 8;
+            const f32x4_t g0 = *reinterpret_cast<const f32x4_t*>(p.gamma + c);
+            const f32x4_t g1 = *reinterpret_cast<const f32x4_t*>(p.gamma + c + 4);
+            const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(p.beta + c);
+            const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(p.beta + c + 4);
+            float o[8];
+            o[0] = (f[it][0] - mean) * rstd * g0.x + b0.x; o[1] = (f[it][1] - mean) * rstd * g0.y + b0.y;
+            o[2] = (f[it][2] - mean) * rstd * g0.z + b0.z; o[3] = (f[it][3] - mean) * rstd * g0.w + b0.w;
+            o[4] = (f[it][4] - mean) * rstd * g1.x + b1.x; o[5] = (f[it][5] - mean) * rstd * g1.y + b1.y;
+            o[6] = (f[it][6] - mean) * rstd * g1.z + b1.z; o[7] = (f[it][7] - mean) * rstd * g1.w + b1.w;
+            *reinterpret_cast<u32x4_t*>(y + c) = pack8(o);
+        }
+    }
+}
+
+int gn_check(const VmvGroupNormParams& p) {
+    if (!p.x || !p.partial) return VMV_ENULL;
+    const int C = p.C0 + p.C1;
+    if (C <= 0 || (C & 31) || (p.C0 & 7) || (p.C1 & 7)) return VMV_EINVAL;
+    if (p.C1 > 0 && !p.x1) return VMV_ENULL;
+    if (p.rows <= 0 || p.rows_per_stat <= 0 || (p.rows % p.rows_per_stat) || p.chunk_rows <= 0) return VMV_EINVAL;
+    if (!vmv_aligned16(p.x) || (p.ld & 7) || (p.C1 > 0 && (!vmv_aligned16(p.x1) || (p.ld1 & 7)))) return VMV_EALIGN;
+    if (C > 4096) return VMV_ERANGE;
+    return VMV_OK;
+}
+
+}  // namespace
+
+extern "C" int vmv_groupnorm_stats(const VmvGroupNormParams* pp, void* stream) {
+    if (!pp) return VMV_ENULL;
+    const VmvGroupNormParams& p = *pp;
+    int rc = gn_check(p);
+    if (rc != VMV_OK) return rc;
+    const int C = p.C0 + p.C1;
+    const int CS = C >> 3;
+    const int TPR = CS < 256 ? CS : 256;
+    const int RPP = 256 / TPR;
+    const int nstat = p.rows / p.rows_per_stat;
+    const int nchunk = (p.rows_per_stat + p.chunk_rows - 1) / p.chunk_rows;
+    const size_t shbytes = (size_t)2 * RPP * C * sizeof(float);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, nstat), dim3(256), shbytes, reinterpret_cast<hipStream_t>(stream), p, nchunk);
+    return vmv_launch_status();
+}
+
+extern "C" int vmv_groupnorm_apply(const VmvGroupNormParams* pp, void* stream) {
+    if (!pp) return VMV_ENULL;
+    const VmvGroupNormParams& p = *pp;
+    int rc = gn_check(p);
+    if (rc != VMV_OK) return rc;
+    if (!p.y || !p.gamma || !p.beta) return VMV_ENULL;
+    if (!vmv_aligned16(p.y) || (p.ldy & 7) || !vmv_aligned16(p.gamma) || !vmv_aligned16(p.beta)) return VMV_EALIGN;
+    const int C = p.C0 + p.C1;
+    const int nstat = p.rows / p.rows_per_stat;
+    const int nchunk = (p.rows_per_stat + p.chunk_rows - 1) / p.chunk_rows;
+    // ~64 KB of input per block: >= 1k blocks in flight at the large levels, table set-up amortised
+    int apply_rows = (65536 / (C * 2));
+    if (apply_rows < 1) apply_rows = 1;
+    const int nblk = (p.rows_per_stat + apply_rows - 1) / apply_rows;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, nstat), dim3(256), (size_t)(2 * C + 64) * sizeof(float),
+                       reinterpret_cast<hipStream_t>(stream), p, nchunk, apply_rows);
+    return vmv_launch_status();
+}
+
+extern "C" int vmv_layernorm(const VmvLayerNormParams* pp, void* stream) {
+    if (!pp) return VMV_ENULL;
+    const VmvLayerNormParams& p = *pp;
+    if (!p.x || !p.y || !p.gamma || !p.beta) return VMV_ENULL;
+    if (p.rows <= 0 || p.C <= 0 || (p.C & 7)) return VMV_EINVAL;
+    if (p.C > LN_MAX_IT * 64 * 8) return VMV_ERANGE;
+    if (!vmv_aligned16(p.x) || !vmv_aligned16(p.y) || (p.ldx & 7) || (p.ldy & 7) || !vmv_aligned16(p.gamma) ||
+        !vmv_aligned16(p.beta)) return VMV_EALIGN;
+    const int blocks = (p.rows + 3) / 4;
+    hipLaunchKernelGGL(layernorm_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+    return vmv_launch_status();
+}

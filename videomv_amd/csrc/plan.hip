@@ -1,0 +1,84 @@
+// plan.hip — recorded launch sequences ("plans") and ABI housekeeping for libvmv_hip.so.
+// A UNet forward is >700 launches; recording the argument blocks once and replaying them from one C call
+// removes the per-launch Python/ctypes cost.  Replay is a plain in-order launch loop on the
+// caller's stream, hence capturable into a hipGraph by the caller.
+#include "common.h"
+#include <vector>
+#include <cstring>
+#include <new>
+
+struct VmvPlan {
+    struct Op { int op; std::vector<unsigned char> args; };
+    std::vector<Op> ops;
+};
+
+namespace {
+int run_op(const VmvPlan::Op& o, void* stream) {
+    switch (o.op) {
+        case VMV_OP_GEMM: return vmv_gemm_bf16(reinterpret_cast<const VmvGemmParams*>(o.args.data()), stream);
+        case VMV_OP_GN_STATS: return vmv_groupnorm_stats(reinterpret_cast<const VmvGroupNormParams*>(o.args.data()), stream);
+        case VMV_OP_GN_APPLY: return vmv_groupnorm_apply(reinterpret_cast<const VmvGroupNormParams*>(o.args.data()), stream);
+        case VMV_OP_LAYERNORM: return vmv_layernorm(reinterpret_cast<const VmvLayerNormParams*>(o.args.data()), stream);
+        case VMV_OP_ATTENTION: return vmv_attention_bf16(reinterpret_cast<const VmvAttnParams*>(o.args.data()), stream);
+        default: return VMV_EINVAL;
+    }
+}
+size_t op_size(int op) {
+    switch (op) {
+        case VMV_OP_GEMM: return sizeof(VmvGemmParams);
+        case VMV_OP_GN_STATS: case VMV_OP_GN_APPLY: return sizeof(VmvGroupNormParams);
+        case VMV_OP_LAYERNORM: return sizeof(VmvLayerNormParams);
+        case VMV_OP_ATTENTION: return sizeof(VmvAttnParams);
+        default: return 0;
+    }
+}
+}  // namespace
+
+extern "C" int vmv_abi_version(void) { return VMV_ABI_VERSION; }
+extern "C" int vmv_sizeof(int which) {
+    switch (which) {
+        case 100: return (int)sizeof(VmvDdimParams);
+        case 101: return (int)sizeof(VmvGemmSeg);
+        case 102: return (int)sizeof(VmvSeqMap);
+        default: return (int)op_size(which);
+    }
+}
+
+extern "C" const char* vmv_error_string(int code) {
+    switch (code) {
+        case VMV_OK: return "ok";
+        case VMV_EINVAL: return "VMV_EINVAL: bad dimension or flag combination";
+        case VMV_EALIGN: return "VMV_EALIGN: pointer or leading dimension not suitably aligned";
+        case VMV_ENULL: return "VMV_ENULL: required pointer is NULL";
+        case VMV_ERANGE: return "VMV_ERANGE: size outside what the kernel supports";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown vmv error";
+    }
+}
+
+extern "C" VmvPlan* vmv_plan_create(void) { return new (std::nothrow) VmvPlan(); }
+extern "C" void vmv_plan_destroy(VmvPlan* plan) { delete plan; }
+extern "C" int vmv_plan_add(VmvPlan* plan, int op, const void* params, size_t nbytes) {
+    if (!plan || !params) return VMV_ENULL;
+    const size_t want = op_size(op);
+    if (want == 0 || nbytes != want) return VMV_EINVAL;
+    VmvPlan::Op o;
+    o.op = op;
+    o.args.resize(nbytes);
+    std::memcpy(o.args.data(), params, nbytes);
+    plan->ops.push_back(std::move(o));
+    return (int)plan->ops.size() - 1;
+}
+extern "C" int vmv_plan_size(const VmvPlan* plan) { return plan ? (int)plan->ops.size() : VMV_ENULL; }
+extern "C" int vmv_plan_run_range(const VmvPlan* plan, int first, int last, void* stream) {
+    if (!plan) return VMV_ENULL;
+    if (first < 0 || last > (int)plan->ops.size() || first > last) return VMV_EINVAL;
+    for (int i = first; i < last; ++i) {
+        const int rc = run_op(plan->ops[i], stream);
+        if (rc != VMV_OK) return rc;
+    }
+    return VMV_OK;
+}
+extern "C" int vmv_plan_run(const VmvPlan* plan, void* stream) {
+    if (!plan) return VMV_ENULL;
+    return vmv_plan_run_range(plan, 0, (int)plan->ops.size(), stream);
+}

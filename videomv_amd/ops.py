@@ -1,0 +1,212 @@
+"""Thin host-side launch layer over the C ABI (``include/vmv.h``).
+
+``Stream`` either launches immediately on the current torch stream (eager) or records the launch into a
+``VmvPlan`` that is replayed with one C call (see ``DESIGN.md`` §5).  Tensors are only used as device-memory
+handles (``data_ptr()``); all arithmetic happens in the HIP kernels.  Nothing here falls back to PyTorch math.
+"""
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+TAPS3x3 = [(dy, dx) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    return t.data_ptr()
+
+
+class Seg:
+    """One K-segment of the implicit GEMM: ``k`` channels of each (gathered) row of ``src``."""
+    __slots__ = ("src", "ld", "k", "mode", "d0", "d1")
+
+    def __init__(self, src, ld, k, mode=L.SEG_LINEAR, d0=0, d1=0):
+        self.src, self.ld, self.k, self.mode, self.d0, self.d1 = src, int(ld), int(k), mode, d0, d1
+
+
+def conv3x3_segs(sources: Sequence[Tuple[torch.Tensor, int, int]]) -> List[Seg]:
+    """sources = [(rows tensor, ld, channels)] (channel-concatenated).  Order: tap-major, then source — the
+    order ``pack_conv3x3`` lays the weights out in."""
+    return [Seg(t, ld, k, L.SEG_SPATIAL, dy, dx) for (dy, dx) in TAPS3x3 for (t, ld, k) in sources]
+
+
+def temporal_segs(src, ld, k) -> List[Seg]:
+    return [Seg(src, ld, k, L.SEG_TEMPORAL, dt, 0) for dt in (-1, 0, 1)]
+
+
+def linear_segs(sources) -> List[Seg]:
+    return [Seg(t, ld, k, L.SEG_LINEAR) for (t, ld, k) in sources]
+
+
+class Geom:
+    """Row <-> pixel geometry for SPATIAL / TEMPORAL segments."""
+
+    def __init__(self, OH=0, OW=0, IH=0, IW=0, stride=1, ups=0, F=0, P=0):
+        self.OH, self.OW, self.IH, self.IW, self.stride, self.ups, self.F, self.P = OH, OW, IH, IW, stride, ups, F, P
+
+
+def gemm_params(M, N, segs: Sequence[Seg], W, out, ldo, bias=None, rowvec=None, rowvec_div=1, rowvec_ld=0,
+                residual=None, ldr=0, epilogue=L.EPI_NONE, act=L.ACT_NONE, out_fp32=False, geom: Optional[Geom] = None,
+                ksplit=0, workspace=None, tile=L.TILE_AUTO) -> L.GemmParams:
+    p = L.GemmParams()
+    p.M, p.N, p.nseg = int(M), int(N), len(segs)
+    if len(segs) > L.VMV_MAX_SEGS:
+        raise ValueError("too many GEMM segments")
+    kt = 0
+    for i, s in enumerate(segs):
+        g = p.seg[i]
+        g.src, g.ld, g.k, g.mode, g.d0, g.d1 = _ptr(s.src), s.ld, s.k, s.mode, s.d0, s.d1
+        kt += s.k
+    p.ktot = kt
+    p.W, p.bias, p.rowvec = _ptr(W), _ptr(bias), _ptr(rowvec)
+    p.rowvec_div, p.rowvec_ld = int(rowvec_div), int(rowvec_ld)
+    p.residual, p.ldr = _ptr(residual), int(ldr)
+    p.epilogue, p.act, p.out_fp32 = epilogue, act, 1 if out_fp32 else 0
+    p.out, p.ldo = _ptr(out), int(ldo)
+    g = geom or Geom()
+    p.OH, p.OW, p.IH, p.IW, p.stride, p.ups, p.F, p.P = g.OH, g.OW, g.IH, g.IW, g.stride, g.ups, g.F, g.P
+    p.ksplit, p.workspace, p.tile = int(ksplit), _ptr(workspace), tile
+    return p
+
+
+def gn_params(x, ld, C0, rows, rows_per_stat, partial, gamma, beta, eps, silu, y, ldy, x1=None, ld1=0, C1=0,
+              chunk_rows=None) -> L.GroupNormParams:
+    p = L.GroupNormParams()
+    p.x, p.x1, p.ld, p.ld1, p.C0, p.C1 = _ptr(x), _ptr(x1), int(ld), int(ld1), int(C0), int(C1)
+    p.rows, p.rows_per_stat = int(rows), int(rows_per_stat)
+    p.chunk_rows = int(chunk_rows or gn_chunk_rows(rows_per_stat, C0 + C1))
+    p.partial, p.gamma, p.beta = _ptr(partial), _ptr(gamma), _ptr(beta)
+    p.eps, p.silu, p.y, p.ldy = float(eps), 1 if silu else 0, _ptr(y), int(ldy)
+    return p
+
+
+def gn_chunk_rows(rows_per_stat: int, C: int) -> int:
+    """Rows per partial-sum block: ~64 KB of input per block, at most 256 chunks per stat group."""
+    r = max(1, 65536 // (C * 2))
+    r = max(r, (rows_per_stat + 255) // 256)
+    return min(r, rows_per_stat)
+
+
+def gn_partial_floats(rows, rows_per_stat, C, chunk_rows=None) -> int:
+    cr = chunk_rows or gn_chunk_rows(rows_per_stat, C)
+    nchunk = (rows_per_stat + cr - 1) // cr
+    return (rows // rows_per_stat) * nchunk * 64
+
+
+def ln_params(x, ldx, y, ldy, gamma, beta, rows, Cc, eps=1e-5) -> L.LayerNormParams:
+    p = L.LayerNormParams()
+    p.x, p.ldx, p.y, p.ldy, p.gamma, p.beta = _ptr(x), int(ldx), _ptr(y), int(ldy), _ptr(gamma), _ptr(beta)
+    p.rows, p.C, p.eps = int(rows), int(Cc), float(eps)
+    return p
+
+
+def seq_map(s_outer, s_inner, s_row, inner=1) -> L.SeqMap:
+    m = L.SeqMap()
+    m.s_outer, m.s_inner, m.s_row, m.inner = int(s_outer), int(s_inner), int(s_row), int(inner)
+    return m
+
+
+def attn_params(q, k, v, o, qm, km, vm, om, n_outer, heads, Nq, Nk, scale, kv_div=1) -> L.AttnParams:
+    p = L.AttnParams()
+    p.q, p.k, p.v, p.o = _ptr(q), _ptr(k), _ptr(v), _ptr(o)
+    p.qm, p.km, p.vm, p.om = qm, km, vm, om
+    p.n_outer, p.kv_div, p.heads, p.Nq, p.Nk, p.scale = int(n_outer), int(kv_div), int(heads), int(Nq), int(Nk), float(scale)
+    return p
+
+
+def _stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Stream:
+    """Eager launcher / plan recorder."""
+
+    def __init__(self, record: bool = False):
+        self.lib = L.load()
+        self.record = record
+        self.plan = self.lib.vmv_plan_create() if record else None
+        self.keep = []          # tensors referenced by recorded argument blocks
+        self.nops = 0
+        self.labels = []        # label per recorded op (profiling / debugging)
+        self.recorded = []      # (op code, params struct) mirror of the C plan (debugging / tests)
+
+    def __del__(self):
+        try:
+            if self.plan:
+                self.lib.vmv_plan_destroy(self.plan)
+                self.plan = None
+        except Exception:
+            pass
+
+    def _go(self, op, params, fn, label):
+        if self.record:
+            rc = self.lib.vmv_plan_add(self.plan, op, C.byref(params), C.sizeof(params))
+            if rc < 0:
+                L.check(rc, f"plan_add {label}")
+            self.labels.append(label)
+            self.recorded.append((op, params))
+            self.nops += 1
+        else:
+            L.check(fn(C.byref(params), _stream_ptr()), label)
+
+    def gemm(self, params, label="gemm"):
+        self._go(L.OP_GEMM, params, self.lib.vmv_gemm_bf16, label)
+
+    def groupnorm(self, params, label="gn"):
+        self._go(L.OP_GN_STATS, params, self.lib.vmv_groupnorm_stats, label + ".stats")
+        self._go(L.OP_GN_APPLY, params, self.lib.vmv_groupnorm_apply, label + ".apply")
+
+    def layernorm(self, params, label="ln"):
+        self._go(L.OP_LAYERNORM, params, self.lib.vmv_layernorm, label)
+
+    def attention(self, params, label="attn"):
+        self._go(L.OP_ATTENTION, params, self.lib.vmv_attention_bf16, label)
+
+    def run(self, first=0, last=None):
+        """Replay the recorded plan on the current torch stream."""
+        assert self.record
+        if last is None:
+            L.check(self.lib.vmv_plan_run(self.plan, _stream_ptr()), "plan_run")
+        else:
+            L.check(self.lib.vmv_plan_run_range(self.plan, first, last, _stream_ptr()), "plan_run_range")
+
+
+# ----------------------------------------------------------------------------------- direct (non-plan) glue
+def latent_to_rows(x: torch.Tensor, rows: torch.Tensor, Cpad: int, nrep: int):
+    nb, Cc, F_, H, W = x.shape
+    lib = L.load()
+    L.check(lib.vmv_latent_to_rows(x.data_ptr(), rows.data_ptr(), nb, Cc, F_, H, W, Cpad, nrep, _stream_ptr()),
+            "latent_to_rows")
+
+
+def rows_to_nchw(rows: torch.Tensor, ld: int, out: torch.Tensor):
+    n, Cc, H, W = out.shape
+    lib = L.load()
+    L.check(lib.vmv_rows_to_nchw(rows.data_ptr(), 1 if rows.dtype == torch.float32 else 0, ld, out.data_ptr(), n, Cc,
+                                 H * W, _stream_ptr()), "rows_to_nchw")
+
+
+def cfg_ddim_step(eps_rows, ld, xt, guide_scale, c_recip, c_recipm1, c_sqrt_ac, c_sqrt_1mac, a_prev, v_pred=False,
+                  x0_out=None):
+    _, Cc, F_, H, W = xt.shape
+    p = L.DdimParams()
+    p.eps_rows, p.ld, p.C, p.F, p.HW = eps_rows.data_ptr(), ld, Cc, F_, H * W
+    p.guide_scale, p.c_recip, p.c_recipm1 = guide_scale, c_recip, c_recipm1
+    p.c_sqrt_ac, p.c_sqrt_1mac, p.a_prev, p.v_pred = c_sqrt_ac, c_sqrt_1mac, a_prev, 1 if v_pred else 0
+    p.xt, p.x0_out = xt.data_ptr(), _ptr(x0_out)
+    L.check(L.load().vmv_cfg_ddim_step(C.byref(p), _stream_ptr()), "cfg_ddim_step")
+
+
+def emb_combine_silu(temb, cam, out, rows, Cc, rows_per_t, cam_rows):
+    L.check(L.load().vmv_emb_combine_silu(temb.data_ptr(), _ptr(cam), out.data_ptr(), rows, Cc, rows_per_t, cam_rows,
+                                          _stream_ptr()), "emb_combine_silu")
+
+
+def sinusoidal(t, out, n, dim):
+    L.check(L.load().vmv_sinusoidal(t.data_ptr(), out.data_ptr(), n, dim, _stream_ptr()), "sinusoidal")

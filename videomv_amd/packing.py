@@ -1,0 +1,73 @@
+"""Weight repacking: reference state-dict tensors (fp32, PyTorch layouts) -> the bf16 ``[N][K]`` matrices the
+implicit-GEMM kernel consumes (``include/vmv.h``).  Done once at load time on the host/device with torch
+tensor ops (pure data movement — no arithmetic of the hot path happens here).
+
+K ordering rules (must match ``ops.conv3x3_segs`` / ``ops.temporal_segs``):
+  * 3x3 conv  [N, C, 3, 3]     -> [N, 9*C']  tap-major (dy, dx row-major), channels within a tap;
+                                  C' = C zero-padded to a multiple of 8 (only the 4-channel latent convs)
+  * temporal  [N, C, 3, 1, 1]  -> [N, 3*C]   taps dt = -1, 0, +1
+  * linear / 1x1 / Conv1d(k=1) -> [N, K]
+  * GEGLU     [2*I, K]         -> rows interleaved in 16-row blocks: x[16j:16j+16], gate[16j:16j+16]
+N is zero-padded to a multiple of 4 (the epilogue stores 4 channels per lane).
+"""
+import torch
+
+BF16 = torch.bfloat16
+
+
+def _pad_rows(w: torch.Tensor, mult=4) -> torch.Tensor:
+    n = w.shape[0]
+    pad = (-n) % mult
+    if pad:
+        w = torch.cat([w, w.new_zeros((pad,) + tuple(w.shape[1:]))], dim=0)
+    return w
+
+
+def pack_linear(w: torch.Tensor, device) -> torch.Tensor:
+    w = w.reshape(w.shape[0], -1)
+    k = w.shape[1]
+    padk = (-k) % 8
+    if padk:
+        w = torch.cat([w, w.new_zeros(w.shape[0], padk)], dim=1)
+    return _pad_rows(w).to(device=device, dtype=BF16).contiguous()
+
+
+def pack_conv3x3(w: torch.Tensor, device) -> torch.Tensor:
+    n, c, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    padc = (-c) % 8
+    if padc:
+        w = torch.cat([w, w.new_zeros(n, padc, 3, 3)], dim=1)
+    w = w.permute(0, 2, 3, 1).reshape(n, -1)
+    return _pad_rows(w).to(device=device, dtype=BF16).contiguous()
+
+
+def pack_tconv(w: torch.Tensor, device) -> torch.Tensor:
+    n, c, kt, kh, kw = w.shape
+    assert kt == 3 and kh == 1 and kw == 1
+    w = w.reshape(n, c, 3).permute(0, 2, 1).reshape(n, 3 * c)
+    return _pad_rows(w).to(device=device, dtype=BF16).contiguous()
+
+
+def geglu_interleave(t: torch.Tensor) -> torch.Tensor:
+    """[2*I, ...] (x rows then gate rows, ``chunk(2)`` order of util.py:548) -> 16-row interleaved."""
+    two_i = t.shape[0]
+    i = two_i // 2
+    assert i % 16 == 0
+    x, g = t[:i], t[i:]
+    rest = tuple(t.shape[1:])
+    x = x.reshape((i // 16, 1, 16) + rest)
+    g = g.reshape((i // 16, 1, 16) + rest)
+    return torch.cat([x, g], dim=1).reshape((two_i,) + rest)
+
+
+def pack_bias(b: torch.Tensor, device, n_pad_to=4) -> torch.Tensor:
+    b = b.reshape(-1).float()
+    pad = (-b.shape[0]) % n_pad_to
+    if pad:
+        b = torch.cat([b, b.new_zeros(pad)])
+    return b.to(device).contiguous()
+
+
+def f32(t: torch.Tensor, device) -> torch.Tensor:
+    return t.detach().float().to(device).contiguous()

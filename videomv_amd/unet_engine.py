@@ -1,0 +1,630 @@
+"""UNet forward as a recorded plan of HIP launches (host side of the hot path).
+
+``UNetEngine`` turns one ``UNetSD_T2VBase`` forward at a fixed shape (B branches x F frames x H x W latent,
+L context tokens) into a static sequence of C-ABI launches over pooled device buffers and replays it.
+Activations are channels-last bf16 "rows" ``[B*F*H*W, C]`` end-to-end: the reference's
+``(b f) c h w`` / ``b (hw) c`` / ``(b hw) f c`` views (unet_t2v.py:348, util.py:362, :1054-1062) are index
+maps over that one buffer, so none of its ~150 ``rearrange(...).contiguous()`` copies exist here.
+
+Block structure and parameter names follow the reference constructor (unet_t2v.py:160-265); the op sequence
+per block follows ``ResBlock._forward`` (util.py:703-730), ``TemporalConvBlock_v2.forward`` (:1381-1392),
+``SpatialTransformer.forward`` (:354-373), ``TemporalTransformer.forward`` (:1043-1089),
+``BasicTransformerBlock.forward`` (:536-540) and ``MemoryEfficientCrossAttention.forward`` (:230-268).
+"""
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+from . import ops
+from . import packing as P
+
+BF16 = torch.bfloat16
+
+
+# --------------------------------------------------------------------------------------------- architecture
+def block_plan(cfg):
+    """(input_blocks, middle_block, output_blocks) as lists of (kind, prefix, meta) — the constructor's
+    loop structure (unet_t2v.py:160-258), including the hard-coded decoder context_dim=1024 (:226) and the
+    init temporal transformer built with ``num_heads`` heads (:171)."""
+    dim = cfg["dim"]
+    dim_mult = list(cfg["dim_mult"])
+    nrb = cfg["num_res_blocks"]
+    hd = cfg["head_dim"]
+    attn_scales = list(cfg["attn_scales"])
+    enc_dims = [dim * u for u in [1] + dim_mult]
+    dec_dims = [dim * u for u in [dim_mult[-1]] + dim_mult[::-1]]
+    shortcut, scale = [], 1.0
+    inp = [[("conv_in", "input_blocks.0.0", dict(cin=cfg["in_dim"], cout=dim)),
+            ("tt", "input_blocks.0.1", dict(c=dim, heads=cfg["num_heads"], dh=hd))]]
+    shortcut.append(dim)
+    idx, out_dim = 1, dim
+    for i, (in_dim, out_dim) in enumerate(zip(enc_dims[:-1], enc_dims[1:])):
+        for j in range(nrb):
+            p = f"input_blocks.{idx}"
+            blk = [("res", f"{p}.0", dict(cin=in_dim, cout=out_dim))]
+            if scale in attn_scales:
+                blk.append(("st", f"{p}.1", dict(c=out_dim, heads=out_dim // hd, dh=hd, ctx=cfg["context_dim"])))
+                blk.append(("tt", f"{p}.2", dict(c=out_dim, heads=out_dim // hd, dh=hd)))
+            in_dim = out_dim
+            inp.append(blk)
+            shortcut.append(out_dim)
+            idx += 1
+            if i != len(dim_mult) - 1 and j == nrb - 1:
+                inp.append([("down", f"input_blocks.{idx}", dict(c=out_dim))])
+                shortcut.append(out_dim)
+                scale /= 2.0
+                idx += 1
+    mid = [("res", "middle_block.0", dict(cin=out_dim, cout=out_dim)),
+           ("st", "middle_block.1", dict(c=out_dim, heads=out_dim // hd, dh=hd, ctx=cfg["context_dim"])),
+           ("tt", "middle_block.2", dict(c=out_dim, heads=out_dim // hd, dh=hd)),
+           ("res", "middle_block.3", dict(cin=out_dim, cout=out_dim))]
+    outb, idx = [], 0
+    for i, (in_dim, out_dim) in enumerate(zip(dec_dims[:-1], dec_dims[1:])):
+        for j in range(nrb + 1):
+            p = f"output_blocks.{idx}"
+            sc = shortcut.pop()
+            blk = [("res", f"{p}.0", dict(cin=in_dim + sc, cout=out_dim, c_main=in_dim, c_skip=sc))]
+            k = 1
+            if scale in attn_scales:
+                blk.append(("st", f"{p}.{k}", dict(c=out_dim, heads=out_dim // hd, dh=hd, ctx=1024)))
+                blk.append(("tt", f"{p}.{k + 1}", dict(c=out_dim, heads=out_dim // hd, dh=hd)))
+                k += 2
+            in_dim = out_dim
+            if i != len(dim_mult) - 1 and j == nrb:
+                blk.append(("up", f"{p}.{k}", dict(c=out_dim)))
+                scale *= 2.0
+            outb.append(blk)
+            idx += 1
+    return inp, mid, outb
+
+
+def _attn_shapes(p, c, inner, ctx):
+    kv = inner if ctx is None else ctx
+    return [(f"{p}.to_q.weight", (inner, c)), (f"{p}.to_k.weight", (inner, kv)), (f"{p}.to_v.weight", (inner, kv)),
+            (f"{p}.to_out.0.weight", (c, inner)), (f"{p}.to_out.0.bias", (c,))]
+
+
+def _tblock_shapes(p, inner, ctx):
+    s = _attn_shapes(f"{p}.attn1", inner, inner, None)
+    s += [(f"{p}.ff.net.0.proj.weight", (inner * 8, inner)), (f"{p}.ff.net.0.proj.bias", (inner * 8,)),
+          (f"{p}.ff.net.2.weight", (inner, inner * 4)), (f"{p}.ff.net.2.bias", (inner,))]
+    s += _attn_shapes(f"{p}.attn2", inner, inner, ctx)
+    for n in ("norm1", "norm2", "norm3"):
+        s += [(f"{p}.{n}.weight", (inner,)), (f"{p}.{n}.bias", (inner,))]
+    return s
+
+
+def param_shapes(cfg) -> "Dict[str, tuple]":
+    """Reference state-dict manifest (key -> shape); checked against tests/golden/manifest_unet_t2v_full.json."""
+    dim = cfg["dim"]
+    E = dim * 4
+    s = [("time_embed.0.weight", (E, dim)), ("time_embed.0.bias", (E,)),
+         ("time_embed.2.weight", (E, E)), ("time_embed.2.bias", (E,))]
+    if cfg.get("use_camera_condition", False):
+        s += [("camera_embedding.0.weight", (E, cfg["camera_dim"])), ("camera_embedding.0.bias", (E,)),
+              ("camera_embedding.2.weight", (E, E)), ("camera_embedding.2.bias", (E,))]
+    if cfg.get("use_fps_condition", False):
+        s += [("fps_embedding.0.weight", (E, dim)), ("fps_embedding.0.bias", (E,)),
+              ("fps_embedding.2.weight", (E, E)), ("fps_embedding.2.bias", (E,))]
+    inp, mid, outb = block_plan(cfg)
+    for blk in inp + [mid] + outb:
+        for kind, p, m in blk:
+            if kind == "conv_in":
+                s += [(f"{p}.weight", (m["cout"], m["cin"], 3, 3)), (f"{p}.bias", (m["cout"],))]
+            elif kind == "res":
+                ci, co = m["cin"], m["cout"]
+                s += [(f"{p}.in_layers.0.weight", (ci,)), (f"{p}.in_layers.0.bias", (ci,)),
+                      (f"{p}.in_layers.2.weight", (co, ci, 3, 3)), (f"{p}.in_layers.2.bias", (co,)),
+                      (f"{p}.emb_layers.1.weight", (co, E)), (f"{p}.emb_layers.1.bias", (co,)),
+                      (f"{p}.out_layers.0.weight", (co,)), (f"{p}.out_layers.0.bias", (co,)),
+                      (f"{p}.out_layers.3.weight", (co, co, 3, 3)), (f"{p}.out_layers.3.bias", (co,))]
+                if ci != co:
+                    s += [(f"{p}.skip_connection.weight", (co, ci, 1, 1)), (f"{p}.skip_connection.bias", (co,))]
+                for name, ix in (("conv1", 2), ("conv2", 3), ("conv3", 3), ("conv4", 3)):
+                    q = f"{p}.temopral_conv.{name}"
+                    s += [(f"{q}.0.weight", (co,)), (f"{q}.0.bias", (co,)),
+                          (f"{q}.{ix}.weight", (co, co, 3, 1, 1)), (f"{q}.{ix}.bias", (co,))]
+            elif kind in ("st", "tt"):
+                c = m["c"]
+                inner = m["heads"] * m["dh"]
+                s += [(f"{p}.norm.weight", (c,)), (f"{p}.norm.bias", (c,))]
+                if kind == "st":
+                    s += [(f"{p}.proj_in.weight", (inner, c)), (f"{p}.proj_in.bias", (inner,))]
+                    s += _tblock_shapes(f"{p}.transformer_blocks.0", inner, m["ctx"])
+                    s += [(f"{p}.proj_out.weight", (inner, c)), (f"{p}.proj_out.bias", (inner,))]
+                else:
+                    s += [(f"{p}.proj_in.weight", (inner, c, 1)), (f"{p}.proj_in.bias", (inner,))]
+                    s += _tblock_shapes(f"{p}.transformer_blocks.0", inner, None)
+                    s += [(f"{p}.proj_out.weight", (c, inner, 1)), (f"{p}.proj_out.bias", (c,))]
+            elif kind == "down":
+                s += [(f"{p}.op.weight", (m["c"], m["c"], 3, 3)), (f"{p}.op.bias", (m["c"],))]
+            elif kind == "up":
+                s += [(f"{p}.conv.weight", (m["c"], m["c"], 3, 3)), (f"{p}.conv.bias", (m["c"],))]
+    s += [("out.0.weight", (dim,)), ("out.0.bias", (dim,)),
+          ("out.2.weight", (cfg["out_dim"], dim, 3, 3)), ("out.2.bias", (cfg["out_dim"],))]
+    return dict(s)
+
+
+# --------------------------------------------------------------------------------------------- device memory
+class Pool:
+    """Size-bucketed reuse of device buffers.  All launches are stream-ordered on ONE stream, so a buffer can
+    be handed to a later op as soon as its last consumer has been *recorded*."""
+
+    def __init__(self, device):
+        self.device = device
+        self.free: Dict[int, List[torch.Tensor]] = {}
+        self.all: List[torch.Tensor] = []
+        self.bytes = 0
+
+    def get(self, nbytes: int) -> torch.Tensor:
+        nbytes = (int(nbytes) + 255) // 256 * 256
+        lst = self.free.get(nbytes)
+        if lst:
+            return lst.pop()
+        t = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self.all.append(t)
+        self.bytes += nbytes
+        return t
+
+    def put(self, t: torch.Tensor):
+        self.free.setdefault(t.numel(), []).append(t)
+
+
+class Act:
+    """A [rows, C] activation living in a pooled buffer."""
+    __slots__ = ("buf", "rows", "C", "dtype")
+
+    def __init__(self, buf, rows, C, dtype=BF16):
+        self.buf, self.rows, self.C, self.dtype = buf, rows, C, dtype
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr()
+
+    def tensor(self) -> torch.Tensor:
+        esz = 2 if self.dtype == BF16 else 4
+        return self.buf[: self.rows * self.C * esz].view(self.dtype).view(self.rows, self.C)
+
+
+# --------------------------------------------------------------------------------------------- the engine
+class UNetEngine:
+    def __init__(self, cfg: dict, weights: Dict[str, torch.Tensor], B: int, F: int, H: int, W: int, L_ctx: int,
+                 device, n_t: int = 1, taps: Optional[dict] = None):
+        """weights: reference-named fp32 state dict (any device).  B = number of batched branches
+        (2 = cond + uncond CFG pair sharing x_t), n_t = number of distinct timesteps rows (B // n_t branches
+        share each)."""
+        self.cfg, self.B, self.F, self.H, self.W, self.L = cfg, B, F, H, W, L_ctx
+        self.device = device
+        self.pool = Pool(device)
+        self.S = ops.Stream(record=True)
+        self._keepalive = []
+        self._ws = None
+        self._gnws = torch.empty(4 << 20, dtype=torch.float32, device=device)
+        self.taps = taps            # optional dict: prefix -> Act (buffers are then never recycled)
+        self.n_t = n_t
+        self.dim = cfg["dim"]
+        self.E = self.dim * 4
+        self.inp, self.mid, self.outb = block_plan(cfg)
+        self._pack(weights)
+        self._static_inputs()
+        self._build()
+
+    # ------------------------------------------------------------------ weights
+    def _pack(self, sd):
+        dev = self.device
+        w: Dict[str, torch.Tensor] = {}
+        self.w = w
+
+        def lin(key, bias=True):
+            w[key + ".weight"] = P.pack_linear(sd[key + ".weight"], dev)
+            if bias and (key + ".bias") in sd:
+                w[key + ".bias"] = P.pack_bias(sd[key + ".bias"], dev)
+
+        def norm(key):
+            w[key + ".weight"] = P.f32(sd[key + ".weight"], dev)
+            w[key + ".bias"] = P.f32(sd[key + ".bias"], dev)
+
+        def tblock(p):
+            for a in ("attn1", "attn2"):
+                q = sd[f"{p}.{a}.to_q.weight"]
+                k = sd[f"{p}.{a}.to_k.weight"]
+                v = sd[f"{p}.{a}.to_v.weight"]
+                if k.shape[1] == q.shape[1]:   # self-attention: fused QKV
+                    w[f"{p}.{a}.qkv"] = P.pack_linear(torch.cat([q, k, v], dim=0), dev)
+                else:                          # cross-attention: Q on tokens, fused KV on the context
+                    w[f"{p}.{a}.q"] = P.pack_linear(q, dev)
+                    w[f"{p}.{a}.kv"] = P.pack_linear(torch.cat([k, v], dim=0), dev)
+                lin(f"{p}.{a}.to_out.0")
+            w[f"{p}.ff.net.0.proj.weight"] = P.pack_linear(P.geglu_interleave(sd[f"{p}.ff.net.0.proj.weight"]), dev)
+            w[f"{p}.ff.net.0.proj.bias"] = P.pack_bias(P.geglu_interleave(sd[f"{p}.ff.net.0.proj.bias"]), dev)
+            lin(f"{p}.ff.net.2")
+            for n in ("norm1", "norm2", "norm3"):
+                norm(f"{p}.{n}")
+
+        lin("time_embed.0"); lin("time_embed.2")
+        self.has_cam = "camera_embedding.0.weight" in sd
+        if self.has_cam:
+            lin("camera_embedding.0"); lin("camera_embedding.2")
+        emb_w, emb_b, self.emb_off = [], [], {}
+        off = 0
+        for blk in self.inp + [self.mid] + self.outb:
+            for kind, p, m in blk:
+                if kind == "conv_in":
+                    w[p + ".weight"] = P.pack_conv3x3(sd[p + ".weight"], dev)
+                    w[p + ".bias"] = P.pack_bias(sd[p + ".bias"], dev)
+                elif kind == "res":
+                    norm(f"{p}.in_layers.0")
+                    w[f"{p}.in_layers.2.weight"] = P.pack_conv3x3(sd[f"{p}.in_layers.2.weight"], dev)
+                    w[f"{p}.in_layers.2.bias"] = P.pack_bias(sd[f"{p}.in_layers.2.bias"], dev)
+                    emb_w.append(sd[f"{p}.emb_layers.1.weight"]); emb_b.append(sd[f"{p}.emb_layers.1.bias"])
+                    self.emb_off[p] = off
+                    off += m["cout"]
+                    norm(f"{p}.out_layers.0")
+                    w2 = sd[f"{p}.out_layers.3.weight"]
+                    b2 = sd[f"{p}.out_layers.3.bias"].float()
+                    w2p = w2.permute(0, 2, 3, 1).reshape(w2.shape[0], -1)
+                    if f"{p}.skip_connection.weight" in sd:   # fold the 1x1 skip into conv2's K loop
+                        ws = sd[f"{p}.skip_connection.weight"].reshape(w2.shape[0], -1)
+                        w2p = torch.cat([w2p, ws], dim=1)
+                        b2 = b2 + sd[f"{p}.skip_connection.bias"].float()
+                    w[f"{p}.conv2.weight"] = P.pack_linear(w2p, dev)
+                    w[f"{p}.conv2.bias"] = P.pack_bias(b2, dev)
+                    for name, ix in (("conv1", 2), ("conv2", 3), ("conv3", 3), ("conv4", 3)):
+                        q = f"{p}.temopral_conv.{name}"
+                        norm(f"{q}.0")
+                        w[f"{q}.weight"] = P.pack_tconv(sd[f"{q}.{ix}.weight"], dev)
+                        w[f"{q}.bias"] = P.pack_bias(sd[f"{q}.{ix}.bias"], dev)
+                elif kind in ("st", "tt"):
+                    norm(f"{p}.norm")
+                    lin(f"{p}.proj_in"); lin(f"{p}.proj_out")
+                    tblock(f"{p}.transformer_blocks.0")
+                elif kind == "down":
+                    w[f"{p}.weight"] = P.pack_conv3x3(sd[f"{p}.op.weight"], dev)
+                    w[f"{p}.bias"] = P.pack_bias(sd[f"{p}.op.bias"], dev)
+                elif kind == "up":
+                    w[f"{p}.weight"] = P.pack_conv3x3(sd[f"{p}.conv.weight"], dev)
+                    w[f"{p}.bias"] = P.pack_bias(sd[f"{p}.conv.bias"], dev)
+        self.emb_total = off
+        w["emb_all.weight"] = P.pack_linear(torch.cat(emb_w, dim=0), dev)
+        w["emb_all.bias"] = P.pack_bias(torch.cat(emb_b, dim=0), dev)
+        norm("out.0")
+        w["out.2.weight"] = P.pack_conv3x3(sd["out.2.weight"], dev)
+        w["out.2.bias"] = P.pack_bias(sd["out.2.bias"], dev)
+        self.out_pad = w["out.2.weight"].shape[0]
+
+    # ------------------------------------------------------------------ static I/O buffers
+    def _static_inputs(self):
+        dev, B, F, H, W = self.device, self.B, self.F, self.H, self.W
+        self.T0 = B * F * H * W
+        self.cin_pad = (self.cfg["in_dim"] + 7) // 8 * 8
+        self.x_rows = torch.zeros(self.T0, self.cin_pad, dtype=BF16, device=dev)
+        self.ctx_rows = torch.zeros(B * self.L, self.cfg["context_dim"], dtype=BF16, device=dev)
+        self.t_dev = torch.zeros(self.n_t, dtype=torch.float32, device=dev)
+        self.cam_rows = torch.zeros(B * F, (self.cfg.get("camera_dim", 16) + 7) // 8 * 8, dtype=BF16, device=dev)
+        self.eps_rows = torch.zeros(self.T0, self.out_pad, dtype=torch.float32, device=dev)
+        # embedding scratch
+        self.sin_emb = torch.zeros(self.n_t, self.dim, dtype=BF16, device=dev)
+        self.te_hidden = torch.zeros(self.n_t, self.E, dtype=BF16, device=dev)
+        self.temb = torch.zeros(self.n_t, self.E, dtype=torch.float32, device=dev)
+        self.cam_hidden = torch.zeros(B * F, self.E, dtype=BF16, device=dev)
+        self.cam_emb = torch.zeros(B * F, self.E, dtype=torch.float32, device=dev)
+        self.n_cam_rows = F
+        self.emb_silu = torch.zeros(B * F, self.E, dtype=BF16, device=dev)
+        self.emb_out = torch.zeros(B * F, self.emb_total, dtype=torch.float32, device=dev)
+        self.cam_valid = False
+
+    # ------------------------------------------------------------------ helpers
+    def act(self, rows, C, dtype=BF16) -> Act:
+        esz = 2 if dtype == BF16 else 4
+        return Act(self.pool.get(rows * C * esz), rows, C, dtype)
+
+    def release(self, a: Act):
+        if self.taps is None:
+            self.pool.put(a.buf)
+
+    def _gemm(self, label, M, N, segs, wkey, out: Act, bias=None, geom=None, **kw):
+        """N is informational: the launch always covers every (4-padded) row of the packed weight."""
+        W = self.w[wkey]
+        ks, ws = self._ksplit(M, W.shape[0], segs)
+        p = ops.gemm_params(M, W.shape[0], segs, W, out.ptr, out.C, bias=bias, geom=geom, ksplit=ks, workspace=ws, **kw)
+        self.S.gemm(p, label)
+
+    def _ksplit(self, M, N, segs):
+        """Split K when the tile grid cannot fill 256 CUs and the reduction is long (small-spatial levels)."""
+        steps = sum((s.k + 63) // 64 for s in segs)
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        if tiles >= 192 or steps < 16:
+            return 0, None
+        ks = min(8, max(1, 512 // tiles), steps // 8)
+        if ks < 2:
+            return 0, None
+        need = ks * M * N * 4
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=self.device)
+            self._keepalive.append(self._ws)   # earlier recorded launches keep pointing at the old slab
+        return ks, self._ws
+
+    def _gn(self, label, srcs, rows, rows_per_stat, wkey, eps, silu) -> Act:
+        C0 = srcs[0].C
+        C1 = srcs[1].C if len(srcs) > 1 else 0
+        C = C0 + C1
+        y = self.act(rows, C)
+        assert ops.gn_partial_floats(rows, rows_per_stat, C) <= self._gnws.numel()
+        p = ops.gn_params(srcs[0].ptr, srcs[0].C, C0, rows, rows_per_stat, self._gnws, self.w[wkey + ".weight"],
+                          self.w[wkey + ".bias"], eps, silu, y.ptr, C,
+                          x1=srcs[1].ptr if C1 else None, ld1=srcs[1].C if C1 else 0, C1=C1)
+        self.S.groupnorm(p, label)
+        return y
+
+    def _ln(self, label, x: Act, wkey) -> Act:
+        y = self.act(x.rows, x.C)
+        self.S.layernorm(ops.ln_params(x.ptr, x.C, y.ptr, y.C, self.w[wkey + ".weight"], self.w[wkey + ".bias"],
+                                       x.rows, x.C, 1e-5), label)
+        return y
+
+    # ------------------------------------------------------------------ blocks
+    def _res_block(self, p, m, srcs: List[Act], h, w) -> Act:
+        B, F = self.B, self.F
+        T = B * F * h * w
+        cout = m["cout"]
+        geom = ops.Geom(OH=h, OW=w, IH=h, IW=w, stride=1, ups=0)
+        h0 = self._gn(p + ".gn1", srcs, T, h * w, f"{p}.in_layers.0", 1e-5, True)
+        h1 = self.act(T, cout)
+        self._gemm(p + ".conv1", T, cout, ops.conv3x3_segs([(h0.ptr, h0.C, h0.C)]), f"{p}.in_layers.2.weight", h1,
+                   bias=self.w[f"{p}.in_layers.2.bias"], geom=geom,
+                   rowvec=self.emb_out.data_ptr() + 4 * self.emb_off[p], rowvec_div=h * w, rowvec_ld=self.emb_total)
+        self.release(h0)
+        h2 = self._gn(p + ".gn2", [h1], T, h * w, f"{p}.out_layers.0", 1e-5, True)
+        self.release(h1)
+        h3 = self.act(T, cout)
+        segs = ops.conv3x3_segs([(h2.ptr, h2.C, h2.C)])
+        if m["cin"] != cout:
+            segs += ops.linear_segs([(s.ptr, s.C, s.C) for s in srcs])
+            self._gemm(p + ".conv2+skip", T, cout, segs, f"{p}.conv2.weight", h3, bias=self.w[f"{p}.conv2.bias"], geom=geom)
+        else:
+            self._gemm(p + ".conv2", T, cout, segs, f"{p}.conv2.weight", h3, bias=self.w[f"{p}.conv2.bias"], geom=geom,
+                       residual=srcs[0].ptr, ldr=srcs[0].C)
+        self.release(h2)
+        # temporal conv block: 4 x [GN over all frames -> SiLU -> (3,1,1) conv], + identity
+        tg = ops.Geom(F=F, P=h * w)
+        cur = h3
+        for i, name in enumerate(("conv1", "conv2", "conv3", "conv4")):
+            q = f"{p}.temopral_conv.{name}"
+            g = self._gn(q + ".gn", [cur], T, F * h * w, f"{q}.0", 1e-5, True)
+            nxt = self.act(T, cout)
+            last = i == 3
+            self._gemm(q, T, cout, ops.temporal_segs(g.ptr, g.C, g.C), f"{q}.weight", nxt, bias=self.w[f"{q}.bias"],
+                       geom=tg, residual=h3.ptr if last else None, ldr=h3.C if last else 0)
+            self.release(g)
+            if cur is not h3:
+                self.release(cur)
+            cur = nxt
+        self.release(h3)
+        return cur
+
+    def _tblock(self, p, a: Act, heads, temporal: bool, h, w, cross_ctx: bool) -> Act:
+        B, F = self.B, self.F
+        T = a.rows
+        inner = a.C
+        hw = h * w
+        scale = 64 ** -0.5
+
+        def maps(ld, col0=0):
+            if temporal:   # problems = (b, pixel); rows strided by hw
+                return ops.seq_map(F * hw * ld, ld, hw * ld, inner=hw)
+            return ops.seq_map(hw * ld, 0, ld, inner=1)
+
+        n_outer = B * hw if temporal else B * F
+        Nq = F if temporal else hw
+
+        def self_attn(tag, x: Act, normkey) -> Act:
+            ln = self._ln(f"{p}.{normkey}", x, f"{p}.{normkey}")
+            qkv = self.act(T, 3 * inner)
+            self._gemm(f"{p}.{tag}.qkv", T, 3 * inner, ops.linear_segs([(ln.ptr, ln.C, ln.C)]), f"{p}.{tag}.qkv", qkv)
+            self.release(ln)
+            ao = self.act(T, inner)
+            ld = 3 * inner
+            self.S.attention(ops.attn_params(qkv.ptr, qkv.ptr + 2 * inner, qkv.ptr + 4 * inner, ao.ptr,
+                                             maps(ld), maps(ld), maps(ld), maps(inner), n_outer, heads, Nq, Nq, scale),
+                             f"{p}.{tag}.attn")
+            self.release(qkv)
+            y = self.act(T, inner)
+            self._gemm(f"{p}.{tag}.out", T, inner, ops.linear_segs([(ao.ptr, ao.C, ao.C)]), f"{p}.{tag}.to_out.0.weight", y,
+                       bias=self.w[f"{p}.{tag}.to_out.0.bias"], residual=x.ptr, ldr=x.C)
+            self.release(ao)
+            return y
+
+        def cross_attn(tag, x: Act, normkey) -> Act:
+            ln = self._ln(f"{p}.{normkey}", x, f"{p}.{normkey}")
+            q = self.act(T, inner)
+            self._gemm(f"{p}.{tag}.q", T, inner, ops.linear_segs([(ln.ptr, ln.C, ln.C)]), f"{p}.{tag}.q", q)
+            self.release(ln)
+            Lc = self.L
+            kv = self.act(B * Lc, 2 * inner)
+            cd = self.ctx_rows.shape[1]
+            self._gemm(f"{p}.{tag}.kv", B * Lc, 2 * inner, ops.linear_segs([(self.ctx_rows.data_ptr(), cd, cd)]),
+                       f"{p}.{tag}.kv", kv)
+            ao = self.act(T, inner)
+            kvm = ops.seq_map(Lc * 2 * inner, 0, 2 * inner, inner=1)
+            self.S.attention(ops.attn_params(q.ptr, kv.ptr, kv.ptr + 2 * inner, ao.ptr, maps(inner), kvm, kvm, maps(inner),
+                                             n_outer, heads, Nq, Lc, scale, kv_div=F), f"{p}.{tag}.attn")
+            self.release(q); self.release(kv)
+            y = self.act(T, inner)
+            self._gemm(f"{p}.{tag}.out", T, inner, ops.linear_segs([(ao.ptr, ao.C, ao.C)]), f"{p}.{tag}.to_out.0.weight", y,
+                       bias=self.w[f"{p}.{tag}.to_out.0.bias"], residual=x.ptr, ldr=x.C)
+            self.release(ao)
+            return y
+
+        a1 = self_attn("attn1", a, "norm1")
+        a2 = cross_attn("attn2", a1, "norm2") if cross_ctx else self_attn("attn2", a1, "norm2")
+        self.release(a1)
+        ln = self._ln(f"{p}.norm3", a2, f"{p}.norm3")
+        ff = self.act(T, 4 * inner)
+        self._gemm(f"{p}.ff.geglu", T, 8 * inner, ops.linear_segs([(ln.ptr, ln.C, ln.C)]), f"{p}.ff.net.0.proj.weight", ff,
+                   bias=self.w[f"{p}.ff.net.0.proj.bias"], epilogue=L.EPI_GEGLU)
+        self.release(ln)
+        a3 = self.act(T, inner)
+        self._gemm(f"{p}.ff.down", T, inner, ops.linear_segs([(ff.ptr, ff.C, ff.C)]), f"{p}.ff.net.2.weight", a3,
+                   bias=self.w[f"{p}.ff.net.2.bias"], residual=a2.ptr, ldr=a2.C)
+        self.release(ff); self.release(a2)
+        return a3
+
+    def _transformer(self, kind, p, m, x: Act, h, w) -> Act:
+        B, F = self.B, self.F
+        T = x.rows
+        C = x.C
+        inner = m["heads"] * m["dh"]
+        if m["dh"] != 64:
+            raise NotImplementedError("the HIP attention kernel is specialised for head_dim 64")
+        temporal = kind == "tt"
+        n0 = self._gn(p + ".norm", [x], T, (F * h * w) if temporal else (h * w), f"{p}.norm", 1e-6, False)
+        a = self.act(T, inner)
+        self._gemm(p + ".proj_in", T, inner, ops.linear_segs([(n0.ptr, n0.C, n0.C)]), f"{p}.proj_in.weight", a,
+                   bias=self.w[f"{p}.proj_in.bias"])
+        self.release(n0)
+        a3 = self._tblock(f"{p}.transformer_blocks.0", a, m["heads"], temporal, h, w, cross_ctx=not temporal)
+        self.release(a)
+        y = self.act(T, C)
+        self._gemm(p + ".proj_out", T, C, ops.linear_segs([(a3.ptr, a3.C, a3.C)]), f"{p}.proj_out.weight", y,
+                   bias=self.w[f"{p}.proj_out.bias"], residual=x.ptr, ldr=x.C)
+        self.release(a3)
+        return y
+
+    def _run_block(self, blk, srcs: List[Act], h, w):
+        """srcs: the block inputs — [x] or [x, skip] (decoder concat, never materialised); they are NOT released
+        here (they may be pending skip connections).  Intermediates are.  Returns (Act, h, w)."""
+        x = None
+        for kind, p, m in blk:
+            ins = srcs if x is None else [x]
+            if kind == "conv_in":
+                y = self.act(self.T0, m["cout"])
+                self._gemm(p, self.T0, m["cout"], ops.conv3x3_segs([(self.x_rows.data_ptr(), self.cin_pad, self.cin_pad)]),
+                           p + ".weight", y, bias=self.w[p + ".bias"], geom=ops.Geom(OH=h, OW=w, IH=h, IW=w))
+            elif kind == "res":
+                y = self._res_block(p, m, ins, h, w)
+            elif kind in ("st", "tt"):
+                y = self._transformer(kind, p, m, ins[0], h, w)
+            elif kind == "down":
+                xin = ins[0]
+                oh, ow = (h + 1) // 2, (w + 1) // 2
+                T = self.B * self.F * oh * ow
+                y = self.act(T, m["c"])
+                self._gemm(p, T, m["c"], ops.conv3x3_segs([(xin.ptr, xin.C, xin.C)]), p + ".weight", y,
+                           bias=self.w[p + ".bias"], geom=ops.Geom(OH=oh, OW=ow, IH=h, IW=w, stride=2))
+                h, w = oh, ow
+            elif kind == "up":
+                xin = ins[0]
+                oh, ow = h * 2, w * 2
+                T = self.B * self.F * oh * ow
+                y = self.act(T, m["c"])
+                self._gemm(p, T, m["c"], ops.conv3x3_segs([(xin.ptr, xin.C, xin.C)]), p + ".weight", y,
+                           bias=self.w[p + ".bias"], geom=ops.Geom(OH=oh, OW=ow, IH=h, IW=w, stride=1, ups=1))
+                h, w = oh, ow
+            else:
+                raise ValueError(kind)
+            if x is not None:
+                self.release(x)
+            x = y
+        return x, h, w
+
+    # ------------------------------------------------------------------ whole forward
+    def _build(self):
+        B, F = self.B, self.F
+        S = self.S
+        # (0) embeddings -> one [B*F, sum Cout] table for all ResBlocks (recorded first)
+        self.n_emb_ops_start = S.nops
+        e = Act(self.emb_silu.view(torch.uint8).view(-1), B * F, self.E)
+        eo = Act(self.emb_out.view(torch.uint8).view(-1), B * F, self.emb_total, torch.float32)
+        self._gemm("emb_all", B * F, self.emb_total, ops.linear_segs([(e.ptr, e.C, e.C)]), "emb_all.weight", eo,
+                   bias=self.w["emb_all.bias"], out_fp32=True)
+        h, w = self.H, self.W
+        xs = []
+        x = None
+        for blk in self.inp:
+            x, h, w = self._run_block(blk, [x] if x is not None else [], h, w)
+            xs.append((x, h, w))
+            if self.taps is not None:
+                self.taps[blk[0][1]] = (x, h, w)
+        # encoder outputs double as skips: _run_block never releases its inputs
+        x_last = x
+        x, h, w = self._run_block(self.mid, [x], h, w)
+        if self.taps is not None:
+            self.taps["middle_block"] = (x, h, w)
+        for blk in self.outb:
+            skip, sh, sw = xs.pop()
+            assert (sh, sw) == (h, w), (sh, sw, h, w)
+            y, h, w = self._run_block(blk, [x, skip], h, w)
+            if x is not skip:          # the first decoder block sees the middle-block output, not a skip
+                self.release(x)
+            self.release(skip)
+            x = y
+            if self.taps is not None:
+                self.taps[blk[0][1]] = (x, h, w)
+        T = self.T0
+        hn = self._gn("out.gn", [x], T, h * w, "out.0", 1e-5, True)
+        self.release(x)
+        eps = Act(self.eps_rows.view(torch.uint8).view(-1), T, self.out_pad, torch.float32)
+        self._gemm("out.conv", T, self.out_pad, ops.conv3x3_segs([(hn.ptr, hn.C, hn.C)]), "out.2.weight", eps,
+                   bias=self.w["out.2.bias"], geom=ops.Geom(OH=h, OW=w, IH=h, IW=w), out_fp32=True)
+        self.release(hn)
+
+    # ------------------------------------------------------------------ execution
+    def set_context(self, y: torch.Tensor):
+        """y [B, L, ctx] -> bf16 context rows (dtype cast only)."""
+        self.ctx_rows.copy_(y.reshape(self.B * self.L, -1).to(BF16))
+
+    def set_camera(self, camera_data: Optional[torch.Tensor]):
+        """camera_data [b, F, 16] with b = 1 (shared by all branches) or b = B: the camera-embedding MLP
+        (unet_t2v.py:330-335) is constant per sample, so it runs once here, not per denoising step."""
+        if not self.has_cam or camera_data is None:
+            self.cam_valid = False
+            return
+        cam = camera_data.reshape(-1, camera_data.shape[-1])
+        n = cam.shape[0]
+        if n not in (self.F, self.B * self.F):
+            raise ValueError(f"camera_data has {n} rows, expected {self.F} or {self.B * self.F}")
+        self.n_cam_rows = n
+        self.cam_rows.zero_()
+        self.cam_rows[:n, : cam.shape[1]].copy_(cam.to(BF16))
+        S = ops.Stream(record=False)
+        cd = self.cam_rows.shape[1]
+        S.gemm(ops.gemm_params(n, self.E, ops.linear_segs([(self.cam_rows, cd, cd)]),
+                               self.w["camera_embedding.0.weight"], self.cam_hidden, self.E,
+                               bias=self.w["camera_embedding.0.bias"], act=L.ACT_SILU), "cam.0")
+        S.gemm(ops.gemm_params(n, self.E, ops.linear_segs([(self.cam_hidden, self.E, self.E)]),
+                               self.w["camera_embedding.2.weight"], self.cam_emb, self.E,
+                               bias=self.w["camera_embedding.2.bias"], out_fp32=True), "cam.2")
+        self.cam_valid = True
+
+    def _embeddings(self):
+        S = ops.Stream(record=False)
+        ops.sinusoidal(self.t_dev, self.sin_emb, self.n_t, self.dim)
+        S.gemm(ops.gemm_params(self.n_t, self.E, ops.linear_segs([(self.sin_emb, self.dim, self.dim)]),
+                               self.w["time_embed.0.weight"], self.te_hidden, self.E,
+                               bias=self.w["time_embed.0.bias"], act=L.ACT_SILU), "time_embed.0")
+        S.gemm(ops.gemm_params(self.n_t, self.E, ops.linear_segs([(self.te_hidden, self.E, self.E)]),
+                               self.w["time_embed.2.weight"], self.temb, self.E,
+                               bias=self.w["time_embed.2.bias"], out_fp32=True), "time_embed.2")
+        rows = self.B * self.F
+        # branch-major rows [b][f]: the B // n_t branches of one timestep row are contiguous
+        ops.emb_combine_silu(self.temb, self.cam_emb if self.cam_valid else None, self.emb_silu, rows, self.E,
+                             rows // self.n_t, self.n_cam_rows)
+
+    def forward_rows(self, x: torch.Tensor, t: torch.Tensor):
+        """x [b, C, F, H, W] fp32 on device (b divides B; replicated to the B branches), t [n_t].
+        Leaves eps in ``self.eps_rows`` (fp32 [B*F*H*W, out_pad])."""
+        nb = x.shape[0]
+        ops.latent_to_rows(x.contiguous(), self.x_rows, self.cin_pad, self.B // nb)
+        self.t_dev.copy_(t.to(torch.float32).reshape(-1)[: self.n_t])
+        self._embeddings()
+        self.S.run()
+        return self.eps_rows
+
+    def eps_ncfhw(self) -> torch.Tensor:
+        """eps rows -> [B, out_dim, F, H, W] fp32 (reference output layout)."""
+        out = torch.empty(self.B * self.F, self.out_pad, self.H, self.W, dtype=torch.float32, device=self.device)
+        ops.rows_to_nchw(self.eps_rows, self.out_pad, out)
+        od = self.cfg["out_dim"]
+        return out[:, :od].reshape(self.B, self.F, od, self.H, self.W).permute(0, 2, 1, 3, 4).contiguous()

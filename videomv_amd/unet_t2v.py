@@ -1,0 +1,151 @@
+"""``UNetSD_T2VBase`` — drop-in for the reference module of the same name (tools/modules/unet/unet_t2v.py:55-433)
+whose forward runs on the hand-written gfx950 kernels of ``libvmv_hip.so``.
+
+What stays identical to the reference:
+  * registry name ``MODEL: UNetSD_T2VBase`` and the constructor keywords (python defaults + YAML keys);
+  * the ``state_dict`` key names/shapes (1484 keys at full size, typos included — SURVEY F13), so reference
+    checkpoints load with ``load_state_dict(sd, strict=False)``;
+  * the ``forward`` signature and the output layout/dtype (``[b, out_dim, f, h, w]``, fp32).
+What differs by design: there is no PyTorch math in ``forward``.  Parameters are repacked to bf16 GEMM
+operands on first use and the whole forward is a recorded plan of HIP launches (``unet_engine.UNetEngine``).
+If the HIP library is missing, construction of the engine raises — there is no CPU fallback.
+
+The LGM refinement branch (``autoencoder is not None`` / ``use_lgm_refine``, unet_t2v.py:404-433) is a
+"next" row of SURVEY §8(f) and raises ``NotImplementedError``.
+"""
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from .registry import MODEL
+from .unet_engine import UNetEngine, param_shapes, block_plan
+
+_ZERO_INIT_SUFFIXES = ("proj_out.weight", "proj_out.bias", "out_layers.3.weight", "out_layers.3.bias",
+                       "temopral_conv.conv4.3.weight", "temopral_conv.conv4.3.bias")
+
+
+class _Holder(nn.Module):
+    """Parameter container that reproduces the reference's dotted state-dict names."""
+
+    def add(self, dotted: str, param: nn.Parameter):
+        head, _, rest = dotted.partition(".")
+        if not rest:
+            self.register_parameter(head, param)
+            return
+        child = self._modules.get(head)
+        if child is None:
+            child = _Holder()
+            self.add_module(head, child)
+        child.add(rest, param)
+
+
+@MODEL.register_class()
+class UNetSD_T2VBase(nn.Module):
+    def __init__(self, config=None, in_dim=4, dim=512, y_dim=512, context_dim=512, hist_dim=156, dim_condition=4,
+                 out_dim=6, num_tokens=4, dim_mult=[1, 2, 3, 4], num_heads=None, head_dim=64, camera_dim=16,
+                 num_res_blocks=3, attn_scales=[1 / 2, 1 / 4, 1 / 8], use_scale_shift_norm=True, dropout=0.1,
+                 temporal_attn_times=1, temporal_attention=True, use_checkpoint=False, use_image_dataset=False,
+                 use_sim_mask=False, training=True, inpainting=True, use_fps_condition=False,
+                 use_camera_condition=False, use_lgm_refine=False, p_all_zero=0.1, p_all_keep=0.1, zero_y=None,
+                 adapter_transformer_layers=1, **kwargs):
+        super().__init__()
+        if not temporal_attention:
+            raise NotImplementedError("temporal_attention=False is not a VideoMV configuration")
+        if use_fps_condition:
+            raise NotImplementedError("use_fps_condition=True (I2VGen front-end) is a later row of SURVEY §8(f)")
+        num_heads = num_heads if num_heads else dim // 32
+        self.zero_y = zero_y
+        self.in_dim, self.dim, self.y_dim, self.context_dim = in_dim, dim, y_dim, context_dim
+        self.out_dim, self.dim_mult, self.num_heads, self.head_dim = out_dim, list(dim_mult), num_heads, head_dim
+        self.num_res_blocks, self.attn_scales = num_res_blocks, list(attn_scales)
+        self.use_camera_condition, self.camera_dim = use_camera_condition, camera_dim
+        self.use_fps_condition = use_fps_condition
+        self.use_lgm_refine = use_lgm_refine
+        self.inpainting = inpainting
+        self.arch = dict(in_dim=in_dim, dim=dim, context_dim=context_dim, out_dim=out_dim, dim_mult=list(dim_mult),
+                         num_heads=num_heads, head_dim=head_dim, num_res_blocks=num_res_blocks,
+                         attn_scales=list(attn_scales), camera_dim=camera_dim,
+                         use_camera_condition=use_camera_condition, use_fps_condition=use_fps_condition)
+        g = torch.Generator().manual_seed(0)
+        for key, shape in param_shapes(self.arch).items():
+            if len(shape) == 1:
+                v = torch.zeros(shape) if key.endswith(".bias") else torch.ones(shape)
+            else:
+                fan_in = 1
+                for d in shape[1:]:
+                    fan_in *= d
+                v = torch.randn(shape, generator=g) / math.sqrt(fan_in)
+            # the layers the reference zero-initialises: a fresh model is ~identity there too
+            if key.endswith(_ZERO_INIT_SUFFIXES) or key == "out.2.weight" or key.startswith("camera_embedding.2."):
+                v = torch.zeros(shape)
+            self._add_param(key, nn.Parameter(v, requires_grad=False))
+        self._engines: Dict[tuple, UNetEngine] = {}
+        self._weights_version = 0
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
+
+    def _add_param(self, dotted, param):
+        head, _, rest = dotted.partition(".")
+        child = self._modules.get(head)
+        if child is None:
+            child = _Holder()
+            self.add_module(head, child)
+        child.add(rest, param)
+
+    def _invalidate(self):
+        self._engines.clear()
+        self._weights_version += 1
+
+    # ------------------------------------------------------------------ engine management
+    def engine_for(self, B, F, H, W, L, device, n_t=1, taps=None) -> UNetEngine:
+        key = (B, F, H, W, L, str(device), n_t, taps is not None)
+        eng = self._engines.get(key)
+        if eng is None:
+            sd = {k: v.detach() for k, v in self.state_dict().items()}
+            eng = UNetEngine(self.arch, sd, B, F, H, W, L, device, n_t=n_t, taps=taps)
+            if taps is None:
+                self._engines[key] = eng
+        return eng
+
+    # ------------------------------------------------------------------ reference forward signature
+    @torch.no_grad()
+    def forward(self, x, t, x0=None, gs_data=None, sqrt_alphas_cumprod=None, sqrt_one_minus_alphas_cumprod=None,
+                sqrt_recip_alphas_cumprod=None, sqrt_recipm1_alphas_cumprod=None, autoencoder=None, y=None, fps=None,
+                masked=None, camera_data=None, video_mask=None, focus_present_mask=None, prob_focus_present=0.,
+                mask_last_frame_num=0, **kwargs):
+        assert self.inpainting or masked is None, 'inpainting is not supported'
+        if autoencoder is not None or (self.use_lgm_refine and x0 is not None):
+            raise NotImplementedError("LGM refinement branch (unet_t2v.py:404-433) is not built yet (SURVEY §8f)")
+        b, c, f, h, w = x.shape
+        dev = x.device
+        if y is None:
+            if self.zero_y is None:
+                raise ValueError("y is None and no zero_y was given")
+            y = self.zero_y.repeat(b, 1, 1)[:, :1, :]
+        # the reference relies on DDP's scatter to move CPU kwargs: do it ourselves
+        y = y.to(dev)
+        if camera_data is not None:
+            camera_data = camera_data.to(dev)
+        eng = self.engine_for(b, f, h, w, y.shape[1], dev, n_t=b)
+        eng.set_context(y.float())
+        eng.set_camera(camera_data if self.use_camera_condition else None)
+        eng.forward_rows(x.float(), t.to(dev))
+        return eng.eps_ncfhw()
+
+    @torch.no_grad()
+    def forward_cfg_rows(self, xt, t, y_cond, y_uncond, camera_data=None):
+        """Both classifier-free-guidance branches in ONE pass (B = 2 rows blocks sharing x_t, so weights stream once
+        per step instead of twice — SURVEY App. C).  Returns (engine, eps_rows fp32 [2*F*H*W, out_pad]):
+        rows [0, F*H*W) are the conditional branch."""
+        b, c, f, h, w = xt.shape
+        if b != 1:
+            raise ValueError("forward_cfg_rows handles one sample (the reference's noise is [1,4,F,h,w])")
+        dev = xt.device
+        eng = self.engine_for(2, f, h, w, y_cond.shape[1], dev, n_t=1)
+        key = (y_cond.data_ptr(), y_uncond.data_ptr(), None if camera_data is None else camera_data.data_ptr())
+        if getattr(eng, "_cond_key", None) != key:      # context / camera are step-invariant: set once per sample
+            eng.set_context(torch.cat([y_cond.to(dev).float(), y_uncond.to(dev).float()], dim=0))
+            eng.set_camera(camera_data.to(dev) if (camera_data is not None and self.use_camera_condition) else None)
+            eng._cond_key = key
+        return eng, eng.forward_rows(xt.float(), t.to(dev))
