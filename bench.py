@@ -1,0 +1,230 @@
+#!/usr/bin/env python
+"""bench.py — denoise-steps/s of the HIP hot path on MI355X (BASELINE.json metric).
+
+One "step" = one DDIM denoising step of the t2v sampler on one 24-view sample:
+    [cond | uncond] UNetSD_T2VBase pass (full-size: dim 320, 1.413 B params, bf16 storage / fp32 accumulate)
+    + classifier-free guidance + x0 + DDIM update                      (diffusion_ddim.py:149-160,192-195,233-243)
+Workload (BASELINE.json configs[1]): t2v_infer.yaml shape, 24 views, 320x512 px = latent [1,4,24,40,64], 77 text
+tokens, guide 9.0, linear_sd schedule, 50-step timestep list (981..1) cycled over the timed steps.
+Synthetic data: seeded randn latents / text features, real orbit cameras replaced by randn [1,24,16]; random-init
+weights of the reference architecture with the zero-inits re-randomised (no checkpoint ships).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): every rank denoises its OWN sample — replicas,
+the reference's only parallelism (inference_text2video_entrance.py:79,152-156) — so scaling is weak and there is no
+data-path collective; `value` = (N * K steps) / max-over-ranks time.
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel = the MFMA implicit-GEMM family, timed per
+launch with events on the launch stream in a separate pass) and `cpu_baseline` (the oracle's fp32 UNet forward on the
+host cores, bounded sample, FLOP-scaled to the metric's unit).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FULL = dict(in_dim=4, dim=320, context_dim=1024, out_dim=4, dim_mult=[1, 2, 4, 4], num_heads=8, head_dim=64,
+            num_res_blocks=2, attn_scales=[1.0, 0.5, 0.25])
+PEAK_BF16_TFLOPS = 2500.0      # dense MFMA bf16, MI355X_MICROARCH.md
+STEP_TFLOP = {(32, 32): 2 * 7.336, (40, 64): 2 * 18.885}     # 2 UNet forwards per step
+
+
+def randomize_(model, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    for name, p in model.named_parameters():
+        if p.dim() == 1:
+            if name.endswith(".bias"):
+                p.normal_(0.0, 0.05, generator=g)
+            else:
+                p.normal_(1.0, 0.1, generator=g)
+        else:
+            fan_in = p[0].numel()
+            p.normal_(0.0, 1.0 / math.sqrt(fan_in), generator=g)
+
+
+def cpu_baseline(frames, cores):
+    """Oracle (CPU fp32 restatement, `port`) on a bounded sample: ONE full-size UNet forward at latent 16x16, 24 frames
+    (1.86 TFLOP by torch's flop counter proportions ~ 18.885 * 256/2560 for conv/linear; attention is smaller than
+    proportional) -> FLOP-scaled to denoise-steps/s at the benchmarked latent."""
+    from oracle.unet_ref import UNetCfg, unet_forward
+    from oracle.weights import unet_param_shapes
+    torch.set_num_threads(cores)
+    ocfg = UNetCfg(**FULL)
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    for k, shp in unet_param_shapes(ocfg).items():
+        if len(shp) == 1:
+            sd[k] = torch.ones(shp) if k.endswith("weight") else torch.zeros(shp)
+        else:
+            fan = 1
+            for d in shp[1:]:
+                fan *= d
+            sd[k] = torch.randn(shp, generator=g) / math.sqrt(fan)
+    h = w = 16
+    x = torch.randn(1, 4, frames, h, w, generator=g)
+    y = torch.randn(1, 77, 1024, generator=g)
+    cam = torch.randn(1, frames, 16, generator=g)
+    t0 = time.time()
+    unet_forward(sd, ocfg, x, torch.tensor([501]), y, cam)
+    dt = time.time() - t0
+    return dt, (h, w)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--latent", type=str, default="40x64", help="latent HxW (40x64 = 320x512 px; 32x32 = reference 256 px)")
+    ap.add_argument("--frames", type=int, default=24)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-op-profile", action="store_true")
+    ap.add_argument("--dump-ops", type=str, default="", help="write the per-launch timing table to this file")
+    args = ap.parse_args()
+    H, W = (int(v) for v in args.latent.split("x"))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from videomv_amd import _lib
+    _lib.load()      # the product path fails loudly without the HIP extension
+    from videomv_amd.registry import MODEL, DIFFUSION
+    import videomv_amd.unet_t2v  # noqa: F401
+    import videomv_amd.diffusion_ddim  # noqa: F401
+    from videomv_amd import _lib as L
+    from videomv_amd.flops import gemm_flops, attn_flops
+
+    with torch.device(dev):
+        model = MODEL.build(dict(type="UNetSD_T2VBase", y_dim=1024, use_camera_condition=True, use_lgm_refine=False, **FULL))
+    randomize_(model, 1234)
+    model.eval()
+    dif = DIFFUSION.build(dict(type="DiffusionDDIM", schedule="linear_sd",
+                               schedule_param=dict(num_timesteps=1000, init_beta=0.00085, last_beta=0.012,
+                                                   zero_terminal_snr=False), mean_type="eps", var_type="fixed_small"))
+    g = torch.Generator(device=dev).manual_seed(11 + rank)     # t2v_infer.yaml seed (+rank, as the reference)
+    noise = torch.randn(1, 4, args.frames, H, W, generator=g, device=dev)
+    y = torch.randn(1, 77, 1024, generator=g, device=dev)
+    y0 = torch.randn(1, 77, 1024, generator=g, device=dev)
+    cam = torch.randn(1, args.frames, 16, generator=g, device=dev)
+    steps = [int(s) for s in dif.ddim_steps(50)]
+    stride = 1000 // 50
+    xt = noise.clone()
+
+    def one_step(i):
+        dif.ddim_step_hip(xt, steps[i % len(steps)], model, y, y0, cam, 9.0, stride)
+
+    for i in range(args.warmup):
+        one_step(i)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+    finite = bool(torch.isfinite(xt).all())
+    steps_per_s = world * args.steps / dt
+    ms_per_step = 1000.0 * dt / args.steps
+    step_tflop = STEP_TFLOP.get((H, W))
+
+    # ---- per-launch timing pass (events on the launch stream = torch's current stream)
+    roof = None
+    if rank == 0 and not args.no_op_profile:
+        eng = model.engine_for(2, args.frames, H, W, 77, dev, n_t=1)
+        rec, labels = eng.S.recorded, eng.S.labels
+        n = len(rec)
+        reps = 3
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(n + 1)] for _ in range(reps)]
+        for r in range(reps):
+            torch.cuda.synchronize()
+            ev[r][0].record()
+            for i in range(n):
+                eng.S.run(i, i + 1)
+                ev[r][i + 1].record()
+        torch.cuda.synchronize()
+        ms = [min(ev[r][i].elapsed_time(ev[r][i + 1]) for r in range(reps)) for i in range(n)]
+        fam = {}
+        for i, (op, p) in enumerate(rec):
+            kind = {L.OP_GEMM: "gemm", L.OP_GN_STATS: "gn_stats", L.OP_GN_APPLY: "gn_apply", L.OP_LAYERNORM: "layernorm",
+                    L.OP_ATTENTION: "attention"}[op]
+            fl = gemm_flops(p) if op == L.OP_GEMM else (attn_flops(p) if op == L.OP_ATTENTION else 0.0)
+            f = fam.setdefault(kind, dict(ms=0.0, flops=0.0, n=0))
+            f["ms"] += ms[i]; f["flops"] += fl; f["n"] += 1
+        tot_ms = sum(f["ms"] for f in fam.values())
+        gm = fam["gemm"]
+        ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
+        roof = dict(bound="mfma", kernel="gemm_kernel<WM,WN> (bf16 MFMA implicit GEMM: conv3x3 / temporal conv / linear)",
+                    achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
+                    traffic=None, launches=gm["n"], avg_launch_us=round(1000.0 * gm["ms"] / gm["n"], 2),
+                    flop_per_launch=gm["flops"] / gm["n"],
+                    families={k: dict(ms=round(v["ms"], 3), share=round(v["ms"] / tot_ms, 4), launches=v["n"],
+                                      tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None)
+                              for k, v in fam.items()},
+                    serial_forward_ms=round(tot_ms, 3))
+        if step_tflop:
+            roof["whole_step"] = dict(algorithmic_tflop=step_tflop, achieved=round(step_tflop * steps_per_s / world, 1),
+                                      frac=round(step_tflop * steps_per_s / world / PEAK_BF16_TFLOPS, 4))
+        if args.dump_ops:
+            os.makedirs(os.path.dirname(os.path.abspath(args.dump_ops)), exist_ok=True)
+            with open(args.dump_ops, "w") as f:
+                f.write("idx\tlabel\tms\tGFLOP\tTFLOP/s\n")
+                for i, (op, p) in enumerate(rec):
+                    fl = gemm_flops(p) if op == L.OP_GEMM else (attn_flops(p) if op == L.OP_ATTENTION else 0.0)
+                    f.write(f"{i}\t{labels[i]}\t{ms[i]:.4f}\t{fl / 1e9:.2f}\t{(fl / (ms[i] * 1e-3) / 1e12) if fl else 0:.1f}\n")
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cores = os.cpu_count() or 1
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except Exception:
+            pass
+        t_fwd, (ch, cw) = cpu_baseline(args.frames, cores)
+        scale = (H * W) / float(ch * cw)                 # conv/linear FLOPs scale with pixels (attention: see DESIGN.md)
+        cpu_steps = 1.0 / (2.0 * t_fwd * scale)
+        cpu = dict(value=round(cpu_steps, 6), unit="denoise-steps/s", cores=cores, kind="port",
+                   sample=f"1 oracle UNet forward (fp32 torch-CPU eager, full-size weights) at latent 24x{ch}x{cw}: "
+                          f"{t_fwd:.2f} s; scaled x{scale:.1f} pixels x2 forwards per step")
+
+    if rank == 0:
+        out = {"metric": "denoise-steps/sec, t2v 320x512x24 (latent 24x%dx%d), CFG 9.0, 50-step DDIM schedule" % (H, W),
+               "value": round(steps_per_s, 4), "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded randn latents/text/cameras; random-init "
+               "weights, zero-inits re-randomised)",
+               "config": {"workload": f"t2v_infer.yaml UNetSD_T2VBase 1.413B, 24 views, latent {H}x{W}, 77 ctx tokens, "
+                                      f"1 sample per GPU (cond+uncond batched)", "parallelism": f"replicas x{world}"},
+               "samples_per_s_unet_only": round(steps_per_s / 50.0, 5), "finite": finite,
+               "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

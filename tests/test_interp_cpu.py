@@ -1,0 +1,111 @@
+"""`not gpu`: the plan interpreter used as the GPU tests' reference is itself checked against torch.nn.functional
+(conv2d incl. stride-2 / nearest-x2 / channel concat + fused 1x1 skip, conv3d (3,1,1), scaled-dot-product
+attention with the three index maps, GEGLU) — this pins the *contract* of include/vmv.h and the weight packing."""
+import pytest
+import torch
+import torch.nn.functional as Fn
+
+from videomv_amd import _lib as L
+from videomv_amd import ops, packing as P
+from tests import plan_interp as I
+
+BF = torch.bfloat16
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def close(a, b, tol=1e-2):
+    a, b = a.float(), b.float()
+    assert float((a - b).abs().max()) <= tol * float(b.abs().max().clamp_min(1e-6)), float((a - b).abs().max())
+
+
+@pytest.mark.parametrize("stride,ups", [(1, 0), (2, 0), (1, 1)])
+def test_conv3x3_contract(stride, ups):
+    n, IH, IW, C0, C1, N = 2, 6, 5, 16, 8, 12
+    OH = (IH + 1) // 2 if stride == 2 else (IH * 2 if ups else IH)
+    OW = (IW + 1) // 2 if stride == 2 else (IW * 2 if ups else IW)
+    Cin = C0 + C1
+    wt = (torch.randn(N, Cin, 3, 3, generator=g(2)) * 0.1).to(BF).float()
+    ws = (torch.randn(N, Cin, 1, 1, generator=g(7)) * 0.1).to(BF).float()
+    x0 = torch.randn(n * IH * IW, C0, generator=g(1)).to(BF)
+    x1 = torch.randn(n * IH * IW, C1, generator=g(4)).to(BF)
+    wp = torch.cat([wt.permute(0, 2, 3, 1).reshape(N, -1), ws.reshape(N, Cin)], dim=1).to(BF).contiguous()
+    b = torch.randn(N, generator=g(3))
+    out = torch.zeros(n * OH * OW, N)
+    srcs = [(x0, C0, C0), (x1, C1, C1)]
+    segs = ops.conv3x3_segs(srcs) + (ops.linear_segs(srcs) if (stride == 1 and not ups) else [])
+    if not (stride == 1 and not ups):
+        wp = wp[:, : 9 * Cin].contiguous()
+    I.gemm(ops.gemm_params(n * OH * OW, N, segs, wp, out, N, bias=b, out_fp32=True,
+                           geom=ops.Geom(OH=OH, OW=OW, IH=IH, IW=IW, stride=stride, ups=ups)))
+    x = torch.cat([x0, x1], dim=1).float().view(n, IH, IW, Cin).permute(0, 3, 1, 2)
+    img = Fn.interpolate(x, scale_factor=2, mode="nearest") if ups else x
+    ref = Fn.conv2d(img, wt, b, stride=stride, padding=1)
+    if stride == 1 and not ups:
+        ref = ref + Fn.conv2d(x, ws)
+    close(out, ref.permute(0, 2, 3, 1).reshape(-1, N), 1e-5)
+
+
+def test_pack_conv3x3_pads_input_channels():
+    w = torch.randn(8, 4, 3, 3, generator=g(1))
+    p = P.pack_conv3x3(w, "cpu")
+    assert p.shape == (8, 72)
+    assert torch.equal(p.view(8, 9, 8)[:, :, 4:], torch.zeros(8, 9, 4, dtype=BF))
+    assert torch.equal(p.view(8, 3, 3, 8)[:, 2, 0, :4], w[:, :, 2, 0].to(BF))
+
+
+def test_temporal_contract():
+    Bn, F_, Pp, Cc = 2, 4, 6, 8
+    M = Bn * F_ * Pp
+    wt = (torch.randn(Cc, Cc, 3, 1, 1, generator=g(2)) * 0.2).to(BF).float()
+    x = torch.randn(M, Cc, generator=g(1)).to(BF)
+    b = torch.randn(Cc, generator=g(3))
+    out = torch.zeros(M, Cc)
+    wp = P.pack_tconv(wt, "cpu")      # keep alive: the argument block only holds raw pointers
+    I.gemm(ops.gemm_params(M, Cc, ops.temporal_segs(x, Cc, Cc), wp, out, Cc, bias=b, out_fp32=True,
+                           geom=ops.Geom(F=F_, P=Pp)))
+    x5 = x.float().view(Bn, F_, Pp, Cc).permute(0, 3, 1, 2)[..., None]
+    ref = Fn.conv3d(x5, wt, b, padding=(1, 0, 0))[..., 0].permute(0, 2, 3, 1).reshape(M, Cc)
+    close(out, ref, 1e-5)
+
+
+def test_geglu_contract():
+    M, I2, K = 10, 64, 16
+    w = (torch.randn(I2, K, generator=g(2)) * 0.3).to(BF)
+    b = torch.randn(I2, generator=g(3))
+    a = torch.randn(M, K, generator=g(1)).to(BF)
+    out = torch.zeros(M, I2 // 2)
+    wi, bi = P.geglu_interleave(w).contiguous(), P.geglu_interleave(b).contiguous()
+    I.gemm(ops.gemm_params(M, I2, ops.linear_segs([(a, K, K)]), wi, out, I2 // 2, bias=bi, epilogue=L.EPI_GEGLU,
+                           out_fp32=True))
+    h = a.float() @ w.float().t() + b
+    x, gate = h.chunk(2, dim=-1)
+    close(out, x * Fn.gelu(gate), 1e-5)
+
+
+def test_attention_maps_contract():
+    B, F_, HW, heads = 2, 3, 5, 2
+    inner = heads * 64
+    T = B * F_ * HW
+    qkv = torch.randn(T, 3 * inner, generator=g(1)).to(BF)
+    q5 = qkv.float().view(B, F_, HW, 3, heads, 64)
+    sc = 64 ** -0.5
+    # spatial
+    o = torch.zeros(T, inner, dtype=BF)
+    mp = lambda ld: ops.seq_map(HW * ld, 0, ld, inner=1)
+    base = qkv.data_ptr()
+    I.attention(ops.attn_params(base, base + 2 * inner, base + 4 * inner, o, mp(3 * inner), mp(3 * inner), mp(3 * inner),
+                                mp(inner), B * F_, heads, HW, HW, sc))
+    q, k, v = (q5[:, :, :, i].permute(0, 1, 3, 2, 4) for i in range(3))          # b f h n d
+    ref = Fn.scaled_dot_product_attention(q, k, v).permute(0, 1, 3, 2, 4).reshape(T, inner)
+    close(o, ref)
+    # temporal: sequences run over f at fixed (b, pixel)
+    o2 = torch.zeros(T, inner, dtype=BF)
+    mt = lambda ld: ops.seq_map(F_ * HW * ld, ld, HW * ld, inner=HW)
+    I.attention(ops.attn_params(base, base + 2 * inner, base + 4 * inner, o2, mt(3 * inner), mt(3 * inner), mt(3 * inner),
+                                mt(inner), B * HW, heads, F_, F_, sc))
+    q, k, v = (q5[:, :, :, i].permute(0, 2, 3, 1, 4) for i in range(3))          # b p h f d
+    ref = Fn.scaled_dot_product_attention(q, k, v).permute(0, 3, 1, 2, 4).reshape(T, inner)
+    close(o2, ref)

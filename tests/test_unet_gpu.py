@@ -1,0 +1,114 @@
+"""GPU parity of the whole hot path through the drop-in API (`pytest -m gpu`): registry-built ``UNetSD_T2VBase``
+(HIP plan) vs (a) the golden eps captured from the imported reference and (b) the oracle, plus the fused
+CFG + DDIM loop vs the oracle's loop.
+
+Tolerances (stated): the HIP path stores activations in bf16 (fp32 accumulate) while the reference /
+oracle are fp32: rel-L2(eps) <= 3e-2 per forward on these 9-19-block tiny nets with re-randomised weights
+(the CPU emulation of the same bf16 storage measures 1.6e-2), per-block taps <= 3e-2, x0 after a 3-step CFG-9
+DDIM loop rel-L2 <= 6e-2 (guidance scale 9 amplifies the eps error ~x9 on the cond-uncond difference)."""
+import dataclasses
+import json
+import os
+
+import pytest
+import torch
+from safetensors import safe_open
+from safetensors.torch import load_file
+
+from oracle.unet_ref import UNetCfg, unet_forward
+from oracle.weights import random_state_dict, unet_param_shapes
+from oracle.ddim_ref import betas_for, DDIMTables, ddim_sample_loop
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    return float((a.float().cpu() - b.float().cpu()).norm() / b.float().norm().clamp_min(1e-12))
+
+
+def build_model(cfg: dict, sd):
+    from videomv_amd.registry import MODEL
+    m = MODEL.build(dict(type="UNetSD_T2VBase", in_dim=cfg["in_dim"], dim=cfg["dim"], y_dim=cfg["context_dim"],
+                         context_dim=cfg["context_dim"], out_dim=cfg["out_dim"], dim_mult=cfg["dim_mult"],
+                         num_heads=cfg["num_heads"], head_dim=cfg["head_dim"], num_res_blocks=cfg["num_res_blocks"],
+                         attn_scales=cfg["attn_scales"], use_camera_condition=True, use_lgm_refine=False))
+    missing = m.load_state_dict(sd, strict=True)
+    return m.eval()
+
+
+def test_unet_matches_reference_golden(golden_dir):
+    """tests/golden/unet_tiny_b: eps of the imported reference (head_dim 64, dims 64/128/128, 19 blocks)."""
+    path = os.path.join(golden_dir, "unet_tiny_b.safetensors")
+    g = load_file(path)
+    with safe_open(path, "pt") as f:
+        meta = f.metadata()
+    cfg = json.loads(meta["cfg"])
+    ocfg = UNetCfg(**cfg)
+    sd = random_state_dict(unet_param_shapes(ocfg), int(meta["seed"]))
+    m = build_model(cfg, sd)
+    eps = m(g["x"].cuda(), g["t"].cuda(), y=g["y"].cuda(), camera_data=g["camera_data"])   # camera stays on CPU (F14)
+    assert eps.shape == g["eps"].shape and eps.dtype == torch.float32
+    e = rel_l2(eps, g["eps"])
+    assert e < 3e-2, e
+    # run-to-run bitwise determinism (no atomics anywhere on the path)
+    eps2 = m(g["x"].cuda(), g["t"].cuda(), y=g["y"].cuda(), camera_data=g["camera_data"])
+    assert torch.equal(eps, eps2)
+
+
+def test_unet_blocks_match_oracle():
+    from videomv_amd.unet_engine import UNetEngine
+    cfg = dict(in_dim=4, dim=64, context_dim=1024, out_dim=4, dim_mult=[1, 2], num_heads=2, head_dim=64,
+               num_res_blocks=1, attn_scales=[1.0, 0.5], camera_dim=16, use_camera_condition=True,
+               use_fps_condition=False)
+    ocfg = UNetCfg(**{k: v for k, v in cfg.items() if k in {f.name for f in dataclasses.fields(UNetCfg)}})
+    sd = random_state_dict(unet_param_shapes(ocfg), 99)
+    B, F_, H, W, L = 2, 24, 16, 24, 77
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(B, 4, F_, H, W, generator=gen)
+    t = torch.tensor([501, 21])
+    y = torch.randn(B, L, 1024, generator=gen)
+    cam = torch.randn(B, F_, 16, generator=gen)
+    taps_ref = {}
+    eps_ref = unet_forward(sd, ocfg, x, t, y, cam, taps=taps_ref)
+    taps = {}
+    eng = UNetEngine(cfg, sd, B, F_, H, W, L, torch.device("cuda"), n_t=B, taps=taps)
+    eng.set_context(y.cuda())
+    eng.set_camera(cam.cuda())
+    eng.forward_rows(x.cuda(), t.cuda())
+    torch.cuda.synchronize()
+    report = {}
+    for key, (act, h, w) in taps.items():
+        mine = act.tensor().float().view(B * F_, h, w, act.C).permute(0, 3, 1, 2)
+        report[key] = rel_l2(mine, taps_ref[key])
+    report["eps"] = rel_l2(eng.eps_ncfhw(), eps_ref)
+    assert all(v < 3e-2 for v in report.values()), report
+
+
+def test_fused_cfg_ddim_loop_matches_oracle():
+    from videomv_amd.registry import DIFFUSION
+    cfg = dict(in_dim=4, dim=64, context_dim=1024, out_dim=4, dim_mult=[1, 2], num_heads=2, head_dim=64,
+               num_res_blocks=1, attn_scales=[1.0, 0.5])
+    ocfg = UNetCfg(**cfg)
+    sd = random_state_dict(unet_param_shapes(ocfg), 31)
+    m = build_model(cfg, sd).cuda()
+    dif = DIFFUSION.build(dict(type="DiffusionDDIM", schedule="linear_sd",
+                               schedule_param=dict(num_timesteps=1000, init_beta=0.00085, last_beta=0.012,
+                                                   zero_terminal_snr=False),
+                               mean_type="eps", var_type="fixed_small"))
+    gen = torch.Generator().manual_seed(11)
+    noise = torch.randn(1, 4, 4, 8, 8, generator=gen)
+    y, y0 = torch.randn(1, 7, 1024, generator=gen), torch.randn(1, 7, 1024, generator=gen)
+    cam = torch.randn(1, 4, 16, generator=gen)
+    kw = [dict(y=y.cuda(), camera_data=cam), dict(y=y0.cuda(), camera_data=cam)]
+    x_hip = dif.ddim_sample_loop(noise=noise.cuda(), model=m, model_kwargs=kw, guide_scale=9.0, ddim_timesteps=3, eta=0.0)
+    tb = DDIMTables(betas_for("linear_sd"))
+    x_ref = ddim_sample_loop(noise.clone(), lambda xt, t, y, camera_data: unet_forward(sd, ocfg, xt, t, y, camera_data),
+                             tb, [dict(y=y, camera_data=cam), dict(y=y0, camera_data=cam)], 9.0, ddim_timesteps=3)
+    e = rel_l2(x_hip, x_ref)
+    assert e < 6e-2, e
+    # the reference-structured generic path (two forwards per step through forward()) must agree with the fused one
+    x_gen = noise.cuda()
+    for step in dif.ddim_steps(3):
+        t = torch.full((1,), int(step), dtype=torch.long, device="cuda")
+        x_gen, _ = dif.ddim_sample(x_gen, t, m, None, kw, guide_scale=9.0, ddim_timesteps=3)
+    assert rel_l2(x_gen, x_hip.cpu()) < 1e-2

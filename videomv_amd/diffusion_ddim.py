@@ -1,0 +1,154 @@
+"""``DiffusionDDIM`` — drop-in for the reference sampler (tools/modules/diffusions/diffusion_ddim.py:18-260,
+schedules.py) registered under ``DIFFUSION``.
+
+Same constructor keywords and the same ``ddim_sample_loop`` / ``ddim_sample`` signatures.  The fp64 schedule
+tables are built once on the host exactly as the reference does (:50-68); the per-step work is different by design:
+when ``model`` is the HIP ``UNetSD_T2VBase`` (possibly DDP-wrapped), one denoising step is
+    [cond | uncond] UNet pass (one batched plan replay)  ->  ``vmv_cfg_ddim_step`` (CFG + x0 + DDIM update fused)
+instead of two sequential forwards plus ~12 elementwise launches and a wasted ``randn_like``.
+Any other callable falls back to the reference's two-call structure (needed only for API compatibility).
+"""
+import math
+
+import torch
+
+from .registry import DIFFUSION
+from . import ops
+
+
+def beta_schedule(schedule="cosine", num_timesteps=1000, zero_terminal_snr=False, **kwargs):
+    """schedules.py:5-21 — 'linear_sd' (t2v) and 'cosine' (+ zero-terminal-SNR rescale, i2v) are the two used."""
+    if schedule == "linear_sd":
+        betas = torch.linspace(kwargs["init_beta"] ** 0.5, kwargs["last_beta"] ** 0.5, num_timesteps,
+                               dtype=torch.float64) ** 2
+    elif schedule == "linear":
+        betas = torch.linspace(kwargs["init_beta"], kwargs["last_beta"], num_timesteps, dtype=torch.float64)
+    elif schedule == "cosine":
+        s = kwargs.get("cosine_s", 0.008)
+        f = lambda u: math.cos((u + s) / (1 + s) * math.pi / 2) ** 2
+        betas = torch.tensor([min(1.0 - f((i + 1) / num_timesteps) / f(i / num_timesteps), 0.999)
+                              for i in range(num_timesteps)], dtype=torch.float64)
+    else:
+        raise NotImplementedError(f"beta schedule {schedule!r}")
+    if zero_terminal_snr and betas.max() != 1.0:
+        ab = (1 - betas).cumprod(0).sqrt()
+        a0, aT = ab[0].clone(), ab[-1].clone()
+        ab = (ab - aT) * (a0 / (a0 - aT))
+        ab = ab ** 2
+        betas = 1 - torch.cat([ab[0:1], ab[1:] / ab[:-1]])
+    return betas
+
+
+def _unwrap(model):
+    return getattr(model, "module", model)      # DistributedDataParallel / DataParallel
+
+
+@DIFFUSION.register_class()
+class DiffusionDDIM(object):
+    def __init__(self, schedule='linear_sd', schedule_param={}, mean_type='eps', var_type='learned_range',
+                 loss_type='mse', epsilon=1e-12, rescale_timesteps=False, noise_strength=0.0, **kwargs):
+        assert mean_type in ['x0', 'x_{t-1}', 'eps', 'v']
+        assert var_type in ['learned', 'learned_range', 'fixed_large', 'fixed_small']
+        betas = beta_schedule(schedule, **schedule_param)
+        assert min(betas) > 0 and max(betas) <= 1
+        self.betas = betas.double()
+        self.num_timesteps = len(betas)
+        self.mean_type, self.var_type, self.loss_type = mean_type, var_type, loss_type
+        self.epsilon, self.rescale_timesteps, self.noise_strength = epsilon, rescale_timesteps, noise_strength
+        alphas = 1 - self.betas
+        self.alphas_cumprod = torch.cumprod(alphas, dim=0)
+        self.alphas_cumprod_prev = torch.cat([alphas.new_ones([1]), self.alphas_cumprod[:-1]])
+        self.alphas_cumprod_next = torch.cat([self.alphas_cumprod[1:], alphas.new_zeros([1])])
+        self.sqrt_alphas_cumprod = torch.sqrt(self.alphas_cumprod)
+        self.sqrt_one_minus_alphas_cumprod = torch.sqrt(1.0 - self.alphas_cumprod)
+        self.log_one_minus_alphas_cumprod = torch.log(1.0 - self.alphas_cumprod)
+        self.sqrt_recip_alphas_cumprod = torch.sqrt(1.0 / self.alphas_cumprod)
+        self.sqrt_recipm1_alphas_cumprod = torch.sqrt(1.0 / self.alphas_cumprod - 1)
+        self.posterior_variance = self.betas * (1.0 - self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_log_variance_clipped = torch.log(self.posterior_variance.clamp(1e-20))
+
+    def _scale_timesteps(self, t):
+        if self.rescale_timesteps:
+            return t.float() * 1000.0 / self.num_timesteps
+        return t
+
+    def ddim_steps(self, ddim_timesteps):
+        T = self.num_timesteps
+        return (1 + torch.arange(0, T, T // ddim_timesteps)).clamp(0, T - 1).flip(0)
+
+    def step_scalars(self, step: int, stride: int):
+        """fp64 table lookups cast to fp32 exactly where the reference casts them (``_i``: :9-15)."""
+        f = lambda tab, i: float(tab[i].to(torch.float32))
+        return dict(c_recip=f(self.sqrt_recip_alphas_cumprod, step), c_recipm1=f(self.sqrt_recipm1_alphas_cumprod, step),
+                    c_sqrt_ac=f(self.sqrt_alphas_cumprod, step), c_sqrt_1mac=f(self.sqrt_one_minus_alphas_cumprod, step),
+                    a_prev=f(self.alphas_cumprod, max(step - stride, 0)))
+
+    # ------------------------------------------------------------------ fused HIP path
+    @torch.no_grad()
+    def ddim_step_hip(self, xt, step, unet, y_cond, y_uncond, camera_data, guide_scale, stride, x0_out=None):
+        t = torch.full((xt.shape[0],), int(step), dtype=torch.long, device=xt.device)
+        eng, eps_rows = unet.forward_cfg_rows(xt, self._scale_timesteps(t), y_cond, y_uncond, camera_data)
+        ops.cfg_ddim_step(eps_rows, eng.out_pad, xt, float(guide_scale), v_pred=(self.mean_type == 'v'),
+                          x0_out=x0_out, **self.step_scalars(int(step), stride))
+        return xt
+
+    @torch.no_grad()
+    def ddim_sample_loop(self, noise, model, autoencoder=None, model_kwargs={}, clamp=None, percentile=None,
+                         condition_fn=None, guide_scale=None, ddim_timesteps=20, eta=0.0):
+        if autoencoder is not None:
+            raise NotImplementedError("LGM-refined sampling (autoencoder=...) is a later row of SURVEY §8(f)")
+        b = noise.size(0)
+        steps = self.ddim_steps(ddim_timesteps)
+        stride = self.num_timesteps // ddim_timesteps
+        unet = _unwrap(model)
+        fused = (hasattr(unet, "forward_cfg_rows") and guide_scale is not None and isinstance(model_kwargs, list)
+                 and len(model_kwargs) == 2 and autoencoder is None and clamp is None and percentile is None
+                 and condition_fn is None and eta == 0.0 and b == 1 and self.mean_type in ('eps', 'v')
+                 and noise.is_cuda)
+        if not fused:
+            xt = noise
+            for idx, step in enumerate(steps):
+                t = torch.full((b,), int(step), dtype=torch.long, device=xt.device)
+                xt, _ = self.ddim_sample(xt, t, model, None, model_kwargs, clamp, percentile, condition_fn, guide_scale,
+                                         ddim_timesteps, eta)
+            return xt
+        assert self.var_type.startswith('fixed'), "learned variance doubles the UNet out channels: not a VideoMV config"
+        xt = noise.detach().clone().float().contiguous()      # updated in place by the fused kernel
+        kc, ku = model_kwargs
+        cam = kc.get("camera_data", None)
+        for idx, step in enumerate(steps):
+            self.ddim_step_hip(xt, int(step), unet, kc["y"], ku["y"], cam, guide_scale, stride)
+        return xt
+
+    # ------------------------------------------------------------------ generic path (foreign models / CPU)
+    @torch.no_grad()
+    def ddim_sample(self, xt, t, model, autoencoder=None, model_kwargs={}, clamp=None, percentile=None, condition_fn=None,
+                    guide_scale=None, ddim_timesteps=20, eta=0.0):
+        """One DDIM step for an arbitrary callable ``model`` (API compatibility; the HIP UNet never takes this
+        route inside ``ddim_sample_loop``).  All samples of a call share one timestep, as in the reference loop."""
+        if autoencoder is not None or condition_fn is not None or percentile is not None:
+            raise NotImplementedError("LGM refinement / classifier guidance / percentile clipping are not on the built path")
+        if eta != 0.0:
+            raise NotImplementedError("stochastic DDIM (eta > 0) is not used by VideoMV")
+        step = int(t.reshape(-1)[0])
+        ts = self._scale_timesteps(t)
+        if guide_scale is None:
+            pred = model(xt, ts, **model_kwargs)
+        else:
+            assert isinstance(model_kwargs, list) and len(model_kwargs) == 2
+            cond, uncond = model(xt, ts, **model_kwargs[0]), model(xt, ts, **model_kwargs[1])
+            pred = uncond + guide_scale * (cond - uncond)
+        k = {n: torch.tensor(v, dtype=xt.dtype, device=xt.device)
+             for n, v in self.step_scalars(step, self.num_timesteps // ddim_timesteps).items()}
+        if self.mean_type == 'eps':
+            x0 = k["c_recip"] * xt - k["c_recipm1"] * pred
+        elif self.mean_type == 'v':
+            x0 = k["c_sqrt_ac"] * xt - k["c_sqrt_1mac"] * pred
+        elif self.mean_type == 'x0':
+            x0 = pred
+        else:
+            raise NotImplementedError(self.mean_type)
+        if clamp is not None:
+            x0 = x0.clamp(-clamp, clamp)
+        eps = (k["c_recip"] * xt - x0) / k["c_recipm1"]
+        return torch.sqrt(k["a_prev"]) * x0 + torch.sqrt(1 - k["a_prev"]) * eps, x0

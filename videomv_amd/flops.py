@@ -1,0 +1,28 @@
+"""Algorithmic work of a recorded plan: 2*M*N*K per GEMM-shaped launch and 4*Nq*Nk*64 per attention problem/head
+(QK^T + PV).  Matches torch.utils.flop_counter on the reference modules (7.336 TFLOP at 24x32x32,
+18.885 TFLOP at 24x40x64 per forward) up to the K zero-padding of the two 4-channel latent convs, which is excluded."""
+from . import _lib as L
+
+
+def gemm_flops(p) -> float:
+    return 2.0 * p.M * p.N * p.ktot
+
+
+def attn_flops(p) -> float:
+    return 4.0 * p.n_outer * p.heads * p.Nq * p.Nk * 64
+
+
+def plan_flops(recorded):
+    """-> dict(total, gemm, attention) in FLOP for a list of (op, params)."""
+    g = a = 0.0
+    for op, p in recorded:
+        if op == L.OP_GEMM:
+            g += gemm_flops(p)
+        elif op == L.OP_ATTENTION:
+            a += attn_flops(p)
+    return dict(total=g + a, gemm=g, attention=a)
+
+
+# reference-counted figures (SURVEY.md §8d / BASELINE.md §2), TFLOP per UNet forward at F = 24
+UNET_FWD_TFLOP = {(32, 32): 7.336, (40, 64): 18.885}
+VAE_DECODE_TFLOP_PER_FRAME = {(32, 32): 0.622, (40, 64): 1.564}

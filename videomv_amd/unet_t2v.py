@@ -68,18 +68,17 @@ class UNetSD_T2VBase(nn.Module):
                          num_heads=num_heads, head_dim=head_dim, num_res_blocks=num_res_blocks,
                          attn_scales=list(attn_scales), camera_dim=camera_dim,
                          use_camera_condition=use_camera_condition, use_fps_condition=use_fps_condition)
-        g = torch.Generator().manual_seed(0)
         for key, shape in param_shapes(self.arch).items():
-            if len(shape) == 1:
+            # the layers the reference zero-initialises (SURVEY F10): a fresh model is ~identity there too
+            if key.endswith(_ZERO_INIT_SUFFIXES) or key == "out.2.weight" or key.startswith("camera_embedding.2."):
+                v = torch.zeros(shape)
+            elif len(shape) == 1:
                 v = torch.zeros(shape) if key.endswith(".bias") else torch.ones(shape)
             else:
                 fan_in = 1
                 for d in shape[1:]:
                     fan_in *= d
-                v = torch.randn(shape, generator=g) / math.sqrt(fan_in)
-            # the layers the reference zero-initialises (SURVEY F10): a fresh model is ~identity there too
-            if key.endswith(_ZERO_INIT_SUFFIXES) or key == "out.2.weight" or key.startswith("camera_embedding.2."):
-                v = torch.zeros(shape)
+                v = torch.empty(shape).normal_(0.0, 1.0 / math.sqrt(fan_in))
             self._add_param(key, nn.Parameter(v, requires_grad=False))
         self._engines: Dict[tuple, UNetEngine] = {}
         self._weights_version = 0
