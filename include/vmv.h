@@ -138,6 +138,17 @@ typedef struct {
 } VmvLayerNormParams;
 int vmv_layernorm(const VmvLayerNormParams* p, void* stream);
 
+/* Row softmax: p[r][c] = softmax_c(scale * s[r][c]), fp32 scores -> bf16 probabilities.  Used by the VAE decoder's
+ * single-head, 512-wide attention (AttnBlock, autoencoder.py:366-390), which runs as GEMM -> softmax -> GEMM. */
+typedef struct {
+    const float* s; int32_t lds;
+    void* p; int32_t ldp;          /* bf16 */
+    int32_t rows, n;               /* n % 4 == 0 */
+    float scale;
+    int32_t _pad;
+} VmvSoftmaxParams;
+int vmv_softmax_rows(const VmvSoftmaxParams* p, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Softmax attention, head_dim 64, no mask/bias, scale given (xformers memory_efficient_attention at
  * util.py:253,258).  One kernel for the three uses, selected by the index maps:
@@ -204,6 +215,7 @@ typedef struct VmvPlan VmvPlan;
 #define VMV_OP_GN_APPLY    3
 #define VMV_OP_LAYERNORM   4
 #define VMV_OP_ATTENTION   5
+#define VMV_OP_SOFTMAX     6
 VmvPlan* vmv_plan_create(void);
 void     vmv_plan_destroy(VmvPlan* plan);
 int      vmv_plan_add(VmvPlan* plan, int op, const void* params, size_t nbytes);

@@ -118,6 +118,11 @@ def attention(p: L.AttnParams):
             of[oi.reshape(-1)] = out.reshape(-1)
 
 
+def softmax_rows(p: L.SoftmaxParams):
+    s = _rows(p.s, p.rows, p.lds, "f32")[:, : p.n]
+    _rows(p.p, p.rows, p.ldp)[:, : p.n] = torch.softmax(s * p.scale, dim=-1).to(torch.bfloat16)
+
+
 def run_recorded(recorded):
     for op, params in recorded:
         if op == L.OP_GEMM:
@@ -130,6 +135,8 @@ def run_recorded(recorded):
             layernorm(params)
         elif op == L.OP_ATTENTION:
             attention(params)
+        elif op == L.OP_SOFTMAX:
+            softmax_rows(params)
         else:
             raise ValueError(op)
 

@@ -74,3 +74,31 @@ def test_pooled_buffers_give_same_result_as_unpooled(monkeypatch):
         eng.forward_rows(x, t)
         outs.append(eng.eps_ncfhw().clone())
     assert torch.equal(outs[0], outs[1])
+
+
+def test_vae_decoder_plan_matches_oracle(monkeypatch):
+    """VAE decode plan (GEMM-softmax-GEMM attention, folded nin_shortcut, nearest-x2 folded into the conv gather)
+    executed by the CPU interpreter vs oracle/vae_ref.py on the golden tiny configuration."""
+    import json, os
+    plan_interp.install(monkeypatch)
+    from videomv_amd.registry import AUTO_ENCODER
+    from videomv_amd.autoencoder import vae_param_shapes
+    from oracle.vae_ref import vae_decode
+    from oracle.weights import vae_decoder_param_shapes
+    dd = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 4, 4],
+              num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    sd = random_state_dict(vae_decoder_param_shapes(ch=32), 77)
+    vae = AUTO_ENCODER.build(dict(type="AutoencoderKL", ddconfig=dd, embed_dim=4))
+    missing = vae.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys
+    z = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(78))
+    img = vae.decode(z)
+    ref = vae_decode(sd, z)
+    assert img.shape == ref.shape == (2, 3, 64, 64)
+    assert rel_l2(img, ref) < 2e-2, rel_l2(img, ref)
+    # full-size manifest == the reference's 248 keys
+    here = os.path.dirname(os.path.abspath(__file__))
+    man = json.load(open(os.path.join(here, "golden", "manifest_vae_full.json")))["keys"]
+    full = vae_param_shapes(dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128,
+                                 ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[]), 4)
+    assert set(full) == set(man) and all(list(full[k]) == man[k] for k in man)

@@ -112,3 +112,20 @@ def test_fused_cfg_ddim_loop_matches_oracle():
         t = torch.full((1,), int(step), dtype=torch.long, device="cuda")
         x_gen, _ = dif.ddim_sample(x_gen, t, m, None, kw, guide_scale=9.0, ddim_timesteps=3)
     assert rel_l2(x_gen, x_hip.cpu()) < 1e-2
+
+
+def test_vae_decode_matches_reference_golden(golden_dir):
+    """tests/golden/vae_tiny: image decoded by the imported reference AutoencoderKL (ch 32, 2 frames of 8x8 latents).
+    Tolerance: rel-L2 <= 2e-2 (bf16 activations through 15 ResnetBlocks + attention)."""
+    from videomv_amd.registry import AUTO_ENCODER
+    from oracle.weights import vae_decoder_param_shapes
+    g = load_file(os.path.join(golden_dir, "vae_tiny.safetensors"))
+    dd = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 4, 4],
+              num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    sd = random_state_dict(vae_decoder_param_shapes(ch=32), 77)
+    vae = AUTO_ENCODER.build(dict(type="AutoencoderKL", ddconfig=dd, embed_dim=4))
+    vae.load_state_dict(sd, strict=False)
+    img = vae.decode(g["z"].cuda())
+    assert img.shape == g["img"].shape
+    e = rel_l2(img, g["img"])
+    assert e < 2e-2, e

@@ -14,7 +14,7 @@ SEG_LINEAR, SEG_SPATIAL, SEG_TEMPORAL = 0, 1, 2
 EPI_NONE, EPI_GEGLU = 0, 1
 ACT_NONE, ACT_SILU = 0, 1
 TILE_AUTO, TILE_128x128, TILE_128x160, TILE_128x64, TILE_64x64 = 0, 1, 2, 3, 4
-OP_GEMM, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTENTION = 1, 2, 3, 4, 5
+OP_GEMM, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTENTION, OP_SOFTMAX = 1, 2, 3, 4, 5, 6
 
 
 class GemmSeg(C.Structure):
@@ -62,6 +62,11 @@ class AttnParams(C.Structure):
                 ("Nq", C.c_int32), ("Nk", C.c_int32), ("scale", C.c_float)]
 
 
+class SoftmaxParams(C.Structure):
+    _fields_ = [("s", C.c_void_p), ("lds", C.c_int32), ("p", C.c_void_p), ("ldp", C.c_int32),
+                ("rows", C.c_int32), ("n", C.c_int32), ("scale", C.c_float), ("_pad", C.c_int32)]
+
+
 class DdimParams(C.Structure):
     _fields_ = [("eps_rows", C.c_void_p), ("ld", C.c_int32), ("C", C.c_int32), ("F", C.c_int32), ("HW", C.c_int32),
                 ("guide_scale", C.c_float), ("c_recip", C.c_float), ("c_recipm1", C.c_float),
@@ -80,6 +85,7 @@ SYMBOLS = {
     "vmv_groupnorm_apply": (C.c_int, [C.POINTER(GroupNormParams), _P]),
     "vmv_layernorm": (C.c_int, [C.POINTER(LayerNormParams), _P]),
     "vmv_attention_bf16": (C.c_int, [C.POINTER(AttnParams), _P]),
+    "vmv_softmax_rows": (C.c_int, [C.POINTER(SoftmaxParams), _P]),
     "vmv_latent_to_rows": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "vmv_rows_to_nchw": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P]),
     "vmv_cfg_ddim_step": (C.c_int, [C.POINTER(DdimParams), _P]),
@@ -113,7 +119,7 @@ def load():
     if lib.vmv_abi_version() != 1:
         raise RuntimeError("libvmv_hip.so ABI version mismatch")
     for which, st in ((OP_GEMM, GemmParams), (OP_GN_STATS, GroupNormParams), (OP_LAYERNORM, LayerNormParams),
-                      (OP_ATTENTION, AttnParams), (100, DdimParams), (101, GemmSeg), (102, SeqMap)):
+                      (OP_ATTENTION, AttnParams), (OP_SOFTMAX, SoftmaxParams), (100, DdimParams), (101, GemmSeg), (102, SeqMap)):
         if lib.vmv_sizeof(which) != C.sizeof(st):
             raise RuntimeError(f"struct layout drift for {st.__name__}: C {lib.vmv_sizeof(which)} vs ctypes "
                                f"{C.sizeof(st)}")

@@ -38,7 +38,20 @@ VMV_DEV u32x4_t pack8(const float* f) {
 }
 
 VMV_DEV float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-VMV_DEV float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16 output ulp): 1 rcp + 1 exp + 6 FMA,
+// ~4x cheaper than libdevice erff in the GEGLU epilogue.  gelu(x) = x * Phi(x), exact-erf form (F.gelu default).
+VMV_DEV float erf_as_f(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    float p = 1.061405429f;
+    p = p * t - 1.453152027f;
+    p = p * t + 1.421413741f;
+    p = p * t - 0.284496736f;
+    p = p * t + 0.254829592f;
+    const float r = 1.0f - p * t * __expf(-ax * ax);
+    return copysignf(r, x);
+}
+VMV_DEV float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as_f(x * 0.70710678118654752f)); }
 
 VMV_DEV float wave_sum(float v) {
 #pragma unroll

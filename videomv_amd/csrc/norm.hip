@@ -178,6 +178,41 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const VmvLayerNormParams
     }
 }
 
+// ------------------------------------------------------------------------------------------------ row softmax
+// One wave per row (4 rows per block); three passes over an L2-resident fp32 row (max, sum of exp2, write bf16).
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const VmvSoftmaxParams p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const float* s = p.s + row * p.lds;
+    const float sc = p.scale * 1.44269504088896341f;
+    const int n4 = p.n >> 2;
+    float mx = -3.0e38f;
+    for (int i = lane; i < n4; i += 64) {
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(s + 4 * i);
+        mx = fmaxf(fmaxf(fmaxf(mx, v.x), fmaxf(v.y, v.z)), v.w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    // scale may be negative in principle; VideoMV's is positive, so max(scale*s) = scale*max(s)
+    const float m2 = mx * sc;
+    float sum = 0.f;
+    for (int i = lane; i < n4; i += 64) {
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(s + 4 * i);
+        sum += __builtin_amdgcn_exp2f(v.x * sc - m2) + __builtin_amdgcn_exp2f(v.y * sc - m2) +
+               __builtin_amdgcn_exp2f(v.z * sc - m2) + __builtin_amdgcn_exp2f(v.w * sc - m2);
+    }
+    const float inv = 1.0f / wave_sum(sum);
+    uint16_t* out = reinterpret_cast<uint16_t*>(p.p) + row * p.ldp;
+    for (int i = lane; i < n4; i += 64) {
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(s + 4 * i);
+        u32x2_t w;
+        w.x = pack_bf16x2(__builtin_amdgcn_exp2f(v.x * sc - m2) * inv, __builtin_amdgcn_exp2f(v.y * sc - m2) * inv);
+        w.y = pack_bf16x2(__builtin_amdgcn_exp2f(v.z * sc - m2) * inv, __builtin_amdgcn_exp2f(v.w * sc - m2) * inv);
+        *reinterpret_cast<u32x2_t*>(out + 4 * i) = w;
+    }
+}
+
 int gn_check(const VmvGroupNormParams& p) {
     if (!p.x || !p.partial) return VMV_ENULL;
     const int C = p.C0 + p.C1;
@@ -236,5 +271,15 @@ extern "C" int vmv_layernorm(const VmvLayerNormParams* pp, void* stream) {
         !vmv_aligned16(p.beta)) return VMV_EALIGN;
     const int blocks = (p.rows + 3) / 4;
     hipLaunchKernelGGL(layernorm_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+    return vmv_launch_status();
+}
+
+extern "C" int vmv_softmax_rows(const VmvSoftmaxParams* pp, void* stream) {
+    if (!pp) return VMV_ENULL;
+    const VmvSoftmaxParams& p = *pp;
+    if (!p.s || !p.p) return VMV_ENULL;
+    if (p.rows <= 0 || p.n <= 0 || (p.n & 3) || p.scale <= 0.f) return VMV_EINVAL;
+    if (!vmv_aligned16(p.s) || (p.lds & 3) || (((uintptr_t)p.p) & 7) || (p.ldp & 3)) return VMV_EALIGN;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((p.rows + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
     return vmv_launch_status();
 }

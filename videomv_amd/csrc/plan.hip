@@ -20,6 +20,7 @@ int run_op(const VmvPlan::Op& o, void* stream) {
         case VMV_OP_GN_APPLY: return vmv_groupnorm_apply(reinterpret_cast<const VmvGroupNormParams*>(o.args.data()), stream);
         case VMV_OP_LAYERNORM: return vmv_layernorm(reinterpret_cast<const VmvLayerNormParams*>(o.args.data()), stream);
         case VMV_OP_ATTENTION: return vmv_attention_bf16(reinterpret_cast<const VmvAttnParams*>(o.args.data()), stream);
+        case VMV_OP_SOFTMAX: return vmv_softmax_rows(reinterpret_cast<const VmvSoftmaxParams*>(o.args.data()), stream);
         default: return VMV_EINVAL;
     }
 }
@@ -29,6 +30,7 @@ size_t op_size(int op) {
         case VMV_OP_GN_STATS: case VMV_OP_GN_APPLY: return sizeof(VmvGroupNormParams);
         case VMV_OP_LAYERNORM: return sizeof(VmvLayerNormParams);
         case VMV_OP_ATTENTION: return sizeof(VmvAttnParams);
+        case VMV_OP_SOFTMAX: return sizeof(VmvSoftmaxParams);
         default: return 0;
     }
 }

@@ -120,6 +120,12 @@ def attn_params(q, k, v, o, qm, km, vm, om, n_outer, heads, Nq, Nk, scale, kv_di
     return p
 
 
+def softmax_params(s, lds, p_out, ldp, rows, n, scale) -> L.SoftmaxParams:
+    p = L.SoftmaxParams()
+    p.s, p.lds, p.p, p.ldp, p.rows, p.n, p.scale = _ptr(s), int(lds), _ptr(p_out), int(ldp), int(rows), int(n), float(scale)
+    return p
+
+
 def _stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -167,6 +173,9 @@ class Stream:
 
     def attention(self, params, label="attn"):
         self._go(L.OP_ATTENTION, params, self.lib.vmv_attention_bf16, label)
+
+    def softmax(self, params, label="softmax"):
+        self._go(L.OP_SOFTMAX, params, self.lib.vmv_softmax_rows, label)
 
     def run(self, first=0, last=None):
         """Replay the recorded plan on the current torch stream."""

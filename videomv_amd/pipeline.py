@@ -1,0 +1,26 @@
+"""Sampling pipeline of the t2v entrance (tools/inferences/inference_text2video_entrance.py:249-289) on the HIP
+path: DDIM loop with batched CFG, then VAE decode of the 24 views in chunks of ``decoder_bs`` frames."""
+import torch
+
+
+@torch.no_grad()
+def sample_views(unet, diffusion, autoencoder, noise, y_cond, y_uncond, camera_data, guide_scale=9.0,
+                 ddim_timesteps=50, decoder_bs=4, scale_factor=0.18215, decode=True):
+    """noise [1, 4, F, h, w] (device) -> (latent x0 [1,4,F,h,w], video [1, 3, F, 8h, 8w] in [-1, 1] or None).
+
+    Mirrors the reference call (``diffusion.ddim_sample_loop(noise=..., model=..., model_kwargs=[cond, uncond],
+    guide_scale=9.0, ddim_timesteps=50, eta=0.0)`` at :259-265) followed by ``1/scale_factor * z`` and the chunked
+    ``autoencoder.decode`` of :280-289."""
+    kw = [dict(y=y_cond, camera_data=camera_data), dict(y=y_uncond, camera_data=camera_data)]
+    x0 = diffusion.ddim_sample_loop(noise=noise, model=unet, model_kwargs=kw, guide_scale=guide_scale,
+                                    ddim_timesteps=ddim_timesteps, eta=0.0)
+    if not decode:
+        return x0, None
+    b, c, f, h, w = x0.shape
+    z = (x0 * (1.0 / scale_factor)).permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)   # b c f h w -> (b f) c h w
+    outs = []
+    for i in range(0, b * f, decoder_bs):
+        outs.append(autoencoder.decode(z[i:i + decoder_bs].contiguous()))
+    img = torch.cat(outs, dim=0)
+    video = img.reshape(b, f, img.shape[1], img.shape[2], img.shape[3]).permute(0, 2, 1, 3, 4).contiguous()
+    return x0, video
