@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-op-profile", action="store_true")
     ap.add_argument("--dump-ops", type=str, default="", help="write the per-launch timing table to this file")
+    ap.add_argument("--no-sample", action="store_true", help="skip the (untimed-region) full 50-step + VAE-decode sample")
     args = ap.parse_args()
     H, W = (int(v) for v in args.latent.split("x"))
     rank = int(os.environ.get("RANK", "0"))
@@ -211,6 +212,30 @@ def main():
                     fl = gemm_flops(p) if op == L.OP_GEMM else (attn_flops(p) if op == L.OP_ATTENTION else 0.0)
                     f.write(f"{i}\t{labels[i]}\t{ms[i]:.4f}\t{fl / 1e9:.2f}\t{(fl / (ms[i] * 1e-3) / 1e12) if fl else 0:.1f}\n")
 
+    # ---- one complete 24-view sample: 50 DDIM steps + VAE decode of 24 frames in chunks of decoder_bs = 4
+    sample = None
+    if rank == 0 and world == 1 and not args.no_sample:
+        from videomv_amd.registry import AUTO_ENCODER
+        import videomv_amd.autoencoder  # noqa: F401
+        from videomv_amd.pipeline import sample_views, decode_views
+        dd = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
+                  num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+        with torch.device(dev):
+            vae = AUTO_ENCODER.build(dict(type="AutoencoderKL", ddconfig=dd, embed_dim=4))
+        randomize_(vae, 4321)
+        decode_views(vae, noise)                     # warm-up: builds the decoder plan
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        x0_lat, _ = sample_views(model, dif, vae, noise, y, y0, cam, guide_scale=9.0, ddim_timesteps=50, decode=False)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        vid = decode_views(vae, x0_lat, decoder_bs=4)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        sample = dict(seconds=round(t3 - t1, 4), ddim50_seconds=round(t2 - t1, 4), vae_decode24_seconds=round(t3 - t2, 4),
+                      samples_per_s=round(1.0 / (t3 - t1), 5), video_shape=list(vid.shape),
+                      finite=bool(torch.isfinite(vid).all() and torch.isfinite(x0_lat).all()))
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cores = os.cpu_count() or 1
@@ -239,7 +264,7 @@ def main():
                "weights, zero-inits re-randomised)",
                "config": {"workload": f"t2v_infer.yaml UNetSD_T2VBase 1.413B, 24 views, latent {H}x{W}, 77 ctx tokens, "
                                       f"1 sample per GPU (cond+uncond batched)", "parallelism": f"replicas x{world}"},
-               "samples_per_s_unet_only": round(steps_per_s / 50.0, 5), "finite": finite,
+               "sample_24view": sample, "finite": finite,
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))
     if dist is not None:

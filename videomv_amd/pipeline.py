@@ -16,11 +16,17 @@ def sample_views(unet, diffusion, autoencoder, noise, y_cond, y_uncond, camera_d
                                     ddim_timesteps=ddim_timesteps, eta=0.0)
     if not decode:
         return x0, None
+    return x0, decode_views(autoencoder, x0, decoder_bs, scale_factor)
+
+
+@torch.no_grad()
+def decode_views(autoencoder, x0, decoder_bs=4, scale_factor=0.18215):
+    """latent [b, 4, F, h, w] -> video [b, 3, F, 8h, 8w]: ``1/scale_factor * z`` then ``autoencoder.decode`` on chunks of
+    ``decoder_bs`` frames (inference_text2video_entrance.py:280-289)."""
     b, c, f, h, w = x0.shape
     z = (x0 * (1.0 / scale_factor)).permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)   # b c f h w -> (b f) c h w
     outs = []
     for i in range(0, b * f, decoder_bs):
         outs.append(autoencoder.decode(z[i:i + decoder_bs].contiguous()))
     img = torch.cat(outs, dim=0)
-    video = img.reshape(b, f, img.shape[1], img.shape[2], img.shape[3]).permute(0, 2, 1, 3, 4).contiguous()
-    return x0, video
+    return img.reshape(b, f, img.shape[1], img.shape[2], img.shape[3]).permute(0, 2, 1, 3, 4).contiguous()
