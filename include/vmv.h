@@ -99,6 +99,8 @@ typedef struct {
 #define VMV_TILE_128x160  2
 #define VMV_TILE_128x64   3
 #define VMV_TILE_64x64    4
+#define VMV_TILE_256x128  5   /* 8-wave LDS-DMA ring kernel (gemm_glds.hip) */
+#define VMV_TILE_256x160  6
 
 int vmv_gemm_bf16(const VmvGemmParams* p, void* stream);
 

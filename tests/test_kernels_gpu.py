@@ -63,7 +63,10 @@ def run_gemm(build, case, out_keys=("out",)):
 # ------------------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,N,K,tile", [(300, 320, 320, 0), (257, 128, 192, 0), (128, 64, 64, 0), (1000, 960, 320, 0),
                                         (77, 256, 1024, 0), (50, 4, 40, 0), (640, 640, 640, L.TILE_128x128),
-                                        (640, 640, 640, L.TILE_128x160), (64, 64, 128, L.TILE_64x64)])
+                                        (640, 640, 640, L.TILE_128x160), (64, 64, 128, L.TILE_64x64),
+                                        (640, 640, 640, L.TILE_256x128), (1000, 960, 320, L.TILE_256x160),
+                                        (300, 320, 320, L.TILE_256x160), (257, 128, 192, L.TILE_256x128),
+                                        (513, 200, 72, L.TILE_256x128), (2000, 1280, 1280, L.TILE_256x160)])
 def test_gemm_linear_bias(M, N, K, tile):
     c = Case(a=rnd((M, K), 1), w=rnd((N, K), 2, K ** -0.5), b=torch.randn(N, generator=g(3)), out=torch.zeros(M, N, dtype=BF))
 
@@ -73,7 +76,8 @@ def test_gemm_linear_bias(M, N, K, tile):
     check(dev["out"], cpu["out"])
 
 
-def test_gemm_fp32_out_rowvec_act_residual():
+@pytest.mark.parametrize("tile", [0, L.TILE_256x160])
+def test_gemm_fp32_out_rowvec_act_residual(tile):
     M, N, K = 384, 320, 128
     c = Case(a=rnd((M, K), 1), w=rnd((N, K), 2, K ** -0.5), b=torch.randn(N, generator=g(3)),
              rv=torch.randn(M // 64, 512, generator=g(4)), res=rnd((M, N), 5), out=torch.zeros(M, N))
@@ -81,12 +85,13 @@ def test_gemm_fp32_out_rowvec_act_residual():
     def build(t):
         return ops.gemm_params(M, N, ops.linear_segs([(t["a"], K, K)]), t["w"], t["out"], N, bias=t["b"],
                                rowvec=t["rv"].data_ptr() + 4 * 64, rowvec_div=64, rowvec_ld=512, act=L.ACT_SILU,
-                               residual=t["res"], ldr=N, out_fp32=True)
+                               residual=t["res"], ldr=N, out_fp32=True, tile=tile)
     cpu, dev = run_gemm(build, c)
     check(dev["out"], cpu["out"], tol_l2=1e-3, tol_max=2e-3)
 
 
-def test_gemm_geglu():
+@pytest.mark.parametrize("tile", [0, L.TILE_256x128])
+def test_gemm_geglu(tile):
     M, I2, K = 200, 512, 128        # 2*I = 512 rows -> 256 outputs
     w = rnd((I2, K), 2, K ** -0.5)
     b = torch.randn(I2, generator=g(3))
@@ -94,7 +99,7 @@ def test_gemm_geglu():
 
     def build(t):
         return ops.gemm_params(M, I2, ops.linear_segs([(t["a"], K, K)]), t["w"], t["out"], I2 // 2, bias=t["b"],
-                               epilogue=L.EPI_GEGLU)
+                               epilogue=L.EPI_GEGLU, tile=tile)
     cpu, dev = run_gemm(build, c)
     check(dev["out"], cpu["out"])
     # and against the un-interleaved definition x * gelu(gate)  (util.py:548-550)
@@ -103,9 +108,10 @@ def test_gemm_geglu():
     check(dev["out"], x * torch.nn.functional.gelu(gate))
 
 
+@pytest.mark.parametrize("tile", [0, L.TILE_256x128])
 @pytest.mark.parametrize("stride,ups,two_src,skip", [(1, 0, False, False), (2, 0, False, False), (1, 1, False, False),
                                                      (1, 0, True, True)])
-def test_gemm_conv3x3(stride, ups, two_src, skip):
+def test_gemm_conv3x3(stride, ups, two_src, skip, tile):
     n, IH, IW, C0, C1, N = 3, 10, 12, 64, (32 if two_src else 0), 128
     OH = (IH + 1) // 2 if stride == 2 else (IH * 2 if ups else IH)
     OW = (IW + 1) // 2 if stride == 2 else (IW * 2 if ups else IW)
@@ -125,7 +131,7 @@ def test_gemm_conv3x3(stride, ups, two_src, skip):
         if skip:
             segs += ops.linear_segs(srcs)
         return ops.gemm_params(M, N, segs, t["w"], t["out"], N, bias=t["b"],
-                               geom=ops.Geom(OH=OH, OW=OW, IH=IH, IW=IW, stride=stride, ups=ups))
+                               geom=ops.Geom(OH=OH, OW=OW, IH=IH, IW=IW, stride=stride, ups=ups), tile=tile)
     cpu, dev = run_gemm(build, c)
     check(dev["out"], cpu["out"])
     # independent check against F.conv2d on the same rounded operands
@@ -141,7 +147,8 @@ def test_gemm_conv3x3(stride, ups, two_src, skip):
     check(dev["out"], ref.permute(0, 2, 3, 1).reshape(M, N))
 
 
-def test_gemm_temporal_conv_residual():
+@pytest.mark.parametrize("tile", [0, L.TILE_256x128])
+def test_gemm_temporal_conv_residual(tile):
     Bn, F_, Pp, Cc = 2, 5, 24, 64
     M = Bn * F_ * Pp
     wt = torch.randn(Cc, Cc, 3, 1, 1, generator=g(2)) * (3 * Cc) ** -0.5
@@ -150,7 +157,7 @@ def test_gemm_temporal_conv_residual():
 
     def build(t):
         return ops.gemm_params(M, Cc, ops.temporal_segs(t["x"], Cc, Cc), t["w"], t["out"], Cc, bias=t["b"],
-                               geom=ops.Geom(F=F_, P=Pp), residual=t["res"], ldr=Cc)
+                               geom=ops.Geom(F=F_, P=Pp), residual=t["res"], ldr=Cc, tile=tile)
     cpu, dev = run_gemm(build, c)
     check(dev["out"], cpu["out"])
     x5 = cpu["x"].float().view(Bn, F_, Pp, Cc).permute(0, 3, 1, 2)[..., None]      # b c f p 1
@@ -159,15 +166,16 @@ def test_gemm_temporal_conv_residual():
     check(dev["out"], ref)
 
 
+@pytest.mark.parametrize("tile", [0, L.TILE_256x128])
 @pytest.mark.parametrize("ks", [2, 5])
-def test_gemm_splitk(ks):
+def test_gemm_splitk(ks, tile):
     M, N, K = 200, 256, 1280
     c = Case(a=rnd((M, K), 1), w=rnd((N, K), 2, K ** -0.5), b=torch.randn(N, generator=g(3)), res=rnd((M, N), 5),
              out=torch.zeros(M, N, dtype=BF), ws=torch.zeros(ks * M * N))
 
     def build(t):
         return ops.gemm_params(M, N, ops.linear_segs([(t["a"], K, K)]), t["w"], t["out"], N, bias=t["b"],
-                               residual=t["res"], ldr=N, ksplit=ks, workspace=t["ws"])
+                               residual=t["res"], ldr=N, ksplit=ks, workspace=t["ws"], tile=tile)
     cpu, dev = run_gemm(build, c)
     check(dev["out"], cpu["out"])
 

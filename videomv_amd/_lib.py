@@ -13,7 +13,7 @@ VMV_MAX_SEGS = 24
 SEG_LINEAR, SEG_SPATIAL, SEG_TEMPORAL = 0, 1, 2
 EPI_NONE, EPI_GEGLU = 0, 1
 ACT_NONE, ACT_SILU = 0, 1
-TILE_AUTO, TILE_128x128, TILE_128x160, TILE_128x64, TILE_64x64 = 0, 1, 2, 3, 4
+TILE_AUTO, TILE_128x128, TILE_128x160, TILE_128x64, TILE_64x64, TILE_256x128, TILE_256x160 = 0, 1, 2, 3, 4, 5, 6
 OP_GEMM, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTENTION, OP_SOFTMAX = 1, 2, 3, 4, 5, 6
 
 

@@ -14,18 +14,14 @@
 //     ds_read_b128 fragment reads and ds_write_b128 staging writes are bank-conflict free.
 //   * blockIdx -> tile is XCD-aware (8 XCDs, private L2): each XCD gets a contiguous range of tiles and walks
 //     the N tiles of one M tile first, so the activation tile is re-used out of that XCD's L2.
-#include "common.h"
+#include "gemm_common.h"
+#include <cstdlib>
+
+using namespace vmv_gemm;
+
+int vmv_gemm_glds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st);   // gemm_glds.hip
 
 namespace {
-
-constexpr int BK = 64;
-
-struct RowInfo {
-    int m;       // global row (or -1 when out of range)
-    int nb;      // spatial: image base row (n * IH * IW)
-    int oy, ox;  // spatial: output pixel
-    int fr;      // temporal: frame index
-};
 
 template <int WM, int WN>
 struct GemmCfg {
@@ -33,55 +29,6 @@ struct GemmCfg {
     static constexpr int BN = 32 * WN;
     static constexpr int LDS_BYTES = 2 * (BM + BN) * BK * 2;
 };
-
-VMV_DEV int seg_row_offset(const VmvGemmParams& p, const VmvGemmSeg& sg, const RowInfo& r) {
-    // element offset of the source row feeding output row r for this segment, or -1 (zero row)
-    if (r.m < 0) return -1;
-    if (sg.mode == VMV_SEG_LINEAR) return r.m * sg.ld;
-    if (sg.mode == VMV_SEG_SPATIAL) {
-        const int iy = r.oy * p.stride + sg.d0;
-        const int ix = r.ox * p.stride + sg.d1;
-        const int VH = p.IH << p.ups, VW = p.IW << p.ups;
-        if (iy < 0 || iy >= VH || ix < 0 || ix >= VW) return -1;
-        return (r.nb + (iy >> p.ups) * p.IW + (ix >> p.ups)) * sg.ld;
-    }
-    // temporal
-    const int f = r.fr + sg.d0;
-    if (f < 0 || f >= p.F) return -1;
-    return (r.m + sg.d0 * p.P) * sg.ld;
-}
-
-// Epilogue for 4 consecutive output channels [n, n+4) of row m.  v = accumulators (x half for GEGLU),
-// g = gate accumulators (GEGLU only).  `n` indexes W rows (pre-GEGLU numbering).
-VMV_DEV void epilogue_store(const VmvGemmParams& p, int m, int n, f32x4_t v, f32x4_t g) {
-    if (m >= p.M || n >= p.N) return;
-    if (p.bias) {
-        const f32x4_t b = *reinterpret_cast<const f32x4_t*>(p.bias + n);
-        v += b;
-        if (p.epilogue == VMV_EPI_GEGLU) g += *reinterpret_cast<const f32x4_t*>(p.bias + n + 16);
-    }
-    int no = n;
-    if (p.epilogue == VMV_EPI_GEGLU) {
-        v.x *= gelu_erf_f(g.x); v.y *= gelu_erf_f(g.y); v.z *= gelu_erf_f(g.z); v.w *= gelu_erf_f(g.w);
-        no = (n >> 5) * 16 + (n & 15);
-    }
-    if (p.rowvec) {
-        const f32x4_t rv = *reinterpret_cast<const f32x4_t*>(p.rowvec + (size_t)(m / p.rowvec_div) * p.rowvec_ld + no);
-        v += rv;
-    }
-    if (p.act == VMV_ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
-    if (p.residual) {
-        const u32x2_t r = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const uint16_t*>(p.residual) + (size_t)m * p.ldr + no);
-        v.x += bf16_lo(r.x); v.y += bf16_hi(r.x); v.z += bf16_lo(r.y); v.w += bf16_hi(r.y);
-    }
-    if (p.out_fp32) {
-        *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + no) = v;
-    } else {
-        u32x2_t o;
-        o.x = pack_bf16x2(v.x, v.y); o.y = pack_bf16x2(v.z, v.w);
-        *reinterpret_cast<u32x2_t*>(reinterpret_cast<uint16_t*>(p.out) + (size_t)m * p.ldo + no) = o;
-    }
-}
 
 template <int WM, int WN>
 __global__ __launch_bounds__(256) void gemm_kernel(const VmvGemmParams p, const int tiles_m, const int tiles_n,
@@ -302,19 +249,20 @@ int launch_cfg(const VmvGemmParams& p, int total_steps, hipStream_t st) {
     }
     dim3 grid(tiles_m * tiles_n, ks, 1);
     hipLaunchKernelGGL((gemm_kernel<WM, WN>), grid, dim3(256), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n, total_steps, sps);
-    int rc = vmv_launch_status();
-    if (rc != VMV_OK) return rc;
-    if (ks > 1) {
-        const long items = (long)p.M * (p.N / 4);
-        int blocks = (int)((items + 255) / 256);
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(gemm_splitk_reduce, dim3(blocks), dim3(256), 0, st, p);
-        rc = vmv_launch_status();
-    }
-    return rc;
+    return vmv_launch_status();
 }
 
-int pick_tile(const VmvGemmParams& p) {
+int gemm_policy() {
+    // VMV_GEMM_POLICY=0 disables the 256-row LDS-DMA kernel (A/B experiments); default 1.
+    static int pol = -1;
+    if (pol < 0) {
+        const char* e = getenv("VMV_GEMM_POLICY");
+        pol = e ? atoi(e) : 1;
+    }
+    return pol;
+}
+
+int pick_tile(const VmvGemmParams& p, int total_steps) {
     if (p.tile != VMV_TILE_AUTO) return p.tile;
     const int geglu = p.epilogue == VMV_EPI_GEGLU;
     auto padded = [&](int bn) { return ((p.N + bn - 1) / bn) * bn; };
@@ -322,6 +270,14 @@ int pick_tile(const VmvGemmParams& p) {
     if (!geglu && padded(160) <= best_pad) { best = VMV_TILE_128x160; best_pad = padded(160); }
     if (padded(64) < best_pad) { best = VMV_TILE_128x64; best_pad = padded(64); }
     if (p.M <= 64 && best == VMV_TILE_128x64) best = VMV_TILE_64x64;
+    if (gemm_policy() >= 1 && p.ksplit <= 1 && (best == VMV_TILE_128x128 || best == VMV_TILE_128x160)) {
+        // the 256-row kernel runs one block per CU: use it when its grid still fills the 256 CUs well
+        const int bn = best == VMV_TILE_128x128 ? 128 : 160;
+        const long tiles = (long)((p.M + 255) / 256) * ((p.N + bn - 1) / bn);
+        const long waves = (tiles + 255) / 256;
+        if (tiles >= 240 && (double)tiles / (double)(waves * 256) >= 0.8)
+            best = best == VMV_TILE_128x128 ? VMV_TILE_256x128 : VMV_TILE_256x160;
+    }
     return best;
 }
 
@@ -354,13 +310,31 @@ extern "C" int vmv_gemm_bf16(const VmvGemmParams* pp, void* stream) {
     if (p.ksplit > 1 && (!p.workspace || !vmv_aligned16(p.workspace))) return VMV_ENULL;
     if ((long)p.M * (long)maxld >= (1L << 31) || (long)p.N * (long)p.ktot >= (1L << 31)) return VMV_ERANGE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    switch (pick_tile(p)) {
-        case VMV_TILE_128x128: return launch_cfg<4, 4>(p, total_steps, st);
+    int rc;
+    switch (pick_tile(p, total_steps)) {
+        case VMV_TILE_128x128: rc = launch_cfg<4, 4>(p, total_steps, st); break;
         case VMV_TILE_128x160:
             if (p.epilogue == VMV_EPI_GEGLU) return VMV_EINVAL;
-            return launch_cfg<4, 5>(p, total_steps, st);
-        case VMV_TILE_128x64: return launch_cfg<4, 2>(p, total_steps, st);
-        case VMV_TILE_64x64: return launch_cfg<2, 2>(p, total_steps, st);
+            rc = launch_cfg<4, 5>(p, total_steps, st); break;
+        case VMV_TILE_128x64: rc = launch_cfg<4, 2>(p, total_steps, st); break;
+        case VMV_TILE_64x64: rc = launch_cfg<2, 2>(p, total_steps, st); break;
+        case VMV_TILE_256x128:
+            rc = vmv_gemm_glds_launch(p, total_steps, VMV_TILE_256x128, st);
+            if (rc == VMV_GLDS_UNSUPPORTED) rc = launch_cfg<4, 4>(p, total_steps, st);
+            break;
+        case VMV_TILE_256x160:
+            rc = vmv_gemm_glds_launch(p, total_steps, VMV_TILE_256x160, st);
+            if (rc == VMV_GLDS_UNSUPPORTED) rc = launch_cfg<4, 5>(p, total_steps, st);
+            break;
         default: return VMV_EINVAL;
     }
+    if (rc != VMV_OK) return rc;
+    if (p.ksplit > 1) {      // deterministic second pass: sum the fp32 slabs and run the epilogue
+        const long items = (long)p.M * (p.N / 4);
+        int blocks = (int)((items + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(gemm_splitk_reduce, dim3(blocks), dim3(256), 0, st, p);
+        rc = vmv_launch_status();
+    }
+    return rc;
 }

@@ -1,0 +1,318 @@
+// gemm_glds.hip — the large-tile variant of the bf16 MFMA implicit GEMM (same contract as gemm.hip / vmv.h).
+//
+//   * block = 512 threads = 8 waves (4 along M x 2 along N), tile 256 x {128,160}, BK = 64, ONE block per CU
+//     (2 waves per SIMD), wave tile 64 x {64,80} of v_mfma_f32_16x16x32_bf16 (transposed product, see gemm.hip).
+//   * operands go global -> LDS directly (LDS-DMA, global_load_lds_dwordx4): no staging VGPRs, no ds_write pass.
+//     Zero fill (conv padding, M/N/K tails) is done by pointing the lane at a zero page instead of predicating.
+//     The LDS image is lane-linear per wave instruction (8 rows x 128 B), so the XOR swizzle that makes the
+//     ds_read_b128 fragment reads conflict-free is applied to the per-lane SOURCE address.
+//   * 3-stage LDS ring (3 x 48/52 KB), loads run TWO chunks ahead of the MFMAs with counted s_waitcnt vmcnt(N)
+//     and one raw s_barrier per chunk:   wait(chunk t landed) -> barrier -> issue(chunk t+2) -> MFMA(chunk t).
+#include "gemm_common.h"
+#include <cstdlib>
+
+using namespace vmv_gemm;
+
+namespace {
+
+constexpr int GL_BM = 256;
+constexpr int GL_STAGES = 3;
+
+template <int WN>
+struct GlCfg {
+    static constexpr int BN = 32 * WN;
+    static constexpr int A_BYTES = GL_BM * 128;
+    static constexpr int W_BYTES = BN * 128;
+    static constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
+    static constexpr int LDS_BYTES = GL_STAGES * STAGE_BYTES;
+    static constexpr int NAI = GL_BM / 64;                 // A wave-instructions per wave per chunk (8 rows each)
+    static constexpr int NWI = (BN / 8 + 7) / 8;           // W wave-instructions per wave per chunk
+    static constexpr int LPT = NAI + NWI;                  // loads per lane per chunk
+};
+
+// 16-byte LDS-DMA through a buffer descriptor: lane address = base + voff + soff; a lane whose voff is out of range
+// (>= num_records) WRITES ZEROS to its LDS slot (verified on gfx950: tools/experiments/buffer_lds_oob.hip) — this is
+// how conv zero padding and the M / N / K tails are produced without a select on 64-bit pointers.
+#define VMV_BLDS16(rsrc, lptr, voff, soff) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lptr), 16, voff, soff, 0, 0)
+constexpr uint32_t OOB = 0x80000000u;          // > num_records of every descriptor below
+constexpr uint32_t SRD_RECORDS = 0x7ffffff0u;
+constexpr uint32_t SRD_FLAGS = 0x00020000u;
+
+template <int N> VMV_DEV void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    else static_assert(N == 0, "add the literal");
+}
+
+template <int WN, int ablate>
+__global__ __launch_bounds__(512) void gemm_glds_kernel(const VmvGemmParams p, const int tiles_m, const int tiles_n,
+                                                        const int total_steps, const int steps_per_split) {
+    // ablate (experiments only, VMV_GEMM_ABLATE): 1 = skip the MFMAs + fragment reads, 2 = skip the LDS-DMA loads
+    using Cfg = GlCfg<WN>;
+    constexpr int WM = 4;
+    constexpr int BN = Cfg::BN;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+
+    // ---- XCD-aware tile mapping (bijective)
+    const int nblk = tiles_m * tiles_n;
+    int logical;
+    {
+        const int bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = logical % tiles_n;
+    const int tile_m = logical / tiles_n;
+    const int m0 = tile_m * GL_BM, n0 = tile_n * BN;
+    const int split = blockIdx.y;
+    const int step_begin = split * steps_per_split;
+    const int step_end = min(total_steps, step_begin + steps_per_split);
+    const int nsteps = step_end - step_begin;
+
+    // ---- load assignment.  Wave instruction covers 8 rows x 128 B; lane -> (row-in-group = lane>>3, physical slot =
+    //      lane&7).  Row r stores logical slot s at physical slot s ^ ((r>>1)&7); for every row this lane touches
+    //      (r = 8*g + (lane>>3), g = 8*i + wave [- 8]) that XOR term is ((wave&1)*4 + (lane>>4)) & 7.
+    const int lrow = lane >> 3;
+    const int lsw = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);    // logical 16-B slot this lane fetches
+
+    RowInfo rinfo[Cfg::NAI];
+#pragma unroll
+    for (int i = 0; i < Cfg::NAI; ++i) {
+        const int m = m0 + (i * 8 + wave) * 8 + lrow;
+        RowInfo r;
+        r.m = (m < p.M) ? m : -1;
+        r.nb = 0; r.oy = 0; r.ox = 0; r.fr = 0;
+        if (p.OH > 0) {
+            const int hw = p.OH * p.OW;
+            const int n = m / hw, rem = m - n * hw;
+            r.nb = n * p.IH * p.IW;
+            r.oy = rem / p.OW;
+            r.ox = rem - r.oy * p.OW;
+        }
+        if (p.P > 0) r.fr = (m / p.P) % p.F;
+        rinfo[i] = r;
+    }
+    uint32_t wvo[Cfg::NWI];                       // per-lane byte offset of its weight row (+ its k-slot) or OOB
+    int wgrp[Cfg::NWI];
+#pragma unroll
+    for (int j = 0; j < Cfg::NWI; ++j) {
+        int g = j * 8 + wave;
+        if (g >= BN / 8) g -= 8;                 // duplicate an earlier row group: keeps the per-wave load count uniform
+        wgrp[j] = g;
+        const int n = n0 + g * 8 + lrow;
+        wvo[j] = (n < p.N) ? (uint32_t)(n * p.ktot + lsw * 8) * 2u : OOB;
+    }
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, SRD_RECORDS, SRD_FLAGS);
+
+    // ---- K-walk state (runs two chunks ahead of the MFMAs)
+    int s = 0, kc = 0, koff = 0;
+    {
+        int skip = step_begin;
+        while (s < p.nseg) {
+            const int nch = (p.seg[s].k + BK - 1) / BK;
+            if (skip < nch) { kc = skip * BK; break; }
+            skip -= nch; koff += p.seg[s].k; ++s;
+        }
+    }
+    uint32_t avo[Cfg::NAI];                       // per-lane byte offset of its gathered source row (+ k-slot) or OOB
+    auto enter_segment = [&]() {
+#pragma unroll
+        for (int i = 0; i < Cfg::NAI; ++i) {
+            const int off = seg_row_offset(p, p.seg[s], rinfo[i]);
+            avo[i] = off >= 0 ? (uint32_t)(off + lsw * 8) * 2u : OOB;
+        }
+    };
+    if (s < p.nseg && nsteps > 0) enter_segment();
+
+    auto issue = [&](int stage) {           // LDS-DMA one chunk into ring slot `stage`, then advance the walk
+        const VmvGemmSeg& sg = p.seg[s];
+        const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(sg.src), 0, SRD_RECORDS, SRD_FLAGS);
+        const bool ktail = (kc + BK) > sg.k;                    // uniform: only the last chunk of a segment with k % 64 != 0
+        const bool kvalid = (kc + lsw * 8) < sg.k;
+        unsigned char* abase = smem + stage * Cfg::STAGE_BYTES + wave * 1024;
+        unsigned char* wbase = smem + stage * Cfg::STAGE_BYTES + Cfg::A_BYTES;
+        const uint32_t a_so = (uint32_t)kc * 2u, w_so = (uint32_t)(koff + kc) * 2u;
+        if (!ktail) {
+#pragma unroll
+            for (int i = 0; i < Cfg::NAI; ++i) VMV_BLDS16(a_rsrc, abase + i * 8192, avo[i], a_so);
+#pragma unroll
+            for (int j = 0; j < Cfg::NWI; ++j) VMV_BLDS16(w_rsrc, wbase + wgrp[j] * 1024, wvo[j], w_so);
+        } else {
+#pragma unroll
+            for (int i = 0; i < Cfg::NAI; ++i) VMV_BLDS16(a_rsrc, abase + i * 8192, kvalid ? avo[i] : OOB, a_so);
+#pragma unroll
+            for (int j = 0; j < Cfg::NWI; ++j) VMV_BLDS16(w_rsrc, wbase + wgrp[j] * 1024, kvalid ? wvo[j] : OOB, w_so);
+        }
+        kc += BK;
+        if (kc >= sg.k) {
+            koff += sg.k; ++s; kc = 0;
+            if (s < p.nseg) enter_segment();
+        }
+    };
+
+    f32x4_t acc[WN][WM];
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int i = 0; i < WM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15;
+    const int fgrp = lane >> 4;
+    const int fswz = (frow >> 1) & 7;
+
+    // ---- software-pipelined main loop.  Fragment registers are double-buffered per k-step (kk = 0/1 of a 64-chunk):
+    //   [ds_read kk1(t)] [MFMA kk0(t)] | chunk t+1 landed? -> lgkmcnt(0) -> s_barrier -> LDS-DMA chunk t+3 into the slot
+    //   just freed | [ds_read kk0(t+1)] [MFMA kk1(t)]
+    // so every MFMA batch runs under the LDS reads of the next one (the lock-step "all waves read, then all waves
+    // multiply" phases of a plain loop leave the matrix pipe idle during the LDS burst), and the barrier of chunk t+1
+    // sits between two MFMA batches that need no LDS.
+    auto read_frags = [&](int slot_idx, int kk, bf16x8_t (&af)[WM], bf16x8_t (&wf)[WN]) {
+        const u32x4_t* a = reinterpret_cast<const u32x4_t*>(smem + slot_idx * Cfg::STAGE_BYTES) + (wave_m * 64 + frow) * 8;
+        const u32x4_t* w = reinterpret_cast<const u32x4_t*>(smem + slot_idx * Cfg::STAGE_BYTES + Cfg::A_BYTES) +
+                           (wave_n * 16 * WN + frow) * 8;
+        const int slot = (kk * 4 + fgrp) ^ fswz;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) af[i] = __builtin_bit_cast(bf16x8_t, a[i * 16 * 8 + slot]);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) wf[j] = __builtin_bit_cast(bf16x8_t, w[j * 16 * 8 + slot]);
+    };
+    auto mma = [&](const bf16x8_t (&af)[WM], const bf16x8_t (&wf)[WN]) {
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+    };
+
+    bf16x8_t a0[WM], w0[WN], a1[WM], w1[WN];
+    int issued = 0;
+    const int pro = nsteps < GL_STAGES ? nsteps : GL_STAGES;
+    for (int i = 0; i < pro; ++i) { issue(i); ++issued; }
+    if (ablate == 2) issued = nsteps;
+    if (nsteps > 0) {
+        if (pro == 3) wait_vmcnt<2 * Cfg::LPT>(); else if (pro == 2) wait_vmcnt<Cfg::LPT>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (ablate != 1) read_frags(0, 0, a0, w0);
+    }
+    int st = 0;                                   // ring slot of chunk t
+    for (int t = 0; t + 1 < nsteps; ++t) {        // (the last chunk is peeled below: no control-flow merge in here)
+        if constexpr (ablate != 1) {
+            read_frags(st, 1, a1, w1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, w0);
+        }
+        int stn = st + 1; if (stn == GL_STAGES) stn = 0;
+        if (t + 2 < nsteps) wait_vmcnt<Cfg::LPT>(); else wait_vmcnt<0>();          // chunk t+1 landed (mine)
+        __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): my reads of slot st are done (builtin: the compiler's
+                                                  // wait-count pass sees it and adds no second drain before the MFMAs)
+        __builtin_amdgcn_s_barrier();             // ... for every wave: slot st is free, chunk t+1 is visible
+        asm volatile("" ::: "memory");
+        if constexpr (ablate != 1) {
+            read_frags(stn, 0, a0, w0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, w1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // address arithmetic, scalar loads of the segment table and the LDS-DMA issue run in the shadow of the
+        // MFMA batch just issued (chunk t+3 -> the slot freed by the barrier above)
+        if (issued < nsteps) { issue(st); ++issued; }
+        __builtin_amdgcn_s_waitcnt(0xc07f);       // retire issue()'s scalar loads here (and the long-finished a0/w0
+                                                  // reads) so the next iteration's first MFMA batch needs no drain
+        st = stn;
+    }
+    if (nsteps > 0) {
+        if constexpr (ablate != 1) {
+            read_frags(st, 1, a1, w1);
+            mma(a0, w0);
+            mma(a1, w1);
+        }
+    }
+
+    // ---- epilogue (identical to gemm.hip)
+    const int mbase = m0 + wave_m * 64 + frow;
+    const int nbase = n0 + wave_n * 16 * WN + 4 * fgrp;
+    if (p.ksplit > 1) {
+        float* ws = p.workspace + (size_t)split * p.M * p.N;
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                const int m = mbase + 16 * i, n = nbase + 16 * j;
+                if (m < p.M && n < p.N) *reinterpret_cast<f32x4_t*>(ws + (size_t)m * p.N + n) = acc[j][i];
+            }
+        return;
+    }
+    if (p.epilogue == VMV_EPI_GEGLU) {
+        if constexpr ((WN & 1) == 0) {
+#pragma unroll
+            for (int j = 0; j < WN; j += 2)
+#pragma unroll
+                for (int i = 0; i < WM; ++i) epilogue_store(p, mbase + 16 * i, nbase + 16 * j, acc[j][i], acc[j + 1][i]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int i = 0; i < WM; ++i) epilogue_store(p, mbase + 16 * i, nbase + 16 * j, acc[j][i], acc[j][i]);
+    }
+}
+
+template <int WN>
+int launch_glds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
+    using Cfg = GlCfg<WN>;
+    static_assert(Cfg::LPT == 6 || Cfg::LPT == 7, "wait_vmcnt literals");
+    const int tiles_m = (p.M + GL_BM - 1) / GL_BM;
+    const int tiles_n = (p.N + Cfg::BN - 1) / Cfg::BN;
+    const int ks = p.ksplit > 1 ? p.ksplit : 1;
+    const int sps = (total_steps + ks - 1) / ks;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<WN, 0>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<WN, 1>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<WN, 2>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    static int ablate = -1;
+    if (ablate < 0) { const char* e = getenv("VMV_GEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
+    dim3 grid(tiles_m * tiles_n, ks, 1);
+    if (ablate == 2)
+        hipLaunchKernelGGL((gemm_glds_kernel<WN, 2>), grid, dim3(512), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n, total_steps, sps);
+    else if (ablate == 1)
+        hipLaunchKernelGGL((gemm_glds_kernel<WN, 1>), grid, dim3(512), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n, total_steps, sps);
+    else
+        hipLaunchKernelGGL((gemm_glds_kernel<WN, 0>), grid, dim3(512), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n, total_steps, sps);
+    return vmv_launch_status();
+}
+
+}  // namespace
+
+// Called by vmv_gemm_bf16 (gemm.hip) after argument validation.  The split-K reduce pass stays in gemm.hip.
+int vmv_gemm_glds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st) {
+    // 32-bit byte offsets through buffer descriptors: every operand must span < 2 GiB
+    long maxrows = p.M;
+    if (p.OH > 0) { const long src_rows = (long)(p.M / (p.OH * p.OW) + 1) * p.IH * p.IW; if (src_rows > maxrows) maxrows = src_rows; }
+    for (int i = 0; i < p.nseg; ++i)
+        if (maxrows * (long)p.seg[i].ld * 2 >= (1L << 31) - 65536) return VMV_GLDS_UNSUPPORTED;
+    if ((long)p.N * p.ktot * 2 >= (1L << 31) - 65536) return VMV_GLDS_UNSUPPORTED;
+    if (tile == VMV_TILE_256x128) return launch_glds<4>(p, total_steps, st);
+    if (tile == VMV_TILE_256x160) {
+        if (p.epilogue == VMV_EPI_GEGLU) return VMV_EINVAL;
+        return launch_glds<5>(p, total_steps, st);
+    }
+    return VMV_EINVAL;
+}
