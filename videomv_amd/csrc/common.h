@@ -59,6 +59,7 @@ VMV_DEV float wave_sum(float v) {
     return v;
 }
 
+VMV_DEV bool vmv_ptr_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int vmv_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 static inline int vmv_launch_status() {
     hipError_t e = hipGetLastError();

@@ -33,8 +33,14 @@ struct GlCfg {
 // 16-byte LDS-DMA through a buffer descriptor: lane address = base + voff + soff; a lane whose voff is out of range
 // (>= num_records) WRITES ZEROS to its LDS slot (verified on gfx950: tools/experiments/buffer_lds_oob.hip) — this is
 // how conv zero padding and the M / N / K tails are produced without a select on 64-bit pointers.
-#define VMV_BLDS16(rsrc, lptr, voff, soff) \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lptr), 16, voff, soff, 0, 0)
+// (the builtin is only visible to the device pass: hipcc's host pass otherwise silently drops the kernel template's
+//  instantiation — stub and handle come out undefined — so the body is compiled for the device only)
+VMV_DEV void blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lptr, uint32_t voff, uint32_t soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lptr), 16, voff, soff, 0, 0);
+#endif
+}
+#define VMV_BLDS16(rsrc, lptr, voff, soff) blds16(rsrc, lptr, voff, soff)
 constexpr uint32_t OOB = 0x80000000u;          // > num_records of every descriptor below
 constexpr uint32_t SRD_RECORDS = 0x7ffffff0u;
 constexpr uint32_t SRD_FLAGS = 0x00020000u;
@@ -253,18 +259,89 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const VmvGemmParams p, c
             }
         return;
     }
-    if (p.epilogue == VMV_EPI_GEGLU) {
-        if constexpr ((WN & 1) == 0) {
+    // ---- bf16 outputs go through LDS: the MFMA layout gives every lane 4 channels of one row (8-byte pieces, a
+    //      128-B line is touched by 4 different store instructions); staging the tile lets the block write whole
+    //      rows with 16-byte lanes and read the residual the same way.  For the short-K linears (5 chunks per tile) the
+    //      epilogue is as long as the main loop, so this matters.
+    const bool geglu = p.epilogue == VMV_EPI_GEGLU;
+    const int out_w = geglu ? BN / 2 : BN;                       // output columns of this tile
+    const int n_out0 = geglu ? n0 / 2 : n0;
+    const int N_out = geglu ? p.N / 2 : p.N;
+    const bool staged = !p.out_fp32 && (p.ldo & 7) == 0 && (N_out & 7) == 0 && vmv_ptr_aligned16(p.out) &&
+                        (!p.residual || ((p.ldr & 7) == 0 && vmv_ptr_aligned16(p.residual)));
+    if (!staged) {
+        if (geglu) {
+            if constexpr ((WN & 1) == 0) {
 #pragma unroll
-            for (int j = 0; j < WN; j += 2)
+                for (int j = 0; j < WN; j += 2)
 #pragma unroll
-                for (int i = 0; i < WM; ++i) epilogue_store(p, mbase + 16 * i, nbase + 16 * j, acc[j][i], acc[j + 1][i]);
+                    for (int i = 0; i < WM; ++i) epilogue_store(p, mbase + 16 * i, nbase + 16 * j, acc[j][i], acc[j + 1][i]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int i = 0; i < WM; ++i) epilogue_store(p, mbase + 16 * i, nbase + 16 * j, acc[j][i], acc[j][i]);
         }
-    } else {
+        return;
+    }
+    __syncthreads();                                             // ring no longer read by anyone
+    const int row_bytes = out_w * 2 + 16;                        // +16 B: spreads the 8-byte writes over the banks
+    {
+        const int trow0 = wave_m * 64 + frow;
+        const int tcol0 = wave_n * 16 * WN + 4 * fgrp;
 #pragma unroll
-        for (int j = 0; j < WN; ++j)
+        for (int j = 0; j < WN; ++j) {
+            if (geglu && (j & 1)) continue;
 #pragma unroll
-            for (int i = 0; i < WM; ++i) epilogue_store(p, mbase + 16 * i, nbase + 16 * j, acc[j][i], acc[j][i]);
+            for (int i = 0; i < WM; ++i) {
+                const int m = mbase + 16 * i, n = nbase + 16 * j;
+                f32x4_t v = acc[j][i];
+                int tc = tcol0 + 16 * j;
+                if (n < p.N) {
+                    if (p.bias) v += *reinterpret_cast<const f32x4_t*>(p.bias + n);
+                    int no = n;
+                    if (geglu) {
+                        if constexpr ((WN & 1) == 0) {
+                            f32x4_t g = acc[(j + 1) % WN][i];
+                            if (p.bias) g += *reinterpret_cast<const f32x4_t*>(p.bias + n + 16);
+                            v.x *= gelu_erf_f(g.x); v.y *= gelu_erf_f(g.y); v.z *= gelu_erf_f(g.z); v.w *= gelu_erf_f(g.w);
+                        }
+                        no = (n >> 5) * 16 + (n & 15);
+                        tc = (tc >> 5) * 16 + (tc & 15);
+                    }
+                    if (p.rowvec && m < p.M)
+                        v += *reinterpret_cast<const f32x4_t*>(p.rowvec + (size_t)(m / p.rowvec_div) * p.rowvec_ld + no);
+                    if (p.act == VMV_ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+                } else if (geglu) {
+                    tc = (tc >> 5) * 16 + (tc & 15);
+                }
+                u32x2_t o;
+                o.x = pack_bf16x2(v.x, v.y); o.y = pack_bf16x2(v.z, v.w);
+                *reinterpret_cast<u32x2_t*>(smem + (trow0 + 16 * i) * row_bytes + tc * 2) = o;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int U = out_w >> 3;                                // 16-byte units per tile row
+        uint16_t* outp = reinterpret_cast<uint16_t*>(p.out);
+        const uint16_t* resp = reinterpret_cast<const uint16_t*>(p.residual);
+        for (int idx = tid; idx < GL_BM * U; idx += 512) {
+            const int r = idx / U, u = idx - r * U;
+            const int m = m0 + r, n = n_out0 + u * 8;
+            if (m >= p.M || n >= N_out) continue;
+            u32x4_t v = *reinterpret_cast<const u32x4_t*>(smem + r * row_bytes + u * 16);
+            if (resp) {
+                const u32x4_t rr = *reinterpret_cast<const u32x4_t*>(resp + (size_t)m * p.ldr + n);
+                float a[8], b[8];
+                unpack8(v, a); unpack8(rr, b);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] += b[e];
+                v = pack8(a);
+            }
+            *reinterpret_cast<u32x4_t*>(outp + (size_t)m * p.ldo + n) = v;
+        }
     }
 }
 
