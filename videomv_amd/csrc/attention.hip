@@ -55,8 +55,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const VmvAttnParams p, const 
     constexpr int NT = (WPP == 4) ? 256 : 64;
     const int stid = (WPP == 4) ? tid : lane;
     unsigned char* region = smem_raw + ((WPP == 4) ? 0 : wave * 16384);
-    u32x4_t* const Ks = reinterpret_cast<u32x4_t*>(region);            // [64 keys][8 slots] 16-B units
-    uint16_t* const Vt = reinterpret_cast<uint16_t*>(region + 8192);   // [64 d][64 keys] bf16
+    // per stage: K tile [64 keys][8 slots] in 16-B units (8 KB) then V^T tile [64 d][64 keys] bf16 (8 KB)
 
     // ---- Q fragments (B operand): row q0 + 16*qt + u, k-slot kk*32 + 8*g
     bf16x8_t qf[2][2];
@@ -82,29 +81,76 @@ __global__ __launch_bounds__(256) void attn_kernel(const VmvAttnParams p, const 
     const float sc = p.scale * 1.44269504088896341f;   // exp2 domain
 
     const int ntile = (p.Nk + 63) >> 6;
-    for (int kt = 0; kt < ntile; ++kt) {
-        const int key0 = kt * 64;
-        __syncthreads();   // previous tile's fragment reads are done
-        // ---- stage K (row-major, swizzled) and V (transposed, swizzled)
-        for (int idx = stid; idx < 512; idx += NT) {
-            const int row = idx >> 3, slot = idx & 7;
-            const int key = key0 + row;
-            u32x4_t kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-            if (wvalid && key < p.Nk) {
-                kv = *reinterpret_cast<const u32x4_t*>(kp + (long)key * p.km.s_row + slot * 8);
-                vv = *reinterpret_cast<const u32x4_t*>(vp + (long)key * p.vm.s_row + slot * 8);
-            }
-            Ks[row * 8 + (slot ^ k_swz(row))] = kv;
-            const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+    // K/V staging.  WPP = 4: two LDS stages; the next tile's global loads are issued BEFORE the current tile's MFMAs
+    // and written to the other stage after them (one barrier per tile, HBM/L2 latency hidden under the math).
+    // WPP = 1 (one short problem per wave, a single tile in practice): plain load -> write -> barrier.
+    constexpr int NPIECE = 512 / NT;               // 16-byte pieces of K (and of V) per lane per tile
+    u32x4_t kreg[(WPP == 4) ? NPIECE : 1], vreg[(WPP == 4) ? NPIECE : 1];
+    auto load_tile = [&](int kt2) {
+        if constexpr (WPP == 4) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int d = slot * 8 + j;
-                const int fk = ((slot ^ (((slot & 1) << 2) | (j >> 1))) & 7) << 3;   // = 8*(((d>>3)^(d>>1))&7)
-                const uint16_t val = (j & 1) ? (uint16_t)(w[j >> 1] >> 16) : (uint16_t)(w[j >> 1] & 0xffffu);
-                Vt[d * 64 + (row ^ fk)] = val;
+            for (int i = 0; i < NPIECE; ++i) {
+                const int idx = stid + i * NT;
+                const int row = idx >> 3, slot = idx & 7;
+                const int key = kt2 * 64 + row;
+                u32x4_t kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+                if (key < p.Nk) {
+                    kv = *reinterpret_cast<const u32x4_t*>(kp + (long)key * p.km.s_row + slot * 8);
+                    vv = *reinterpret_cast<const u32x4_t*>(vp + (long)key * p.vm.s_row + slot * 8);
+                }
+                kreg[i] = kv; vreg[i] = vv;
             }
         }
+    };
+    auto write_piece = [&](u32x4_t* Ksd, uint16_t* Vtd, int idx, const u32x4_t& kv, const u32x4_t& vv) {
+        const int row = idx >> 3, slot = idx & 7;
+        Ksd[row * 8 + (slot ^ k_swz(row))] = kv;
+        const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = slot * 8 + j;
+            const int fk = ((slot ^ (((slot & 1) << 2) | (j >> 1))) & 7) << 3;   // = 8*(((d>>3)^(d>>1))&7)
+            const uint16_t val = (j & 1) ? (uint16_t)(w[j >> 1] >> 16) : (uint16_t)(w[j >> 1] & 0xffffu);
+            Vtd[d * 64 + (row ^ fk)] = val;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        if constexpr (WPP == 4) {
+            u32x4_t* Ksd = reinterpret_cast<u32x4_t*>(region + buf * 16384);
+            uint16_t* Vtd = reinterpret_cast<uint16_t*>(region + buf * 16384 + 8192);
+#pragma unroll
+            for (int i = 0; i < NPIECE; ++i) write_piece(Ksd, Vtd, stid + i * NT, kreg[i], vreg[i]);
+        }
+    };
+    if constexpr (WPP == 4) {
+        load_tile(0);
+        store_tile(0);
         __syncthreads();
+    }
+    for (int kt = 0; kt < ntile; ++kt) {
+        const int key0 = kt * 64;
+        const u32x4_t* Ks;
+        const uint16_t* Vt;
+        if constexpr (WPP == 4) {
+            if (kt + 1 < ntile) load_tile(kt + 1);
+            Ks = reinterpret_cast<const u32x4_t*>(region + (kt & 1) * 16384);
+            Vt = reinterpret_cast<const uint16_t*>(region + (kt & 1) * 16384 + 8192);
+        } else {
+            u32x4_t* Ksd = reinterpret_cast<u32x4_t*>(region);
+            uint16_t* Vtd = reinterpret_cast<uint16_t*>(region + 8192);
+            __syncthreads();   // previous tile's fragment reads are done
+            for (int idx = stid; idx < 512; idx += NT) {
+                const int key = key0 + (idx >> 3);
+                u32x4_t kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+                if (wvalid && key < p.Nk) {
+                    kv = *reinterpret_cast<const u32x4_t*>(kp + (long)key * p.km.s_row + (idx & 7) * 8);
+                    vv = *reinterpret_cast<const u32x4_t*>(vp + (long)key * p.vm.s_row + (idx & 7) * 8);
+                }
+                write_piece(Ksd, Vtd, idx, kv, vv);
+            }
+            __syncthreads();
+            Ks = Ksd; Vt = Vtd;
+        }
 
         // ---- S^T tiles
         f32x4_t s[2][4];
@@ -182,6 +228,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const VmvAttnParams p, const 
                     oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][kk], oacc[qt][dt], 0, 0, 0);
             }
         }
+        if constexpr (WPP == 4) {
+            if (kt + 1 < ntile) store_tile((kt + 1) & 1);     // the other stage: last read two tiles ago
+            __syncthreads();
+        }
     }
 
     // ---- normalise and store: lane owns O[q = q0 + 16 qt + u][d = 16 dt + 4 g + 0..3]
@@ -232,7 +282,7 @@ extern "C" int vmv_attention_bf16(const VmvAttnParams* pp, void* stream) {
         hipLaunchKernelGGL((attn_kernel<1>), dim3((nproblems + 3) / 4), dim3(256), 65536, st, p, nproblems);
     } else {
         if (p.n_outer > 65535 || p.heads > 65535) return VMV_ERANGE;
-        hipLaunchKernelGGL((attn_kernel<4>), dim3((p.Nq + 127) / 128, p.heads, p.n_outer), dim3(256), 16384, st, p, 0);
+        hipLaunchKernelGGL((attn_kernel<4>), dim3((p.Nq + 127) / 128, p.heads, p.n_outer), dim3(256), 32768, st, p, 0);
     }
     return vmv_launch_status();
 }

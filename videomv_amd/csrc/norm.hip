@@ -3,6 +3,7 @@
 // wave-shuffle + LDS reductions, and NO atomics (partial sums are written per chunk and reduced in a fixed
 // order, so results are bitwise reproducible run to run).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -38,7 +39,20 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const VmvGroupNormParams 
             const bool first = c < p.C0;
             const uint16_t* base = first ? (x0 + c) : (x1 + (c - p.C0));
             const long ld = first ? p.ld : p.ld1;
-            for (long r = row0 + rl; r < row_end; r += RPP) {
+            long r = row0 + rl;
+            for (; r + 3L * RPP < row_end; r += 4L * RPP) {      // 4 independent 16-B loads in flight per lane
+                u32x4_t v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const u32x4_t*>(base + (r + (long)k * RPP) * ld);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float f[8];
+                    unpack8(v[k], f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+                }
+            }
+            for (; r < row_end; r += RPP) {
                 const u32x4_t v = *reinterpret_cast<const u32x4_t*>(base + r * ld);
                 float f[8];
                 unpack8(v, f);
@@ -76,16 +90,21 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const VmvGroupNormParams 
     float* shift = sh + C;    // [C]
     float* s_mean = sh + 2 * C;   // [32]  (all LDS in the one dynamic region: keeps the base 16-B aligned)
     float* s_rstd = s_mean + 32;  // [32]
-    if (tid < 32) {
+    {   // fold the per-chunk partial sums: 8 lanes per group, fixed order (lane-strided sums, then xor-shuffles)
+        const int g = tid >> 3, sub = tid & 7;
         float s = 0.f, q = 0.f;
-        const float* pp = p.partial + ((long)stat * nchunk * 32 + tid) * 2;
-        for (int c = 0; c < nchunk; ++c) { s += pp[(long)c * 64]; q += pp[(long)c * 64 + 1]; }
-        const float n = (float)p.rows_per_stat * (float)cpg;
-        const float mean = s / n;
-        float var = q / n - mean * mean;
-        var = var < 0.f ? 0.f : var;
-        s_mean[tid] = mean;
-        s_rstd[tid] = rsqrtf(var + p.eps);
+        const float* pp = p.partial + ((long)stat * nchunk * 32 + g) * 2;
+        for (int c = sub; c < nchunk; c += 8) { s += pp[(long)c * 64]; q += pp[(long)c * 64 + 1]; }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+        if (sub == 0) {
+            const float n = (float)p.rows_per_stat * (float)cpg;
+            const float mean = s / n;
+            float var = q / n - mean * mean;
+            var = var < 0.f ? 0.f : var;
+            s_mean[g] = mean;
+            s_rstd[g] = rsqrtf(var + p.eps);
+        }
     }
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
@@ -99,30 +118,49 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const VmvGroupNormParams 
     long row_end = row0 + apply_rows;
     const long stat_end = (long)(stat + 1) * p.rows_per_stat;
     if (row_end > stat_end) row_end = stat_end;
-    const int nitem = (int)(row_end - row0) * CS;
+    // thread -> fixed 16-byte column slot (its 8 scale/shift pairs live in registers), rows strided: no integer
+    // division and no LDS traffic in the streaming loop, 4 independent loads in flight per lane.
+    const int TPR = CS < 256 ? CS : 256;
+    const int RPP = 256 / TPR;
+    const int rl = tid / TPR, cl = tid - rl * TPR;
     const uint16_t* x0 = reinterpret_cast<const uint16_t*>(p.x);
     const uint16_t* x1 = reinterpret_cast<const uint16_t*>(p.x1);
     uint16_t* y = reinterpret_cast<uint16_t*>(p.y);
-    for (int it = tid; it < nitem; it += 256) {
-        const int rr = it / CS;
-        const int cs = it - rr * CS;
-        const long r = row0 + rr;
-        const int c = cs * 8;
-        const u32x4_t v = (c < p.C0) ? *reinterpret_cast<const u32x4_t*>(x0 + r * p.ld + c)
-                                     : *reinterpret_cast<const u32x4_t*>(x1 + r * p.ld1 + (c - p.C0));
-        float f[8];
-        unpack8(v, f);
-        const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(scale + c);
-        const f32x4_t a1 = *reinterpret_cast<const f32x4_t*>(scale + c + 4);
-        const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(shift + c);
-        const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(shift + c + 4);
-        f[0] = f[0] * a0.x + b0.x; f[1] = f[1] * a0.y + b0.y; f[2] = f[2] * a0.z + b0.z; f[3] = f[3] * a0.w + b0.w;
-        f[4] = f[4] * a1.x + b1.x; f[5] = f[5] * a1.y + b1.y; f[6] = f[6] * a1.z + b1.z; f[7] = f[7] * a1.w + b1.w;
-        if (p.silu) {
+    if (rl < RPP) {
+        for (int cs = cl; cs < CS; cs += TPR) {
+            const int c = cs * 8;
+            float a[8], b[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e]);
+            for (int e = 0; e < 8; ++e) { a[e] = scale[c + e]; b[e] = shift[c + e]; }
+            const bool first = c < p.C0;
+            const uint16_t* src = first ? (x0 + c) : (x1 + (c - p.C0));
+            const long ld = first ? p.ld : p.ld1;
+            uint16_t* dst = y + c;
+            auto stream = [&](auto silu_tag) {
+                constexpr bool SILU = decltype(silu_tag)::value;
+                auto xform = [&](const u32x4_t& v) {
+                    float f[8];
+                    unpack8(v, f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        f[e] = f[e] * a[e] + b[e];
+                        if constexpr (SILU) f[e] = silu_f(f[e]);
+                    }
+                    return pack8(f);
+                };
+                long r = row0 + rl;
+                for (; r + 3L * RPP < row_end; r += 4L * RPP) {
+                    u32x4_t v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const u32x4_t*>(src + (r + (long)k * RPP) * ld);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4_t*>(dst + (r + (long)k * RPP) * p.ldy) = xform(v[k]);
+                }
+                for (; r < row_end; r += RPP)
+                    *reinterpret_cast<u32x4_t*>(dst + r * p.ldy) = xform(*reinterpret_cast<const u32x4_t*>(src + r * ld));
+            };
+            if (p.silu) stream(std::true_type{}); else stream(std::false_type{});
         }
-        *reinterpret_cast<u32x4_t*>(y + r * p.ldy + c) = pack8(f);
     }
 }
 
