@@ -170,6 +170,20 @@ def manifest_case(ns):
         json.dump({"n_keys": len(man), "keys": man}, f, indent=0)
 
 
+def camera_case():
+    """Orbit cameras of the t2v entrance (utils/camera_utils.py get_camera + the row flips at
+    inference_text2video_entrance.py:186-191) -> camera_data [1,24,16]."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_camera_utils", os.path.join(shim.REF_ROOT, "utils", "camera_utils.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    cam = m.get_camera(24, elevation=15, azimuth_start=0, azimuth_span=360, camera_distance=2.0).unsqueeze(0)
+    cam = cam.reshape(1, 24, 4, 4)
+    cam[:, :, 1, :] *= -1
+    cam[:, :, [0, 1], :] = cam[:, :, [1, 0], :]
+    save_file({"camera_data": cam.reshape(1, 24, 16).contiguous()}, os.path.join(GOLD, "camera_24.safetensors"))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ns = shim.load_reference()
@@ -180,6 +194,7 @@ def main():
     unet_case(ns, "unet_tiny_b", TINY_B, seed=4321, F_=3, H=8, W=12, L=5)
     vae_case(ns)
     manifest_case(ns)
+    camera_case()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,61 @@
+"""BASELINE configs[0] (plumbing): `inference.py --cfg configs/t2v_infer.yaml` with 4 views and 2 DDIM steps through
+config loading -> registries -> entrance -> sampler -> VAE decode -> files.  No GPU here: launches are routed to the
+test-side interpreter (tests/plan_interp.py), the product code path is otherwise unchanged."""
+import os
+
+import torch
+import pytest
+
+from tests import plan_interp
+
+
+def test_config_layers_and_overrides(tmp_path):
+    from videomv_amd.config import Config, default_cfg, merge_into
+    c = Config(load=True, argv=["--cfg", "configs/t2v_infer.yaml", "guide_scale", "7.5", "UNet.head_dim", "32", "seed", "3"])
+    d = c.cfg_dict
+    assert d["TASK_TYPE"] == "inference_text2video_entrance" and d["ENABLE"] is True      # base.yaml merged
+    assert d["guide_scale"] == 7.5 and d["UNet"]["head_dim"] == 32 and d["seed"] == 3
+    assert c.UNet.dim_mult == [1, 2, 4, 4]
+    cfg = merge_into(default_cfg(), d)
+    # dim / attn_scales come only from the python defaults and survive the dict merge
+    assert cfg["UNet"]["dim"] == 320 and cfg["UNet"]["attn_scales"] == [1.0, 0.5, 0.25]
+    assert cfg["UNet"]["type"] == "UNetSD_T2VBase" and cfg["UNet"]["out_dim"] == 4
+    with pytest.raises(AssertionError):
+        Config(load=True, argv=["--cfg", "configs/t2v_infer.yaml", "UNet.nonexistent.key", "1"])
+
+
+def test_camera_matches_reference_golden(golden_dir):
+    from safetensors.torch import load_file
+    from videomv_amd.camera import entrance_camera_data
+    g = load_file(os.path.join(golden_dir, "camera_24.safetensors"))
+    assert torch.equal(entrance_camera_data(24, elevation=15, camera_distance=2.0), g["camera_data"])
+
+
+def test_entrance_four_views_two_steps(monkeypatch, tmp_path):
+    plan_interp.install(monkeypatch)
+    from videomv_amd.config import Config
+    from videomv_amd.registry import INFER_ENGINE
+    import videomv_amd.entrance  # noqa: F401
+    prompts = tmp_path / "prompts.txt"
+    prompts.write_text("a wooden chair\n# skipped\n")
+    argv = ["--cfg", "configs/t2v_infer.yaml", "--debug",
+            "device", "cpu", "allow_random_init", "True", "num_views", "4", "ddim_timesteps", "2",
+            "test_list_path", str(prompts), "log_dir", str(tmp_path / "out"),
+            "UNet.num_heads", "2", "UNet.num_res_blocks", "1", "UNet.dim_mult", "[1, 2]",
+            "test_model", "none.pth"]
+    cu = Config(load=True, argv=argv)
+    cu.cfg_dict["UNet"]["dim"] = 64                               # tiny net for the CPU interpreter
+    cu.cfg_dict["UNet"]["attn_scales"] = [1.0, 0.5]
+    cu.cfg_dict["resolution"] = [64, 64]                          # latent 8x8 (overrides the vldm_cfg 256x256)
+    cu.cfg_dict["auto_encoder"] = {"type": "AutoencoderKL", "embed_dim": 4, "pretrained": "none.pth",
+                                   "ddconfig": {"double_z": True, "z_channels": 4, "resolution": 64, "in_channels": 3,
+                                                "out_ch": 3, "ch": 32, "ch_mult": [1, 2, 4, 4], "num_res_blocks": 2,
+                                                "attn_resolutions": [], "dropout": 0.0}}
+    cu.cfg_dict["vldm_cfg"] = "configs/t2v_train.yaml"
+    cfg = INFER_ENGINE.build(dict(type=cu.TASK_TYPE), cfg_update=cu.cfg_dict)
+    assert cfg.Diffusion["schedule"] == "linear_sd"               # came from the vldm_cfg overlay
+    out = [f for f in os.listdir(cfg.log_dir) if f.endswith(".pt")]
+    assert len(out) == 1 and out[0].startswith("rank_01_00_0000_a_wooden_chair_3d_asset_15_2.00")
+    blob = torch.load(os.path.join(cfg.log_dir, out[0]))
+    assert blob["latent"].shape == (1, 4, 4, 8, 8) and blob["video"].shape == (1, 3, 4, 64, 64)
+    assert torch.isfinite(blob["video"]).all()

@@ -1,0 +1,182 @@
+"""Configuration loading with the reference's three layers (utils/config.py:10-228, tools/modules/config.py):
+python defaults  <-  YAML (``--cfg``, with ``_BASE`` / ``_BASE_RUN`` / ``_BASE_MODEL`` inheritance and ``configs/base.yaml``)
+<-  trailing ``key value`` CLI overrides (dotted keys, depth <= 4).  Nested dict keys *update* defaults, scalars
+replace them (inference_text2video_entrance.py:39-43); ``vldm_cfg`` names a second YAML that is overlaid at worker
+start (utils/assign_cfg.py:64-76).  Own implementation; only keys the inference hot path reads are defaulted."""
+import argparse
+import copy
+import json
+import os
+
+import yaml
+
+
+class AttrDict(dict):
+    """dict with attribute access (the reference uses easydict.EasyDict for ``cfg``)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def __deepcopy__(self, memo):
+        return AttrDict({k: copy.deepcopy(v, memo) for k, v in self.items()})
+
+
+def default_cfg() -> AttrDict:
+    """Python-side defaults (tools/modules/config.py): F1 of SURVEY — ``dim`` and ``attn_scales`` live ONLY here."""
+    c = AttrDict()
+    c.mean, c.std = [0.5, 0.5, 0.5], [0.5, 0.5, 0.5]
+    c.max_words, c.num_workers = 1000, 8
+    c.resolution = [448, 256]
+    c.vit_out_dim = 1024
+    c.seed, c.max_frames, c.batch_size = 8888, 16, 1
+    c.scale_factor = 0.18215
+    c.use_fp16 = True
+    c.ddim_timesteps = 50
+    c.guide_scale = 3.0
+    c.decoder_bs, c.chunk_size = 4, 2
+    c.Diffusion = {'type': 'DiffusionDDIM', 'schedule': 'cosine',
+                   'schedule_param': {'num_timesteps': 1000, 'cosine_s': 0.008, 'zero_terminal_snr': True},
+                   'mean_type': 'v', 'loss_type': 'mse', 'var_type': 'fixed_small', 'rescale_timesteps': False,
+                   'noise_strength': 0.1, 'ddim_timesteps': 50}
+    c.UNet = {'type': 'UNetSD', 'in_dim': 4, 'dim': 320, 'y_dim': 1024, 'context_dim': 1024, 'out_dim': 8,
+              'dim_mult': [1, 2, 4, 4], 'num_heads': 8, 'head_dim': 64, 'num_res_blocks': 2,
+              'attn_scales': [1 / 1, 1 / 2, 1 / 4], 'dropout': 0.1, 'temporal_attention': True,
+              'temporal_attn_times': 1, 'use_checkpoint': True, 'use_fps_condition': False, 'use_sim_mask': False}
+    c.auto_encoder = {'type': 'AutoencoderKL',
+                      'ddconfig': {'double_z': True, 'z_channels': 4, 'resolution': 256, 'in_channels': 3, 'out_ch': 3,
+                                   'ch': 128, 'ch_mult': [1, 2, 4, 4], 'num_res_blocks': 2, 'attn_resolutions': [],
+                                   'dropout': 0.0, 'video_kernel_size': [3, 1, 1]},
+                      'embed_dim': 4, 'pretrained': './pretrained_models/modelscope_t2v/VQGAN_autoencoder.pth'}
+    c.embedder = {'type': 'FrozenOpenCLIPEmbedder', 'layer': 'penultimate',
+                  'pretrained': './pretrained_models/modelscope_t2v/open_clip_pytorch_model.bin'}
+    c.log_dir = 'workspace/output_data'
+    c.debug = False
+    # keys added by this implementation (defaults preserve the reference behaviour)
+    c.device = 'cuda'                 # the hot path has no CPU implementation; tests route launches to an interpreter
+    c.allow_random_init = False       # run with random weights when a checkpoint file is missing (benchmarks / CI)
+    c.num_views = None                # None -> max_frames
+    return c
+
+
+def merge_into(cfg: dict, upd: dict) -> dict:
+    """dict values update, everything else replaces (inference_text2video_entrance.py:39-43)."""
+    for k, v in upd.items():
+        if isinstance(v, dict) and k in cfg and isinstance(cfg[k], dict):
+            cfg[k].update(v)
+        else:
+            cfg[k] = v
+    return cfg
+
+
+def _coerce(val):
+    if not isinstance(val, str):
+        return val
+    try:
+        return yaml.safe_load(val)
+    except Exception:
+        return val
+
+
+class Config(object):
+    def __init__(self, load=True, cfg_dict=None, cfg_level=None, argv=None):
+        self._level = "cfg" + ("." + cfg_level if cfg_level is not None else "")
+        if load:
+            self.args = self._parse_args(argv)
+            base = self._load_file(self._base_yaml(self.args.cfg_file)) or {}
+            cfg_dict = self._merge(base, self._load_yaml(self.args.cfg_file))
+            cfg_dict = self._apply_opts(cfg_dict, self.args.opts)
+            for k, v in vars(self.args).items():
+                cfg_dict[k] = v
+            self.cfg_dict = cfg_dict
+        self._update_dict(cfg_dict)
+
+    @staticmethod
+    def _parse_args(argv=None):
+        p = argparse.ArgumentParser(description="videomv_amd inference / benchmark configuration")
+        p.add_argument("--cfg", dest="cfg_file", default="configs/t2v_infer.yaml", help="Path to the configuration file")
+        p.add_argument("--init_method", default="tcp://localhost:9999", type=str)
+        p.add_argument("--debug", action="store_true", default=False)
+        p.add_argument("opts", default=None, nargs=argparse.REMAINDER, help="key value pairs overriding the YAML")
+        return p.parse_args(argv)
+
+    @staticmethod
+    def _load_file(path):
+        if path and os.path.exists(path):
+            with open(path, "r") as f:
+                return yaml.load(f.read(), Loader=yaml.SafeLoader) or {}
+        return None
+
+    @staticmethod
+    def _base_yaml(cfg_file):
+        here = os.path.join(os.path.dirname(os.path.abspath(cfg_file)), "base.yaml")
+        return here if os.path.exists(here) else os.path.join("configs", "base.yaml")
+
+    def _load_yaml(self, path):
+        cfg = self._load_file(path)
+        if cfg is None:
+            raise FileNotFoundError(path)
+        for key, keep in (("_BASE", False), ("_BASE_RUN", True), ("_BASE_MODEL", False)):
+            if key in cfg:
+                parent = os.path.normpath(os.path.join(os.path.dirname(path), cfg[key]))
+                cfg = self._merge(self._load_yaml(parent), cfg, preserve_base=keep)
+        return cfg
+
+    def _merge(self, base, new, preserve_base=False):
+        for k, v in new.items():
+            if k in base:
+                if isinstance(v, dict) and isinstance(base[k], dict):
+                    self._merge(base[k], v)
+                else:
+                    base[k] = v
+            elif "BASE" not in k or preserve_base:
+                base[k] = v
+        return base
+
+    @staticmethod
+    def _apply_opts(cfg, opts):
+        opts = list(opts or [])
+        assert len(opts) % 2 == 0, f"Override list {opts} has odd length: {len(opts)}."
+        for key, val in zip(opts[0::2], opts[1::2]):
+            parts = key.split(".")
+            assert len(parts) <= 4, f"Key depth error. Maximum depth: 3, got {len(parts)}"
+            node = cfg
+            for part in parts[:-1]:
+                assert part in node, f"Non-existant key: {key}."
+                node = node[part]
+            node[parts[-1]] = _coerce(val)
+        return cfg
+
+    def _update_dict(self, cfg_dict):
+        for k, v in (cfg_dict or {}).items():
+            if type(v) is dict:
+                v = Config(load=False, cfg_dict=v, cfg_level=k)
+            elif type(v) is str and v[1:3] == "e-":       # the reference's '1e-4' -> float quirk (utils/config.py:209)
+                v = float(v)
+            self.__dict__[k] = v
+
+    def get_args(self):
+        return self.args
+
+    def dump(self):
+        return json.dumps(self.cfg_dict, indent=2, default=str)
+
+    def __repr__(self):
+        return "{}\n".format(self.dump())
+
+    def deep_copy(self):
+        return copy.deepcopy(self)
+
+
+def assign_signle_cfg(cfg, cfg_update, tname):
+    """Overlay the YAML named by ``cfg_update[tname]`` (e.g. ``vldm_cfg``) on a copy of cfg (utils/assign_cfg.py:64-76;
+    the typo is the reference's public name)."""
+    out = copy.deepcopy(cfg)
+    with open(cfg_update[tname], "r") as f:
+        upd = yaml.load(f.read(), Loader=yaml.SafeLoader) or {}
+    return merge_into(out, upd)
