@@ -129,3 +129,25 @@ def test_vae_decode_matches_reference_golden(golden_dir):
     assert img.shape == g["img"].shape
     e = rel_l2(img, g["img"])
     assert e < 2e-2, e
+
+
+def test_inference_py_entry_on_gpu(tmp_path):
+    """`python inference.py --cfg configs/t2v_infer.yaml ...` end to end on the GPU (random weights, 4 views, 2 steps,
+    latent 32x32 = the reference's real shape): config layering -> registries -> HIP UNet -> fused CFG/DDIM -> HIP VAE."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prompts = tmp_path / "p.txt"
+    prompts.write_text("a wooden chair\n")
+    cmd = [sys.executable, "inference.py", "--cfg", "configs/t2v_infer.yaml", "--debug", "allow_random_init", "True",
+           "num_views", "4", "ddim_timesteps", "2", "test_list_path", str(prompts), "log_dir", str(tmp_path / "out"),
+           "UNet.num_res_blocks", "1", "UNet.dim_mult", "[1, 2]", "test_model", "none.pth"]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    outdir = tmp_path / "out" / "p"
+    pts = [f for f in os.listdir(outdir) if f.endswith(".pt")]
+    assert len(pts) == 1
+    blob = torch.load(os.path.join(outdir, pts[0]))
+    assert blob["latent"].shape == (1, 4, 4, 32, 32) and blob["video"].shape == (1, 3, 4, 256, 256)
+    assert torch.isfinite(blob["video"]).all()
+    assert any(f.endswith(".png") for f in os.listdir(outdir))
