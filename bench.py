@@ -140,8 +140,10 @@ def main():
     stride = 1000 // 50
     xt = noise.clone()
 
+    kw_c, kw_u = dict(y=y, camera_data=cam), dict(y=y0, camera_data=cam)
+
     def one_step(i):
-        dif.ddim_step_hip(xt, steps[i % len(steps)], model, y, y0, cam, 9.0, stride)
+        dif.ddim_step_hip(xt, steps[i % len(steps)], model, kw_c, kw_u, 9.0, stride)
 
     for i in range(args.warmup):
         one_step(i)

@@ -184,6 +184,9 @@ int vmv_attention_bf16(const VmvAttnParams* p, void* stream);
  * whole volume written nrep times: the cond / uncond CFG branches see the same x_t) */
 int vmv_latent_to_rows(const float* x, void* rows, int nb_src, int C, int F, int H, int W, int Cpad, int nrep,
                        void* stream);
+/* same gather, but ONLY channels [0, C) of each ld-wide row are written (the rest of the row is left untouched): the
+ * I2VGen input rows carry x_t in channels 0..3 and the step-invariant image `concat` in 4..7 (unet_i2vgen.py:383) */
+int vmv_latent_to_rows_keep(const float* x, void* rows, int nb, int C, int F, int H, int W, int ld, int nrep, void* stream);
 /* rows [n*HW][ld] (bf16 or fp32) -> image/latent [n][C][H][W] fp32 (C <= ld) */
 int vmv_rows_to_nchw(const void* rows, int rows_fp32, int ld, float* out, int n, int C, int HW, void* stream);
 
@@ -206,6 +209,20 @@ int vmv_emb_combine_silu(const float* temb, const float* cam, void* out, int row
                          int cam_rows, void* stream);
 /* sinusoidal timestep embedding (cos || sin), out fp32->bf16 [n][dim]  (util.py:177-189) */
 int vmv_sinusoidal(const float* t, void* out_bf16, int n, int dim, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * I2VGen-XL front-end helpers (once per sample; unet_i2vgen.py:331-346, 156-162).
+ * ---------------------------------------------------------------------------------------------------- */
+/* TransformerV2(depth 1, dim 4, heads 2, dim_head 4, mlp 16) over the F frames of every pixel (util.py:1091-1148):
+ *   x = to_out(softmax(q k^T / 2) v) + x  with q,k,v = to_qkv(LayerNorm(x));   x = W2 gelu(W1 x + b1) + b2 + x
+ * in: bf16 rows [F*HW][ld_in] (4 channels used); out: `scale` * result written to bf16 rows [nrep][F*HW][ld_out] at
+ * channel offset 0 of `out` (pass out = base + 4 to fill channels 4..7).  w = packed fp32 parameter block:
+ *   ln_g[4] ln_b[4] Wqkv[24][4] Wo[4][8] bo[4] W1[16][4] b1[16] W2[4][16] b2[4]   (288 floats). */
+int vmv_i2v_temporal_adapter(const void* in, int ld_in, void* out, int ld_out, const float* w, int F, int HW, int nrep,
+                             float scale, void* stream);
+/* nn.AdaptiveAvgPool2d((OH,OW)) on channels-last rows: in [n*IH*IW][ld] -> out [n*OH*OW][ldo], C % 8 == 0 */
+int vmv_adaptive_avgpool_rows(const void* in, int ld, void* out, int ldo, int n, int C, int IH, int IW, int OH, int OW,
+                              void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Plan: a recorded sequence of the launches above, replayed with one call (host-side launch overhead of

@@ -170,6 +170,45 @@ def manifest_case(ns):
         json.dump({"n_keys": len(man), "keys": man}, f, indent=0)
 
 
+def i2v_case(ns):
+    """Tiny UNetSD_I2VGen (I2VGen-XL front-end, BASELINE configs[3] analogue): eps/v + concat + context tokens."""
+    import importlib
+    from .unet_i2v_ref import i2v_param_shapes
+    torch.Tensor.cuda = lambda self, *a, **k: self          # unet_i2vgen.py:334 hard-codes .cuda()
+    m = importlib.import_module("tools.modules.unet.unet_i2vgen")
+    c = dict(in_dim=4, dim=64, context_dim=1024, out_dim=4, dim_mult=[1, 2], num_heads=2, head_dim=64,
+             num_res_blocks=1, attn_scales=[1.0, 0.5])
+    ref = m.UNetSD_I2VGen(y_dim=1024, dropout=0.1, temporal_attention=True, use_checkpoint=False,
+                          use_camera_condition=True, use_lgm_refine=False, use_fps_condition=False, concat_dim=4,
+                          **c).eval()
+    cfg = UNetCfg(**c)
+    trunk = unet_param_shapes(UNetCfg(**dict(c, in_dim=8)))
+    shapes = dict(trunk)
+    shapes.update(i2v_param_shapes(cfg))
+    ref_sd = ref.state_dict()
+    assert set(ref_sd.keys()) == set(shapes.keys()), set(ref_sd.keys()) ^ set(shapes.keys())
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), (k, v.shape, shapes[k])
+    ordered = {k: shapes[k] for k in sorted(shapes)}          # generation order = sorted keys (order-independent)
+    sd = random_state_dict(ordered, 2024)
+    ref.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(2025)
+    B, F_, H, W, L = 2, 3, 8, 8, 5
+    x = torch.randn(B, 4, F_, H, W, generator=g)
+    t = torch.tensor([481, 41])
+    y = torch.randn(B, L, 1024, generator=g)
+    img = torch.randn(B, 1, 1024, generator=g)
+    li = torch.randn(B, 4, H, W, generator=g)
+    cam = torch.randn(B, F_, 16, generator=g)
+    fps = torch.tensor([8, 8])
+    with torch.no_grad():
+        out = ref(x, t, y=y, image=img, local_image=li.unsqueeze(2).repeat_interleave(F_, dim=2), fps=fps, camera_data=cam)
+    save_file({"x": x, "t": t, "y": y, "image": img, "local_image": li, "camera_data": cam, "fps": fps,
+               "out": out.contiguous(), "weights_checksum": torch.tensor([checksum(sd)], dtype=torch.float64)},
+              os.path.join(GOLD, "unet_i2v_tiny.safetensors"), metadata={"cfg": json.dumps(c), "seed": "2024"})
+    print("i2v", tuple(out.shape), float(out.abs().mean()))
+
+
 def camera_case():
     """Orbit cameras of the t2v entrance (utils/camera_utils.py get_camera + the row flips at
     inference_text2video_entrance.py:186-191) -> camera_data [1,24,16]."""
@@ -195,6 +234,7 @@ def main():
     vae_case(ns)
     manifest_case(ns)
     camera_case()
+    i2v_case(ns)
 
 
 if __name__ == "__main__":

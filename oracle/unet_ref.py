@@ -251,6 +251,14 @@ def unet_forward(sd: Dict[str, torch.Tensor], cfg: UNetCfg, x: torch.Tensor, t: 
     if cfg.use_camera_condition and camera_data is not None:
         emb = emb + _mlp(sd, "camera_embedding", camera_data.reshape(b * f, -1))
     context = y.repeat_interleave(f, dim=0)
+    return unet_trunk(sd, cfg, x, emb, context, taps)
+
+
+@torch.no_grad()
+def unet_trunk(sd, cfg: UNetCfg, x, emb, context, taps=None):
+    """Shared encoder / middle / decoder / head (unet_t2v.py:348-368 == unet_i2vgen.py:385-404).
+    x [b, c_in, f, h, w]; emb [(b f), E]; context [(b f), L, ctx]."""
+    b, c, f, h, w = x.shape
     x = x.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)
     inp, mid, outb = block_plan(cfg)
     xs = []

@@ -150,6 +150,40 @@ def latent_to_rows(x, rows, Cpad, nrep):
     rows.copy_(full.repeat(nrep, 1).to(torch.bfloat16))
 
 
+def latent_to_rows_keep(x, rows, ld, nrep):
+    nb, Cc, F_, H, W = x.shape
+    r = x.permute(0, 2, 3, 4, 1).reshape(nb * F_ * H * W, Cc).to(torch.bfloat16)
+    rows.view(nrep, nb * F_ * H * W, ld)[:, :, :Cc] = r[None]
+
+
+def i2v_temporal_adapter(inp, ld_in, out_ptr, ld_out, w, F_, HW, nrep, scale):
+    import torch.nn.functional as Fn
+    x = _rows(_p(inp), F_ * HW, ld_in)[:, :4].float().view(F_, HW, 4).permute(1, 0, 2)        # pix f c
+    ln_g, ln_b, Wqkv, Wo, bo = w[0:4], w[4:8], w[8:104].view(24, 4), w[104:136].view(4, 8), w[136:140]
+    W1, b1, W2, b2 = w[140:204].view(16, 4), w[204:220], w[220:284].view(4, 16), w[284:288]
+    hn = Fn.layer_norm(x, (4,), ln_g, ln_b, 1e-5)
+    q, k, v = (hn @ Wqkv.t()).chunk(3, dim=-1)
+    sp = lambda t: t.reshape(HW, F_, 2, 4).permute(0, 2, 1, 3)
+    a = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) * 0.5, dim=-1) @ sp(v)
+    y = a.permute(0, 2, 1, 3).reshape(HW, F_, 8) @ Wo.t() + bo + x
+    z = Fn.gelu(y @ W1.t() + b1) @ W2.t() + b2 + y
+    res = (scale * z).permute(1, 0, 2).reshape(F_ * HW, 4).to(torch.bfloat16)
+    out = _view(_p(out_ptr), (nrep * F_ * HW - 1) * ld_out + 4, "bf16")
+    idx = torch.arange(nrep * F_ * HW)[:, None] * ld_out + torch.arange(4)[None, :]
+    out[idx.reshape(-1)] = res.repeat(nrep, 1).reshape(-1)
+
+
+def adaptive_avgpool_rows(inp, ld, out, ldo, n, Cc, IH, IW, OH, OW):
+    import torch.nn.functional as Fn
+    x = _rows(_p(inp), n * IH * IW, ld)[:, :Cc].float().view(n, IH, IW, Cc).permute(0, 3, 1, 2)
+    y = Fn.adaptive_avg_pool2d(x, (OH, OW)).permute(0, 2, 3, 1).reshape(n * OH * OW, Cc)
+    _rows(_p(out), n * OH * OW, ldo)[:, :Cc] = y.to(torch.bfloat16)
+
+
+def _p(t):
+    return t if isinstance(t, int) else t.data_ptr()
+
+
 def rows_to_nchw(rows, ld, out):
     n, Cc, H, W = out.shape
     out.copy_(rows.view(n, H * W, ld)[:, :, :Cc].float().permute(0, 2, 1).reshape(n, Cc, H, W))
@@ -211,5 +245,6 @@ def install(monkeypatch):
     monkeypatch.setattr(ops.Stream, "__init__", init)
     monkeypatch.setattr(ops.Stream, "_go", _go)
     monkeypatch.setattr(ops.Stream, "run", run)
-    for name in ("latent_to_rows", "rows_to_nchw", "emb_combine_silu", "sinusoidal", "cfg_ddim_step"):
+    for name in ("latent_to_rows", "latent_to_rows_keep", "rows_to_nchw", "emb_combine_silu", "sinusoidal", "cfg_ddim_step",
+                 "i2v_temporal_adapter", "adaptive_avgpool_rows"):
         monkeypatch.setattr(ops, name, globals()[name])

@@ -321,3 +321,34 @@ def test_layout_and_ddim_kernels():
     s_ref = torch.zeros(2, 320, dtype=BF)
     I.sinusoidal(t, s_ref, 2, 320)
     assert (s.cpu().float() - s_ref.float()).abs().max() < 2e-2     # sin/cos of ~1e3 rad: fp32 range reduction differs
+
+
+def test_i2v_frontend_kernels():
+    """vmv_i2v_temporal_adapter / vmv_adaptive_avgpool_rows / vmv_latent_to_rows_keep vs the torch restatement."""
+    F_, HW = 24, 40
+    a3 = rnd((F_ * HW, 4), 1)
+    w = torch.randn(288, generator=g(2)) * 0.5
+    w[0:4] = 1 + 0.1 * w[0:4]
+    out_ref = torch.zeros(2 * F_ * HW, 8, dtype=BF)
+    I.i2v_temporal_adapter(a3, 4, out_ref.data_ptr() + 8, 8, w, F_, HW, 2, 2.0)
+    out = torch.zeros(2 * F_ * HW, 8, dtype=BF, device="cuda")
+    a3d, wd = a3.cuda(), w.cuda()
+    ops.i2v_temporal_adapter(a3d, 4, out.data_ptr() + 8, 8, wd, F_, HW, 2, 2.0)
+    torch.cuda.synchronize()
+    assert torch.equal(out[:, :4].cpu(), torch.zeros(2 * F_ * HW, 4, dtype=BF))          # channels 0..3 untouched
+    check(out[:, 4:], out_ref[:, 4:], tol_l2=5e-3, tol_max=1.5e-2)
+    for (ih, iw) in ((8, 8), (40, 64), (32, 32)):
+        x = rnd((2 * ih * iw, 32), 3)
+        y_ref = torch.zeros(2 * 32 * 32, 32, dtype=BF)
+        I.adaptive_avgpool_rows(x, 32, y_ref, 32, 2, 32, ih, iw, 32, 32)
+        y = torch.zeros(2 * 32 * 32, 32, dtype=BF, device="cuda")
+        xd = x.cuda()
+        ops.adaptive_avgpool_rows(xd, 32, y, 32, 2, 32, ih, iw, 32, 32)
+        torch.cuda.synchronize()
+        check(y, y_ref, tol_l2=4e-3, tol_max=1e-2)
+    lat = torch.randn(1, 4, 3, 5, 6, generator=g(4))
+    rows_ref = torch.full((2 * 3 * 30, 8), 7.0, dtype=BF)
+    I.latent_to_rows_keep(lat, rows_ref, 8, 2)
+    rows = torch.full((2 * 3 * 30, 8), 7.0, dtype=BF, device="cuda")
+    ops.latent_to_rows_keep(lat.cuda(), rows, 8, 2)
+    assert torch.equal(rows.cpu(), rows_ref) and float(rows[:, 4:].float().min()) == 7.0

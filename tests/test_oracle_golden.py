@@ -118,3 +118,19 @@ def test_full_size_manifest(golden_dir):
         vman = json.load(f)["keys"]
     for k, shp in vae_decoder_param_shapes().items():
         assert list(shp) == vman[k], k
+
+
+def test_i2vgen_forward_matches_reference(golden_dir):
+    """UNetSD_I2VGen front-end (concat x2 bug included, 64 local + 4 image context tokens, fps embedding) + trunk."""
+    from oracle.unet_i2v_ref import unet_i2v_forward, i2v_param_shapes
+    path = os.path.join(golden_dir, "unet_i2v_tiny.safetensors")
+    g = load_file(path)
+    meta = _meta(path)
+    c = json.loads(meta["cfg"])
+    cfg = UNetCfg(**c)
+    shapes = dict(unet_param_shapes(UNetCfg(**dict(c, in_dim=8))))
+    shapes.update(i2v_param_shapes(cfg))
+    sd = random_state_dict({k: shapes[k] for k in sorted(shapes)}, int(meta["seed"]))
+    assert checksum(sd) == pytest.approx(float(g["weights_checksum"][0]), rel=1e-12)
+    out = unet_i2v_forward(sd, cfg, g["x"], g["t"], g["y"], g["image"], g["local_image"], g["fps"], g["camera_data"])
+    assert _rel(out, g["out"]) < 1e-5

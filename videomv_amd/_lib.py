@@ -87,6 +87,9 @@ SYMBOLS = {
     "vmv_attention_bf16": (C.c_int, [C.POINTER(AttnParams), _P]),
     "vmv_softmax_rows": (C.c_int, [C.POINTER(SoftmaxParams), _P]),
     "vmv_latent_to_rows": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "vmv_latent_to_rows_keep": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "vmv_i2v_temporal_adapter": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
+    "vmv_adaptive_avgpool_rows": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "vmv_rows_to_nchw": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P]),
     "vmv_cfg_ddim_step": (C.c_int, [C.POINTER(DdimParams), _P]),
     "vmv_emb_combine_silu": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

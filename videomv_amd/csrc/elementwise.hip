@@ -24,6 +24,132 @@ __global__ void latent_to_rows_kernel(const float* __restrict__ x, uint16_t* __r
     }
 }
 
+__global__ void latent_to_rows_keep_kernel(const float* __restrict__ x, uint16_t* __restrict__ rows, int nb, int C, int F,
+                                           long HW, int ld, int nrep) {
+    const long per = (long)nb * F * HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i % HW;
+        const long bf = i / HW;
+        const int f = (int)(bf % F);
+        const int b = (int)(bf / F);
+        for (int rep = 0; rep < nrep; ++rep) {
+            uint16_t* dst = rows + ((long)rep * per + i) * ld;
+            for (int c = 0; c < C; ++c) dst[c] = (uint16_t)f32_to_bf16_bits(x[(((long)b * C + c) * F + f) * HW + pix]);
+        }
+    }
+}
+
+// One wave per pixel, lane = frame (F <= 64).  Everything for a pixel lives in registers; k/v of other frames are
+// fetched with wave shuffles.  Tiny (2560 pixels x ~10 kFLOP): latency only, runs once per sample.
+__global__ __launch_bounds__(256) void i2v_temporal_adapter_kernel(const uint16_t* __restrict__ in, int ld_in,
+                                                                   uint16_t* __restrict__ out, int ld_out,
+                                                                   const float* __restrict__ w, int F, int HW, int nrep,
+                                                                   float scale) {
+    const int lane = threadIdx.x & 63;
+    const int pix = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= HW) return;
+    const float* ln_g = w; const float* ln_b = w + 4; const float* Wqkv = w + 8; const float* Wo = w + 104;
+    const float* bo = w + 136; const float* W1 = w + 140; const float* b1 = w + 204; const float* W2 = w + 220;
+    const float* b2 = w + 284;
+    const bool act = lane < F;
+    float x[4] = {0.f, 0.f, 0.f, 0.f};
+    if (act) {
+        const uint16_t* src = in + ((long)lane * HW + pix) * ld_in;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) x[c] = bf16_to_f32(src[c]);
+    }
+    // LayerNorm over the 4 channels (eps 1e-5)
+    const float mean = 0.25f * (x[0] + x[1] + x[2] + x[3]);
+    float var = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) var += (x[c] - mean) * (x[c] - mean);
+    const float rstd = rsqrtf(0.25f * var + 1e-5f);
+    float hn[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) hn[c] = (x[c] - mean) * rstd * ln_g[c] + ln_b[c];
+    float qkv[24];
+#pragma unroll
+    for (int o = 0; o < 24; ++o) {
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a += Wqkv[o * 4 + c] * hn[c];
+        qkv[o] = a;
+    }
+    // attention: heads 2, dim_head 4, scale 4^-0.5; q = qkv[0:8], k = qkv[8:16], v = qkv[16:24], head h -> [4h, 4h+4)
+    float o8[8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float m = -3.0e38f, l = 0.f, acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < F; ++j) {
+            float s = 0.f, vj[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                s += qkv[4 * h + d] * __shfl(qkv[8 + 4 * h + d], j, 64);
+                vj[d] = __shfl(qkv[16 + 4 * h + d], j, 64);
+            }
+            s *= 0.5f;
+            const float mn = fmaxf(m, s);
+            const float a = __expf(m - mn), e = __expf(s - mn);
+            l = l * a + e;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) acc[d] = acc[d] * a + e * vj[d];
+            m = mn;
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o8[4 * h + d] = acc[d] / l;
+    }
+    float y[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float a = bo[c];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a += Wo[c * 8 + k] * o8[k];
+        y[c] = a + x[c];
+    }
+    float hid[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        float a = b1[k];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a += W1[k * 4 + c] * y[c];
+        hid[k] = gelu_erf_f(a);
+    }
+    if (act) {
+        uint16_t r[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float a = b2[c];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a += W2[c * 16 + k] * hid[k];
+            r[c] = (uint16_t)f32_to_bf16_bits(scale * (a + y[c]));
+        }
+        for (int rep = 0; rep < nrep; ++rep) {
+            uint16_t* dst = out + (((long)rep * F + lane) * HW + pix) * ld_out;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dst[c] = r[c];
+        }
+    }
+}
+
+__global__ void adaptive_avgpool_rows_kernel(const uint16_t* __restrict__ in, int ld, uint16_t* __restrict__ out, int ldo,
+                                             int n, int C, int IH, int IW, int OH, int OW) {
+    const long total = (long)n * OH * OW * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long t = i / C;
+        const int ox = (int)(t % OW); t /= OW;
+        const int oy = (int)(t % OH);
+        const int img = (int)(t / OH);
+        // PyTorch bins: [floor(o*I/O), ceil((o+1)*I/O))
+        const int y0 = (oy * IH) / OH, y1 = ((oy + 1) * IH + OH - 1) / OH;
+        const int x0 = (ox * IW) / OW, x1 = ((ox + 1) * IW + OW - 1) / OW;
+        float s = 0.f;
+        for (int yy = y0; yy < y1; ++yy)
+            for (int xx = x0; xx < x1; ++xx) s += bf16_to_f32(in[(((long)img * IH + yy) * IW + xx) * ld + c]);
+        out[(((long)img * OH + oy) * OW + ox) * ldo + c] = (uint16_t)f32_to_bf16_bits(s / (float)((y1 - y0) * (x1 - x0)));
+    }
+}
+
 __global__ void rows_to_nchw_kernel(const void* __restrict__ rows, int rows_fp32, int ld, float* __restrict__ out, long n,
                                     int C, long HW) {
     const long total = n * C * HW;
@@ -103,6 +229,36 @@ extern "C" int vmv_latent_to_rows(const float* x, void* rows, int nb, int C, int
     const long HW = (long)H * W;
     hipLaunchKernelGGL(latent_to_rows_kernel, dim3(grid_for((long)nb * F * HW)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), x, reinterpret_cast<uint16_t*>(rows), nb, C, F, HW, Cpad, nrep);
+    return vmv_launch_status();
+}
+
+extern "C" int vmv_latent_to_rows_keep(const float* x, void* rows, int nb, int C, int F, int H, int W, int ld, int nrep,
+                                       void* stream) {
+    if (!x || !rows) return VMV_ENULL;
+    if (nb <= 0 || C <= 0 || F <= 0 || H <= 0 || W <= 0 || ld < C || nrep <= 0) return VMV_EINVAL;
+    const long HW = (long)H * W;
+    hipLaunchKernelGGL(latent_to_rows_keep_kernel, dim3(grid_for((long)nb * F * HW)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), x, reinterpret_cast<uint16_t*>(rows), nb, C, F, HW, ld, nrep);
+    return vmv_launch_status();
+}
+
+extern "C" int vmv_i2v_temporal_adapter(const void* in, int ld_in, void* out, int ld_out, const float* w, int F, int HW,
+                                        int nrep, float scale, void* stream) {
+    if (!in || !out || !w) return VMV_ENULL;
+    if (F <= 0 || F > 64 || HW <= 0 || ld_in < 4 || ld_out < 4 || nrep <= 0) return VMV_EINVAL;
+    hipLaunchKernelGGL(i2v_temporal_adapter_kernel, dim3((HW + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const uint16_t*>(in), ld_in, reinterpret_cast<uint16_t*>(out), ld_out, w, F, HW, nrep,
+                       scale);
+    return vmv_launch_status();
+}
+
+extern "C" int vmv_adaptive_avgpool_rows(const void* in, int ld, void* out, int ldo, int n, int C, int IH, int IW, int OH,
+                                         int OW, void* stream) {
+    if (!in || !out) return VMV_ENULL;
+    if (n <= 0 || C <= 0 || IH <= 0 || IW <= 0 || OH <= 0 || OW <= 0 || ld < C || ldo < C) return VMV_EINVAL;
+    hipLaunchKernelGGL(adaptive_avgpool_rows_kernel, dim3(grid_for((long)n * OH * OW * C)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const uint16_t*>(in), ld,
+                       reinterpret_cast<uint16_t*>(out), ldo, n, C, IH, IW, OH, OW);
     return vmv_launch_status();
 }
 

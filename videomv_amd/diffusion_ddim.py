@@ -85,9 +85,9 @@ class DiffusionDDIM(object):
 
     # ------------------------------------------------------------------ fused HIP path
     @torch.no_grad()
-    def ddim_step_hip(self, xt, step, unet, y_cond, y_uncond, camera_data, guide_scale, stride, x0_out=None):
+    def ddim_step_hip(self, xt, step, unet, cond_kwargs, uncond_kwargs, guide_scale, stride, x0_out=None):
         t = torch.full((xt.shape[0],), int(step), dtype=torch.long, device=xt.device)
-        eng, eps_rows = unet.forward_cfg_rows(xt, self._scale_timesteps(t), y_cond, y_uncond, camera_data)
+        eng, eps_rows = unet.forward_cfg_rows(xt, self._scale_timesteps(t), cond_kwargs, uncond_kwargs)
         ops.cfg_ddim_step(eps_rows, eng.out_pad, xt, float(guide_scale), v_pred=(self.mean_type == 'v'),
                           x0_out=x0_out, **self.step_scalars(int(step), stride))
         return xt
@@ -115,9 +115,8 @@ class DiffusionDDIM(object):
         assert self.var_type.startswith('fixed'), "learned variance doubles the UNet out channels: not a VideoMV config"
         xt = noise.detach().clone().float().contiguous()      # updated in place by the fused kernel
         kc, ku = model_kwargs
-        cam = kc.get("camera_data", None)
         for idx, step in enumerate(steps):
-            self.ddim_step_hip(xt, int(step), unet, kc["y"], ku["y"], cam, guide_scale, stride)
+            self.ddim_step_hip(xt, int(step), unet, kc, ku, guide_scale, stride)
         return xt
 
     # ------------------------------------------------------------------ generic path (foreign models / CPU)

@@ -194,6 +194,23 @@ def latent_to_rows(x: torch.Tensor, rows: torch.Tensor, Cpad: int, nrep: int):
             "latent_to_rows")
 
 
+def latent_to_rows_keep(x: torch.Tensor, rows: torch.Tensor, ld: int, nrep: int):
+    """Write only channels [0, C) of each ld-wide row (the others keep their contents)."""
+    nb, Cc, F_, H, W = x.shape
+    L.check(L.load().vmv_latent_to_rows_keep(x.data_ptr(), rows.data_ptr(), nb, Cc, F_, H, W, ld, nrep, _stream_ptr()),
+            "latent_to_rows_keep")
+
+
+def i2v_temporal_adapter(inp, ld_in, out_ptr, ld_out, w, F_, HW, nrep, scale):
+    L.check(L.load().vmv_i2v_temporal_adapter(_ptr(inp), ld_in, _ptr(out_ptr), ld_out, w.data_ptr(), F_, HW, nrep,
+                                              float(scale), _stream_ptr()), "i2v_temporal_adapter")
+
+
+def adaptive_avgpool_rows(inp, ld, out, ldo, n, Cc, IH, IW, OH, OW):
+    L.check(L.load().vmv_adaptive_avgpool_rows(_ptr(inp), ld, _ptr(out), ldo, n, Cc, IH, IW, OH, OW, _stream_ptr()),
+            "adaptive_avgpool_rows")
+
+
 def rows_to_nchw(rows: torch.Tensor, ld: int, out: torch.Tensor):
     n, Cc, H, W = out.shape
     lib = L.load()

@@ -314,6 +314,7 @@ class UNetEngine:
         self.emb_silu = torch.zeros(B * F, self.E, dtype=BF16, device=dev)
         self.emb_out = torch.zeros(B * F, self.emb_total, dtype=torch.float32, device=dev)
         self.cam_valid = False
+        self.extra_emb = None        # optional fp32 [n_t, E] added to the time embedding (I2VGen: fps_embedding)
 
     # ------------------------------------------------------------------ helpers
     def act(self, rows, C, dtype=BF16) -> Act:
@@ -606,7 +607,8 @@ class UNetEngine:
                                bias=self.w["time_embed.0.bias"], act=L.ACT_SILU), "time_embed.0")
         S.gemm(ops.gemm_params(self.n_t, self.E, ops.linear_segs([(self.te_hidden, self.E, self.E)]),
                                self.w["time_embed.2.weight"], self.temb, self.E,
-                               bias=self.w["time_embed.2.bias"], out_fp32=True), "time_embed.2")
+                               bias=self.w["time_embed.2.bias"], out_fp32=True,
+                               rowvec=self.extra_emb, rowvec_div=1, rowvec_ld=self.E), "time_embed.2")
         rows = self.B * self.F
         # branch-major rows [b][f]: the B // n_t branches of one timestep row are contiguous
         ops.emb_combine_silu(self.temb, self.cam_emb if self.cam_valid else None, self.emb_silu, rows, self.E,
@@ -616,7 +618,9 @@ class UNetEngine:
         """x [b, C, F, H, W] fp32 on device (b divides B; replicated to the B branches), t [n_t].
         Leaves eps in ``self.eps_rows`` (fp32 [B*F*H*W, out_pad])."""
         nb = x.shape[0]
-        ops.latent_to_rows(x.contiguous(), self.x_rows, self.cin_pad, self.B // nb)
+        # only the latent's own channels are written: channels >= x.shape[1] hold zeros (T2V) or the step-invariant
+        # image `concat` of the I2VGen front-end (unet_i2vgen.py:383)
+        ops.latent_to_rows_keep(x.contiguous(), self.x_rows, self.cin_pad, self.B // nb)
         self.t_dev.copy_(t.to(torch.float32).reshape(-1)[: self.n_t])
         self._embeddings()
         self.S.run()

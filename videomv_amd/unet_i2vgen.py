@@ -1,0 +1,247 @@
+"""``UNetSD_I2VGen`` — drop-in for the reference image-to-multi-view UNet (tools/modules/unet/unet_i2vgen.py:27-404,
+registry name ``MODEL: UNetSD_I2VGen``; BASELINE configs[3]) on the HIP hot path.
+
+The trunk (encoder / middle / decoder / head) is the T2V trunk with an ``in_dim + concat_dim`` channel input conv and
+145 context tokens; this file adds the I2VGen-XL *front-end*, which depends only on the conditioning image and is
+therefore run ONCE per sample, not on each of the 100 forwards as the reference does:
+  * ``local_image_concat`` (3 convs) + ``local_temporal_encoder`` (TransformerV2 over the frames of every pixel) ->
+    ``concat`` written twice as in the reference (:345-346), stored in channels 4..7 of the input rows;
+  * ``local_image_embedding`` (conv, adaptive-avg-pool 32x32, two stride-2 convs) -> 64 context tokens;
+  * ``context_embedding`` (CLIP image feature -> ``num_tokens`` tokens); ``fps_embedding`` added to the time embedding.
+Everything runs on libvmv_hip.so (implicit-GEMM convs, ``vmv_i2v_temporal_adapter``, ``vmv_adaptive_avgpool_rows``).
+The LGM branch raises ``NotImplementedError`` as in ``unet_t2v.py``.
+"""
+import math
+from typing import Dict
+
+import torch
+import torch.nn as nn
+
+from .registry import MODEL
+from . import _lib as L
+from . import ops
+from . import packing as P
+from .unet_engine import UNetEngine, param_shapes, BF16
+from .unet_t2v import _Holder, _ZERO_INIT_SUFFIXES
+
+
+def i2v_extra_shapes(arch: dict, concat_dim: int, num_tokens: int, y_dim: int) -> Dict[str, tuple]:
+    dim, ctx = arch["dim"], arch["context_dim"]
+    E, cd = dim * 4, concat_dim
+    s = [("context_embedding.0.weight", (E, y_dim)), ("context_embedding.0.bias", (E,)),
+         ("context_embedding.2.weight", (ctx * num_tokens, E)), ("context_embedding.2.bias", (ctx * num_tokens,)),
+         ("fps_embedding.0.weight", (E, dim)), ("fps_embedding.0.bias", (E,)),
+         ("fps_embedding.2.weight", (E, E)), ("fps_embedding.2.bias", (E,)),
+         ("local_image_concat.0.weight", (cd * 4, 4, 3, 3)), ("local_image_concat.0.bias", (cd * 4,)),
+         ("local_image_concat.2.weight", (cd * 4, cd * 4, 3, 3)), ("local_image_concat.2.bias", (cd * 4,)),
+         ("local_image_concat.4.weight", (cd, cd * 4, 3, 3)), ("local_image_concat.4.bias", (cd,)),
+         ("local_temporal_encoder.layers.0.0.norm.weight", (cd,)), ("local_temporal_encoder.layers.0.0.norm.bias", (cd,)),
+         ("local_temporal_encoder.layers.0.0.fn.to_qkv.weight", (2 * cd * 3, cd)),
+         ("local_temporal_encoder.layers.0.0.fn.to_out.0.weight", (cd, 2 * cd)),
+         ("local_temporal_encoder.layers.0.0.fn.to_out.0.bias", (cd,)),
+         ("local_temporal_encoder.layers.0.1.net.0.0.weight", (cd * 4, cd)),
+         ("local_temporal_encoder.layers.0.1.net.0.0.bias", (cd * 4,)),
+         ("local_temporal_encoder.layers.0.1.net.2.weight", (cd, cd * 4)),
+         ("local_temporal_encoder.layers.0.1.net.2.bias", (cd,)),
+         ("local_image_embedding.0.weight", (cd * 8, 4, 3, 3)), ("local_image_embedding.0.bias", (cd * 8,)),
+         ("local_image_embedding.3.weight", (cd * 16, cd * 8, 3, 3)), ("local_image_embedding.3.bias", (cd * 16,)),
+         ("local_image_embedding.5.weight", (1024, cd * 16, 3, 3)), ("local_image_embedding.5.bias", (1024,))]
+    return dict(s)
+
+
+class I2VFrontEnd:
+    """Once-per-sample image conditioning on the HIP kernels; writes into a ``UNetEngine``'s static buffers."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], dim: int, num_tokens: int, device):
+        self.dev, self.dim, self.E, self.num_tokens = device, dim, dim * 4, num_tokens
+        w = {}
+        for k in ("local_image_concat.0", "local_image_concat.2", "local_image_concat.4", "local_image_embedding.0",
+                  "local_image_embedding.3", "local_image_embedding.5"):
+            w[k + ".weight"] = P.pack_conv3x3(sd[k + ".weight"], device)
+            w[k + ".bias"] = P.pack_bias(sd[k + ".bias"], device)
+        for k in ("context_embedding.0", "context_embedding.2", "fps_embedding.0", "fps_embedding.2"):
+            w[k + ".weight"] = P.pack_linear(sd[k + ".weight"], device)
+            w[k + ".bias"] = P.pack_bias(sd[k + ".bias"], device)
+        p = "local_temporal_encoder.layers.0"
+        blob = [sd[f"{p}.0.norm.weight"], sd[f"{p}.0.norm.bias"], sd[f"{p}.0.fn.to_qkv.weight"],
+                sd[f"{p}.0.fn.to_out.0.weight"], sd[f"{p}.0.fn.to_out.0.bias"], sd[f"{p}.1.net.0.0.weight"],
+                sd[f"{p}.1.net.0.0.bias"], sd[f"{p}.1.net.2.weight"], sd[f"{p}.1.net.2.bias"]]
+        w["adapter"] = torch.cat([t.detach().float().reshape(-1) for t in blob]).to(device).contiguous()
+        assert w["adapter"].numel() == 288, "local_temporal_encoder must be TransformerV2(heads=2, dim=4, mlp 16)"
+        self.w = w
+        self._keep = []
+
+    def _conv(self, S, x, cin, key, n, ih, iw, stride=1, silu=False):
+        oh, ow = (ih + stride - 1) // stride, (iw + stride - 1) // stride
+        W = self.w[key + ".weight"]
+        y = torch.empty(n * oh * ow, W.shape[0], dtype=BF16, device=self.dev)
+        S.gemm(ops.gemm_params(n * oh * ow, W.shape[0], ops.conv3x3_segs([(x, cin, cin)]), W, y, W.shape[0],
+                               bias=self.w[key + ".bias"], act=L.ACT_SILU if silu else L.ACT_NONE,
+                               geom=ops.Geom(OH=oh, OW=ow, IH=ih, IW=iw, stride=stride)), key)
+        self._keep += [x, y]
+        return y, oh, ow
+
+    def _mlp(self, S, x_rows, key, out_fp32):
+        n, k = x_rows.shape
+        hid = torch.empty(n, self.E, dtype=BF16, device=self.dev)
+        W0, W2 = self.w[key + ".0.weight"], self.w[key + ".2.weight"]
+        S.gemm(ops.gemm_params(n, self.E, ops.linear_segs([(x_rows, k, k)]), W0, hid, self.E, bias=self.w[key + ".0.bias"],
+                               act=L.ACT_SILU), key + ".0")
+        out = torch.empty(n, W2.shape[0], dtype=torch.float32 if out_fp32 else BF16, device=self.dev)
+        S.gemm(ops.gemm_params(n, W2.shape[0], ops.linear_segs([(hid, self.E, self.E)]), W2, out, W2.shape[0],
+                               bias=self.w[key + ".2.bias"], out_fp32=out_fp32), key + ".2")
+        self._keep += [x_rows, hid, out]
+        return out
+
+    @torch.no_grad()
+    def run(self, eng: UNetEngine, local_images, ys, images, fps):
+        """local_images [B,4,h,w] fp32, ys [B,Ly,ctx], images [B,1,y_dim] (one row per branch), fps [n_t].
+        Fills eng.x_rows[:, 4:8], eng.ctx_rows and eng.extra_emb."""
+        dev, B, F, h, w = self.dev, eng.B, eng.F, eng.H, eng.W
+        S = ops.Stream(record=False)
+        self._keep = []
+        Ly = ys.shape[1]
+        assert eng.L == Ly + 64 + self.num_tokens, "context length must be Ly + 64 local + num_tokens image tokens"
+        ctx = eng.ctx_rows.view(B, eng.L, -1)
+        ctx[:, :Ly].copy_(ys.to(BF16))
+        img_tok = self._mlp(S, images.reshape(B, -1).to(BF16).contiguous(), "context_embedding", out_fp32=False)
+        ctx[:, Ly + 64:].copy_(img_tok.view(B, self.num_tokens, -1))
+        ld = eng.cin_pad
+        for b in range(B):
+            if b > 0 and torch.equal(local_images[b], local_images[0]):      # CFG pair: same conditioning image
+                eng.x_rows.view(B, -1, ld)[b, :, 4:8].copy_(eng.x_rows.view(B, -1, ld)[0, :, 4:8])
+                ctx[b, Ly:Ly + 64].copy_(ctx[0, Ly:Ly + 64])
+                continue
+            li = local_images[b:b + 1].float()
+            seq = torch.empty(1, 4, F, h, w, dtype=torch.float32, device=dev)                 # :333-335
+            seq[:, :, 0] = li
+            for i in range(1, F):
+                seq[:, :, i] = i / (F - 1)
+            rows_a = torch.zeros(F * h * w, 8, dtype=BF16, device=dev)
+            ops.latent_to_rows_keep(seq, rows_a, 8, 1)
+            a1, _, _ = self._conv(S, rows_a, 8, "local_image_concat.0", F, h, w, silu=True)
+            a2, _, _ = self._conv(S, a1, a1.shape[1], "local_image_concat.2", F, h, w, silu=True)
+            a3, _, _ = self._conv(S, a2, a2.shape[1], "local_image_concat.4", F, h, w)
+            xr = eng.x_rows.view(B, -1, ld)[b]
+            ops.i2v_temporal_adapter(a3, a3.shape[1], xr.data_ptr() + 8, ld, self.w["adapter"], F, h * w, 1, 2.0)
+            rows_l = torch.zeros(h * w, 8, dtype=BF16, device=dev)
+            ops.latent_to_rows_keep(li.reshape(1, 4, 1, h, w).contiguous(), rows_l, 8, 1)
+            l1, _, _ = self._conv(S, rows_l, 8, "local_image_embedding.0", 1, h, w, silu=True)
+            l2 = torch.empty(32 * 32, l1.shape[1], dtype=BF16, device=dev)
+            ops.adaptive_avgpool_rows(l1, l1.shape[1], l2, l2.shape[1], 1, l1.shape[1], h, w, 32, 32)
+            l3, oh, ow = self._conv(S, l2, l2.shape[1], "local_image_embedding.3", 1, 32, 32, stride=2, silu=True)
+            l4, oh, ow = self._conv(S, l3, l3.shape[1], "local_image_embedding.5", 1, oh, ow, stride=2)
+            ctx[b, Ly:Ly + 64].copy_(l4.view(64, -1))
+            self._keep += [seq, rows_a, rows_l, l2]
+        t_f = fps.to(dev).float().reshape(-1)
+        sin = torch.empty(t_f.numel(), self.dim, dtype=BF16, device=dev)
+        ops.sinusoidal(t_f, sin, t_f.numel(), self.dim)
+        fe = self._mlp(S, sin, "fps_embedding", out_fp32=True)
+        eng.extra_emb = fe if fe.shape[0] == eng.n_t else fe[:1].expand(eng.n_t, -1).contiguous()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()          # temporaries above are released when this returns
+        self._keep = []
+
+
+@MODEL.register_class()
+class UNetSD_I2VGen(nn.Module):
+    def __init__(self, config=None, in_dim=4, dim=512, y_dim=512, context_dim=512, hist_dim=156, concat_dim=8,
+                 dim_condition=4, out_dim=6, num_tokens=4, dim_mult=[1, 2, 3, 4], num_heads=None, head_dim=64,
+                 num_res_blocks=3, attn_scales=[1 / 2, 1 / 4, 1 / 8], use_scale_shift_norm=True, dropout=0.1,
+                 temporal_attn_times=1, temporal_attention=True, use_checkpoint=False, use_image_dataset=False,
+                 use_sim_mask=False, training=True, inpainting=True, camera_dim=16, use_fps_condition=False,
+                 use_camera_condition=False, use_lgm_refine=False, p_all_zero=0.1, p_all_keep=0.1, zero_y=None,
+                 adapter_transformer_layers=1, **kwargs):
+        super().__init__()
+        concat_dim = in_dim                           # the reference overrides the argument (unet_i2vgen.py:93)
+        if concat_dim != 4 or adapter_transformer_layers != 1:
+            raise NotImplementedError("I2VGen front-end is built for concat_dim = in_dim = 4, one adapter layer")
+        num_heads = num_heads if num_heads else dim // 32
+        self.zero_y, self.in_dim, self.dim, self.y_dim, self.context_dim = zero_y, in_dim, dim, y_dim, context_dim
+        self.out_dim, self.num_tokens, self.concat_dim = out_dim, num_tokens, concat_dim
+        self.use_camera_condition, self.use_lgm_refine, self.inpainting = use_camera_condition, use_lgm_refine, inpainting
+        self.arch = dict(in_dim=in_dim + concat_dim, dim=dim, context_dim=context_dim, out_dim=out_dim,
+                         dim_mult=list(dim_mult), num_heads=num_heads, head_dim=head_dim, num_res_blocks=num_res_blocks,
+                         attn_scales=list(attn_scales), camera_dim=camera_dim, use_camera_condition=use_camera_condition,
+                         use_fps_condition=False)
+        shapes = dict(param_shapes(self.arch))
+        shapes.update(i2v_extra_shapes(self.arch, concat_dim, num_tokens, y_dim))
+        for key, shape in shapes.items():
+            if key.endswith(_ZERO_INIT_SUFFIXES) or key == "out.2.weight" or key.startswith(("camera_embedding.2.", "fps_embedding.2.")):
+                v = torch.zeros(shape)
+            elif len(shape) == 1:
+                v = torch.zeros(shape) if key.endswith(".bias") else torch.ones(shape)
+            else:
+                fan = 1
+                for d in shape[1:]:
+                    fan *= d
+                v = torch.empty(shape).normal_(0.0, 1.0 / math.sqrt(fan))
+            head, _, rest = key.partition(".")
+            child = self._modules.get(head)
+            if child is None:
+                child = _Holder()
+                self.add_module(head, child)
+            child.add(rest, nn.Parameter(v, requires_grad=False))
+        self._engines, self._front = {}, {}
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
+
+    def _invalidate(self):
+        self._engines.clear()
+        self._front.clear()
+
+    def _get(self, B, F, H, W, L, device, n_t):
+        key = (B, F, H, W, L, str(device), n_t)
+        if key not in self._engines:
+            sd = {k: v.detach() for k, v in self.state_dict().items()}
+            self._engines[key] = UNetEngine(self.arch, sd, B, F, H, W, L, device, n_t=n_t)
+            if str(device) not in self._front:
+                self._front[str(device)] = I2VFrontEnd(sd, self.dim, self.num_tokens, device)
+        return self._engines[key], self._front[str(device)]
+
+    @staticmethod
+    def _first_frame(local_image):
+        if local_image.ndim == 5:
+            return local_image[:, :, 0]
+        return local_image
+
+    @torch.no_grad()
+    def forward(self, x, t, x0=None, gs_data=None, sqrt_alphas_cumprod=None, sqrt_one_minus_alphas_cumprod=None,
+                sqrt_recip_alphas_cumprod=None, sqrt_recipm1_alphas_cumprod=None, autoencoder=None, y=None, image=None,
+                local_image=None, camera_data=None, masked=None, fps=None, video_mask=None, focus_present_mask=None,
+                prob_focus_present=0., mask_last_frame_num=0, **kwargs):
+        assert self.inpainting or masked is None, 'inpainting is not supported'
+        if autoencoder is not None or (self.use_lgm_refine and x0 is not None):
+            raise NotImplementedError("LGM refinement branch is not built yet (SURVEY §8f)")
+        if local_image is None or image is None or y is None or fps is None:
+            raise ValueError("UNetSD_I2VGen needs y, image, local_image and fps")
+        b, c, f, h, w = x.shape
+        dev = x.device
+        L_ctx = y.shape[1] + 64 + self.num_tokens
+        eng, front = self._get(b, f, h, w, L_ctx, dev, n_t=b)
+        front.run(eng, self._first_frame(local_image).to(dev), y.to(dev).float(), image.to(dev).float(), fps)
+        eng.set_camera(camera_data.to(dev) if (camera_data is not None and self.use_camera_condition) else None)
+        eng.forward_rows(x.float(), t.to(dev))
+        return eng.eps_ncfhw()
+
+    @torch.no_grad()
+    def forward_cfg_rows(self, xt, t, cond_kwargs, uncond_kwargs):
+        """cond / uncond branches in one pass; image conditioning is evaluated once per sample (cached on the tensors'
+        identity).  kwargs as in inference_i2vgen_entrance.py:267-269: y, image, local_image, fps, camera_data."""
+        b, c, f, h, w = xt.shape
+        if b != 1:
+            raise ValueError("forward_cfg_rows handles one sample")
+        dev = xt.device
+        kc, ku = cond_kwargs, uncond_kwargs
+        if ku.get("image") is None:
+            raise NotImplementedError("uncond branch without image tokens (use_zero_infer=False) has a shorter context")
+        L_ctx = kc["y"].shape[1] + 64 + self.num_tokens
+        eng, front = self._get(2, f, h, w, L_ctx, dev, n_t=1)
+        key = tuple(v.data_ptr() for v in (kc["y"], ku["y"], kc["image"], ku["image"], kc["local_image"]))
+        if getattr(eng, "_cond_key", None) != key:
+            li = self._first_frame(kc["local_image"]).to(dev)
+            front.run(eng, torch.cat([li, li], dim=0), torch.cat([kc["y"], ku["y"]], dim=0).to(dev).float(),
+                      torch.cat([kc["image"], ku["image"]], dim=0).to(dev).float(), kc["fps"][:1])
+            cam = kc.get("camera_data")
+            eng.set_camera(cam.to(dev) if (cam is not None and self.use_camera_condition) else None)
+            eng._cond_key = key
+        return eng, eng.forward_rows(xt.float(), t.to(dev))

@@ -133,10 +133,14 @@ class UNetSD_T2VBase(nn.Module):
         return eng.eps_ncfhw()
 
     @torch.no_grad()
-    def forward_cfg_rows(self, xt, t, y_cond, y_uncond, camera_data=None):
+    def forward_cfg_rows(self, xt, t, cond_kwargs, uncond_kwargs):
         """Both classifier-free-guidance branches in ONE pass (B = 2 rows blocks sharing x_t, so weights stream once
-        per step instead of twice — SURVEY App. C).  Returns (engine, eps_rows fp32 [2*F*H*W, out_pad]):
-        rows [0, F*H*W) are the conditional branch."""
+        per step instead of twice — SURVEY App. C).  ``cond_kwargs`` / ``uncond_kwargs`` are the two ``model_kwargs``
+        dicts of ``ddim_sample_loop`` (keys ``y``, ``camera_data``; ``fps`` is ignored as in the reference when
+        ``use_fps_condition`` is False).  Returns (engine, eps_rows fp32 [2*F*H*W, out_pad]); rows [0, F*H*W) are the
+        conditional branch."""
+        y_cond, y_uncond = cond_kwargs["y"], uncond_kwargs["y"]
+        camera_data = cond_kwargs.get("camera_data", None)
         b, c, f, h, w = xt.shape
         if b != 1:
             raise ValueError("forward_cfg_rows handles one sample (the reference's noise is [1,4,F,h,w])")
