@@ -199,3 +199,36 @@ def test_i2vgen_matches_reference_golden_and_vpred_loop(golden_dir):
     assert torch.isfinite(x_hip).all()
     e2 = rel_l2(x_hip, x_ref)
     assert e2 < 6e-2, e2
+
+
+def test_full_size_architecture_parity_small_latent():
+    """The REAL architecture (dim 320, 1.413 B parameters, 28 blocks, heads 5/10/20) on a small latent (24 x 8 x 8) vs the
+    fp32 oracle on the host: measures how the bf16 storage error accumulates over the full depth.
+    Stated tolerance: rel-L2(eps) <= 2.5e-2 per forward with fully random (non-zero-init) weights (measured 1.35e-2,
+    per-block 0.5e-2 .. 1.5e-2, saturating after the first encoder level)."""
+    from videomv_amd.unet_engine import UNetEngine
+    cfg = dict(in_dim=4, dim=320, context_dim=1024, out_dim=4, dim_mult=[1, 2, 4, 4], num_heads=8, head_dim=64,
+               num_res_blocks=2, attn_scales=[1.0, 0.5, 0.25], camera_dim=16, use_camera_condition=True,
+               use_fps_condition=False)
+    ocfg = UNetCfg(**{k: v for k, v in cfg.items() if k in {f.name for f in dataclasses.fields(UNetCfg)}})
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    sd = random_state_dict(unet_param_shapes(ocfg), 5)
+    B, F_, H, W, L = 1, 24, 8, 8, 77
+    gen = torch.Generator().manual_seed(6)
+    x = torch.randn(B, 4, F_, H, W, generator=gen)
+    t = torch.tensor([601])
+    y = torch.randn(B, L, 1024, generator=gen)
+    cam = torch.randn(B, F_, 16, generator=gen)
+    taps_ref = {}
+    eps_ref = unet_forward(sd, ocfg, x, t, y, cam, taps=taps_ref)
+    taps = {}
+    eng = UNetEngine(cfg, sd, B, F_, H, W, L, torch.device("cuda"), n_t=B, taps=taps)
+    eng.set_context(y.cuda())
+    eng.set_camera(cam.cuda())
+    eng.forward_rows(x.cuda(), t.cuda())
+    torch.cuda.synchronize()
+    report = {k: round(rel_l2(a.tensor().float().view(B * F_, h, w, a.C).permute(0, 3, 1, 2), taps_ref[k]), 4)
+              for k, (a, h, w) in taps.items()}
+    e = rel_l2(eng.eps_ncfhw(), eps_ref)
+    print("full-size per-block rel-L2:", report, "eps:", e)
+    assert e < 2.5e-2, (e, report)
