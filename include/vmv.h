@@ -204,6 +204,10 @@ typedef struct {
 } VmvDdimParams;
 int vmv_cfg_ddim_step(const VmvDdimParams* p, void* stream);
 
+/* DiagonalGaussianDistribution.sample() * scale (autoencoder.py:213-226, get_first_stage_encoding :19-28):
+ * moments rows fp32 [n*HW][ld] = (mean[zc] | logvar[zc]); z[n][zc][HW] = scale * (mean + exp(0.5*clamp(logvar,-30,20)) * noise) */
+int vmv_posterior_sample(const float* moments_rows, int ld, const float* noise, float* z, int n, int zc, int HW, float scale,
+                         void* stream);
 /* e[r][c] = silu(temb[(r / rows_per_t)][c] + (cam ? cam[r % cam_rows][c] : 0)) -> bf16 [rows][C] */
 int vmv_emb_combine_silu(const float* temb, const float* cam, void* out, int rows, int C, int rows_per_t,
                          int cam_rows, void* stream);

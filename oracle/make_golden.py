@@ -149,6 +149,27 @@ def vae_case(ns):
     print("vae", tuple(img.shape), float(img.abs().mean()))
 
 
+def vae_enc_case(ns):
+    from .weights import vae_encoder_param_shapes
+    A = ns.autoencoder.AutoencoderKL
+    dd = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=32,
+              ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    vae = A(ddconfig=dd, embed_dim=4).eval()
+    shapes = vae_encoder_param_shapes(ch=32)
+    ref_sd = {k: v for k, v in vae.state_dict().items() if k.startswith("encoder.") or k.startswith("quant_conv.")}
+    assert set(ref_sd.keys()) == set(shapes.keys()), set(ref_sd.keys()) ^ set(shapes.keys())
+    sd = random_state_dict(shapes, 91)
+    vae.load_state_dict(sd, strict=False)
+    g = torch.Generator().manual_seed(92)
+    img = torch.randn(2, 3, 64, 72, generator=g)
+    with torch.no_grad():
+        post = vae.encode(img)
+    save_file({"img": img, "moments": post.parameters.contiguous(),
+               "weights_checksum": torch.tensor([checksum(sd)], dtype=torch.float64)},
+              os.path.join(GOLD, "vae_enc_tiny.safetensors"))
+    print("vae enc", tuple(post.parameters.shape), float(post.parameters.abs().mean()))
+
+
 def manifest_case(ns):
     """Full-size key/shape manifests (G7): text, no tensors."""
     full = dict(in_dim=4, dim=320, context_dim=1024, out_dim=4, dim_mult=[1, 2, 4, 4], num_heads=8, head_dim=64,
@@ -232,6 +253,7 @@ def main():
     ddim_case(ns, ref_a, TINY_A)
     unet_case(ns, "unet_tiny_b", TINY_B, seed=4321, F_=3, H=8, W=12, L=5)
     vae_case(ns)
+    vae_enc_case(ns)
     manifest_case(ns)
     camera_case()
     i2v_case(ns)

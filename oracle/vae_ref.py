@@ -1,4 +1,4 @@
-"""ORACLE (test infrastructure, CPU, fp32) — restatement of the reference SD-VAE *decoder*.
+"""ORACLE (test infrastructure, CPU, fp32) — restatement of the reference SD-VAE decoder and encoder.
 
 Follows ``AutoencoderKL.decode`` (tools/modules/autoencoder.py:101-104), ``Decoder.forward`` (:654-687),
 ``ResnetBlock.forward`` (:316-336), ``AttnBlock.forward`` (:366-390; single head, scale c^-0.5),
@@ -53,3 +53,28 @@ def vae_decode(sd, z, ch_mult=(1, 2, 4, 4), num_res_blocks=2):
                          sd[f"decoder.up.{lvl}.upsample.conv.bias"], padding=1)
     h = _swish(_gn(sd, "decoder.norm_out", h))
     return F.conv2d(h, sd["decoder.conv_out.weight"], sd["decoder.conv_out.bias"], padding=1)
+
+
+@torch.no_grad()
+def vae_encode_moments(sd, x, ch_mult=(1, 2, 4, 4), num_res_blocks=2):
+    """image [n, 3, H, W] -> moments [n, 2*zc, H/8, W/8] = quant_conv(Encoder(x)) (autoencoder.py:76-80, Encoder.forward
+    :548-576; Downsample = pad (0,1,0,1) then valid stride-2 conv, :475-479)."""
+    h = F.conv2d(x, sd["encoder.conv_in.weight"], sd["encoder.conv_in.bias"], padding=1)
+    for lvl in range(len(ch_mult)):
+        for i in range(num_res_blocks):
+            h = _res(sd, f"encoder.down.{lvl}.block.{i}", h)
+        if lvl != len(ch_mult) - 1:
+            h = F.pad(h, (0, 1, 0, 1))
+            h = F.conv2d(h, sd[f"encoder.down.{lvl}.downsample.conv.weight"], sd[f"encoder.down.{lvl}.downsample.conv.bias"],
+                         stride=2)
+    h = _res(sd, "encoder.mid.block_1", h)
+    h = _attn(sd, "encoder.mid.attn_1", h)
+    h = _res(sd, "encoder.mid.block_2", h)
+    h = F.conv2d(_swish(_gn(sd, "encoder.norm_out", h)), sd["encoder.conv_out.weight"], sd["encoder.conv_out.bias"], padding=1)
+    return F.conv2d(h, sd["quant_conv.weight"], sd["quant_conv.bias"])
+
+
+def posterior_sample(moments, noise, scale_factor=1.0):
+    """DiagonalGaussianDistribution.sample() * scale_factor (autoencoder.py:213-226, :19-28) with the noise given."""
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    return scale_factor * (mean + torch.exp(0.5 * logvar.clamp(-30.0, 20.0)) * noise)

@@ -125,6 +125,38 @@ def vae_decoder_param_shapes(ch=128, out_ch=3, ch_mult=(1, 2, 4, 4), num_res_blo
     return OrderedDict(s)
 
 
+def vae_encoder_param_shapes(ch=128, in_ch=3, ch_mult=(1, 2, 4, 4), num_res_blocks=2, z_channels=4, embed_dim=4):
+    """Keys of ``encoder.*`` + ``quant_conv`` (autoencoder.py:51, 483-546)."""
+    def res(p, ci, co):
+        r = [(f"{p}.norm1.weight", (ci,)), (f"{p}.norm1.bias", (ci,)), (f"{p}.conv1.weight", (co, ci, 3, 3)),
+             (f"{p}.conv1.bias", (co,)), (f"{p}.norm2.weight", (co,)), (f"{p}.norm2.bias", (co,)),
+             (f"{p}.conv2.weight", (co, co, 3, 3)), (f"{p}.conv2.bias", (co,))]
+        if ci != co:
+            r += [(f"{p}.nin_shortcut.weight", (co, ci, 1, 1)), (f"{p}.nin_shortcut.bias", (co,))]
+        return r
+    s = [("encoder.conv_in.weight", (ch, in_ch, 3, 3)), ("encoder.conv_in.bias", (ch,))]
+    in_mult = (1,) + tuple(ch_mult)
+    block_in = ch
+    for lvl in range(len(ch_mult)):
+        block_in, block_out = ch * in_mult[lvl], ch * ch_mult[lvl]
+        for i in range(num_res_blocks):
+            s += res(f"encoder.down.{lvl}.block.{i}", block_in, block_out)
+            block_in = block_out
+        if lvl != len(ch_mult) - 1:
+            s += [(f"encoder.down.{lvl}.downsample.conv.weight", (block_in, block_in, 3, 3)),
+                  (f"encoder.down.{lvl}.downsample.conv.bias", (block_in,))]
+    s += res("encoder.mid.block_1", block_in, block_in)
+    p = "encoder.mid.attn_1"
+    s += [(f"{p}.norm.weight", (block_in,)), (f"{p}.norm.bias", (block_in,))]
+    for n in ("q", "k", "v", "proj_out"):
+        s += [(f"{p}.{n}.weight", (block_in, block_in, 1, 1)), (f"{p}.{n}.bias", (block_in,))]
+    s += res("encoder.mid.block_2", block_in, block_in)
+    s += [("encoder.norm_out.weight", (block_in,)), ("encoder.norm_out.bias", (block_in,)),
+          ("encoder.conv_out.weight", (2 * z_channels, block_in, 3, 3)), ("encoder.conv_out.bias", (2 * z_channels,)),
+          ("quant_conv.weight", (2 * embed_dim, 2 * z_channels, 1, 1)), ("quant_conv.bias", (2 * embed_dim,))]
+    return OrderedDict(s)
+
+
 def random_state_dict(shapes, seed: int, gain: float = 1.0, dtype=torch.float32):
     """Deterministic synthetic weights: matrices/filters ~ N(0, gain/fan_in), norm scales ~ 1 + 0.1 N,
     biases ~ 0.05 N.  Every tensor is random (zero-inits re-randomised).  Values are rounded to

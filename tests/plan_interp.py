@@ -180,6 +180,14 @@ def adaptive_avgpool_rows(inp, ld, out, ldo, n, Cc, IH, IW, OH, OW):
     _rows(_p(out), n * OH * OW, ldo)[:, :Cc] = y.to(torch.bfloat16)
 
 
+def posterior_sample(moments_rows, ld, noise, z, scale):
+    n, zc, H, W = z.shape
+    m = moments_rows.view(n, H * W, ld)
+    mean = m[:, :, :zc].permute(0, 2, 1).reshape(n, zc, H, W)
+    logvar = m[:, :, zc:2 * zc].permute(0, 2, 1).reshape(n, zc, H, W).clamp(-30.0, 20.0)
+    z.copy_(scale * (mean + torch.exp(0.5 * logvar) * noise))
+
+
 def _p(t):
     return t if isinstance(t, int) else t.data_ptr()
 
@@ -246,5 +254,5 @@ def install(monkeypatch):
     monkeypatch.setattr(ops.Stream, "_go", _go)
     monkeypatch.setattr(ops.Stream, "run", run)
     for name in ("latent_to_rows", "latent_to_rows_keep", "rows_to_nchw", "emb_combine_silu", "sinusoidal", "cfg_ddim_step",
-                 "i2v_temporal_adapter", "adaptive_avgpool_rows"):
+                 "i2v_temporal_adapter", "adaptive_avgpool_rows", "posterior_sample"):
         monkeypatch.setattr(ops, name, globals()[name])

@@ -134,3 +134,28 @@ def test_i2vgen_plan_matches_reference_golden(monkeypatch, golden_dir):
             camera_data=g["camera_data"])
     assert out.shape == g["out"].shape
     assert rel_l2(out, g["out"]) < 2.5e-2, rel_l2(out, g["out"])
+
+
+def test_vae_encoder_plan_matches_reference_golden(monkeypatch, golden_dir):
+    """VAE encoder plan (asymmetric-pad stride-2 convs, quant_conv, posterior sampling kernel) on the CPU interpreter vs
+    the moments captured from the imported reference (non-square 64x72 image)."""
+    from safetensors.torch import load_file
+    plan_interp.install(monkeypatch)
+    from videomv_amd.registry import AUTO_ENCODER
+    from oracle.weights import vae_encoder_param_shapes
+    from oracle.vae_ref import posterior_sample
+    g = load_file(os.path.join(golden_dir, "vae_enc_tiny.safetensors"))
+    dd = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 4, 4],
+              num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    sd = random_state_dict(vae_encoder_param_shapes(ch=32), 91)
+    vae = AUTO_ENCODER.build(dict(type="AutoencoderKL", ddconfig=dd, embed_dim=4))
+    vae.load_state_dict(sd, strict=False)
+    post = vae.encode(g["img"])
+    mom = post.parameters
+    assert mom.shape == g["moments"].shape
+    assert rel_l2(mom, g["moments"]) < 2e-2, rel_l2(mom, g["moments"])
+    torch.manual_seed(5)
+    z = vae.encode_firsr_stage(g["img"], 0.18215)
+    torch.manual_seed(5)
+    noise = torch.randn(2, 4, 8, 9)
+    assert rel_l2(z, posterior_sample(g["moments"], noise, 0.18215)) < 2e-2

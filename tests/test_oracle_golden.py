@@ -134,3 +134,12 @@ def test_i2vgen_forward_matches_reference(golden_dir):
     assert checksum(sd) == pytest.approx(float(g["weights_checksum"][0]), rel=1e-12)
     out = unet_i2v_forward(sd, cfg, g["x"], g["t"], g["y"], g["image"], g["local_image"], g["fps"], g["camera_data"])
     assert _rel(out, g["out"]) < 1e-5
+
+
+def test_vae_encoder_matches_reference(golden_dir):
+    from oracle.vae_ref import vae_encode_moments
+    from oracle.weights import vae_encoder_param_shapes
+    g = load_file(os.path.join(golden_dir, "vae_enc_tiny.safetensors"))
+    sd = random_state_dict(vae_encoder_param_shapes(ch=32), 91)
+    assert checksum(sd) == pytest.approx(float(g["weights_checksum"][0]), rel=1e-12)
+    assert _rel(vae_encode_moments(sd, g["img"]), g["moments"]) < 1e-5

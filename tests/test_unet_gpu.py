@@ -232,3 +232,25 @@ def test_full_size_architecture_parity_small_latent():
     e = rel_l2(eng.eps_ncfhw(), eps_ref)
     print("full-size per-block rel-L2:", report, "eps:", e)
     assert e < 2.5e-2, (e, report)
+
+
+def test_vae_encode_matches_reference_golden(golden_dir):
+    """tests/golden/vae_enc_tiny: posterior moments of the imported reference AutoencoderKL.encode (64x72 image) and
+    encode_firsr_stage's scale * (mean + std * noise) with the host-RNG noise the reference would draw."""
+    from videomv_amd.registry import AUTO_ENCODER
+    from oracle.weights import vae_encoder_param_shapes
+    from oracle.vae_ref import posterior_sample
+    g = load_file(os.path.join(golden_dir, "vae_enc_tiny.safetensors"))
+    dd = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 4, 4],
+              num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    sd = random_state_dict(vae_encoder_param_shapes(ch=32), 91)
+    vae = AUTO_ENCODER.build(dict(type="AutoencoderKL", ddconfig=dd, embed_dim=4))
+    vae.load_state_dict(sd, strict=False)
+    post = vae.encode(g["img"].cuda())
+    e = rel_l2(post.parameters, g["moments"])
+    assert e < 2e-2, e
+    torch.manual_seed(5)
+    z = vae.encode_firsr_stage(g["img"].cuda(), 0.18215)
+    torch.manual_seed(5)
+    noise = torch.randn(2, 4, 8, 9)
+    assert rel_l2(z, posterior_sample(g["moments"], noise, 0.18215)) < 2e-2

@@ -92,6 +92,7 @@ SYMBOLS = {
     "vmv_adaptive_avgpool_rows": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "vmv_rows_to_nchw": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P]),
     "vmv_cfg_ddim_step": (C.c_int, [C.POINTER(DdimParams), _P]),
+    "vmv_posterior_sample": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
     "vmv_emb_combine_silu": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "vmv_sinusoidal": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "vmv_plan_create": (_P, []),

@@ -4,8 +4,8 @@
 
 State-dict names/shapes are the reference's (248 keys at full size, encoder included so that
 ``VQGAN_autoencoder.pth`` loads with ``strict=True`` after the ``first_stage_model.`` prefix filter, :65-74).
-``encode`` / ``encode_firsr_stage`` (only needed by the LGM refinement loop and training) are a "next" row
- and raise ``NotImplementedError``.
+``encode`` / ``encode_firsr_stage`` (used by the I2VGen entrance for ``local_image`` and by the LGM refinement loop) run on
+the same kernels (``VaeEncoderEngine``); the posterior noise is drawn on the host RNG like the reference.
 
 Decoder plan (channels-last bf16 rows, one chunk of n frames):
   post_quant 1x1 -> conv_in 3x3 -> Res -> Attn(1 head, d = C: GEMM QK^T -> row softmax -> GEMM PV per frame)
@@ -84,8 +84,8 @@ def vae_param_shapes(dd: dict, embed_dim: int) -> Dict[str, tuple]:
     return dict(s)
 
 
-class VaeDecoderEngine:
-    """Recorded plan for ``decode`` of n latent frames of h x w."""
+class _VaeEngine:
+    """Shared pieces of the decoder / encoder plans: packing, GroupNorm(1e-6)+swish, ResnetBlock, 1-head AttnBlock."""
 
     def __init__(self, dd: dict, sd: Dict[str, torch.Tensor], n: int, h: int, w: int, device):
         self.dd, self.n, self.h, self.w, self.device = dd, n, h, w, device
@@ -93,13 +93,12 @@ class VaeDecoderEngine:
         self.S = ops.Stream(record=True)
         self._keep = []
         self._gnws = torch.empty(4 << 20, dtype=torch.float32, device=device)
+        self.wt = {}
         self._pack(sd)
         self._build()
 
-    # ---- weights
-    def _pack(self, sd):
-        dev, w = self.device, {}
-        self.wt = w
+    def _packers(self, sd):
+        dev, w = self.device, self.wt
 
         def conv(key, fold_skip=None):
             ww = sd[key + ".weight"]
@@ -123,23 +122,13 @@ class VaeDecoderEngine:
         def res(p):
             norm(p + ".norm1"); conv(p + ".conv1"); norm(p + ".norm2"); conv(p + ".conv2", fold_skip=p + ".nin_shortcut")
 
-        lin("post_quant_conv")
-        conv("decoder.conv_in")
-        res("decoder.mid.block_1"); res("decoder.mid.block_2")
-        a = "decoder.mid.attn_1"
-        norm(a + ".norm")
-        for nme in ("q", "k", "v", "proj_out"):
-            lin(f"{a}.{nme}")
-        # V^T = Wv . hn^T is computed with Wv as the *activation* operand: needs Wv as bf16 rows [C][C]
-        ch_mult, nrb = list(self.dd["ch_mult"]), self.dd["num_res_blocks"]
-        for lvl in range(len(ch_mult)):
-            for i in range(nrb + 1):
-                res(f"decoder.up.{lvl}.block.{i}")
-            if lvl != 0:
-                conv(f"decoder.up.{lvl}.upsample.conv")
-        norm("decoder.norm_out")
-        conv("decoder.conv_out")
-        self.out_pad = w["decoder.conv_out.weight"].shape[0]
+        def attn(a):
+            norm(a + ".norm")
+            for nme in ("q", "k", "v", "proj_out"):
+                lin(f"{a}.{nme}")
+
+        return conv, norm, lin, res, attn
+
 
     # ---- helpers
     def act(self, rows, C, dtype=BF16):
@@ -217,6 +206,27 @@ class VaeDecoderEngine:
         self.rel(ao)
         return y
 
+
+class VaeDecoderEngine(_VaeEngine):
+    """Recorded plan for ``decode`` of n latent frames of h x w."""
+
+    def _pack(self, sd):
+        conv, norm, lin, res, attn = self._packers(sd)
+        w = self.wt
+        lin("post_quant_conv")
+        conv("decoder.conv_in")
+        res("decoder.mid.block_1"); res("decoder.mid.block_2")
+        attn("decoder.mid.attn_1")
+        ch_mult, nrb = list(self.dd["ch_mult"]), self.dd["num_res_blocks"]
+        for lvl in range(len(ch_mult)):
+            for i in range(nrb + 1):
+                res(f"decoder.up.{lvl}.block.{i}")
+            if lvl != 0:
+                conv(f"decoder.up.{lvl}.upsample.conv")
+        norm("decoder.norm_out")
+        conv("decoder.conv_out")
+        self.out_pad = w["decoder.conv_out.weight"].shape[0]
+
     def _build(self):
         n, h, w = self.n, self.h, self.w
         dev = self.device
@@ -272,6 +282,94 @@ class VaeDecoderEngine:
         return out[:, : self.dd["out_ch"]].contiguous()
 
 
+class VaeEncoderEngine(_VaeEngine):
+    """Recorded plan for ``encode`` of n images of h x w pixels (h, w multiples of 8): conv_in -> 4 levels x 2 ResnetBlocks
+    with pad-(0,1,0,1) stride-2 down-sampling convs -> mid (Res, Attn, Res) -> GN + swish -> conv_out -> quant_conv;
+    leaves the posterior moments as fp32 rows [n*(h/8)*(w/8), 2*zc]  (Encoder.forward, autoencoder.py:548-576)."""
+
+    def _pack(self, sd):
+        conv, norm, lin, res, attn = self._packers(sd)
+        conv("encoder.conv_in")
+        ch_mult, nrb = list(self.dd["ch_mult"]), self.dd["num_res_blocks"]
+        for lvl in range(len(ch_mult)):
+            for i in range(nrb):
+                res(f"encoder.down.{lvl}.block.{i}")
+            if lvl != len(ch_mult) - 1:
+                conv(f"encoder.down.{lvl}.downsample.conv")
+        res("encoder.mid.block_1"); attn("encoder.mid.attn_1"); res("encoder.mid.block_2")
+        norm("encoder.norm_out")
+        conv("encoder.conv_out")
+        lin("quant_conv")
+
+    def _build(self):
+        n, h, w, dev = self.n, self.h, self.w, self.device
+        cin = self.dd["in_channels"]
+        self.cpad = (cin + 7) // 8 * 8
+        self.x_rows = torch.zeros(n * h * w, self.cpad, dtype=BF16, device=dev)
+        c0 = self.wt["encoder.conv_in.weight"].shape[0]
+        x = self.act(n * h * w, c0)
+        self._gemm("conv_in", n * h * w, ops.conv3x3_segs([(self.x_rows.data_ptr(), self.cpad, self.cpad)]),
+                   "encoder.conv_in.weight", x, bias=self.wt["encoder.conv_in.bias"], geom=ops.Geom(OH=h, OW=w, IH=h, IW=w))
+        ch_mult, nrb = list(self.dd["ch_mult"]), self.dd["num_res_blocks"]
+        for lvl in range(len(ch_mult)):
+            for i in range(nrb):
+                y = self._res(f"encoder.down.{lvl}.block.{i}", x, h, w)
+                self.rel(x)
+                x = y
+            if lvl != len(ch_mult) - 1:
+                p = f"encoder.down.{lvl}.downsample.conv"
+                oh, ow = h // 2, w // 2
+                y = self.act(n * oh * ow, x.C)
+                self._gemm(p, y.rows, ops.conv3x3_segs([(x.ptr, x.C, x.C)], shift=1), p + ".weight", y,
+                           bias=self.wt[p + ".bias"], geom=ops.Geom(OH=oh, OW=ow, IH=h, IW=w, stride=2))
+                self.rel(x)
+                x, h, w = y, oh, ow
+        for fn, p in ((self._res, "encoder.mid.block_1"), (self._attn, "encoder.mid.attn_1"), (self._res, "encoder.mid.block_2")):
+            y = fn(p, x, h, w)
+            self.rel(x)
+            x = y
+        hn = self._gn("norm_out", x, h * w, "encoder.norm_out", True)
+        self.rel(x)
+        T = n * h * w
+        co = self.act(T, self.wt["encoder.conv_out.weight"].shape[0])
+        self._gemm("conv_out", T, ops.conv3x3_segs([(hn.ptr, hn.C, hn.C)]), "encoder.conv_out.weight", co,
+                   bias=self.wt["encoder.conv_out.bias"], geom=ops.Geom(OH=h, OW=w, IH=h, IW=w))
+        self.rel(hn)
+        self.mc = self.wt["quant_conv.weight"].shape[0]
+        self.moment_rows = torch.zeros(T, self.mc, dtype=torch.float32, device=dev)
+        self._gemm("quant_conv", T, ops.linear_segs([(co.ptr, co.C, co.C)]), "quant_conv.weight",
+                   self.moment_rows.data_ptr(), ldo=self.mc, bias=self.wt["quant_conv.bias"], out_fp32=True)
+        self.LH, self.LW = h, w
+
+    def encode(self, x: torch.Tensor) -> torch.Tensor:
+        """x [n, 3, H, W] fp32 on device -> moments rows fp32 [n*LH*LW, 2*zc] (valid until the next call)."""
+        n, c, h, w = x.shape
+        ops.latent_to_rows_keep(x.reshape(n, c, 1, h, w).contiguous(), self.x_rows, self.cpad, 1)
+        self.S.run()
+        return self.moment_rows
+
+
+class DiagonalGaussianDistribution(object):
+    """Posterior handle returned by ``AutoencoderKL.encode`` (autoencoder.py:213-226): holds the moments produced by the
+    HIP encoder; ``sample()`` draws the noise on the HOST RNG exactly like the reference (``torch.randn(shape).to(device)``)
+    and evaluates mean + std * noise in ``vmv_posterior_sample``."""
+
+    def __init__(self, moment_rows, n, zc, h, w, device):
+        self.moment_rows, self.n, self.zc, self.h, self.w, self.device = moment_rows.clone(), n, zc, h, w, device
+
+    @property
+    def parameters(self):
+        out = torch.empty(self.n, 2 * self.zc, self.h, self.w, dtype=torch.float32, device=self.device)
+        ops.rows_to_nchw(self.moment_rows, 2 * self.zc, out)
+        return out
+
+    def sample(self, scale=1.0):
+        noise = torch.randn(self.n, self.zc, self.h, self.w).to(device=self.device)
+        z = torch.empty(self.n, self.zc, self.h, self.w, dtype=torch.float32, device=self.device)
+        ops.posterior_sample(self.moment_rows, 2 * self.zc, noise, z, scale)
+        return z
+
+
 @AUTO_ENCODER.register_class()
 class AutoencoderKL(nn.Module):
     def __init__(self, ddconfig, embed_dim, pretrained=None, ignore_keys=[], image_key="image", colorize_nlabels=None,
@@ -321,11 +419,25 @@ class AutoencoderKL(nn.Module):
             self._engines[key] = eng
         return eng.decode(z.float())
 
+    @torch.no_grad()
     def encode(self, x):
-        raise NotImplementedError("VAE encoder on HIP is a later row (SURVEY §8f rank 2)")
+        """-> posterior (``.parameters`` [n, 2*zc, h/8, w/8], ``.sample()``); quant_conv(Encoder(x)) on HIP (:76-80)."""
+        n, c, h, w = x.shape
+        if (h % 8) or (w % 8):
+            raise ValueError("image sides must be multiples of 8")
+        key = ("enc", n, h, w, str(x.device))
+        eng = self._engines.get(key)
+        if eng is None:
+            sd = {k: v.detach() for k, v in self.state_dict().items() if k.startswith("encoder.") or k.startswith("quant_conv.")}
+            eng = VaeEncoderEngine(self.ddconfig, sd, n, h, w, x.device)
+            self._engines[key] = eng
+        rows = eng.encode(x.float())
+        return DiagonalGaussianDistribution(rows, n, self.ddconfig["z_channels"], eng.LH, eng.LW, x.device)
 
+    @torch.no_grad()
     def encode_firsr_stage(self, x, scale_factor=1.0):
-        raise NotImplementedError("VAE encoder on HIP is a later row (SURVEY §8f rank 2)")
+        """scale_factor * posterior.sample()  (autoencoder.py:86-91; the typo is the reference's public name)."""
+        return self.encode(x).sample(scale=scale_factor)
 
     def forward(self, input, sample_posterior=True):
         raise NotImplementedError("training-time autoencoding is out of scope (inference hot path only)")

@@ -186,6 +186,20 @@ __global__ void cfg_ddim_kernel(const VmvDdimParams p) {
     }
 }
 
+__global__ void posterior_sample_kernel(const float* __restrict__ mom, int ld, const float* __restrict__ noise,
+                                        float* __restrict__ z, long n, int zc, long HW, float scale) {
+    const long total = n * zc * HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i % HW;
+        const long t = i / HW;
+        const int c = (int)(t % zc);
+        const long img = t / zc;
+        const float* m = mom + (img * HW + pix) * ld;
+        const float lv = fminf(fmaxf(m[zc + c], -30.0f), 20.0f);
+        z[i] = scale * (m[c] + __expf(0.5f * lv) * noise[i]);
+    }
+}
+
 __global__ void emb_combine_kernel(const float* __restrict__ temb, const float* __restrict__ cam, uint16_t* __restrict__ out,
                                    int rows, int C, int rows_per_t, int cam_rows) {
     const long total = (long)rows * C;
@@ -277,6 +291,15 @@ extern "C" int vmv_cfg_ddim_step(const VmvDdimParams* pp, void* stream) {
     if (p.C <= 0 || p.F <= 0 || p.HW <= 0 || p.ld < p.C) return VMV_EINVAL;
     hipLaunchKernelGGL(cfg_ddim_kernel, dim3(grid_for((long)p.C * p.F * p.HW)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), p);
+    return vmv_launch_status();
+}
+
+extern "C" int vmv_posterior_sample(const float* moments_rows, int ld, const float* noise, float* z, int n, int zc, int HW,
+                                    float scale, void* stream) {
+    if (!moments_rows || !noise || !z) return VMV_ENULL;
+    if (n <= 0 || zc <= 0 || HW <= 0 || ld < 2 * zc) return VMV_EINVAL;
+    hipLaunchKernelGGL(posterior_sample_kernel, dim3(grid_for((long)n * zc * HW)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), moments_rows, ld, noise, z, (long)n, zc, (long)HW, scale);
     return vmv_launch_status();
 }
 

@@ -30,10 +30,11 @@ class Seg:
         self.src, self.ld, self.k, self.mode, self.d0, self.d1 = src, int(ld), int(k), mode, d0, d1
 
 
-def conv3x3_segs(sources: Sequence[Tuple[torch.Tensor, int, int]]) -> List[Seg]:
+def conv3x3_segs(sources: Sequence[Tuple[torch.Tensor, int, int]], shift: int = 0) -> List[Seg]:
     """sources = [(rows tensor, ld, channels)] (channel-concatenated).  Order: tap-major, then source — the
-    order ``pack_conv3x3`` lays the weights out in."""
-    return [Seg(t, ld, k, L.SEG_SPATIAL, dy, dx) for (dy, dx) in TAPS3x3 for (t, ld, k) in sources]
+    order ``pack_conv3x3`` lays the weights out in.  ``shift=1`` moves the taps to (0..2, 0..2): the VAE encoder's
+    pad-(0,1,0,1)-then-valid stride-2 convolution (autoencoder.py:475-479)."""
+    return [Seg(t, ld, k, L.SEG_SPATIAL, dy + shift, dx + shift) for (dy, dx) in TAPS3x3 for (t, ld, k) in sources]
 
 
 def temporal_segs(src, ld, k) -> List[Seg]:
@@ -227,6 +228,12 @@ def cfg_ddim_step(eps_rows, ld, xt, guide_scale, c_recip, c_recipm1, c_sqrt_ac, 
     p.c_sqrt_ac, p.c_sqrt_1mac, p.a_prev, p.v_pred = c_sqrt_ac, c_sqrt_1mac, a_prev, 1 if v_pred else 0
     p.xt, p.x0_out = xt.data_ptr(), _ptr(x0_out)
     L.check(L.load().vmv_cfg_ddim_step(C.byref(p), _stream_ptr()), "cfg_ddim_step")
+
+
+def posterior_sample(moments_rows, ld, noise, z, scale):
+    n, zc, H, W = z.shape
+    L.check(L.load().vmv_posterior_sample(moments_rows.data_ptr(), ld, noise.data_ptr(), z.data_ptr(), n, zc, H * W,
+                                          float(scale), _stream_ptr()), "posterior_sample")
 
 
 def emb_combine_silu(temb, cam, out, rows, Cc, rows_per_t, cam_rows):
