@@ -153,6 +153,25 @@ def test_inference_py_entry_on_gpu(tmp_path):
     assert any(f.endswith(".png") for f in os.listdir(outdir))
 
 
+def test_inference_py_i2vgen_entry_on_gpu(tmp_path):
+    """`python inference.py --cfg configs/i2vgen_xl_infer.yaml ...` (BASELINE configs[3]) on the GPU: image -> HIP VAE
+    encode -> UNetSD_I2VGen v-prediction DDIM -> HIP VAE decode (random weights, 4 views, 4 steps, full 256x256 image)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "inference.py", "--cfg", "configs/i2vgen_xl_infer.yaml", "--debug", "allow_random_init", "True",
+           "num_views", "4", "ddim_timesteps", "4", "log_dir", str(tmp_path / "out"),
+           "UNet.num_res_blocks", "1", "UNet.dim_mult", "[1, 2]", "test_model", "none.pth"]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    outdir = tmp_path / "out" / "test_images"
+    pts = [f for f in os.listdir(outdir) if f.endswith(".pt")]
+    assert len(pts) == 1
+    blob = torch.load(os.path.join(outdir, pts[0]))
+    assert blob["latent"].shape == (1, 4, 4, 32, 32) and blob["video"].shape == (1, 3, 4, 256, 256)
+    assert torch.isfinite(blob["video"]).all()
+
+
 def test_i2vgen_matches_reference_golden_and_vpred_loop(golden_dir):
     """BASELINE configs[3] analogue: UNetSD_I2VGen on HIP vs the imported reference's output (tolerance 3e-2, bf16
     storage), then the fused CFG + v-prediction DDIM loop (cosine schedule with zero terminal SNR, guide 6) vs the oracle."""

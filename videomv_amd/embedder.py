@@ -17,7 +17,17 @@ class _TextFeatures(torch.nn.Module):
         self.table = torch.load(features_path, map_location="cpu") if features_path else None
 
     def forward(self, text=None, image=None):
-        """-> (None, y_text [B,1,W], y_words [B,T,W]) like FrozenOpenCLIPTtxtVisualEmbedder(text=...) (:145-227)."""
+        """-> (y_visual [B,W] or None, y_text [B,1,W], y_words [B,T,W]) like FrozenOpenCLIPTtxtVisualEmbedder (:145-227).
+        ``image`` (a normalised image tensor) yields a deterministic stand-in for the CLIP image embedding."""
+        if isinstance(text, str):
+            text = [text]
+        y_visual = None
+        if image is not None:
+            vis = []
+            for im in image:
+                seed = int.from_bytes(hashlib.sha256(im.detach().cpu().float().numpy().tobytes()).digest()[:8], "little") % (2 ** 63)
+                vis.append(torch.randn(self.width, generator=torch.Generator().manual_seed(seed)))
+            y_visual = torch.stack(vis, 0)
         outs = []
         for t in text:
             if self.table is not None and t in self.table:
@@ -27,7 +37,7 @@ class _TextFeatures(torch.nn.Module):
             g = torch.Generator().manual_seed(seed)
             outs.append(torch.randn(self.tokens, self.width, generator=g))
         y_words = torch.stack(outs, 0)
-        return None, y_words.mean(dim=1, keepdim=True), y_words
+        return y_visual, y_words.mean(dim=1, keepdim=True), y_words
 
 
 @EMBEDDER.register_class()

@@ -141,6 +141,125 @@ def worker(gpu, cfg, cfg_update):
     return cfg
 
 
+def center_crop_wide(img, size):
+    """utils/transforms.py:163-183 — BOX-resize so that the image covers ``size`` (w, h), then centre-crop."""
+    from PIL import Image
+    scale = min(img.size[0] / size[0], img.size[1] / size[1])
+    img = img.resize((round(img.width // scale), round(img.height // scale)), resample=Image.BOX)
+    x1, y1 = (img.width - size[0]) // 2, (img.height - size[1]) // 2
+    return img.crop((x1, y1, x1 + size[0], y1 + size[1]))
+
+
+def _to_normalised_tensor(img, mean, std):
+    import numpy as np
+    a = torch.from_numpy(np.asarray(img, dtype=np.float32) / 255.0).permute(2, 0, 1)
+    return (a - torch.tensor(mean).view(3, 1, 1)) / torch.tensor(std).view(3, 1, 1)
+
+
+@INFER_ENGINE.register_function()
+def inference_i2vgen_entrance(cfg_update, **kwargs):
+    """Image -> 24 views (tools/inferences/inference_i2vgen_entrance.py): RGBA image on a white background -> VAE-encoded
+    ``local_image`` + CLIP image feature -> UNetSD_I2VGen with v-prediction / cosine-ZTSNR DDIM, guide 6, orbit cameras
+    at elevation 5 / distance 1.7 (:136-147), fps 8; decode in ``decoder_bs`` chunks."""
+    cfg = default_cfg()
+    cfg.negative_prompt = 'Distorted, discontinuous, Ugly, blurry, low resolution, motionless, static, disfigured, ' \
+                          'disconnected limbs, Ugly faces, incomplete arms'
+    merge_into(cfg, _plain(dict(cfg_update)))
+    cfg.pmi_rank, cfg.pmi_world_size = int(os.getenv('RANK', 0)), int(os.getenv('WORLD_SIZE', 1))
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29534')
+    cfg.world_size = 1 if cfg.debug else cfg.pmi_world_size
+    return worker_i2v(int(os.getenv('LOCAL_RANK', 0)), cfg, cfg_update)
+
+
+@torch.no_grad()
+def worker_i2v(gpu, cfg, cfg_update):
+    from PIL import Image
+    if 'vldm_cfg' in cfg_update and cfg_update['vldm_cfg']:
+        cfg = AttrDict(assign_signle_cfg(cfg, cfg_update, 'vldm_cfg'))
+        merge_into(cfg, _plain(dict(cfg_update)))
+    cfg.gpu, cfg.seed, cfg.rank = gpu, int(cfg.seed), cfg.pmi_rank
+    torch.manual_seed(rank_seed(cfg.seed, cfg.rank))
+    on_gpu = str(cfg.device).startswith("cuda")
+    device = torch.device("cuda", gpu) if on_gpu else torch.device(cfg.device)
+    if on_gpu:
+        torch.cuda.set_device(gpu)
+    if cfg.world_size > 1:
+        dist.init_process_group(backend='nccl' if on_gpu else 'gloo', world_size=cfg.world_size, rank=cfg.rank)
+    exp_name = osp.basename(cfg.test_list_path).split('.')[0]
+    cfg.log_dir = osp.join(cfg.log_dir, exp_name)
+    os.makedirs(cfg.log_dir, exist_ok=True)
+    logging.basicConfig(level=logging.INFO, format='[%(asctime)s] %(levelname)s: %(message)s', force=True,
+                        handlers=[logging.FileHandler(osp.join(cfg.log_dir, 'log_%02d.txt' % cfg.rank)),
+                                  logging.StreamHandler(stream=sys.stdout)])
+    logging.info(f"Going into inference_i2vgen_entrance inference on {gpu} gpu (HIP hot path)")
+    diffusion = DIFFUSION.build(dict(cfg.Diffusion))
+    clip_encoder = EMBEDDER.build(dict(cfg.embedder))
+    _, _, zero_y_negative = clip_encoder(text=cfg.negative_prompt)
+    black_image_feature = torch.zeros([1, 1, cfg.UNet['y_dim']])
+    autoencoder = AUTO_ENCODER.build({k: v for k, v in cfg.auto_encoder.items() if k != 'pretrained'})
+    _load_weights(autoencoder, cfg.auto_encoder.get('pretrained'), cfg.allow_random_init, "autoencoder",
+                  prefix_filter='first_stage_model.')
+    autoencoder.eval()
+    unet_cfg = dict(cfg.UNet)
+    if unet_cfg.get('use_lgm_refine'):
+        logging.info("use_lgm_refine=True: the LGM-refined second loop is not built yet; running the plain loop only")
+        unet_cfg['use_lgm_refine'] = False
+    model = MODEL.build(unet_cfg)
+    _load_weights(model, cfg.get('test_model'), cfg.allow_random_init, "UNet")
+    model.eval()
+    F = int(cfg.num_views or cfg.max_frames)
+    elevation, camera_dist = 5, 1.7
+    camera_data = entrance_camera_data(F, elevation=elevation, camera_distance=camera_dist)
+    with open(cfg.test_list_path, 'r') as f:
+        test_list = [ln.strip() for ln in f.readlines() for _ in range(int(cfg.get('round', 1)))]
+    lat_h, lat_w = int(cfg.resolution[1] / cfg.scale), int(cfg.resolution[0] / cfg.scale)
+    outputs = []
+    for idx, line in enumerate(test_list):
+        if line.startswith('#') or line == "":
+            logging.info(f'Skip {line!r}')
+            continue
+        try:
+            rgba = Image.open(line).convert('RGBA')
+        except Exception as e:
+            logging.info(f'cannot open {line}: {e}')
+            continue
+        logging.info(f"[{idx}]/[{len(test_list)}] Begin to sample {line} ...")
+        image = Image.new('RGB', size=rgba.size, color=(255, 255, 255))
+        image.paste(rgba, (0, 0), mask=rgba)
+        vit_img = center_crop_wide(image, (cfg.resolution[0], cfg.resolution[0])).resize(tuple(cfg.get('vit_resolution', [224, 224])))
+        y_visual, _, y_words = clip_encoder(image=_to_normalised_tensor(vit_img, cfg.mean, cfg.std).unsqueeze(0), text=[""])
+        y_visual = y_visual.unsqueeze(1)
+        img_t = _to_normalised_tensor(center_crop_wide(image, tuple(cfg.resolution)), cfg.mean, cfg.std).unsqueeze(0).to(device)
+        local_image = autoencoder.encode_firsr_stage(img_t, cfg.scale_factor)
+        local_image = local_image.unsqueeze(2).repeat_interleave(repeats=F, dim=2)
+        fps_tensor = torch.tensor([cfg.target_fps], dtype=torch.long, device=device)
+        noise = torch.randn([1, 4, F, lat_h, lat_w]).to(device)
+        infer_img = black_image_feature if cfg.use_zero_infer else None
+        kw = [{'y': y_words.to(device), 'image': y_visual.to(device), 'local_image': local_image, 'fps': fps_tensor,
+               'camera_data': camera_data},
+              {'y': zero_y_negative.to(device), 'image': None if infer_img is None else infer_img.to(device),
+               'local_image': local_image, 'fps': fps_tensor, 'camera_data': camera_data}]
+        x0 = diffusion.ddim_sample_loop(noise=noise, model=model, model_kwargs=kw, guide_scale=cfg.guide_scale,
+                                        ddim_timesteps=int(cfg.ddim_timesteps), eta=0.0)
+        from .pipeline import decode_views
+        video = decode_views(autoencoder, x0, int(cfg.decoder_bs), cfg.scale_factor)
+        stem = f'rank_{cfg.world_size:02d}_{cfg.rank:02d}_{idx:04d}_{osp.basename(line).split(".")[0]}_{int(elevation):02d}_{camera_dist:.02f}'
+        path = osp.join(cfg.log_dir, stem + '.pt')
+        torch.save({'latent': x0.cpu(), 'video': video.cpu(), 'image': line}, path)
+        _save_contact_sheet(video.cpu(), osp.join(cfg.log_dir, stem + '.png'), cfg.mean, cfg.std)
+        logging.info('Save views to %s' % path)
+        outputs.append(path)
+    logging.info('Congratulations! The inference is completed!')
+    if on_gpu:
+        torch.cuda.synchronize()
+    if cfg.world_size > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    cfg.outputs = outputs
+    return cfg
+
+
 def _save_contact_sheet(video, path, mean, std):
     """video [1, 3, F, H, W] in normalised range -> one PNG with the F views side by side (best effort)."""
     try:
