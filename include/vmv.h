@@ -124,6 +124,9 @@ typedef struct {
     int32_t silu;          /* 1: y = silu(gn(x)) */
     void* y;               /* bf16 [rows][ldy] */
     int32_t ldy;
+    int32_t fold_ranks;    /* 0/1: `partial` holds this launch's sums.  R > 1 (frame-sharded 5-D norms): apply
+                              folds `partial` = [R][nstat][nchunk][32][2] — the all-gathered sums of R equally sized shards of
+                              each stat group — and normalises by R * rows_per_stat rows.  Ignored by _stats.            */
 } VmvGroupNormParams;
 
 int vmv_groupnorm_stats(const VmvGroupNormParams* p, void* stream);
@@ -229,6 +232,21 @@ int vmv_adaptive_avgpool_rows(const void* in, int ld, void* out, int ldo, int n,
                               void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * Block permute-copy (frame-sharded sampling, DESIGN.md §8: packs / unpacks the all-to-all buffers that switch an
+ * activation between the frame-major shard [B][F/R][HW][C] and the pixel-major shard [B][F][HW/R][C]; the reference has
+ * no counterpart — its multi-GPU mode is replicas only, inference_text2video_entrance.py:152-156).
+ * dst[i0][i1][i2][0..inner) = src[i0*ss0 + i1*ss1 + i2*ss2 + (0..inner)], dst contiguous; all counts in 16-byte units.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const void* src;
+    void* dst;
+    int32_t n0, n1, n2;
+    int32_t inner16;              /* contiguous 16-byte vectors per (i0,i1,i2) block */
+    int64_t ss0, ss1, ss2;        /* source strides, 16-byte units */
+} VmvCopyParams;
+int vmv_permute_copy(const VmvCopyParams* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
  * Plan: a recorded sequence of the launches above, replayed with one call (host-side launch overhead of
  * >1000 kernels per forward would otherwise dominate).
  * ---------------------------------------------------------------------------------------------------- */
@@ -239,6 +257,7 @@ typedef struct VmvPlan VmvPlan;
 #define VMV_OP_LAYERNORM   4
 #define VMV_OP_ATTENTION   5
 #define VMV_OP_SOFTMAX     6
+#define VMV_OP_COPY        7
 VmvPlan* vmv_plan_create(void);
 void     vmv_plan_destroy(VmvPlan* plan);
 int      vmv_plan_add(VmvPlan* plan, int op, const void* params, size_t nbytes);

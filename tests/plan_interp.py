@@ -76,20 +76,52 @@ def gemm(p: L.GemmParams):
     out[:, :No] = acc if p.out_fp32 else acc.to(torch.bfloat16)
 
 
-def groupnorm(p: L.GroupNormParams):
+def _gn_input(p):
     Cc = p.C0 + p.C1
     x = _rows(p.x, p.rows, p.ld)[:, : p.C0].float()
     if p.C1:
         x = torch.cat([x, _rows(p.x1, p.rows, p.ld1)[:, : p.C1].float()], dim=1)
+    return x, Cc
+
+
+def groupnorm_stats(p: L.GroupNormParams):
+    """partial[stat][chunk][group] = (sum, sum of squares) over chunk_rows rows x C/32 channels."""
+    x, Cc = _gn_input(p)
     nstat = p.rows // p.rows_per_stat
+    nchunk = (p.rows_per_stat + p.chunk_rows - 1) // p.chunk_rows
+    part = _view(p.partial, nstat * nchunk * 64, "f32").view(nstat, nchunk, 32, 2)
     xg = x.view(nstat, p.rows_per_stat, 32, Cc // 32)
-    mean = xg.mean(dim=(1, 3), keepdim=True)
-    var = xg.var(dim=(1, 3), unbiased=False, keepdim=True)
-    y = ((xg - mean) * torch.rsqrt(var + p.eps)).view(p.rows, Cc)
+    for c in range(nchunk):
+        blk = xg[:, c * p.chunk_rows:(c + 1) * p.chunk_rows]
+        part[:, c, :, 0] = blk.sum(dim=(1, 3))
+        part[:, c, :, 1] = (blk * blk).sum(dim=(1, 3))
+
+
+def groupnorm(p: L.GroupNormParams):
+    """apply: fold the partial sums (of `fold_ranks` gathered shards when > 1), normalise, affine, optional SiLU."""
+    x, Cc = _gn_input(p)
+    nstat = p.rows // p.rows_per_stat
+    nchunk = (p.rows_per_stat + p.chunk_rows - 1) // p.chunk_rows
+    R = max(1, p.fold_ranks)
+    part = _view(p.partial, R * nstat * nchunk * 64, "f32").view(R, nstat, nchunk, 32, 2).double().sum(dim=(0, 2))
+    n = float(p.rows_per_stat) * (Cc // 32) * R
+    mean = part[..., 0] / n
+    var = (part[..., 1] / n - mean * mean).clamp_min(0.0)
+    xg = x.view(nstat, p.rows_per_stat, 32, Cc // 32)
+    y = ((xg - mean.float()[:, None, :, None]) * torch.rsqrt(var.float() + p.eps)[:, None, :, None]).view(p.rows, Cc)
     y = y * _view(p.gamma, Cc, "f32") + _view(p.beta, Cc, "f32")
     if p.silu:
         y = torch.nn.functional.silu(y)
     _rows(p.y, p.rows, p.ldy)[:, :Cc] = y.to(torch.bfloat16)
+
+
+def permute_copy(p: L.CopyParams):
+    """dst[i0][i1][i2][:] = src[i0*ss0 + i1*ss1 + i2*ss2 + :], 16-byte units (8 bf16)."""
+    span = (p.n0 - 1) * p.ss0 + (p.n1 - 1) * p.ss1 + (p.n2 - 1) * p.ss2 + p.inner16
+    src = _view(p.src, span * 8, "bf16").view(torch.int16)
+    dst = _view(p.dst, p.n0 * p.n1 * p.n2 * p.inner16 * 8, "bf16").view(torch.int16)
+    v = torch.as_strided(src, (p.n0, p.n1, p.n2, p.inner16 * 8), (p.ss0 * 8, p.ss1 * 8, p.ss2 * 8, 1))
+    dst.view(p.n0, p.n1, p.n2, p.inner16 * 8).copy_(v)
 
 
 def layernorm(p: L.LayerNormParams):
@@ -128,7 +160,7 @@ def run_recorded(recorded):
         if op == L.OP_GEMM:
             gemm(params)
         elif op == L.OP_GN_STATS:
-            pass                      # folded into GN_APPLY below
+            groupnorm_stats(params)
         elif op == L.OP_GN_APPLY:
             groupnorm(params)
         elif op == L.OP_LAYERNORM:
@@ -137,6 +169,8 @@ def run_recorded(recorded):
             attention(params)
         elif op == L.OP_SOFTMAX:
             softmax_rows(params)
+        elif op == L.OP_COPY:
+            permute_copy(params)
         else:
             raise ValueError(op)
 

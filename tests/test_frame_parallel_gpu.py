@@ -1,0 +1,120 @@
+"""Frame-parallel sampling on the GPU (`pytest -m gpu`; BASELINE configs[2]).  The GPU box has ONE device,
+so the collectives are exercised two ways: (1) world 1 — the sharded plan (pack / all-to-all / unpack, gathered GroupNorm
+sums, plan cut at its collectives) must reproduce the unsharded plan bit for bit; (2) two processes sharing cuda:0 with a
+gloo group (device tensors staged through host memory by ``comm.FrameComm``) — every rank's frames against the single-rank
+HIP result and the fp32 oracle.  RCCL itself is reached through the same two ``torch.distributed`` calls at N > 1.
+
+Tolerances (rel-L2 on eps): vs the oracle <= 3e-2 (bf16 storage; same bound as tests/test_unet_gpu.py); sharded vs
+single-rank <= 3e-2 (the two runs' bf16 rounding noise decorrelates once the GroupNorm fold order differs)."""
+import dataclasses
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(in_dim=4, dim=64, context_dim=1024, out_dim=4, dim_mult=[1, 2], num_heads=2, head_dim=64,
+           num_res_blocks=1, attn_scales=[1.0, 0.5], camera_dim=16, use_camera_condition=True,
+           use_fps_condition=False)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def rel_l2(a, b):
+    return float((a.float().cpu() - b.float().cpu()).norm() / b.float().cpu().norm().clamp_min(1e-12))
+
+
+def _case(F_, H, W, L=7, seed=5):
+    from oracle.unet_ref import UNetCfg
+    from oracle.weights import random_state_dict, unet_param_shapes
+    ocfg = UNetCfg(**{k: v for k, v in CFG.items() if k in {f.name for f in dataclasses.fields(UNetCfg)}})
+    sd = random_state_dict(unet_param_shapes(ocfg), 99)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(1, 4, F_, H, W, generator=g)
+    t = torch.tensor([501])
+    y = torch.randn(2, L, 1024, generator=g)
+    cam = torch.randn(1, F_, 16, generator=g)
+    return ocfg, sd, x, t, y, cam
+
+
+def test_world1_sharded_plan_is_bitwise_the_unsharded_plan():
+    from videomv_amd.comm import FrameComm
+    from videomv_amd.unet_engine import UNetEngine
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
+    try:
+        ocfg, sd, x, t, y, cam = _case(4, 16, 16)
+        dev = torch.device("cuda", 0)
+        outs = []
+        for comm in (None, FrameComm()):
+            eng = UNetEngine(CFG, sd, 2, 4, 16, 16, y.shape[1], dev, n_t=1, comm=comm)
+            eng.set_context(y.to(dev)); eng.set_camera(cam.to(dev))
+            eng.forward_rows(x.to(dev), t.to(dev))
+            outs.append(eng.eps_ncfhw().cpu())
+            if comm is not None:
+                assert len(eng.breaks) > 30 and comm.n_all_to_all > 0 and comm.n_all_gather > 0
+        assert torch.isfinite(outs[0]).all()
+        assert torch.equal(outs[0], outs[1])
+    finally:
+        dist.destroy_process_group()
+
+
+def _worker(rank, world, port, F_, H, W, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from oracle.unet_ref import unet_forward
+        from videomv_amd.comm import FrameComm
+        from videomv_amd.unet_engine import UNetEngine
+        ocfg, sd, x, t, y, cam = _case(F_, H, W)
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        ref = UNetEngine(CFG, sd, 2, F_, H, W, y.shape[1], dev, n_t=1)
+        ref.set_context(y.to(dev)); ref.set_camera(cam.to(dev))
+        ref.forward_rows(x.to(dev), t.to(dev))
+        eps_single = ref.eps_ncfhw().cpu()
+        eps_oracle = torch.cat([unet_forward(sd, ocfg, x, t, y[i:i + 1], cam) for i in range(2)], dim=0)
+        comm = FrameComm()
+        fl = F_ // world
+        sl = slice(rank * fl, (rank + 1) * fl)
+        eng = UNetEngine(CFG, sd, 2, F_, H, W, y.shape[1], dev, n_t=1, comm=comm)
+        eng.set_context(y.to(dev)); eng.set_camera(cam.to(dev))
+        eng.forward_rows(x[:, :, sl].contiguous().to(dev), t.to(dev))
+        eps_shard = eng.eps_ncfhw().cpu()
+        q.put(dict(rank=rank, e_single=rel_l2(eps_shard, eps_single[:, :, sl]), e_oracle=rel_l2(eps_shard, eps_oracle[:, :, sl]),
+                   e_single_oracle=rel_l2(eps_single, eps_oracle), a2a=comm.n_all_to_all, ag=comm.n_all_gather))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put(dict(rank=rank, error=traceback.format_exc()))
+
+
+@pytest.mark.parametrize("F_,H,W", [(4, 8, 8), (6, 16, 8)])
+def test_two_ranks_one_gpu_host_staged_collectives(F_, H, W):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, F_, H, W, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=420) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert "error" not in r, r["error"]
+    for r in res:
+        assert r["a2a"] > 0 and r["ag"] > 0
+        assert r["e_oracle"] < 3e-2, r
+        assert abs(r["e_oracle"] - r["e_single_oracle"]) < 5e-3, r
+        assert r["e_single"] < 3e-2, r

@@ -207,11 +207,62 @@ def test_groupnorm(rows, rps, C0, C1, silu, eps):
         return ops.gn_params(t["x"], C0, C0, rows, rps, t["part"], t["gamma"], t["beta"], eps, silu, t["y"], Cc,
                              x1=t["x1"] if C1 else None, ld1=max(C1, 8) if C1 else 0, C1=C1)
     cpu = c.on("cpu")
+    I.groupnorm_stats(build(cpu))
     I.groupnorm(build(cpu))
     dev = c.on("cuda")
     ops.Stream(record=False).groupnorm(build(dev))
     torch.cuda.synchronize()
     check(dev["y"], cpu["y"], tol_l2=5e-3, tol_max=1.5e-2)
+
+
+@pytest.mark.parametrize("R,B,rps_loc,Cc", [(2, 2, 96, 320), (8, 2, 15, 1280), (4, 1, 640, 64)])
+def test_groupnorm_sharded_statistics(R, B, rps_loc, Cc):
+    """Frame-parallel 5-D norm: R ranks each hold rps_loc rows of every stat group; stats per shard, partial sums gathered
+    as [R][nstat][nchunk][64], apply with fold_ranks=R.  Reference = torch group_norm over the UNsharded rows."""
+    xs = [rnd((B * rps_loc, Cc), 10 + r, 1.5) + 0.2 * r for r in range(R)]
+    gamma, beta = 1 + 0.1 * torch.randn(Cc, generator=g(3)), 0.1 * torch.randn(Cc, generator=g(4))
+    full = torch.cat([x.view(B, rps_loc, Cc) for x in xs], dim=1).float()            # [B][R*rps_loc][C]
+    ref = torch.nn.functional.group_norm(full.permute(0, 2, 1), 32, gamma, beta, 1e-5).permute(0, 2, 1)
+    ref = torch.nn.functional.silu(ref)
+    nfl = ops.gn_partial_floats(B * rps_loc, rps_loc, Cc)
+    part_all = torch.zeros(R * nfl, device="cuda")
+    S = ops.Stream(record=False)
+    xd = [x.cuda() for x in xs]
+    gd, bd = gamma.cuda(), beta.cuda()
+    ys = [torch.zeros(B * rps_loc, Cc, dtype=BF, device="cuda") for _ in range(R)]
+    for r in range(R):      # each "rank" writes its partial sums straight into its slot of the gathered buffer
+        S.groupnorm_stats(ops.gn_params(xd[r], Cc, Cc, B * rps_loc, rps_loc, part_all[r * nfl:], gd, bd, 1e-5, True, ys[r], Cc))
+    for r in range(R):
+        S.groupnorm_apply(ops.gn_params(xd[r], Cc, Cc, B * rps_loc, rps_loc, part_all, gd, bd, 1e-5, True, ys[r], Cc,
+                                        fold_ranks=R))
+    torch.cuda.synchronize()
+    got = torch.cat([y.view(B, rps_loc, Cc) for y in ys], dim=1)
+    check(got, ref.to(BF), tol_l2=5e-3, tol_max=3e-2)
+
+
+def test_permute_copy_matches_torch():
+    """The four pack / unpack permutations of the frame-major <-> pixel-major layout switch (unet_engine._switch)."""
+    R, B, Fl, Pl, Cc = 4, 2, 3, 10, 64
+    cv = Cc // 8
+    x = rnd((B * Fl * R * Pl, Cc), 7).cuda()
+    S = ops.Stream(record=False)
+    out = torch.zeros_like(x)
+    S.copy(ops.copy_params(x, out, R, B * Fl, 1, Pl * cv, Pl * cv, R * Pl * cv))      # send[s][bf][p c] <- x[bf][s][p c]
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(R, B * Fl, Pl, Cc), x.view(B * Fl, R, Pl, Cc).permute(1, 0, 2, 3))
+    blk = Fl * Pl * cv
+    S.copy(ops.copy_params(x, out, B, R, 1, blk, blk, B * blk))                       # y[b][r][...] <- recv[r][b][...]
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(B, R, Fl * Pl, Cc), x.view(R, B, Fl * Pl, Cc).permute(1, 0, 2, 3))
+    S.copy(ops.copy_params(x, out, R, B, 1, blk, blk, R * blk))                       # send[r][b][...] <- x[b][r][...]
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(R, B, Fl * Pl, Cc), x.view(B, R, Fl * Pl, Cc).permute(1, 0, 2, 3))
+    S.copy(ops.copy_params(x, out, B * Fl, R, 1, Pl * cv, Pl * cv, B * Fl * Pl * cv))  # y[bf][s][p c] <- recv[s][bf][p c]
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(B * Fl, R, Pl, Cc), x.view(R, B * Fl, Pl, Cc).permute(1, 0, 2, 3))
+    bad = ops.copy_params(x, out, 0, 1, 1, 1, 0, 0)
+    import ctypes
+    assert L.load().vmv_permute_copy(ctypes.byref(bad), None) == -1          # VMV_EINVAL
 
 
 @pytest.mark.parametrize("rows,Cc", [(37, 320), (1000, 1280), (5, 512), (64, 64), (3, 2048)])

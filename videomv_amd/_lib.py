@@ -14,7 +14,7 @@ SEG_LINEAR, SEG_SPATIAL, SEG_TEMPORAL = 0, 1, 2
 EPI_NONE, EPI_GEGLU = 0, 1
 ACT_NONE, ACT_SILU = 0, 1
 TILE_AUTO, TILE_128x128, TILE_128x160, TILE_128x64, TILE_64x64, TILE_256x128, TILE_256x160 = 0, 1, 2, 3, 4, 5, 6
-OP_GEMM, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTENTION, OP_SOFTMAX = 1, 2, 3, 4, 5, 6
+OP_GEMM, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTENTION, OP_SOFTMAX, OP_COPY = 1, 2, 3, 4, 5, 6, 7
 
 
 class GemmSeg(C.Structure):
@@ -41,7 +41,12 @@ class GroupNormParams(C.Structure):
     _fields_ = [("x", C.c_void_p), ("x1", C.c_void_p), ("ld", C.c_int32), ("ld1", C.c_int32),
                 ("C0", C.c_int32), ("C1", C.c_int32), ("rows", C.c_int32), ("rows_per_stat", C.c_int32),
                 ("chunk_rows", C.c_int32), ("partial", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
-                ("eps", C.c_float), ("silu", C.c_int32), ("y", C.c_void_p), ("ldy", C.c_int32)]
+                ("eps", C.c_float), ("silu", C.c_int32), ("y", C.c_void_p), ("ldy", C.c_int32), ("fold_ranks", C.c_int32)]
+
+
+class CopyParams(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("n0", C.c_int32), ("n1", C.c_int32), ("n2", C.c_int32),
+                ("inner16", C.c_int32), ("ss0", C.c_int64), ("ss1", C.c_int64), ("ss2", C.c_int64)]
 
 
 class LayerNormParams(C.Structure):
@@ -86,6 +91,7 @@ SYMBOLS = {
     "vmv_layernorm": (C.c_int, [C.POINTER(LayerNormParams), _P]),
     "vmv_attention_bf16": (C.c_int, [C.POINTER(AttnParams), _P]),
     "vmv_softmax_rows": (C.c_int, [C.POINTER(SoftmaxParams), _P]),
+    "vmv_permute_copy": (C.c_int, [C.POINTER(CopyParams), _P]),
     "vmv_latent_to_rows": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "vmv_latent_to_rows_keep": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "vmv_i2v_temporal_adapter": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
@@ -123,7 +129,7 @@ def load():
     if lib.vmv_abi_version() != 1:
         raise RuntimeError("libvmv_hip.so ABI version mismatch")
     for which, st in ((OP_GEMM, GemmParams), (OP_GN_STATS, GroupNormParams), (OP_LAYERNORM, LayerNormParams),
-                      (OP_ATTENTION, AttnParams), (OP_SOFTMAX, SoftmaxParams), (100, DdimParams), (101, GemmSeg), (102, SeqMap)):
+                      (OP_ATTENTION, AttnParams), (OP_SOFTMAX, SoftmaxParams), (OP_COPY, CopyParams), (100, DdimParams), (101, GemmSeg), (102, SeqMap)):
         if lib.vmv_sizeof(which) != C.sizeof(st):
             raise RuntimeError(f"struct layout drift for {st.__name__}: C {lib.vmv_sizeof(which)} vs ctypes "
                                f"{C.sizeof(st)}")

@@ -1,0 +1,52 @@
+"""Frame-parallel communicator: the two collectives the frame-sharded sampler needs, on top of
+``torch.distributed`` (backend "nccl" = RCCL over xGMI on the GPU node).
+
+  * ``all_to_all(out, inp)`` — equal splits along dim 0; switches an activation between the frame-major shard
+    ([B][F/R][HW][C]: spatial convs, per-frame GroupNorm, spatial / cross attention) and the pixel-major shard
+    ([B][F][HW/R][C]: temporal convs, temporal attention).  On the fully connected xGMI mesh every rank talks to its
+    7 peers at once, and the volume is (R-1)/R of the local shard — 8x less than all-gathering K and V.
+  * ``all_gather(out, inp)`` — the per-chunk GroupNorm partial sums of the 5-D norms whose statistics span all frames.
+
+With a "gloo" group the same calls work on CPU tensors (the world_size-2 CPU tests) and, for device tensors, stage
+through host memory — a debugging aid that lets two processes share one GPU; it is never the fast path.
+"""
+import torch
+import torch.distributed as dist
+
+
+class FrameComm:
+    def __init__(self, group=None):
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("frame-parallel sampling needs an initialised torch.distributed process group")
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        self.n_all_to_all = 0
+        self.n_all_gather = 0
+
+    def _staged(self, t):
+        return self.backend == "gloo" and t.is_cuda
+
+    def all_to_all(self, out: torch.Tensor, inp: torch.Tensor):
+        self.n_all_to_all += 1
+        if self.world == 1:
+            out.copy_(inp)
+        elif self._staged(inp):
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(o, inp.cpu(), group=self.group)
+            out.copy_(o)
+        else:
+            dist.all_to_all_single(out, inp, group=self.group)
+
+    def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
+        self.n_all_gather += 1
+        out, inp = out.view(-1), inp.view(-1)          # [R * n] <- n per rank (gloo insists on flat tensors)
+        if self.world == 1:
+            out.copy_(inp)
+        elif self._staged(inp):
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(o, inp.cpu(), group=self.group)
+            out.copy_(o)
+        else:
+            dist.all_gather_into_tensor(out, inp, group=self.group)

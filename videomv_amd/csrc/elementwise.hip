@@ -39,6 +39,21 @@ __global__ void latent_to_rows_keep_kernel(const float* __restrict__ x, uint16_t
     }
 }
 
+// dst (contiguous [n0][n1][n2][inner16] of 16-byte vectors) <- src with per-axis strides: both sides move whole
+// channel rows, so every lane does 16-byte loads and stores and consecutive lanes touch consecutive vectors.
+__global__ __launch_bounds__(256) void permute_copy_kernel(const VmvCopyParams p, const long total) {
+    const u32x4_t* __restrict__ src = reinterpret_cast<const u32x4_t*>(p.src);
+    u32x4_t* __restrict__ dst = reinterpret_cast<u32x4_t*>(p.dst);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long v = i % p.inner16;
+        long blk = i / p.inner16;
+        const long i2 = blk % p.n2; blk /= p.n2;
+        const long i1 = blk % p.n1;
+        const long i0 = blk / p.n1;
+        dst[i] = src[i0 * p.ss0 + i1 * p.ss1 + i2 * p.ss2 + v];
+    }
+}
+
 // One wave per pixel, lane = frame (F <= 64).  Everything for a pixel lives in registers; k/v of other frames are
 // fetched with wave shuffles.  Tiny (2560 pixels x ~10 kFLOP): latency only, runs once per sample.
 __global__ __launch_bounds__(256) void i2v_temporal_adapter_kernel(const uint16_t* __restrict__ in, int ld_in,
@@ -235,6 +250,19 @@ inline int grid_for(long n, int block = 256, int cap = 8192) {
 }
 
 }  // namespace
+
+extern "C" int vmv_permute_copy(const VmvCopyParams* pp, void* stream) {
+    if (!pp) return VMV_ENULL;
+    const VmvCopyParams& p = *pp;
+    if (!p.src || !p.dst) return VMV_ENULL;
+    if (p.n0 < 1 || p.n1 < 1 || p.n2 < 1 || p.inner16 < 1 || p.ss0 < 0 || p.ss1 < 0 || p.ss2 < 0) return VMV_EINVAL;
+    if (!vmv_aligned16(p.src) || !vmv_aligned16(p.dst)) return VMV_EALIGN;
+    const long total = (long)p.n0 * p.n1 * p.n2 * p.inner16;
+    long blocks = (total + 1023) / 1024;      // 4 vectors per thread
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(permute_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, total);
+    return vmv_launch_status();
+}
 
 extern "C" int vmv_latent_to_rows(const float* x, void* rows, int nb, int C, int F, int H, int W, int Cpad, int nrep,
                                   void* stream) {

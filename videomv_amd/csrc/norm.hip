@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const VmvGroupNormParams 
 // mean / rstd for the 32 groups and expands them to per-channel scale/shift tables in LDS, then streams its
 // rows: y = [silu](x * scale[c] + shift[c]).
 __global__ __launch_bounds__(256) void gn_apply_kernel(const VmvGroupNormParams p, const int nchunk,
-                                                       const int apply_rows) {
+                                                       const int apply_rows, const int nstat) {
     extern __shared__ __attribute__((aligned(16))) float sh[];
     const int C = p.C0 + p.C1;
     const int CS = C >> 3;
@@ -93,12 +93,16 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const VmvGroupNormParams 
     {   // fold the per-chunk partial sums: 8 lanes per group, fixed order (lane-strided sums, then xor-shuffles)
         const int g = tid >> 3, sub = tid & 7;
         float s = 0.f, q = 0.f;
-        const float* pp = p.partial + ((long)stat * nchunk * 32 + g) * 2;
-        for (int c = sub; c < nchunk; c += 8) { s += pp[(long)c * 64]; q += pp[(long)c * 64 + 1]; }
+        // fold_ranks R > 1: partial = [R][nstat][nchunk][64] (all-gathered shards); every rank folds in the same order
+        const int R = p.fold_ranks > 1 ? p.fold_ranks : 1;
+        for (int r = 0; r < R; ++r) {
+            const float* pp = p.partial + (((long)r * nstat + stat) * nchunk * 32 + g) * 2;
+            for (int c = sub; c < nchunk; c += 8) { s += pp[(long)c * 64]; q += pp[(long)c * 64 + 1]; }
+        }
 #pragma unroll
         for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
         if (sub == 0) {
-            const float n = (float)p.rows_per_stat * (float)cpg;
+            const float n = (float)p.rows_per_stat * (float)cpg * (float)R;
             const float mean = s / n;
             float var = q / n - mean * mean;
             var = var < 0.f ? 0.f : var;
@@ -295,7 +299,7 @@ extern "C" int vmv_groupnorm_apply(const VmvGroupNormParams* pp, void* stream) {
     if (apply_rows < 1) apply_rows = 1;
     const int nblk = (p.rows_per_stat + apply_rows - 1) / apply_rows;
     hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, nstat), dim3(256), (size_t)(2 * C + 64) * sizeof(float),
-                       reinterpret_cast<hipStream_t>(stream), p, nchunk, apply_rows);
+                       reinterpret_cast<hipStream_t>(stream), p, nchunk, apply_rows, nstat);
     return vmv_launch_status();
 }
 

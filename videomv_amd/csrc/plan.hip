@@ -21,6 +21,7 @@ int run_op(const VmvPlan::Op& o, void* stream) {
         case VMV_OP_LAYERNORM: return vmv_layernorm(reinterpret_cast<const VmvLayerNormParams*>(o.args.data()), stream);
         case VMV_OP_ATTENTION: return vmv_attention_bf16(reinterpret_cast<const VmvAttnParams*>(o.args.data()), stream);
         case VMV_OP_SOFTMAX: return vmv_softmax_rows(reinterpret_cast<const VmvSoftmaxParams*>(o.args.data()), stream);
+        case VMV_OP_COPY: return vmv_permute_copy(reinterpret_cast<const VmvCopyParams*>(o.args.data()), stream);
         default: return VMV_EINVAL;
     }
 }
@@ -31,6 +32,7 @@ size_t op_size(int op) {
         case VMV_OP_LAYERNORM: return sizeof(VmvLayerNormParams);
         case VMV_OP_ATTENTION: return sizeof(VmvAttnParams);
         case VMV_OP_SOFTMAX: return sizeof(VmvSoftmaxParams);
+        case VMV_OP_COPY: return sizeof(VmvCopyParams);
         default: return 0;
     }
 }

@@ -113,10 +113,17 @@ class DiffusionDDIM(object):
                                          ddim_timesteps, eta)
             return xt
         assert self.var_type.startswith('fixed'), "learned variance doubles the UNet out channels: not a VideoMV config"
+        comm = getattr(unet, "frame_comm", None)
+        if comm is not None:   # frame-parallel: every rank denoises its own frames of the same noise; one gather at the end
+            fl = noise.shape[2] // comm.world
+            noise = noise[:, :, comm.rank * fl:(comm.rank + 1) * fl]
         xt = noise.detach().clone().float().contiguous()      # updated in place by the fused kernel
         kc, ku = model_kwargs
         for idx, step in enumerate(steps):
             self.ddim_step_hip(xt, int(step), unet, kc, ku, guide_scale, stride)
+        if comm is not None:
+            from .unet_t2v import gather_frames
+            xt = gather_frames(comm, xt)
         return xt
 
     # ------------------------------------------------------------------ generic path (foreign models / CPU)

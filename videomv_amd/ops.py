@@ -77,13 +77,13 @@ def gemm_params(M, N, segs: Sequence[Seg], W, out, ldo, bias=None, rowvec=None, 
 
 
 def gn_params(x, ld, C0, rows, rows_per_stat, partial, gamma, beta, eps, silu, y, ldy, x1=None, ld1=0, C1=0,
-              chunk_rows=None) -> L.GroupNormParams:
+              chunk_rows=None, fold_ranks=0) -> L.GroupNormParams:
     p = L.GroupNormParams()
     p.x, p.x1, p.ld, p.ld1, p.C0, p.C1 = _ptr(x), _ptr(x1), int(ld), int(ld1), int(C0), int(C1)
     p.rows, p.rows_per_stat = int(rows), int(rows_per_stat)
     p.chunk_rows = int(chunk_rows or gn_chunk_rows(rows_per_stat, C0 + C1))
     p.partial, p.gamma, p.beta = _ptr(partial), _ptr(gamma), _ptr(beta)
-    p.eps, p.silu, p.y, p.ldy = float(eps), 1 if silu else 0, _ptr(y), int(ldy)
+    p.eps, p.silu, p.y, p.ldy, p.fold_ranks = float(eps), 1 if silu else 0, _ptr(y), int(ldy), int(fold_ranks)
     return p
 
 
@@ -124,6 +124,13 @@ def attn_params(q, k, v, o, qm, km, vm, om, n_outer, heads, Nq, Nk, scale, kv_di
 def softmax_params(s, lds, p_out, ldp, rows, n, scale) -> L.SoftmaxParams:
     p = L.SoftmaxParams()
     p.s, p.lds, p.p, p.ldp, p.rows, p.n, p.scale = _ptr(s), int(lds), _ptr(p_out), int(ldp), int(rows), int(n), float(scale)
+    return p
+
+
+def copy_params(src, dst, n0, n1, n2, inner16, ss0, ss1, ss2=0) -> L.CopyParams:
+    p = L.CopyParams()
+    p.src, p.dst, p.n0, p.n1, p.n2, p.inner16 = _ptr(src), _ptr(dst), int(n0), int(n1), int(n2), int(inner16)
+    p.ss0, p.ss1, p.ss2 = int(ss0), int(ss1), int(ss2)
     return p
 
 
@@ -168,6 +175,15 @@ class Stream:
     def groupnorm(self, params, label="gn"):
         self._go(L.OP_GN_STATS, params, self.lib.vmv_groupnorm_stats, label + ".stats")
         self._go(L.OP_GN_APPLY, params, self.lib.vmv_groupnorm_apply, label + ".apply")
+
+    def groupnorm_stats(self, params, label="gn"):
+        self._go(L.OP_GN_STATS, params, self.lib.vmv_groupnorm_stats, label + ".stats")
+
+    def groupnorm_apply(self, params, label="gn"):
+        self._go(L.OP_GN_APPLY, params, self.lib.vmv_groupnorm_apply, label + ".apply")
+
+    def copy(self, params, label="copy"):
+        self._go(L.OP_COPY, params, self.lib.vmv_permute_copy, label)
 
     def layernorm(self, params, label="ln"):
         self._go(L.OP_LAYERNORM, params, self.lib.vmv_layernorm, label)

@@ -191,17 +191,29 @@ class Act:
 # --------------------------------------------------------------------------------------------- the engine
 class UNetEngine:
     def __init__(self, cfg: dict, weights: Dict[str, torch.Tensor], B: int, F: int, H: int, W: int, L_ctx: int,
-                 device, n_t: int = 1, taps: Optional[dict] = None):
+                 device, n_t: int = 1, taps: Optional[dict] = None, comm=None):
         """weights: reference-named fp32 state dict (any device).  B = number of batched branches
         (2 = cond + uncond CFG pair sharing x_t), n_t = number of distinct timesteps rows (B // n_t branches
-        share each)."""
+        share each).  F = number of frames of the whole sample.
+
+        comm (``comm.FrameComm``) turns on frame-parallel execution: this rank owns frames
+        [rank*F/R, (rank+1)*F/R); ``self.F`` is then the LOCAL frame count and ``self.Fg`` the sample's."""
+        self.comm = comm
+        self.R = comm.world if comm is not None else 1
+        self.rk = comm.rank if comm is not None else 0
+        self.Fg = F
+        if F % self.R:
+            raise ValueError(f"{F} frames do not split over {self.R} ranks")
+        F = F // self.R
         self.cfg, self.B, self.F, self.H, self.W, self.L = cfg, B, F, H, W, L_ctx
         self.device = device
+        self.breaks = []            # (op index, callable): collectives issued before that recorded op
         self.pool = Pool(device)
         self.S = ops.Stream(record=True)
         self._keepalive = []
         self._ws = None
         self._gnws = torch.empty(4 << 20, dtype=torch.float32, device=device)
+        self._gnws_all = torch.empty((4 << 20) * self.R, dtype=torch.float32, device=device) if comm is not None else None
         self.taps = taps            # optional dict: prefix -> Act (buffers are then never recycled)
         self.n_t = n_t
         self.dim = cfg["dim"]
@@ -347,16 +359,63 @@ class UNetEngine:
             self._keepalive.append(self._ws)   # earlier recorded launches keep pointing at the old slab
         return ks, self._ws
 
-    def _gn(self, label, srcs, rows, rows_per_stat, wkey, eps, silu) -> Act:
+    def _gn(self, label, srcs, rows, rows_per_stat, wkey, eps, silu, all_frames=False) -> Act:
+        """all_frames: a 5-D norm whose statistics span every frame.  Frame-parallel: the input is the
+        pixel-major shard, so each rank sums its HW/R pixels of all frames, the per-chunk partial sums are
+        all-gathered, and every rank folds all R shards in the same order (bitwise identical statistics)."""
         C0 = srcs[0].C
         C1 = srcs[1].C if len(srcs) > 1 else 0
         C = C0 + C1
         y = self.act(rows, C)
-        assert ops.gn_partial_floats(rows, rows_per_stat, C) <= self._gnws.numel()
+        nfl = ops.gn_partial_floats(rows, rows_per_stat, C)
+        assert nfl <= self._gnws.numel()
+        kw = dict(x1=srcs[1].ptr if C1 else None, ld1=srcs[1].C if C1 else 0, C1=C1)
+        if self.comm is None or not all_frames:
+            p = ops.gn_params(srcs[0].ptr, srcs[0].C, C0, rows, rows_per_stat, self._gnws, self.w[wkey + ".weight"],
+                              self.w[wkey + ".bias"], eps, silu, y.ptr, C, **kw)
+            self.S.groupnorm(p, label)
+            return y
         p = ops.gn_params(srcs[0].ptr, srcs[0].C, C0, rows, rows_per_stat, self._gnws, self.w[wkey + ".weight"],
-                          self.w[wkey + ".bias"], eps, silu, y.ptr, C,
-                          x1=srcs[1].ptr if C1 else None, ld1=srcs[1].C if C1 else 0, C1=C1)
-        self.S.groupnorm(p, label)
+                          self.w[wkey + ".bias"], eps, silu, y.ptr, C, **kw)
+        self.S.groupnorm_stats(p, label)
+        loc, allr = self._gnws[:nfl], self._gnws_all[: nfl * self.R]
+        self._break(lambda: self.comm.all_gather(allr, loc))
+        p2 = ops.gn_params(srcs[0].ptr, srcs[0].C, C0, rows, rows_per_stat, self._gnws_all, self.w[wkey + ".weight"],
+                           self.w[wkey + ".bias"], eps, silu, y.ptr, C, fold_ranks=self.R, **kw)
+        self.S.groupnorm_apply(p2, label)
+        return y
+
+    # ------------------------------------------------------------------ frame-parallel layout switches
+    def _break(self, fn):
+        self.breaks.append((self.S.nops, fn))
+
+    def _switch(self, x: Act, hw: int, to_pixel: bool, release_in: bool = True) -> Act:
+        """frame-major shard [B][F/R][HW][C]  <->  pixel-major shard [B][F][HW/R][C]: pack -> all-to-all -> unpack.
+        Chunk j of the packed buffer goes to rank j; chunk i of the received buffer came from rank i."""
+        R, B, Fl = self.R, self.B, self.F
+        if hw % R:
+            raise ValueError(f"{hw} pixels per frame do not split over {R} ranks")
+        Pl = hw // R
+        T, Cc = x.rows, x.C
+        assert T == B * Fl * hw and Cc % 8 == 0
+        cv = Cc // 8                                 # 16-byte vectors per row
+        send, recv, y = self.act(T, Cc), self.act(T, Cc), self.act(T, Cc)
+        tag = "F2P" if to_pixel else "P2F"
+        if to_pixel:   # send[s][b f][p c] <- x[b f][s][p c]
+            self.S.copy(ops.copy_params(x.ptr, send.ptr, R, B * Fl, 1, Pl * cv, Pl * cv, hw * cv), f"shard.{tag}.pack")
+        else:          # send[r][b][f p c] <- x[b][r][f p c]
+            blk = Fl * Pl * cv
+            self.S.copy(ops.copy_params(x.ptr, send.ptr, R, B, 1, blk, blk, R * blk), f"shard.{tag}.pack")
+        if release_in:
+            self.release(x)
+        st, rt = send.tensor().view(R, -1), recv.tensor().view(R, -1)
+        self._break(lambda: self.comm.all_to_all(rt, st))
+        if to_pixel:   # y[b][r][f p c] <- recv[r][b][f p c]
+            blk = Fl * Pl * cv
+            self.S.copy(ops.copy_params(recv.ptr, y.ptr, B, R, 1, blk, blk, B * blk), f"shard.{tag}.unpack")
+        else:          # y[b f][s][p c] <- recv[s][b f][p c]
+            self.S.copy(ops.copy_params(recv.ptr, y.ptr, B * Fl, R, 1, Pl * cv, Pl * cv, B * Fl * Pl * cv), f"shard.{tag}.unpack")
+        self.release(send); self.release(recv)
         return y
 
     def _ln(self, label, x: Act, wkey) -> Act:
@@ -388,12 +447,15 @@ class UNetEngine:
             self._gemm(p + ".conv2", T, cout, segs, f"{p}.conv2.weight", h3, bias=self.w[f"{p}.conv2.bias"], geom=geom,
                        residual=srcs[0].ptr, ldr=srcs[0].C)
         self.release(h2)
-        # temporal conv block: 4 x [GN over all frames -> SiLU -> (3,1,1) conv], + identity
-        tg = ops.Geom(F=F, P=h * w)
+        # temporal conv block: 4 x [GN over all frames -> SiLU -> (3,1,1) conv], + identity.  Frame-parallel: pixel-local,
+        # so it runs on the pixel-major shard (all Fg frames of HW/R pixels) between two layout switches.
+        if self.comm is not None:
+            h3 = self._switch(h3, h * w, to_pixel=True)
+        tg = ops.Geom(F=self.Fg, P=(h * w) // self.R)
         cur = h3
         for i, name in enumerate(("conv1", "conv2", "conv3", "conv4")):
             q = f"{p}.temopral_conv.{name}"
-            g = self._gn(q + ".gn", [cur], T, F * h * w, f"{q}.0", 1e-5, True)
+            g = self._gn(q + ".gn", [cur], T, F * h * w, f"{q}.0", 1e-5, True, all_frames=True)
             nxt = self.act(T, cout)
             last = i == 3
             self._gemm(q, T, cout, ops.temporal_segs(g.ptr, g.C, g.C), f"{q}.weight", nxt, bias=self.w[f"{q}.bias"],
@@ -403,6 +465,8 @@ class UNetEngine:
                 self.release(cur)
             cur = nxt
         self.release(h3)
+        if self.comm is not None:
+            cur = self._switch(cur, h * w, to_pixel=False)
         return cur
 
     def _tblock(self, p, a: Act, heads, temporal: bool, h, w, cross_ctx: bool) -> Act:
@@ -411,6 +475,9 @@ class UNetEngine:
         inner = a.C
         hw = h * w
         scale = 64 ** -0.5
+
+        if temporal:       # frame-parallel: `a` is the pixel-major shard — all Fg frames of hw / R pixels
+            hw, F = hw // self.R, self.Fg
 
         def maps(ld, col0=0):
             if temporal:   # problems = (b, pixel); rows strided by hw
@@ -480,7 +547,11 @@ class UNetEngine:
         if m["dh"] != 64:
             raise NotImplementedError("the HIP attention kernel is specialised for head_dim 64")
         temporal = kind == "tt"
-        n0 = self._gn(p + ".norm", [x], T, (F * h * w) if temporal else (h * w), f"{p}.norm", 1e-6, False)
+        sharded = temporal and self.comm is not None
+        if sharded:        # the whole TemporalTransformer is pixel-local: run it on the pixel-major shard
+            x = self._switch(x, h * w, to_pixel=True, release_in=False)
+        n0 = self._gn(p + ".norm", [x], T, (F * h * w) if temporal else (h * w), f"{p}.norm", 1e-6, False,
+                      all_frames=temporal)
         a = self.act(T, inner)
         self._gemm(p + ".proj_in", T, inner, ops.linear_segs([(n0.ptr, n0.C, n0.C)]), f"{p}.proj_in.weight", a,
                    bias=self.w[f"{p}.proj_in.bias"])
@@ -491,6 +562,9 @@ class UNetEngine:
         self._gemm(p + ".proj_out", T, C, ops.linear_segs([(a3.ptr, a3.C, a3.C)]), f"{p}.proj_out.weight", y,
                    bias=self.w[f"{p}.proj_out.bias"], residual=x.ptr, ldr=x.C)
         self.release(a3)
+        if sharded:
+            self.release(x)
+            y = self._switch(y, h * w, to_pixel=False)
         return y
 
     def _run_block(self, blk, srcs: List[Act], h, w):
@@ -582,6 +656,8 @@ class UNetEngine:
         if not self.has_cam or camera_data is None:
             self.cam_valid = False
             return
+        if self.comm is not None:       # this rank's frames
+            camera_data = camera_data.reshape(-1, self.Fg, camera_data.shape[-1])[:, self.rk * self.F:(self.rk + 1) * self.F]
         cam = camera_data.reshape(-1, camera_data.shape[-1])
         n = cam.shape[0]
         if n not in (self.F, self.B * self.F):
@@ -615,7 +691,8 @@ class UNetEngine:
                              rows // self.n_t, self.n_cam_rows)
 
     def forward_rows(self, x: torch.Tensor, t: torch.Tensor):
-        """x [b, C, F, H, W] fp32 on device (b divides B; replicated to the B branches), t [n_t].
+        """x [b, C, F, H, W] fp32 on device (b divides B; replicated to the B branches; frame-parallel: this rank's
+        F/R frames), t [n_t].
         Leaves eps in ``self.eps_rows`` (fp32 [B*F*H*W, out_pad])."""
         nb = x.shape[0]
         # only the latent's own channels are written: channels >= x.shape[1] hold zeros (T2V) or the step-invariant
@@ -623,8 +700,22 @@ class UNetEngine:
         ops.latent_to_rows_keep(x.contiguous(), self.x_rows, self.cin_pad, self.B // nb)
         self.t_dev.copy_(t.to(torch.float32).reshape(-1)[: self.n_t])
         self._embeddings()
-        self.S.run()
+        self.run_plan()
         return self.eps_rows
+
+    def run_plan(self):
+        """Replay the recorded launches; frame-parallel plans are cut at their collectives."""
+        if not self.breaks:
+            self.S.run()
+            return
+        first = 0
+        for idx, fn in self.breaks:
+            if idx > first:
+                self.S.run(first, idx)
+            fn()
+            first = idx
+        if first < self.S.nops:
+            self.S.run(first, self.S.nops)
 
     def eps_ncfhw(self) -> torch.Tensor:
         """eps rows -> [B, out_dim, F, H, W] fp32 (reference output layout)."""

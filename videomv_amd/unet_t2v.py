@@ -41,6 +41,14 @@ class _Holder(nn.Module):
         child.add(rest, param)
 
 
+def gather_frames(comm, x_local: torch.Tensor) -> torch.Tensor:
+    """[b, c, F/R, h, w] per rank -> [b, c, F, h, w] on every rank (frame-parallel sampling)."""
+    x_local = x_local.contiguous()
+    out = torch.empty((comm.world,) + tuple(x_local.shape), dtype=x_local.dtype, device=x_local.device)
+    comm.all_gather(out.view(comm.world, -1), x_local.view(-1))
+    return torch.cat(list(out.unbind(0)), dim=2)
+
+
 @MODEL.register_class()
 class UNetSD_T2VBase(nn.Module):
     def __init__(self, config=None, in_dim=4, dim=512, y_dim=512, context_dim=512, hist_dim=156, dim_condition=4,
@@ -81,6 +89,7 @@ class UNetSD_T2VBase(nn.Module):
                 v = torch.empty(shape).normal_(0.0, 1.0 / math.sqrt(fan_in))
             self._add_param(key, nn.Parameter(v, requires_grad=False))
         self._engines: Dict[tuple, UNetEngine] = {}
+        self.frame_comm = None        # comm.FrameComm: frame-parallel execution over the ranks of one sample
         self._weights_version = 0
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
 
@@ -97,12 +106,20 @@ class UNetSD_T2VBase(nn.Module):
         self._weights_version += 1
 
     # ------------------------------------------------------------------ engine management
+    def set_frame_parallel(self, comm):
+        """Shard the frames of every sample over the ranks of ``comm`` (``comm.FrameComm``; None = off).  BASELINE
+        configs[2]: 24 views, 3 per GPU.  ``forward`` keeps taking / returning whole samples; the fused sampler
+        (``forward_cfg_rows``) works on this rank's frames.  No reference counterpart (its multi-GPU mode is replicas)."""
+        self.frame_comm = comm
+        self._engines.clear()
+
     def engine_for(self, B, F, H, W, L, device, n_t=1, taps=None) -> UNetEngine:
+        """F = frames of the whole sample."""
         key = (B, F, H, W, L, str(device), n_t, taps is not None)
         eng = self._engines.get(key)
         if eng is None:
             sd = {k: v.detach() for k, v in self.state_dict().items()}
-            eng = UNetEngine(self.arch, sd, B, F, H, W, L, device, n_t=n_t, taps=taps)
+            eng = UNetEngine(self.arch, sd, B, F, H, W, L, device, n_t=n_t, taps=taps, comm=self.frame_comm)
             if taps is None:
                 self._engines[key] = eng
         return eng
@@ -129,12 +146,18 @@ class UNetSD_T2VBase(nn.Module):
         eng = self.engine_for(b, f, h, w, y.shape[1], dev, n_t=b)
         eng.set_context(y.float())
         eng.set_camera(camera_data if self.use_camera_condition else None)
-        eng.forward_rows(x.float(), t.to(dev))
-        return eng.eps_ncfhw()
+        if self.frame_comm is None:
+            eng.forward_rows(x.float(), t.to(dev))
+            return eng.eps_ncfhw()
+        comm = self.frame_comm                    # whole sample in, whole sample out: run this rank's frames, gather
+        fl = f // comm.world
+        eng.forward_rows(x[:, :, comm.rank * fl:(comm.rank + 1) * fl].float().contiguous(), t.to(dev))
+        return gather_frames(comm, eng.eps_ncfhw())
 
     @torch.no_grad()
     def forward_cfg_rows(self, xt, t, cond_kwargs, uncond_kwargs):
-        """Both classifier-free-guidance branches in ONE pass (B = 2 rows blocks sharing x_t, so weights stream once
+        """(Frame-parallel: ``xt`` holds THIS rank's frames only; camera_data / y stay whole-sample.)
+        Both classifier-free-guidance branches in ONE pass (B = 2 rows blocks sharing x_t, so weights stream once
         per step instead of twice — SURVEY App. C).  ``cond_kwargs`` / ``uncond_kwargs`` are the two ``model_kwargs``
         dicts of ``ddim_sample_loop`` (keys ``y``, ``camera_data``; ``fps`` is ignored as in the reference when
         ``use_fps_condition`` is False).  Returns (engine, eps_rows fp32 [2*F*H*W, out_pad]); rows [0, F*H*W) are the
@@ -145,6 +168,8 @@ class UNetSD_T2VBase(nn.Module):
         if b != 1:
             raise ValueError("forward_cfg_rows handles one sample (the reference's noise is [1,4,F,h,w])")
         dev = xt.device
+        if self.frame_comm is not None:
+            f = f * self.frame_comm.world
         eng = self.engine_for(2, f, h, w, y_cond.shape[1], dev, n_t=1)
         key = (y_cond.data_ptr(), y_uncond.data_ptr(), None if camera_data is None else camera_data.data_ptr())
         if getattr(eng, "_cond_key", None) != key:      # context / camera are step-invariant: set once per sample
