@@ -11,7 +11,10 @@ weights of the reference architecture with the zero-inits re-randomised (no chec
 
 N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): every rank denoises its OWN sample — replicas,
 the reference's only parallelism (inference_text2video_entrance.py:79,152-156) — so scaling is weak and there is no
-data-path collective; `value` = (N * K steps) / max-over-ranks time.
+data-path collective; `value` = (N * K steps) / max-over-ranks time.  The same run then times the frame-parallel mode
+(BASELINE configs[2]: ONE sample, 24/N views per GPU, all-to-all layout switches + gathered GroupNorm sums over RCCL,
+DESIGN.md §8) and reports it as the extra object `frame_parallel` (strong scaling of one sample's latency); a watchdog
+bounds that leg so that a collective problem can never cost the headline line.
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel = the MFMA implicit-GEMM family, timed per
 launch with events on the launch stream in a separate pass) and `cpu_baseline` (the oracle's fp32 UNet forward on the
@@ -100,6 +103,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-op-profile", action="store_true")
     ap.add_argument("--dump-ops", type=str, default="", help="write the per-launch timing table to this file")
+    ap.add_argument("--no-frame-parallel", action="store_true", help="N > 1: skip the frame-parallel (one sample over all GPUs) leg")
+    ap.add_argument("--frame-parallel-budget", type=float, default=300.0, help="seconds before the watchdog abandons that leg")
     ap.add_argument("--no-sample", action="store_true", help="skip the (untimed-region) full 50-step + VAE-decode sample")
     args = ap.parse_args()
     H, W = (int(v) for v in args.latent.split("x"))
@@ -214,6 +219,70 @@ def main():
                     fl = gemm_flops(p) if op == L.OP_GEMM else (attn_flops(p) if op == L.OP_ATTENTION else 0.0)
                     f.write(f"{i}\t{labels[i]}\t{ms[i]:.4f}\t{fl / 1e9:.2f}\t{(fl / (ms[i] * 1e-3) / 1e12) if fl else 0:.1f}\n")
 
+    def headline():
+        return {"metric": "denoise-steps/sec, t2v 320x512x24 (latent 24x%dx%d), CFG 9.0, 50-step DDIM schedule" % (H, W),
+               "value": round(steps_per_s, 4), "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded randn latents/text/cameras; random-init "
+               "weights, zero-inits re-randomised)",
+               "config": {"workload": f"t2v_infer.yaml UNetSD_T2VBase 1.413B, 24 views, latent {H}x{W}, 77 ctx tokens, "
+                                      f"1 sample per GPU (cond+uncond batched)", "parallelism": f"replicas x{world}"},
+               "finite": finite, "roofline": roof}
+
+    # ---- frame-parallel leg: ONE sample over all ranks (strong scaling of a sample's latency)
+    fpar = None
+    if dist is not None and args.frames % world == 0 and not args.no_frame_parallel:
+        import threading
+        done = threading.Event()
+        state = {"stage": "init"}
+
+        def watchdog():
+            if not done.wait(args.frame_parallel_budget):
+                if rank == 0:
+                    out = headline()
+                    out["frame_parallel"] = {"error": f"leg exceeded {args.frame_parallel_budget}s at stage {state['stage']}"}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            from videomv_amd.comm import FrameComm
+            comm = FrameComm()
+            model.set_frame_parallel(comm)
+            gs = torch.Generator(device=dev).manual_seed(11)       # the SAME sample on every rank
+            noise_s = torch.randn(1, 4, args.frames, H, W, generator=gs, device=dev)
+            ys, y0s = torch.randn(1, 77, 1024, generator=gs, device=dev), torch.randn(1, 77, 1024, generator=gs, device=dev)
+            cams = torch.randn(1, args.frames, 16, generator=gs, device=dev)
+            fl = args.frames // world
+            xs = noise_s[:, :, rank * fl:(rank + 1) * fl].clone().contiguous()
+            kc, ku = dict(y=ys, camera_data=cams), dict(y=y0s, camera_data=cams)
+            state["stage"] = "warmup"
+            for i in range(max(1, args.warmup)):
+                dif.ddim_step_hip(xs, steps[i % len(steps)], model, kc, ku, 9.0, stride)
+            fence()
+            state["stage"] = "timed"
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                dif.ddim_step_hip(xs, steps[(args.warmup + i) % len(steps)], model, kc, ku, 9.0, stride)
+            fence()
+            dtf = time.perf_counter() - t0
+            tt = torch.tensor([dtf], device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dtf = float(tt[0])
+            eng = model.engine_for(2, args.frames, H, W, 77, dev, n_t=1)
+            fpar = dict(steps_per_s=round(args.steps / dtf, 4), ms_per_step=round(1000.0 * dtf / args.steps, 3),
+                        scaling="strong", views_per_gpu=fl, collectives_per_step=len(eng.breaks),
+                        all_to_all_per_step=sum(1 for i, _ in eng.breaks if eng.S.labels[i].endswith(".unpack")),
+                        finite=bool(torch.isfinite(xs).all()),
+                        parallelism=f"frames x{world} (frame-major <-> pixel-major all-to-all, DESIGN.md §8)")
+            if step_tflop:
+                fpar["whole_step_frac_of_peak"] = round(step_tflop * fpar["steps_per_s"] / world / PEAK_BF16_TFLOPS, 4)
+        except Exception as e:      # the headline (replicas) line must survive any problem in this leg
+            fpar = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            model.set_frame_parallel(None)
+            done.set()
+
     # ---- one complete 24-view sample: 50 DDIM steps + VAE decode of 24 frames in chunks of decoder_bs = 4
     sample = None
     if rank == 0 and world == 1 and not args.no_sample:
@@ -259,16 +328,9 @@ def main():
                        sample="oracle forward did not finish inside the 150 s budget")
 
     if rank == 0:
-        out = {"metric": "denoise-steps/sec, t2v 320x512x24 (latent 24x%dx%d), CFG 9.0, 50-step DDIM schedule" % (H, W),
-               "value": round(steps_per_s, 4), "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded randn latents/text/cameras; random-init "
-               "weights, zero-inits re-randomised)",
-               "config": {"workload": f"t2v_infer.yaml UNetSD_T2VBase 1.413B, 24 views, latent {H}x{W}, 77 ctx tokens, "
-                                      f"1 sample per GPU (cond+uncond batched)", "parallelism": f"replicas x{world}"},
-               "sample_24view": sample, "finite": finite,
-               "roofline": roof, "cpu_baseline": cpu}
-        print(json.dumps(out))
+        out = headline()
+        out.update({"sample_24view": sample, "frame_parallel": fpar, "cpu_baseline": cpu})
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

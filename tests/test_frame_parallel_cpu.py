@@ -128,3 +128,59 @@ def test_two_rank_frame_parallel_plan_matches_single_rank_and_oracle():
         assert r["e_single"] < 3e-2, r
         assert r["e_module"] < 3e-2, r
         assert r["e_ddim"] < 6e-2, r
+
+
+def _entrance_worker(rank, world, port, tmp, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          LOCAL_RANK=str(rank))
+        torch.set_num_threads(2)
+        from tests import plan_interp
+        plan_interp.install(_Patch)
+        from videomv_amd.config import Config
+        from videomv_amd.registry import INFER_ENGINE
+        import videomv_amd.entrance  # noqa: F401
+        argv = ["--cfg", "configs/t2v_infer.yaml", "device", "cpu", "allow_random_init", "True", "num_views", "4",
+                "ddim_timesteps", "2", "test_list_path", os.path.join(tmp, "prompts.txt"), "log_dir", os.path.join(tmp, f"out{world}"),
+                "UNet.num_heads", "2", "UNet.num_res_blocks", "1", "UNet.dim_mult", "[1, 2]", "test_model", "none.pth",
+                "frame_parallel", "True"]
+        cu = Config(load=True, argv=argv)
+        cu.cfg_dict["UNet"]["dim"] = 64
+        cu.cfg_dict["UNet"]["attn_scales"] = [1.0, 0.5]
+        cu.cfg_dict["resolution"] = [64, 64]
+        cu.cfg_dict["auto_encoder"] = {"type": "AutoencoderKL", "embed_dim": 4, "pretrained": "none.pth",
+                                       "ddconfig": {"double_z": True, "z_channels": 4, "resolution": 64, "in_channels": 3,
+                                                    "out_ch": 3, "ch": 32, "ch_mult": [1, 2, 4, 4], "num_res_blocks": 2,
+                                                    "attn_resolutions": [], "dropout": 0.0}}
+        cfg = INFER_ENGINE.build(dict(type=cu.TASK_TYPE), cfg_update=cu.cfg_dict)
+        q.put(dict(rank=rank, outputs=list(cfg.outputs)))
+    except Exception:
+        import traceback
+        q.put(dict(rank=rank, error=traceback.format_exc()))
+
+
+def test_entrance_frame_parallel_two_ranks_matches_one_rank(tmp_path):
+    """`frame_parallel True` through the t2v entrance: 2 gloo ranks x 2 views produce the views a single rank produces
+    (same seed => same noise / text features / random-init weights).  Video rel-L2 <= 8e-2: two CFG-9 DDIM steps amplify
+    the decorrelated bf16 rounding noise of the two plans (see the module docstring)."""
+    (tmp_path / "prompts.txt").write_text("a wooden chair\n")
+    ctx = mp.get_context("spawn")
+    results = {}
+    for world in (1, 2):
+        q, port = ctx.Queue(), _free_port()
+        procs = [ctx.Process(target=_entrance_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=600) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+        for r in res:
+            assert "error" not in r, r["error"]
+        results[world] = {r["rank"]: r["outputs"] for r in res}
+    assert len(results[1][0]) == 1 and len(results[2][0]) == 1 and results[2][1] == []      # rank 0 writes the sample
+    a = torch.load(results[1][0][0])
+    b = torch.load(results[2][0][0])
+    assert a["video"].shape == b["video"].shape == (1, 3, 4, 64, 64)
+    assert torch.isfinite(b["video"]).all()
+    assert rel_l2(b["latent"], a["latent"]) < 8e-2, rel_l2(b["latent"], a["latent"])
+    assert rel_l2(b["video"], a["video"]) < 8e-2, rel_l2(b["video"], a["video"])

@@ -10,6 +10,8 @@
 With a "gloo" group the same calls work on CPU tensors (the world_size-2 CPU tests) and, for device tensors, stage
 through host memory — a debugging aid that lets two processes share one GPU; it is never the fast path.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -22,6 +24,8 @@ class FrameComm:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
+        # world 1 needs no exchange; VMV_COMM_FORCE=1 still issues the collectives (smoke-tests RCCL on a 1-GPU box)
+        self.local_only = self.world == 1 and os.environ.get("VMV_COMM_FORCE") != "1"
         self.n_all_to_all = 0
         self.n_all_gather = 0
 
@@ -30,7 +34,7 @@ class FrameComm:
 
     def all_to_all(self, out: torch.Tensor, inp: torch.Tensor):
         self.n_all_to_all += 1
-        if self.world == 1:
+        if self.local_only:
             out.copy_(inp)
         elif self._staged(inp):
             o = torch.empty(out.shape, dtype=out.dtype)
@@ -42,7 +46,7 @@ class FrameComm:
     def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
         self.n_all_gather += 1
         out, inp = out.view(-1), inp.view(-1)          # [R * n] <- n per rank (gloo insists on flat tensors)
-        if self.world == 1:
+        if self.local_only:
             out.copy_(inp)
         elif self._staged(inp):
             o = torch.empty(out.shape, dtype=out.dtype)

@@ -74,7 +74,9 @@ def worker(gpu, cfg, cfg_update):
         merge_into(cfg, _plain(dict(cfg_update)))
     cfg.gpu, cfg.seed = gpu, int(cfg.seed)
     cfg.rank = cfg.pmi_rank
-    torch.manual_seed(rank_seed(cfg.seed, cfg.rank))
+    # frame_parallel (not a reference key; BASELINE configs[2]): the ranks share ONE sample — same seed, F / N views each
+    fpar = bool(cfg.get('frame_parallel', False)) and cfg.world_size > 1
+    torch.manual_seed(cfg.seed if fpar else rank_seed(cfg.seed, cfg.rank))
     on_gpu = str(cfg.device).startswith("cuda")
     device = torch.device("cuda", gpu) if on_gpu else torch.device(cfg.device)
     if on_gpu:
@@ -104,6 +106,10 @@ def worker(gpu, cfg, cfg_update):
     model = MODEL.build(unet_cfg)
     _load_weights(model, cfg.get('test_model'), cfg.allow_random_init, "UNet")
     model.eval()
+    if fpar:
+        from .comm import FrameComm
+        model.set_frame_parallel(FrameComm())
+        logging.info(f"frame-parallel sampling: {cfg.world_size} ranks x {int(cfg.num_views or cfg.max_frames) // cfg.world_size} views")
 
     with open(cfg.test_list_path, 'r') as f:
         test_list = [ln.strip() for ln in f.readlines()]
@@ -124,6 +130,8 @@ def worker(gpu, cfg, cfg_update):
         x0, video = sample_views(model, diffusion, autoencoder, noise, y_words.to(device), zero_y_negative.to(device),
                                  camera_data, guide_scale=cfg.guide_scale, ddim_timesteps=int(cfg.ddim_timesteps),
                                  decoder_bs=int(cfg.decoder_bs), scale_factor=cfg.scale_factor)
+        if fpar and cfg.rank != 0:          # every rank holds the gathered views; rank 0 writes them
+            continue
         cap_name = re.sub(r'[^\w\s]', '', caption).replace(' ', '_')
         stem = f'rank_{cfg.world_size:02d}_{cfg.rank:02d}_{idx:04d}_{cap_name}_{int(elevation):02d}_{camera_dist:.02f}'
         path = osp.join(cfg.log_dir, stem + '.pt')

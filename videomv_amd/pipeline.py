@@ -16,7 +16,14 @@ def sample_views(unet, diffusion, autoencoder, noise, y_cond, y_uncond, camera_d
                                     ddim_timesteps=ddim_timesteps, eta=0.0)
     if not decode:
         return x0, None
-    return x0, decode_views(autoencoder, x0, decoder_bs, scale_factor)
+    comm = getattr(getattr(unet, "module", unet), "frame_comm", None)
+    if comm is None:
+        return x0, decode_views(autoencoder, x0, decoder_bs, scale_factor)
+    # frame-parallel: the VAE is per-frame, so every rank decodes its own views; one gather of the images
+    from .unet_t2v import gather_frames
+    fl = x0.shape[2] // comm.world
+    mine = decode_views(autoencoder, x0[:, :, comm.rank * fl:(comm.rank + 1) * fl].contiguous(), decoder_bs, scale_factor)
+    return x0, gather_frames(comm, mine)
 
 
 @torch.no_grad()
