@@ -101,6 +101,12 @@ typedef struct {
 #define VMV_TILE_64x64    4
 #define VMV_TILE_256x128  5   /* 8-wave LDS-DMA ring kernel (gemm_glds.hip) */
 #define VMV_TILE_256x160  6
+#define VMV_TILE_G128x128 7   /* 4-wave LDS-DMA kernel, 2-stage ring, two blocks per CU (short-K linears) */
+#define VMV_TILE_G128x160 8
+#define VMV_TILE_P256x128 9   /* persistent 8-wave LDS-DMA kernel: ring kept full across tiles (gemm_pglds.hip) */
+#define VMV_TILE_P256x160 10
+#define VMV_TILE_PP256x128 11  /* 8-wave LDS-DMA kernel, ping-pong wave schedule */
+#define VMV_TILE_PP256x160 12
 
 int vmv_gemm_bf16(const VmvGemmParams* p, void* stream);
 

@@ -1,12 +1,15 @@
 #!/usr/bin/env python
 """Micro-benchmark of the implicit-GEMM kernels on the UNet's characteristic shapes (GPU only).
-   python tools/gemm_bench.py [tile ...]   — prints TFLOP/s per (shape, tile)."""
+   python tools/gemm_bench.py [tile ...]   — prints TFLOP/s per (shape, tile); tile 0 = the dispatcher's choice."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from videomv_amd import _lib as L, ops
 
 BF = torch.bfloat16
+N160 = (L.TILE_128x160, L.TILE_256x160, L.TILE_G128x160, L.TILE_P256x160, L.TILE_PP256x160)
+
+
 def bench(fn, reps=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()
@@ -16,37 +19,59 @@ def bench(fn, reps=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 
+
 def main():
     tiles = [int(t) for t in sys.argv[1:]] or [L.TILE_128x160, L.TILE_256x160]
     S = ops.Stream(record=False)
     dev = "cuda"
-    shapes = [  # (name, M, N, C, kind)
-        ("lin  L0 N320 K320", 122880, 320, 320, "lin"), ("qkv  L0 N960 K320", 122880, 960, 320, "lin"),
-        ("down L0 N320 K1280", 122880, 320, 1280, "lin"), ("conv L0 320->320", 122880, 320, 320, "conv"),
-        ("tcnv L0 320", 122880, 320, 320, "tconv"), ("conv L1 640->640", 30720, 640, 640, "conv"),
-        ("lin  L1 N640 K640", 30720, 640, 640, "lin"), ("conv L2 1280", 7680, 1280, 1280, "conv"),
+    M0, M1, M2 = 122880, 30720, 7680
+    shapes = [  # (name, M, N, C(=K per tap), kind)
+        ("lin+res L0 N320 K320", M0, 320, 320, "linres"), ("qkv  L0 N960 K320", M0, 960, 320, "lin"),
+        ("geglu L0 N2560 K320", M0, 2560, 320, "geglu"), ("down L0 N320 K1280", M0, 320, 1280, "linres"),
+        ("lin+res L1 N640 K640", M1, 640, 640, "linres"), ("qkv  L1 N1920 K640", M1, 1920, 640, "lin"),
+        ("geglu L1 N5120 K640", M1, 5120, 640, "geglu"), ("down L1 N640 K2560", M1, 640, 2560, "linres"),
+        ("lin+res L2 N1280 K1280", M2, 1280, 1280, "linres"), ("geglu L2 N10240 K1280", M2, 10240, 1280, "geglu"),
+        ("conv L0 320->320", M0, 320, 320, "conv"), ("tcnv L0 320", M0, 320, 320, "tconv"),
+        ("conv L1 640->640", M1, 640, 640, "conv"), ("tcnv L1 640", M1, 640, 640, "tconv"),
+        ("conv L2 1280", M2, 1280, 1280, "conv"),
     ]
     for name, M, N, C, kind in shapes:
         x = torch.randn(M, C, device=dev).to(BF)
-        if kind == "lin":
+        kw = {}
+        No = N
+        if kind in ("lin", "linres", "geglu"):
             K = C; segs = ops.linear_segs([(x, C, C)]); geom = None
+            if kind == "geglu":
+                kw["epilogue"] = L.EPI_GEGLU; No = N // 2
         elif kind == "conv":
             K = 9 * C; segs = ops.conv3x3_segs([(x, C, C)])
-            hw = {122880: (40, 64), 30720: (20, 32), 7680: (10, 16)}[M]
+            hw = {M0: (40, 64), M1: (20, 32), M2: (10, 16)}[M]
             geom = ops.Geom(OH=hw[0], OW=hw[1], IH=hw[0], IW=hw[1])
         else:
             K = 3 * C; segs = ops.temporal_segs(x, C, C); geom = ops.Geom(F=24, P=M // 48)
         w = (torch.randn(N, K, device=dev) * K ** -0.5).to(BF)
         b = torch.randn(N, device=dev)
-        out = torch.empty(M, N, device=dev, dtype=BF)
-        line = f"{name:22s}"
+        out = torch.empty(M, No, device=dev, dtype=BF)
+        if kind == "linres":
+            res = torch.randn(M, No, device=dev).to(BF)
+            kw.update(residual=res, ldr=No)
+        line = f"{name:24s}"
         for tile in tiles:
-            if tile in (L.TILE_128x160, L.TILE_256x160) and N % 160: 
-                line += "      -   "; continue
-            p = ops.gemm_params(M, N, segs, w, out, N, bias=b, geom=geom, tile=tile)
+            if tile in N160 and (N % 160 or kind == "geglu"):
+                line += "      -    "; continue
+            stamps = torch.zeros(4 * 64, dtype=torch.int64, device=dev) if os.environ.get("VMV_GEMM_ABLATE") in ("4", "7", "8") else None
+            p = ops.gemm_params(M, N, segs, w, out, No, bias=b, geom=geom, tile=tile, workspace=stamps, **kw)
             ms = bench(lambda: S.gemm(p))
             line += f" t{tile}:{2.0 * M * N * K / ms / 1e9:7.1f}"
+            if stamps is not None and tile in (L.TILE_P256x128, L.TILE_P256x160):
+                t = stamps.cpu().view(-1, 4)
+                t = t[t[:, 0] > 0]
+                if len(t):
+                    base = int(t[0, 0])
+                    rows = [" ".join(f"{int(v) - base:7d}" for v in r) for r in t[:6]]
+                    line += "\n      stamps(block0; tile start / loop done / epi start / epi end, 100MHz ticks?):\n      " + "\n      ".join(rows)
         print(line, flush=True)
+
 
 if __name__ == "__main__":
     main()

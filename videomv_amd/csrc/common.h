@@ -14,14 +14,14 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
 // bf16 <-> fp32 (round-to-nearest-even; NaN not expected on this path)
 VMV_DEV float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
 VMV_DEV float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
-VMV_DEV uint32_t f32_to_bf16_bits(float f) {
-    uint32_t u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
-}
+// (gfx950 converts in hardware: one v_cvt_pk_bf16_f32 per pair instead of ~9 integer instructions)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 VMV_DEV uint32_t pack_bf16x2(float lo, float hi) {
-    return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+    const f32x2_t f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
 }
+VMV_DEV uint32_t f32_to_bf16_bits(float f) { return pack_bf16x2(f, 0.f) & 0xffffu; }
 VMV_DEV float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
 VMV_DEV void unpack8(const u32x4_t& v, float* f) {

@@ -20,6 +20,7 @@
 using namespace vmv_gemm;
 
 int vmv_gemm_glds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st);   // gemm_glds.hip
+int vmv_gemm_pglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st);  // gemm_pglds.hip
 
 namespace {
 
@@ -253,11 +254,12 @@ int launch_cfg(const VmvGemmParams& p, int total_steps, hipStream_t st) {
 }
 
 int gemm_policy() {
-    // VMV_GEMM_POLICY=0 disables the 256-row LDS-DMA kernel (A/B experiments); default 1.
+    // VMV_GEMM_POLICY (A/B experiments): 0 = 128-row register-staged kernel only, 1 = + the 256-row LDS-DMA kernel,
+    // 2 (default) = + the persistent LDS-DMA kernel for short-K linears.
     static int pol = -1;
     if (pol < 0) {
         const char* e = getenv("VMV_GEMM_POLICY");
-        pol = e ? atoi(e) : 1;
+        pol = e ? atoi(e) : 2;
     }
     return pol;
 }
@@ -275,7 +277,18 @@ int pick_tile(const VmvGemmParams& p, int total_steps) {
         const int bn = best == VMV_TILE_128x128 ? 128 : 160;
         const long tiles = (long)((p.M + 255) / 256) * ((p.N + bn - 1) / bn);
         const long waves = (tiles + 255) / 256;
-        if (tiles >= 240 && (double)tiles / (double)(waves * 256) >= 0.8)
+        const bool big = tiles >= 240 && (double)tiles / (double)(waves * 256) >= 0.8;
+        // Short reductions over plain rows (the transformer blocks' linears, K = C .. 4C at the two large levels): the tile's
+        // fill, epilogue round trips and store drain are as long as its main loop, so the persistent kernel — ring kept
+        // full across tiles, epilogue loads prefetched under the last MFMAs — wins by 10-40 % once every CU gets >= 2 tiles
+        // (measured per shape: DESIGN.md §7).  Long reductions and conv gathers stay on the one-tile-per-block kernel.
+        bool linear = true;
+        for (int i = 0; i < p.nseg; ++i) linear = linear && p.seg[i].mode == VMV_SEG_LINEAR;
+        const bool p160 = best == VMV_TILE_128x160;
+        const long ptiles = (long)((p.M + (p160 ? 191 : 255)) / (p160 ? 192 : 256)) * ((p.N + bn - 1) / bn);
+        if (gemm_policy() >= 2 && linear && total_steps <= 24 && ptiles >= 2 * 256)
+            best = p160 ? VMV_TILE_P256x160 : VMV_TILE_P256x128;
+        else if (big)
             best = best == VMV_TILE_128x128 ? VMV_TILE_256x128 : VMV_TILE_256x160;
     }
     return best;
@@ -324,6 +337,32 @@ extern "C" int vmv_gemm_bf16(const VmvGemmParams* pp, void* stream) {
             break;
         case VMV_TILE_256x160:
             rc = vmv_gemm_glds_launch(p, total_steps, VMV_TILE_256x160, st);
+            if (rc == VMV_GLDS_UNSUPPORTED) rc = launch_cfg<4, 5>(p, total_steps, st);
+            break;
+        case VMV_TILE_P256x128:
+            rc = vmv_gemm_pglds_launch(p, total_steps, VMV_TILE_P256x128, st);
+            if (rc == VMV_GLDS_UNSUPPORTED) rc = vmv_gemm_glds_launch(p, total_steps, VMV_TILE_256x128, st);
+            if (rc == VMV_GLDS_UNSUPPORTED) rc = launch_cfg<4, 4>(p, total_steps, st);
+            break;
+        case VMV_TILE_P256x160:
+            rc = vmv_gemm_pglds_launch(p, total_steps, VMV_TILE_P256x160, st);
+            if (rc == VMV_GLDS_UNSUPPORTED) rc = vmv_gemm_glds_launch(p, total_steps, VMV_TILE_256x160, st);
+            if (rc == VMV_GLDS_UNSUPPORTED) rc = launch_cfg<4, 5>(p, total_steps, st);
+            break;
+        case VMV_TILE_PP256x128:
+            rc = vmv_gemm_glds_launch(p, total_steps, VMV_TILE_PP256x128, st);
+            if (rc == VMV_GLDS_UNSUPPORTED) rc = launch_cfg<4, 4>(p, total_steps, st);
+            break;
+        case VMV_TILE_PP256x160:
+            rc = vmv_gemm_glds_launch(p, total_steps, VMV_TILE_PP256x160, st);
+            if (rc == VMV_GLDS_UNSUPPORTED) rc = launch_cfg<4, 5>(p, total_steps, st);
+            break;
+        case VMV_TILE_G128x128:
+            rc = vmv_gemm_glds_launch(p, total_steps, VMV_TILE_G128x128, st);
+            if (rc == VMV_GLDS_UNSUPPORTED) rc = launch_cfg<4, 4>(p, total_steps, st);
+            break;
+        case VMV_TILE_G128x160:
+            rc = vmv_gemm_glds_launch(p, total_steps, VMV_TILE_G128x160, st);
             if (rc == VMV_GLDS_UNSUPPORTED) rc = launch_cfg<4, 5>(p, total_steps, st);
             break;
         default: return VMV_EINVAL;

@@ -1,66 +1,36 @@
-// gemm_glds.hip — the large-tile variant of the bf16 MFMA implicit GEMM (same contract as gemm.hip / vmv.h).
+// gemm_glds.hip — the LDS-DMA variants of the bf16 MFMA implicit GEMM (same contract as gemm.hip / vmv.h).
 //
-//   * block = 512 threads = 8 waves (4 along M x 2 along N), tile 256 x {128,160}, BK = 64, ONE block per CU
-//     (2 waves per SIMD), wave tile 64 x {64,80} of v_mfma_f32_16x16x32_bf16 (transposed product, see gemm.hip).
+//   * wave tile 64 x {64,80} of v_mfma_f32_16x16x32_bf16 (transposed product, see gemm.hip), BK = 64, and two block shapes:
+//       - 8 waves (4 along M x 2 along N), tile 256 x {128,160}, 3-stage ring (144/156 KB): ONE block per CU — the
+//         long-K workhorse (conv3x3 / temporal conv / FF-down): least LDS-fill traffic per flop, loads two chunks ahead;
+//       - 4 waves (2 x 2), tile 128 x {128,160}, 2-stage ring (64/72 KB): TWO blocks per CU — for the short-K linears
+//         (K = C = 320/640: 5-10 chunks per tile), where a tile's fill + epilogue (GEGLU: ~as many VALU cycles as the
+//         tile has MFMA cycles) is as long as its main loop; two co-resident blocks run one's epilogue / prologue
+//         under the other's MFMAs.
 //   * operands go global -> LDS directly (LDS-DMA, global_load_lds_dwordx4): no staging VGPRs, no ds_write pass.
 //     Zero fill (conv padding, M/N/K tails) is done by pointing the lane at a zero page instead of predicating.
 //     The LDS image is lane-linear per wave instruction (8 rows x 128 B), so the XOR swizzle that makes the
 //     ds_read_b128 fragment reads conflict-free is applied to the per-lane SOURCE address.
 //   * 3-stage LDS ring (3 x 48/52 KB), loads run TWO chunks ahead of the MFMAs with counted s_waitcnt vmcnt(N)
 //     and one raw s_barrier per chunk:   wait(chunk t landed) -> barrier -> issue(chunk t+2) -> MFMA(chunk t).
-#include "gemm_common.h"
+#include "gemm_glds_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 using namespace vmv_gemm;
 
 namespace {
 
-constexpr int GL_BM = 256;
-constexpr int GL_STAGES = 3;
-
-template <int WN>
-struct GlCfg {
-    static constexpr int BN = 32 * WN;
-    static constexpr int A_BYTES = GL_BM * 128;
-    static constexpr int W_BYTES = BN * 128;
-    static constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
-    static constexpr int LDS_BYTES = GL_STAGES * STAGE_BYTES;
-    static constexpr int NAI = GL_BM / 64;                 // A wave-instructions per wave per chunk (8 rows each)
-    static constexpr int NWI = (BN / 8 + 7) / 8;           // W wave-instructions per wave per chunk
-    static constexpr int LPT = NAI + NWI;                  // loads per lane per chunk
-};
-
-// 16-byte LDS-DMA through a buffer descriptor: lane address = base + voff + soff; a lane whose voff is out of range
-// (>= num_records) WRITES ZEROS to its LDS slot (verified on gfx950: tools/experiments/buffer_lds_oob.hip) — this is
-// how conv zero padding and the M / N / K tails are produced without a select on 64-bit pointers.
-// (the builtin is only visible to the device pass: hipcc's host pass otherwise silently drops the kernel template's
-//  instantiation — stub and handle come out undefined — so the body is compiled for the device only)
-VMV_DEV void blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lptr, uint32_t voff, uint32_t soff) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lptr), 16, voff, soff, 0, 0);
-#endif
-}
-#define VMV_BLDS16(rsrc, lptr, voff, soff) blds16(rsrc, lptr, voff, soff)
-constexpr uint32_t OOB = 0x80000000u;          // > num_records of every descriptor below
-constexpr uint32_t SRD_RECORDS = 0x7ffffff0u;
-constexpr uint32_t SRD_FLAGS = 0x00020000u;
-
-template <int N> VMV_DEV void wait_vmcnt() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-    else static_assert(N == 0, "add the literal");
-}
-
-template <int WN, int ablate>
-__global__ __launch_bounds__(512) void gemm_glds_kernel(const VmvGemmParams p, const int tiles_m, const int tiles_n,
-                                                        const int total_steps, const int steps_per_split) {
+template <int WMW, int WN, int STAGES, int ablate, bool PP = false>
+__global__ __launch_bounds__(128 * WMW, WMW == 2 ? 2 : 1) void gemm_glds_kernel(const VmvGemmParams p, const int tiles_m, const int tiles_n,
+                                                              const int total_steps, const int steps_per_split) {
     // ablate (experiments only, VMV_GEMM_ABLATE): 1 = skip the MFMAs + fragment reads, 2 = skip the LDS-DMA loads
-    using Cfg = GlCfg<WN>;
-    constexpr int WM = 4;
+    using Cfg = GlCfg<WMW, WN, STAGES>;
+    constexpr int WM = 4;                         // 16-row MFMA tiles per wave along M (wave tile = 64 rows)
     constexpr int BN = Cfg::BN;
+    constexpr int GL_BM = Cfg::BM;
+    constexpr int GL_STAGES = STAGES;
+    constexpr int NW = Cfg::NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -87,14 +57,14 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const VmvGemmParams p, c
 
     // ---- load assignment.  Wave instruction covers 8 rows x 128 B; lane -> (row-in-group = lane>>3, physical slot =
     //      lane&7).  Row r stores logical slot s at physical slot s ^ ((r>>1)&7); for every row this lane touches
-    //      (r = 8*g + (lane>>3), g = 8*i + wave [- 8]) that XOR term is ((wave&1)*4 + (lane>>4)) & 7.
+    //      (r = 8*g + (lane>>3), g = NW*i + wave [- NW], NW even) that XOR term is ((wave&1)*4 + (lane>>4)) & 7.
     const int lrow = lane >> 3;
     const int lsw = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);    // logical 16-B slot this lane fetches
 
     RowInfo rinfo[Cfg::NAI];
 #pragma unroll
     for (int i = 0; i < Cfg::NAI; ++i) {
-        const int m = m0 + (i * 8 + wave) * 8 + lrow;
+        const int m = m0 + (i * NW + wave) * 8 + lrow;
         RowInfo r;
         r.m = (m < p.M) ? m : -1;
         r.nb = 0; r.oy = 0; r.ox = 0; r.fr = 0;
@@ -112,8 +82,8 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const VmvGemmParams p, c
     int wgrp[Cfg::NWI];
 #pragma unroll
     for (int j = 0; j < Cfg::NWI; ++j) {
-        int g = j * 8 + wave;
-        if (g >= BN / 8) g -= 8;                 // duplicate an earlier row group: keeps the per-wave load count uniform
+        int g = j * NW + wave;
+        if (g >= BN / 8) g -= NW;                // duplicate an earlier row group: keeps the per-wave load count uniform
         wgrp[j] = g;
         const int n = n0 + g * 8 + lrow;
         wvo[j] = (n < p.N) ? (uint32_t)(n * p.ktot + lsw * 8) * 2u : OOB;
@@ -150,12 +120,12 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const VmvGemmParams p, c
         const uint32_t a_so = (uint32_t)kc * 2u, w_so = (uint32_t)(koff + kc) * 2u;
         if (!ktail) {
 #pragma unroll
-            for (int i = 0; i < Cfg::NAI; ++i) VMV_BLDS16(a_rsrc, abase + i * 8192, avo[i], a_so);
+            for (int i = 0; i < Cfg::NAI; ++i) VMV_BLDS16(a_rsrc, abase + i * (NW * 1024), avo[i], a_so);
 #pragma unroll
             for (int j = 0; j < Cfg::NWI; ++j) VMV_BLDS16(w_rsrc, wbase + wgrp[j] * 1024, wvo[j], w_so);
         } else {
 #pragma unroll
-            for (int i = 0; i < Cfg::NAI; ++i) VMV_BLDS16(a_rsrc, abase + i * 8192, kvalid ? avo[i] : OOB, a_so);
+            for (int i = 0; i < Cfg::NAI; ++i) VMV_BLDS16(a_rsrc, abase + i * (NW * 1024), kvalid ? avo[i] : OOB, a_so);
 #pragma unroll
             for (int j = 0; j < Cfg::NWI; ++j) VMV_BLDS16(w_rsrc, wbase + wgrp[j] * 1024, kvalid ? wvo[j] : OOB, w_so);
         }
@@ -201,47 +171,95 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const VmvGemmParams p, c
     };
 
     bf16x8_t a0[WM], w0[WN], a1[WM], w1[WN];
-    int issued = 0;
-    const int pro = nsteps < GL_STAGES ? nsteps : GL_STAGES;
-    for (int i = 0; i < pro; ++i) { issue(i); ++issued; }
-    if (ablate == 2) issued = nsteps;
-    if (nsteps > 0) {
-        if (pro == 3) wait_vmcnt<2 * Cfg::LPT>(); else if (pro == 2) wait_vmcnt<Cfg::LPT>(); else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (ablate != 1) read_frags(0, 0, a0, w0);
-    }
-    int st = 0;                                   // ring slot of chunk t
-    for (int t = 0; t + 1 < nsteps; ++t) {        // (the last chunk is peeled below: no control-flow merge in here)
-        if constexpr (ablate != 1) {
-            read_frags(st, 1, a1, w1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(a0, w0);
+    if constexpr (PP) {
+        // ---- ping-pong schedule (8 waves; waves w and w+4 share a SIMD).  Every chunk has a LOAD phase (fragment reads of
+        //      chunk t + LDS-DMA issue of chunk t+2) and a MATRIX phase (its 40 MFMAs), separated by block barriers; the
+        //      waves 4-7 run one phase behind the waves 0-3, so on every SIMD one wave multiplies while its partner
+        //      reads / issues.  Ring invariants: chunk t+1 is waited for by everyone before the barrier that opens the
+        //      first group's LOAD(t+1); the slot of chunk t-1 is refilled only after both groups' LOAD(t-1).
+        static_assert(!PP || (WMW == 4 && STAGES == 3), "ping-pong needs the 8-wave 3-stage block");
+        const int grp = wave >> 2;
+        int issued = 0;
+        const int pro = nsteps < 2 ? nsteps : 2;
+        for (int i = 0; i < pro; ++i) { issue(i); ++issued; }
+        if (nsteps > 0) {
+            if (pro == 2) wait_vmcnt<Cfg::LPT>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+            if (grp == 1) __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            int st = 0;
+            for (int t = 0; t < nsteps; ++t) {
+                // LOAD(t)
+                if constexpr (ablate != 1) { read_frags(st, 0, a0, w0); read_frags(st, 1, a1, w1); }
+                int s2 = st + 2; if (s2 >= 3) s2 -= 3;
+                const bool more = issued < nsteps;
+                if (more) { if (ablate != 2) issue(s2); ++issued; }
+                if (grp == 1) { if (more) wait_vmcnt<Cfg::LPT>(); else wait_vmcnt<0>(); }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                // MATRIX(t)
+                if constexpr (ablate != 1) { mma(a0, w0); mma(a1, w1); }
+                __builtin_amdgcn_sched_barrier(0);
+                if (grp == 0) { if (more) wait_vmcnt<Cfg::LPT>(); else wait_vmcnt<0>(); }
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                st = st + 1 == 3 ? 0 : st + 1;
+            }
+            if (grp == 0) __builtin_amdgcn_s_barrier();
         }
-        int stn = st + 1; if (stn == GL_STAGES) stn = 0;
-        if (t + 2 < nsteps) wait_vmcnt<Cfg::LPT>(); else wait_vmcnt<0>();          // chunk t+1 landed (mine)
-        __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): my reads of slot st are done (builtin: the compiler's
-                                                  // wait-count pass sees it and adds no second drain before the MFMAs)
-        __builtin_amdgcn_s_barrier();             // ... for every wave: slot st is free, chunk t+1 is visible
-        asm volatile("" ::: "memory");
-        if constexpr (ablate != 1) {
-            read_frags(stn, 0, a0, w0);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(a1, w1);
-            __builtin_amdgcn_sched_barrier(0);
+    } else {
+        int issued = 0;
+        const int pro = nsteps < GL_STAGES ? nsteps : GL_STAGES;
+        for (int i = 0; i < pro; ++i) { issue(i); ++issued; }
+        if (ablate == 2 || ablate >= 5) issued = nsteps;       // 5: MFMAs only; 6: MFMAs + fragment reads (no barriers, no DMA)
+        if (nsteps > 0) {
+            if (pro == 3) wait_vmcnt<(GL_STAGES == 3 ? 2 : 0) * Cfg::LPT>(); else if (pro == 2) wait_vmcnt<Cfg::LPT>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (ablate != 1 && ablate != 5) read_frags(0, 0, a0, w0);
+            else if (ablate == 5) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i) { a0[i] = bf16x8_t{}; a1[i] = bf16x8_t{}; }
+#pragma unroll
+                for (int j = 0; j < WN; ++j) { w0[j] = bf16x8_t{}; w1[j] = bf16x8_t{}; }
+            }
         }
-        // address arithmetic, scalar loads of the segment table and the LDS-DMA issue run in the shadow of the
-        // MFMA batch just issued (chunk t+3 -> the slot freed by the barrier above)
-        if (issued < nsteps) { issue(st); ++issued; }
-        __builtin_amdgcn_s_waitcnt(0xc07f);       // retire issue()'s scalar loads here (and the long-finished a0/w0
-                                                  // reads) so the next iteration's first MFMA batch needs no drain
-        st = stn;
-    }
-    if (nsteps > 0) {
-        if constexpr (ablate != 1) {
-            read_frags(st, 1, a1, w1);
-            mma(a0, w0);
-            mma(a1, w1);
+        int st = 0;                                   // ring slot of chunk t
+        for (int t = 0; t + 1 < nsteps; ++t) {        // (the last chunk is peeled below: no control-flow merge in here)
+            if constexpr (ablate != 1) {
+                if constexpr (ablate != 5) read_frags(st, 1, a1, w1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a0, w0);
+            }
+            int stn = st + 1; if (stn == GL_STAGES) stn = 0;
+            // chunk t+1 landed (mine): chunks up to t+STAGES-1 are in flight, so a 3-stage ring may leave one outstanding
+            if (GL_STAGES == 3 && t + 2 < nsteps) wait_vmcnt<(GL_STAGES == 3 ? 1 : 0) * Cfg::LPT>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): my reads of slot st are done (builtin: the compiler's
+                                                      // wait-count pass sees it and adds no second drain before the MFMAs)
+            if constexpr (ablate < 5) __builtin_amdgcn_s_barrier();             // ... for every wave: slot st is free, chunk t+1 is visible
+            asm volatile("" ::: "memory");
+            if constexpr (ablate != 1) {
+                if constexpr (ablate != 5) read_frags(stn, 0, a0, w0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a1, w1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // address arithmetic, scalar loads of the segment table and the LDS-DMA issue run in the shadow of the
+            // MFMA batch just issued (chunk t+3 -> the slot freed by the barrier above)
+            if (issued < nsteps) { issue(st); ++issued; }
+            __builtin_amdgcn_s_waitcnt(0xc07f);       // retire issue()'s scalar loads here (and the long-finished a0/w0
+                                                      // reads) so the next iteration's first MFMA batch needs no drain
+            st = stn;
+        }
+        if (nsteps > 0) {
+            if constexpr (ablate != 1) {
+                if constexpr (ablate != 5) read_frags(st, 1, a1, w1);
+                mma(a0, w0);
+                mma(a1, w1);
+            }
         }
     }
 
@@ -305,7 +323,8 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const VmvGemmParams p, c
                         if constexpr ((WN & 1) == 0) {
                             f32x4_t g = acc[(j + 1) % WN][i];
                             if (p.bias) g += *reinterpret_cast<const f32x4_t*>(p.bias + n + 16);
-                            v.x *= gelu_erf_f(g.x); v.y *= gelu_erf_f(g.y); v.z *= gelu_erf_f(g.z); v.w *= gelu_erf_f(g.w);
+                            if constexpr (ablate == 3) { v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w; }    // (experiment: no GELU)
+                            else { v.x *= gelu_erf_f(g.x); v.y *= gelu_erf_f(g.y); v.z *= gelu_erf_f(g.z); v.w *= gelu_erf_f(g.w); }
                         }
                         no = (n >> 5) * 16 + (n & 15);
                         tc = (tc >> 5) * 16 + (tc & 15);
@@ -327,7 +346,7 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const VmvGemmParams p, c
         const int U = out_w >> 3;                                // 16-byte units per tile row
         uint16_t* outp = reinterpret_cast<uint16_t*>(p.out);
         const uint16_t* resp = reinterpret_cast<const uint16_t*>(p.residual);
-        for (int idx = tid; idx < GL_BM * U; idx += 512) {
+        for (int idx = tid; idx < GL_BM * U; idx += Cfg::NT) {
             const int r = idx / U, u = idx - r * U;
             const int m = m0 + r, n = n_out0 + u * 8;
             if (m >= p.M || n >= N_out) continue;
@@ -345,34 +364,41 @@ __global__ __launch_bounds__(512) void gemm_glds_kernel(const VmvGemmParams p, c
     }
 }
 
-template <int WN>
+template <int WMW, int WN, int STAGES, bool PP = false>
 int launch_glds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
-    using Cfg = GlCfg<WN>;
-    static_assert(Cfg::LPT == 6 || Cfg::LPT == 7, "wait_vmcnt literals");
-    const int tiles_m = (p.M + GL_BM - 1) / GL_BM;
+    using Cfg = GlCfg<WMW, WN, STAGES>;
+    static_assert(Cfg::LPT >= 6 && Cfg::LPT <= 9 && (STAGES == 2 || 2 * Cfg::LPT <= 14), "wait_vmcnt literals");
+    static_assert(Cfg::BM * (Cfg::BN * 2 + 16) <= Cfg::LDS_BYTES, "epilogue staging fits in the ring");
+    const int tiles_m = (p.M + Cfg::BM - 1) / Cfg::BM;
     const int tiles_n = (p.N + Cfg::BN - 1) / Cfg::BN;
     const int ks = p.ksplit > 1 ? p.ksplit : 1;
     const int sps = (total_steps + ks - 1) / ks;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<WN, 0>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<WN, 1>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<WN, 2>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
     static int ablate = -1;
     if (ablate < 0) { const char* e = getenv("VMV_GEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
     dim3 grid(tiles_m * tiles_n, ks, 1);
-    if (ablate == 2)
-        hipLaunchKernelGGL((gemm_glds_kernel<WN, 2>), grid, dim3(512), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n, total_steps, sps);
-    else if (ablate == 1)
-        hipLaunchKernelGGL((gemm_glds_kernel<WN, 1>), grid, dim3(512), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n, total_steps, sps);
-    else
-        hipLaunchKernelGGL((gemm_glds_kernel<WN, 0>), grid, dim3(512), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n, total_steps, sps);
+    auto go = [&](auto tag) -> int {
+        constexpr int AB = decltype(tag)::value;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<WMW, WN, STAGES, AB, PP>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((gemm_glds_kernel<WMW, WN, STAGES, AB, PP>), grid, dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n,
+                           total_steps, sps);
+        return VMV_OK;
+    };
+    int rc;
+    switch (ablate) {
+        case 1: rc = go(std::integral_constant<int, 1>{}); break;
+        case 2: rc = go(std::integral_constant<int, 2>{}); break;
+        case 3: rc = go(std::integral_constant<int, 3>{}); break;
+        case 5: rc = go(std::integral_constant<int, 5>{}); break;
+        case 6: rc = go(std::integral_constant<int, 6>{}); break;
+        default: rc = go(std::integral_constant<int, 0>{}); break;
+    }
+    if (rc != VMV_OK) return rc;
     return vmv_launch_status();
 }
 
@@ -386,10 +412,16 @@ int vmv_gemm_glds_launch(const VmvGemmParams& p, int total_steps, int tile, hipS
     for (int i = 0; i < p.nseg; ++i)
         if (maxrows * (long)p.seg[i].ld * 2 >= (1L << 31) - 65536) return VMV_GLDS_UNSUPPORTED;
     if ((long)p.N * p.ktot * 2 >= (1L << 31) - 65536) return VMV_GLDS_UNSUPPORTED;
-    if (tile == VMV_TILE_256x128) return launch_glds<4>(p, total_steps, st);
-    if (tile == VMV_TILE_256x160) {
+    if (tile == VMV_TILE_PP256x128) return launch_glds<4, 4, 3, true>(p, total_steps, st);
+    if (tile == VMV_TILE_PP256x160) {
         if (p.epilogue == VMV_EPI_GEGLU) return VMV_EINVAL;
-        return launch_glds<5>(p, total_steps, st);
+        return launch_glds<4, 5, 3, true>(p, total_steps, st);
+    }
+    if (tile == VMV_TILE_256x128) return launch_glds<4, 4, 3>(p, total_steps, st);
+    if (tile == VMV_TILE_G128x128) return launch_glds<2, 4, 2>(p, total_steps, st);
+    if (tile == VMV_TILE_256x160 || tile == VMV_TILE_G128x160) {
+        if (p.epilogue == VMV_EPI_GEGLU) return VMV_EINVAL;
+        return tile == VMV_TILE_256x160 ? launch_glds<4, 5, 3>(p, total_steps, st) : launch_glds<2, 5, 2>(p, total_steps, st);
     }
     return VMV_EINVAL;
 }

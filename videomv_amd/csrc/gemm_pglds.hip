@@ -1,0 +1,517 @@
+// gemm_pglds.hip — PERSISTENT variant of the LDS-DMA bf16 MFMA implicit GEMM (same contract as gemm.hip / vmv.h).
+//
+// Why: for the short-K linears of the transformer blocks (K = C = 320 / 640: 5-10 chunks of 64 per tile) a
+// one-tile-per-block kernel spends most of a tile's life outside its main loop — block launch, per-tile address
+// set-up, the first HBM round trip of the ring, and an epilogue that all 8 waves run in lock-step — and with one
+// block per CU nothing overlaps any of it (measured: 330-490 TFLOP/s on those shapes, no better with two smaller
+// blocks per CU; the MFMA-free and the load-free ablations each run as slowly as the full kernel).  Here ONE block
+// per CU walks a list of tiles and the 3-stage ring never drains:
+//   * the loader runs two chunks ahead of the MFMAs ACROSS tile boundaries, so tile i+1's first chunks (and its
+//     address set-up) are in flight under tile i's last MFMAs and its epilogue;
+//   * the epilogue is per-wave: each wave transposes its own 64 x {64,80} accumulator block, 16 rows at a time,
+//     through a private slab in the ring slot that tile i has just freed, and writes whole 16-byte lanes
+//     (residual prefetched 16 bytes per lane); no block-wide phases, so waves drift apart and one wave's stores
+//     overlap another's GELU;
+//   * one refill is delayed by one chunk per tile (the slab's slot), two barriers per tile are added.
+// Same tile shapes, LDS image, swizzle and fragment schedule as gemm_glds.hip (256 x {128,160}, 8 waves, BK = 64).
+// Tile order: item v -> logical tile through the XCD-aware bijection, so the 32 CUs of an XCD work on 32 consecutive
+// tiles (same rows of A, neighbouring weight columns) in every round.
+#include "gemm_glds_common.h"
+#include <cstdlib>
+#include <type_traits>
+
+using namespace vmv_gemm;
+
+namespace {
+
+// 8 waves (4 along M x 2 along N), wave tile 16*WM x 16*WN, block tile 64*WM x 32*WN, 3-stage ring
+template <int WM_, int WN>
+struct PgCfg {
+    static constexpr int NW = 8, NT = 512;
+    static constexpr int BM = 64 * WM_;
+    static constexpr int BN = 32 * WN;
+    static constexpr int A_BYTES = BM * 128;
+    static constexpr int W_BYTES = BN * 128;
+    static constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
+    static constexpr int LDS_BYTES = 3 * STAGE_BYTES;
+    static constexpr int NAI = BM / 64;                    // A wave-instructions per wave per chunk (8 rows each)
+    static constexpr int NWI = (BN / 8 + 7) / 8;
+    static constexpr int LPT = NAI + NWI;
+};
+
+template <int WM, int WN, int ablate>
+__global__ __launch_bounds__(512) void gemm_pglds_kernel(const VmvGemmParams p, const int tiles_n, const int total_steps,
+                                                         const int nitems) {
+    using Cfg = PgCfg<WM, WN>;
+    constexpr int BN = Cfg::BN;
+    constexpr int BM = Cfg::BM;
+    constexpr int NW = Cfg::NW;
+    constexpr int S = 3;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int G = gridDim.x;
+    const int bid = blockIdx.x;
+
+    auto item_tile = [&](int v, int& m0, int& n0) {      // XCD-aware bijection item -> tile (see gemm_glds.hip)
+        const int q = nitems >> 3, r = nitems & 7;
+        const int xcd = v & 7, idx = v >> 3;
+        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int tn = logical % tiles_n;
+        m0 = (logical / tiles_n) * BM;
+        n0 = tn * BN;
+    };
+
+    const int lrow = lane >> 3;
+    const int lsw = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);    // logical 16-B slot this lane fetches
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, SRD_RECORDS, SRD_FLAGS);
+
+    // ------------------------------------------------------------------ loader state (runs ahead of the MFMAs)
+    // (LINEAR segments only — the launcher sends conv / temporal-conv GEMMs, whose K is long anyway, to gemm_glds.hip: a
+    //  row's gather state is then just its index, which keeps the loader's registers out of the MFMA loop's way)
+    int L_item = bid, L_left = 0;
+    int rowm[Cfg::NAI];
+    uint32_t wvo[Cfg::NWI], avo[Cfg::NAI];
+    int wgrp[Cfg::NWI];
+#pragma unroll
+    for (int j = 0; j < Cfg::NWI; ++j) {
+        int g = j * NW + wave;
+        if (g >= BN / 8) g -= NW;
+        wgrp[j] = g;
+    }
+    int s = 0, kc = 0, koff = 0, islot = 0;
+    auto enter_segment = [&]() {
+#pragma unroll
+        for (int i = 0; i < Cfg::NAI; ++i)
+            avo[i] = rowm[i] >= 0 ? (uint32_t)(rowm[i] * p.seg[s].ld + lsw * 8) * 2u : OOB;
+    };
+    auto setup_item = [&](int v) {
+        int m0, n0;
+        item_tile(v, m0, n0);
+#pragma unroll
+        for (int i = 0; i < Cfg::NAI; ++i) {
+            const int m = m0 + (i * NW + wave) * 8 + lrow;
+            rowm[i] = (m < p.M) ? m : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < Cfg::NWI; ++j) {
+            const int n = n0 + wgrp[j] * 8 + lrow;
+            wvo[j] = (n < p.N) ? (uint32_t)(n * p.ktot + lsw * 8) * 2u : OOB;
+        }
+        s = 0; kc = 0; koff = 0;
+        L_left = total_steps;
+        enter_segment();
+    };
+    auto issue_one = [&]() {                 // LDS-DMA the loader's next chunk into ring slot `islot`
+        const VmvGemmSeg& sg = p.seg[s];
+        const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(sg.src), 0, SRD_RECORDS, SRD_FLAGS);
+        const bool ktail = (kc + BK) > sg.k;
+        const bool kvalid = (kc + lsw * 8) < sg.k;
+        unsigned char* abase = smem + islot * Cfg::STAGE_BYTES + wave * 1024;
+        unsigned char* wbase = smem + islot * Cfg::STAGE_BYTES + Cfg::A_BYTES;
+        const uint32_t a_so = (uint32_t)kc * 2u, w_so = (uint32_t)(koff + kc) * 2u;
+        if constexpr (ablate != 2) {
+            if (!ktail) {
+#pragma unroll
+                for (int i = 0; i < Cfg::NAI; ++i) VMV_BLDS16(a_rsrc, abase + i * (NW * 1024), avo[i], a_so);
+#pragma unroll
+                for (int j = 0; j < Cfg::NWI; ++j) VMV_BLDS16(w_rsrc, wbase + wgrp[j] * 1024, wvo[j], w_so);
+            } else {
+#pragma unroll
+                for (int i = 0; i < Cfg::NAI; ++i) VMV_BLDS16(a_rsrc, abase + i * (NW * 1024), kvalid ? avo[i] : OOB, a_so);
+#pragma unroll
+                for (int j = 0; j < Cfg::NWI; ++j) VMV_BLDS16(w_rsrc, wbase + wgrp[j] * 1024, kvalid ? wvo[j] : OOB, w_so);
+            }
+        }
+        islot = islot + 1 == S ? 0 : islot + 1;
+        kc += BK;
+        --L_left;
+        if (kc >= sg.k) {
+            koff += sg.k; ++s; kc = 0;
+            if (L_left > 0) enter_segment();
+        }
+        if (L_left == 0) {                   // next tile of this block: its address set-up runs under the current MFMAs
+            L_item += G;
+            if (L_item < nitems) setup_item(L_item);
+        }
+    };
+
+    // ------------------------------------------------------------------ MFMA side
+    f32x4_t acc[WN][WM];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int i = 0; i < WM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
+    const int frow = lane & 15;
+    const int fgrp = lane >> 4;
+    const int fswz = (frow >> 1) & 7;
+    auto read_frags = [&](int slot_idx, int kk, bf16x8_t (&af)[WM], bf16x8_t (&wf)[WN]) {
+        const u32x4_t* a = reinterpret_cast<const u32x4_t*>(smem + slot_idx * Cfg::STAGE_BYTES) + (wave_m * 16 * WM + frow) * 8;
+        const u32x4_t* w = reinterpret_cast<const u32x4_t*>(smem + slot_idx * Cfg::STAGE_BYTES + Cfg::A_BYTES) +
+                           (wave_n * 16 * WN + frow) * 8;
+        const int slot = (kk * 4 + fgrp) ^ fswz;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) af[i] = __builtin_bit_cast(bf16x8_t, a[i * 16 * 8 + slot]);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) wf[j] = __builtin_bit_cast(bf16x8_t, w[j * 16 * 8 + slot]);
+    };
+    auto mma = [&](const bf16x8_t (&af)[WM], const bf16x8_t (&wf)[WN]) {
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+    };
+
+    // ------------------------------------------------------------------ per-wave epilogue through a private LDS slab
+    const bool geglu = p.epilogue == VMV_EPI_GEGLU;
+    const int N_out = geglu ? p.N / 2 : p.N;
+    const bool staged = !p.out_fp32 && (p.ldo & 7) == 0 && (N_out & 7) == 0 && vmv_ptr_aligned16(p.out) &&
+                        (!p.residual || ((p.ldr & 7) == 0 && vmv_ptr_aligned16(p.residual)));
+    // Split in two so that every global LOAD of the epilogue (bias, residual) is issued in one burst right after the tile's
+    // last MFMAs were issued — their latency then overlaps the MFMA drain and the ring wait — and the staging/store part
+    // runs without a single memory round trip.  (One load -> use -> store chain per 16-row group, as a naive loop does,
+    // costs a full HBM latency per group: measured 11.6k cycles per 256x160 tile without and 21.6k with a residual,
+    // against 13k cycles of main loop at K = 320.)  Output / residual go through buffer descriptors: one 32-bit lane
+    // offset per 16-byte unit serves all four row groups (the group base is a scalar offset), and out-of-range lanes
+    // get the OOB offset — dropped stores, zero loads — instead of 64-bit pointers and exec-masked branches.
+    constexpr int OWC_MAX = 16 * WN;
+    constexpr int NR_MAX = (16 * (OWC_MAX / 8) + 63) / 64;
+    // bias: staged per wave in the 512 B it owns behind the ring (keeps 4*WN registers out of the tile's last MFMAs);
+    // residual: two 16-row groups in flight, refilled as soon as a group has been added to its rows
+    float* bias_lds = reinterpret_cast<float*>(smem + S * Cfg::STAGE_BYTES + wave * 512);
+    u32x4_t resv[2][NR_MAX];
+    f32x4_t bias_hold = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, SRD_RECORDS, SRD_FLAGS);
+    const __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual), 0, SRD_RECORDS, SRD_FLAGS);
+    const bool has_res = staged && p.residual != nullptr;
+    auto unit_offsets = [&](int m0, int n0, int i, int r, int ld, auto geglu_tag) -> uint32_t {
+        // byte offset (relative to the group's scalar base) of 16-byte unit `lane + 64 r` of row group i, or OOB
+        constexpr bool GEGLU = decltype(geglu_tag)::value;
+        constexpr int OWC = GEGLU ? 8 * WN : 16 * WN;
+        constexpr int UW = OWC / 8;
+        constexpr int NU = 16 * UW;
+        const int unit = lane + 64 * r;
+        const int rr = unit / UW, u = unit - rr * UW;
+        const int m = m0 + wave_m * 16 * WM + 16 * i + rr;
+        const int n = (GEGLU ? n0 / 2 : n0) + wave_n * OWC + u * 8;
+        return (unit < NU && m < p.M && n < N_out) ? (uint32_t)(rr * ld + u * 8) * 2u : OOB;
+    };
+    auto group_base = [&](int m0, int n0, int i, int ld, auto geglu_tag) -> uint32_t {
+        constexpr bool GEGLU = decltype(geglu_tag)::value;
+        constexpr int OWC = GEGLU ? 8 * WN : 16 * WN;
+        const int row0 = m0 + wave_m * 16 * WM + 16 * i;
+        const int col0 = (GEGLU ? n0 / 2 : n0) + wave_n * OWC;
+        return (uint32_t)__builtin_amdgcn_readfirstlane(row0 * ld + col0) * 2u;
+    };
+    auto epilogue_prefetch = [&](int m0, int n0, auto geglu_tag) {
+        constexpr bool GEGLU = decltype(geglu_tag)::value;
+        constexpr int OWC = GEGLU ? 8 * WN : 16 * WN;
+        constexpr int NR = (16 * (OWC / 8) + 63) / 64;
+        const int nbase = n0 + wave_n * 16 * WN + 4 * fgrp;
+        {   // this wave's 16*WN bias values: loaded now (lane l < 4*WN holds 4 of them), written to the wave's LDS strip at the
+            // start of the epilogue — writing it here would put a vmcnt(0) drain of the ring into the main loop
+            const int n = n0 + wave_n * 16 * WN + 4 * lane;
+            bias_hold = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (p.bias && lane < 4 * WN && n < p.N) bias_hold = *reinterpret_cast<const f32x4_t*>(p.bias + n);
+        }
+        if (has_res) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint32_t sb = group_base(m0, n0, i, p.ldr, geglu_tag);
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+                    resv[i][r] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, unit_offsets(m0, n0, i, r, p.ldr, geglu_tag), sb, 0);
+            }
+        }
+        (void)nbase;
+    };
+    auto epilogue = [&](int m0, int n0, unsigned char* slot_base, auto geglu_tag) {
+        constexpr bool GEGLU = decltype(geglu_tag)::value;
+        const int mbase = m0 + wave_m * 16 * WM + frow;
+        const int nbase = n0 + wave_n * 16 * WN + 4 * fgrp;
+        if (!staged) {
+            if constexpr (GEGLU) {
+                if constexpr ((WN & 1) == 0) {
+#pragma unroll
+                    for (int j = 0; j < WN; j += 2)
+#pragma unroll
+                        for (int i = 0; i < WM; ++i) epilogue_store(p, mbase + 16 * i, nbase + 16 * j, acc[j][i], acc[j + 1][i]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+#pragma unroll
+                    for (int i = 0; i < WM; ++i) epilogue_store(p, mbase + 16 * i, nbase + 16 * j, acc[j][i], acc[j][i]);
+            }
+            return;
+        }
+        constexpr int OWC = GEGLU ? 8 * WN : 16 * WN;         // output columns of this wave
+        constexpr int UW = OWC / 8;                           // 16-byte units per slab row
+        constexpr int RB = OWC * 2 + 16;                      // slab row pitch (+16 B: spreads the 8-byte writes over banks)
+        constexpr int NU = 16 * UW;                           // units per 16-row group
+        constexpr int NR = (NU + 63) / 64;
+        if (lane < 4 * WN) *reinterpret_cast<f32x4_t*>(bias_lds + 4 * lane) = bias_hold;
+        asm volatile("" ::: "memory");
+        constexpr bool DEDICATED = Cfg::LDS_BYTES + 4096 + 8 * 2816 <= 160 * 1024;
+        unsigned char* slab = DEDICATED ? smem + Cfg::LDS_BYTES + 4096 + wave * 2816 : slot_base + wave * 4096;   // 16 rows x RB <= 2816 B
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const int m = mbase + 16 * i;
+            f32x4_t rv[WN];
+            if (p.rowvec) {                                   // (conv1's per-image embedding row: L2 hits, one burst per group)
+                const float* rvp = p.rowvec + (size_t)((m < p.M ? m : 0) / p.rowvec_div) * p.rowvec_ld;
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    if (GEGLU && (j & 1)) continue;
+                    const int n = nbase + 16 * j;
+                    const int no = GEGLU ? (n >> 5) * 16 + (n & 15) : n;
+                    rv[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    if (n < p.N) rv[j] = *reinterpret_cast<const f32x4_t*>(rvp + no);
+                }
+            }
+            // Two phases, separated for the scheduler: (A) bias reads + math for every column tile, (B) the slab writes.
+            u32x2_t packed[WN];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                if (GEGLU && (j & 1)) continue;
+                f32x4_t v = acc[j][i] + *reinterpret_cast<const f32x4_t*>(bias_lds + 16 * j + 4 * fgrp);
+                if constexpr (GEGLU) {
+                    if constexpr ((WN & 1) == 0) {
+                        const f32x4_t g = acc[(j + 1) % WN][i] +
+                                          *reinterpret_cast<const f32x4_t*>(bias_lds + 16 * ((j + 1) % WN) + 4 * fgrp);
+                        if constexpr (ablate == 3) { v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w; }
+                        else { v.x *= gelu_erf_f(g.x); v.y *= gelu_erf_f(g.y); v.z *= gelu_erf_f(g.z); v.w *= gelu_erf_f(g.w); }
+                    }
+                }
+                if (p.rowvec) v += rv[j];
+                if (p.act == VMV_ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+                packed[j].x = pack_bf16x2(v.x, v.y); packed[j].y = pack_bf16x2(v.z, v.w);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                if (GEGLU && (j & 1)) continue;
+                const int tc = (GEGLU ? 8 * j : 16 * j) + 4 * fgrp;
+                if constexpr (ablate != 8) *reinterpret_cast<u32x2_t*>(slab + frow * RB + tc * 2) = packed[j];
+                else if (packed[j].x == 0x12345u) bias_lds[lane] = 1.f;
+            }
+            // (same wave wrote the slab: LDS executes a wave's instructions in order, no barrier needed — but the COMPILER
+            //  must not move the differently-typed reads above the writes, nor the next group's writes above these reads)
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            asm volatile("" ::: "memory");
+            const uint32_t sb = group_base(m0, n0, i, p.ldo, geglu_tag);
+            // All slab reads of the group first, THEN its stores.  The straightforward loop (read unit r -> store it -> read
+            // unit r+1 into the same registers) compiled to `buffer_store_dwordx4 v[a:a+3]` directly followed by
+            // `ds_read_b128 v[a:a+3]`, and on gfx950 the store intermittently picked up the NEXT unit's first dword in some
+            // 16-lane groups (seen as wrong / zero column pairs in rows 7, 9-12 of a group, only when the store path was
+            // backed up).  Keeping a store's data registers untouched until the group's reads are done avoids it.
+            u32x4_t vout[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int unit = lane + 64 * r;
+                const int rr = unit / UW, u = unit - rr * UW;
+                vout[r] = u32x4_t{0u, 0u, 0u, 0u};
+                if constexpr (ablate != 8) { if (unit < NU) vout[r] = *reinterpret_cast<const u32x4_t*>(slab + rr * RB + u * 16); }
+                else vout[r].x = (uint32_t)i;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                u32x4_t v = vout[r];
+                if (has_res) {
+                    float a[8], b[8];
+                    unpack8(v, a); unpack8(resv[i & 1][r], b);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a[e] += b[e];
+                    v = pack8(a);
+                }
+                if constexpr (ablate != 7)
+                    __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, unit_offsets(m0, n0, i, r, p.ldo, geglu_tag), sb, 0);
+                else if (v.x == 0x12345u) bias_lds[lane] = 1.f;          // (keep the value alive)
+            }
+            asm volatile("" ::: "memory");
+            if (has_res && i + 2 < WM) {                      // refill the slot just consumed with group i + 2
+                const uint32_t sr = group_base(m0, n0, i + 2, p.ldr, geglu_tag);
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+                    resv[i & 1][r] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, unit_offsets(m0, n0, i + 2, r, p.ldr, geglu_tag), sr, 0);
+            }
+        }
+    };
+
+    // ------------------------------------------------------------------ the flattened chunk pipeline
+    const int my_items = bid < nitems ? (nitems - 1 - bid) / G + 1 : 0;
+    if (my_items == 0) return;
+    const int total = my_items * total_steps;
+    setup_item(L_item);
+    int issued = 0;
+    const int pro = total < S ? total : S;
+    for (int i = 0; i < pro; ++i) { issue_one(); ++issued; }
+    int consumed = 0;                 // chunks fully multiplied
+    int st = 0;                       // ring slot of the next chunk to consume
+    bool first = true;
+    bf16x8_t a0[WM], w0[WN], a1[WM], w1[WN];
+    // ablate == 4 (experiments): block 0, wave 0 stamps s_memtime at {tile start, main loop done, epilogue start, epilogue
+    // end} into p.workspace (uint64 x 4 per tile)
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(p.workspace);
+    int tile_no = 0;
+    auto stamp = [&](int k) {
+        if constexpr (ablate == 4 || ablate == 7 || ablate == 8) {
+            if (bid == 0 && tid == 0 && stamps) stamps[tile_no * 4 + k] = __builtin_readcyclecounter();
+        }
+    };
+    for (int item = bid; item < nitems; item += G) {
+        stamp(0);
+        // ---- tile prologue: chunk `consumed` must be visible to every wave
+        if (first) {
+            if (pro == 3) wait_vmcnt<2 * Cfg::LPT>(); else if (pro == 2) wait_vmcnt<Cfg::LPT>(); else wait_vmcnt<0>();
+        }   // (later tiles: everything issued so far was waited for before the previous epilogue)
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();             // also: every wave has left the previous epilogue's slab
+        asm volatile("" ::: "memory");
+        if (!first && issued < total) { issue_one(); ++issued; }      // the refill that the epilogue's slab delayed
+        if constexpr (ablate != 1) read_frags(st, 0, a0, w0);
+        bool known_landed = !first;               // chunk consumed+1 was waited for before the previous epilogue
+        int m0, n0;
+        item_tile(item, m0, n0);
+        for (int t = 0; t + 1 < total_steps; ++t) {
+            if constexpr (ablate != 1) {
+                read_frags(st, 1, a1, w1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a0, w0);
+            }
+            const int stn = st + 1 == S ? 0 : st + 1;
+            if (!known_landed) {                  // chunk consumed+1 landed (mine); one younger chunk may stay in flight
+                if (issued - consumed >= 3) wait_vmcnt<Cfg::LPT>(); else wait_vmcnt<0>();
+            }
+            known_landed = false;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();         // slot st is free, chunk consumed+1 is visible
+            asm volatile("" ::: "memory");
+            if constexpr (ablate != 1) {
+                read_frags(stn, 0, a0, w0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a1, w1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (issued < total) { issue_one(); ++issued; }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            st = stn;
+            ++consumed;
+        }
+        // bias + residual start their round trip under the tile's last 2 x (WM*WN) MFMAs (issuing them earlier, inside the
+        // loop, measurably slowed the loop itself; later, after the MFMAs, exposes ~4k cycles of HBM latency per tile)
+        asm volatile("" ::: "memory");
+        if (geglu) epilogue_prefetch(m0, n0, std::true_type{}); else epilogue_prefetch(m0, n0, std::false_type{});
+        asm volatile("" ::: "memory");
+        if constexpr (ablate != 1) {              // last chunk of the tile
+            read_frags(st, 1, a1, w1);
+            mma(a0, w0);
+            mma(a1, w1);
+        }
+        ++consumed;
+        stamp(1);
+        unsigned char* slab_slot = smem + st * Cfg::STAGE_BYTES;
+        st = st + 1 == S ? 0 : st + 1;
+        // ---- everything in flight (the next tile's first chunks, issued >= 1 MFMA batch ago) lands; then all waves have
+        //      finished reading slot `st-1`, which becomes the epilogue's slab space
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stamp(2);
+        if (geglu) epilogue(m0, n0, slab_slot, std::true_type{}); else epilogue(m0, n0, slab_slot, std::false_type{});
+        zero_acc();
+        first = false;
+        stamp(3);
+        ++tile_no;
+    }
+}
+
+template <int WM, int WN>
+int launch_pglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
+    using Cfg = PgCfg<WM, WN>;
+    constexpr int PG_EXTRA = (Cfg::LDS_BYTES + 4096 + 8 * 2816 <= 160 * 1024) ? 8 * 2816 : 0;
+    static_assert(Cfg::LPT == 6 || Cfg::LPT == 7, "wait_vmcnt literals");
+    static_assert(8 * 4096 <= Cfg::STAGE_BYTES && 16 * (16 * WN * 2 + 16) <= 4096, "per-wave slabs fit in one ring slot");
+    static_assert(Cfg::LDS_BYTES + 8 * 512 <= 160 * 1024 && 16 * WN * 4 <= 512, "bias strips fit behind the ring");
+    const int tiles_m = (p.M + Cfg::BM - 1) / Cfg::BM;
+    const int tiles_n = (p.N + Cfg::BN - 1) / Cfg::BN;
+    const int nitems = tiles_m * tiles_n;
+    static int ncu = 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pglds_kernel<WM, WN, 0>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES + 4096 + PG_EXTRA);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pglds_kernel<WM, WN, 1>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES + 4096 + PG_EXTRA);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pglds_kernel<WM, WN, 2>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES + 4096 + PG_EXTRA);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pglds_kernel<WM, WN, 3>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES + 4096 + PG_EXTRA);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pglds_kernel<WM, WN, 7>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES + 4096 + PG_EXTRA);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pglds_kernel<WM, WN, 8>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES + 4096 + PG_EXTRA);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pglds_kernel<WM, WN, 4>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES + 4096 + PG_EXTRA);
+        if (e != hipSuccess) return (int)e;
+        if (ncu < 8) ncu = 8;
+        ncu &= ~7;                                   // whole XCD groups: item & 7 == block & 7 in every round
+        attr_set = true;
+    }
+    static int ablate = -1;
+    if (ablate < 0) { const char* e = getenv("VMV_GEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
+    const int G = nitems < ncu ? nitems : ncu;
+    dim3 grid(G, 1, 1);
+    if (ablate == 8)
+        hipLaunchKernelGGL((gemm_pglds_kernel<WM, WN, 8>), grid, dim3(512), Cfg::LDS_BYTES + 4096 + PG_EXTRA, st, p, tiles_n, total_steps, nitems);
+    else if (ablate == 7)
+        hipLaunchKernelGGL((gemm_pglds_kernel<WM, WN, 7>), grid, dim3(512), Cfg::LDS_BYTES + 4096 + PG_EXTRA, st, p, tiles_n, total_steps, nitems);
+    else if (ablate == 4)
+        hipLaunchKernelGGL((gemm_pglds_kernel<WM, WN, 4>), grid, dim3(512), Cfg::LDS_BYTES + 4096 + PG_EXTRA, st, p, tiles_n, total_steps, nitems);
+    else if (ablate == 3)
+        hipLaunchKernelGGL((gemm_pglds_kernel<WM, WN, 3>), grid, dim3(512), Cfg::LDS_BYTES + 4096 + PG_EXTRA, st, p, tiles_n, total_steps, nitems);
+    else if (ablate == 2)
+        hipLaunchKernelGGL((gemm_pglds_kernel<WM, WN, 2>), grid, dim3(512), Cfg::LDS_BYTES + 4096 + PG_EXTRA, st, p, tiles_n, total_steps, nitems);
+    else if (ablate == 1)
+        hipLaunchKernelGGL((gemm_pglds_kernel<WM, WN, 1>), grid, dim3(512), Cfg::LDS_BYTES + 4096 + PG_EXTRA, st, p, tiles_n, total_steps, nitems);
+    else
+        hipLaunchKernelGGL((gemm_pglds_kernel<WM, WN, 0>), grid, dim3(512), Cfg::LDS_BYTES + 4096 + PG_EXTRA, st, p, tiles_n, total_steps, nitems);
+    return vmv_launch_status();
+}
+
+}  // namespace
+
+// Called by vmv_gemm_bf16 (gemm.hip) after argument validation; split-K shapes stay on the non-persistent kernels.
+int vmv_gemm_pglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st) {
+    if (p.ksplit > 1) return VMV_GLDS_UNSUPPORTED;
+    for (int i = 0; i < p.nseg; ++i)
+        if (p.seg[i].mode != VMV_SEG_LINEAR) return VMV_GLDS_UNSUPPORTED;
+    long maxrows = p.M;
+    if (p.OH > 0) { const long src_rows = (long)(p.M / (p.OH * p.OW) + 1) * p.IH * p.IW; if (src_rows > maxrows) maxrows = src_rows; }
+    for (int i = 0; i < p.nseg; ++i)
+        if (maxrows * (long)p.seg[i].ld * 2 >= (1L << 31) - 65536) return VMV_GLDS_UNSUPPORTED;
+    if ((long)p.N * p.ktot * 2 >= (1L << 31) - 65536) return VMV_GLDS_UNSUPPORTED;
+    // the epilogue addresses out / residual through buffer descriptors too (32-bit byte offsets)
+    if ((long)(p.M + 256) * p.ldo * (p.out_fp32 ? 4 : 2) >= (1L << 31) - 65536) return VMV_GLDS_UNSUPPORTED;
+    if (p.residual && (long)(p.M + 256) * p.ldr * 2 >= (1L << 31) - 65536) return VMV_GLDS_UNSUPPORTED;
+    if (tile == VMV_TILE_P256x128) return launch_pglds<4, 4>(p, total_steps, st);
+    if (tile == VMV_TILE_P256x160) {
+        if (p.epilogue == VMV_EPI_GEGLU) return VMV_EINVAL;
+        return launch_pglds<3, 5>(p, total_steps, st);     // 192 x 160: the 160-wide wave tile needs 20 fewer accumulators
+    }
+    return VMV_EINVAL;
+}
