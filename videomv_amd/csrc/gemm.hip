@@ -272,6 +272,9 @@ int pick_tile(const VmvGemmParams& p, int total_steps) {
     if (!geglu && padded(160) <= best_pad) { best = VMV_TILE_128x160; best_pad = padded(160); }
     if (padded(64) < best_pad) { best = VMV_TILE_128x64; best_pad = padded(64); }
     if (p.M <= 64 && best == VMV_TILE_128x64) best = VMV_TILE_64x64;
+    if (gemm_policy() >= 1 && p.ksplit > 1 && p.M > 64 && (best == VMV_TILE_128x128 || best == VMV_TILE_128x160))
+        // split-K (small-M levels): the 4-wave LDS-DMA kernel instead of the register-staged one (same 128-row tiles)
+        best = best == VMV_TILE_128x128 ? VMV_TILE_G128x128 : VMV_TILE_G128x160;
     if (gemm_policy() >= 1 && p.ksplit <= 1 && (best == VMV_TILE_128x128 || best == VMV_TILE_128x160)) {
         // the 256-row kernel runs one block per CU: use it when its grid still fills the 256 CUs well
         const int bn = best == VMV_TILE_128x128 ? 128 : 160;
@@ -290,6 +293,8 @@ int pick_tile(const VmvGemmParams& p, int total_steps) {
             best = p160 ? VMV_TILE_P256x160 : VMV_TILE_P256x128;
         else if (big)
             best = best == VMV_TILE_128x128 ? VMV_TILE_256x128 : VMV_TILE_256x160;
+        else if (p.M > 64)
+            best = best == VMV_TILE_128x128 ? VMV_TILE_G128x128 : VMV_TILE_G128x160;
     }
     return best;
 }

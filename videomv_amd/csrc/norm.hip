@@ -169,41 +169,50 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const VmvGroupNormParams 
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
-// One wave per row (4 rows per block); the row lives in registers (<= 4 x 8 values per lane), two-pass
-// mean / variance for accuracy, then a single write.
-constexpr int LN_MAX_IT = 4;   // C <= 4 * 64 * 8 = 2048
+// LPR lanes per row (64 / LPR rows per wave, 4 waves per block): a 320-channel row is only 40 16-byte slots, so with a
+// whole wave per row 24 lanes idle and too few bytes are in flight; LPR = 8 / 16 / 32 / 64 for C = 320 / 640 / 1280 /
+// 2048 keeps every lane on <= 5 slots.  The row lives in registers, two-pass mean / variance, shuffles over the LPR lanes.
+constexpr int LN_MAX_IT = 5;   // C <= 5 * 64 * 8 = 2560
+template <int LPR>
 __global__ __launch_bounds__(256) void layernorm_kernel(const VmvLayerNormParams p) {
+    constexpr int RPW = 64 / LPR;                        // rows per wave
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= p.rows) return;
+    const int sub = lane % LPR;
+    const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const bool live = row < p.rows;
     const int CS = p.C >> 3;
-    const uint16_t* x = reinterpret_cast<const uint16_t*>(p.x) + row * p.ldx;
+    const uint16_t* x = reinterpret_cast<const uint16_t*>(p.x) + (live ? row : 0) * p.ldx;
     float f[LN_MAX_IT][8];
     float s = 0.f;
 #pragma unroll
     for (int it = 0; it < LN_MAX_IT; ++it) {
-        const int cs = lane + it * 64;
+        const int cs = sub + it * LPR;
         if (cs < CS) {
             unpack8(*reinterpret_cast<const u32x4_t*>(x + cs * 8), f[it]);
 #pragma unroll
             for (int e = 0; e < 8; ++e) s += f[it][e];
         }
     }
-    const float mean = wave_sum(s) / (float)p.C;
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)p.C;
     float q = 0.f;
 #pragma unroll
     for (int it = 0; it < LN_MAX_IT; ++it) {
-        const int cs = lane + it * 64;
+        const int cs = sub + it * LPR;
         if (cs < CS) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float d = f[it][e] - mean; q += d * d; }
         }
     }
-    const float rstd = rsqrtf(wave_sum(q) / (float)p.C + p.eps);
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = rsqrtf(q / (float)p.C + p.eps);
+    if (!live) return;
     uint16_t* y = reinterpret_cast<uint16_t*>(p.y) + row * p.ldy;
 #pragma unroll
     for (int it = 0; it < LN_MAX_IT; ++it) {
-        const int cs = lane + it * 64;
+        const int cs = sub + it * LPR;
         if (cs < CS) {
             const int c = cs * 8;
             const f32x4_t g0 = *reinterpret_cast<const f32x4_t*>(p.gamma + c);
@@ -311,8 +320,18 @@ extern "C" int vmv_layernorm(const VmvLayerNormParams* pp, void* stream) {
     if (p.C > LN_MAX_IT * 64 * 8) return VMV_ERANGE;
     if (!vmv_aligned16(p.x) || !vmv_aligned16(p.y) || (p.ldx & 7) || (p.ldy & 7) || !vmv_aligned16(p.gamma) ||
         !vmv_aligned16(p.beta)) return VMV_EALIGN;
-    const int blocks = (p.rows + 3) / 4;
-    hipLaunchKernelGGL(layernorm_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+    const int CS = p.C >> 3;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    auto go = [&](auto lpr_tag) {
+        constexpr int LPR = decltype(lpr_tag)::value;
+        const int rows_per_block = 4 * (64 / LPR);
+        const int blocks = (p.rows + rows_per_block - 1) / rows_per_block;
+        hipLaunchKernelGGL(layernorm_kernel<LPR>, dim3(blocks), dim3(256), 0, st, p);
+    };
+    if (CS <= 8 * LN_MAX_IT) go(std::integral_constant<int, 8>{});
+    else if (CS <= 16 * LN_MAX_IT) go(std::integral_constant<int, 16>{});
+    else if (CS <= 32 * LN_MAX_IT) go(std::integral_constant<int, 32>{});
+    else go(std::integral_constant<int, 64>{});
     return vmv_launch_status();
 }
 

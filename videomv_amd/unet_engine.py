@@ -347,10 +347,12 @@ class UNetEngine:
     def _ksplit(self, M, N, segs):
         """Split K when the tile grid cannot fill 256 CUs and the reduction is long (small-spatial levels)."""
         steps = sum((s.k + 63) // 64 for s in segs)
-        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        bn = 160 if N % 160 == 0 else 128
+        tiles = ((M + 127) // 128) * ((N + bn - 1) // bn)
         if tiles >= 192 or steps < 16:
             return 0, None
-        ks = min(8, max(1, 512 // tiles), steps // 8)
+        # the split-K shapes run on the 4-wave LDS-DMA kernel, two blocks per CU: aim at ~2 x 256 blocks
+        ks = min(8, max(1, (480 + tiles // 2) // tiles), steps // 8)
         if ks < 2:
             return 0, None
         need = ks * M * N * 4
