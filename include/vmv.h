@@ -107,6 +107,8 @@ typedef struct {
 #define VMV_TILE_P256x160 10
 #define VMV_TILE_PP256x128 11  /* 8-wave LDS-DMA kernel, ping-pong wave schedule */
 #define VMV_TILE_PP256x160 12
+#define VMV_TILE_Q128x128 13   /* persistent, 4 waves, 2-stage ring, TWO blocks per CU (gemm_pglds.hip) */
+#define VMV_TILE_Q96x160  14
 
 int vmv_gemm_bf16(const VmvGemmParams* p, void* stream);
 

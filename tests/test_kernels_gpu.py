@@ -77,7 +77,12 @@ def run_gemm(build, case, out_keys=("out",)):
                                         (66000, 160, 64, L.TILE_P256x160),
                                         (640, 640, 640, L.TILE_PP256x128), (1000, 960, 320, L.TILE_PP256x160),
                                         (300, 320, 64, L.TILE_PP256x160), (257, 128, 192, L.TILE_PP256x128),
-                                        (513, 200, 72, L.TILE_PP256x128), (2000, 1280, 1280, L.TILE_PP256x160)])
+                                        (513, 200, 72, L.TILE_PP256x128), (2000, 1280, 1280, L.TILE_PP256x160),
+                                        (640, 640, 640, L.TILE_Q128x128), (1000, 960, 320, L.TILE_Q96x160),
+                                        (300, 320, 64, L.TILE_Q96x160), (257, 128, 192, L.TILE_Q128x128),
+                                        (513, 200, 72, L.TILE_Q128x128), (2000, 1280, 1280, L.TILE_Q96x160),
+                                        (70000, 320, 320, L.TILE_Q96x160), (70000, 384, 128, L.TILE_Q128x128),
+                                        (66000, 160, 64, L.TILE_Q96x160)])
 def test_gemm_linear_bias(M, N, K, tile):
     c = Case(a=rnd((M, K), 1), w=rnd((N, K), 2, K ** -0.5), b=torch.randn(N, generator=g(3)), out=torch.zeros(M, N, dtype=BF))
 
@@ -87,7 +92,7 @@ def test_gemm_linear_bias(M, N, K, tile):
     check(dev["out"], cpu["out"])
 
 
-@pytest.mark.parametrize("tile", [0, L.TILE_256x160, L.TILE_G128x160, L.TILE_P256x160, L.TILE_PP256x160])
+@pytest.mark.parametrize("tile", [0, L.TILE_256x160, L.TILE_G128x160, L.TILE_P256x160, L.TILE_PP256x160, L.TILE_Q96x160])
 def test_gemm_fp32_out_rowvec_act_residual(tile):
     M, N, K = 384, 320, 128
     c = Case(a=rnd((M, K), 1), w=rnd((N, K), 2, K ** -0.5), b=torch.randn(N, generator=g(3)),
@@ -101,7 +106,7 @@ def test_gemm_fp32_out_rowvec_act_residual(tile):
     check(dev["out"], cpu["out"], tol_l2=1e-3, tol_max=2e-3)
 
 
-@pytest.mark.parametrize("tile", [0, L.TILE_256x128, L.TILE_G128x128, L.TILE_P256x128, L.TILE_PP256x128])
+@pytest.mark.parametrize("tile", [0, L.TILE_256x128, L.TILE_G128x128, L.TILE_P256x128, L.TILE_PP256x128, L.TILE_Q128x128])
 def test_gemm_geglu(tile):
     M, I2, K = 200, 512, 128        # 2*I = 512 rows -> 256 outputs
     w = rnd((I2, K), 2, K ** -0.5)
@@ -119,7 +124,7 @@ def test_gemm_geglu(tile):
     check(dev["out"], x * torch.nn.functional.gelu(gate))
 
 
-@pytest.mark.parametrize("tile", [0, L.TILE_256x128, L.TILE_G128x128, L.TILE_P256x128, L.TILE_PP256x128])
+@pytest.mark.parametrize("tile", [0, L.TILE_256x128, L.TILE_G128x128, L.TILE_P256x128, L.TILE_PP256x128, L.TILE_Q128x128])
 @pytest.mark.parametrize("stride,ups,two_src,skip", [(1, 0, False, False), (2, 0, False, False), (1, 1, False, False),
                                                      (1, 0, True, True)])
 def test_gemm_conv3x3(stride, ups, two_src, skip, tile):
@@ -158,7 +163,7 @@ def test_gemm_conv3x3(stride, ups, two_src, skip, tile):
     check(dev["out"], ref.permute(0, 2, 3, 1).reshape(M, N))
 
 
-@pytest.mark.parametrize("tile", [0, L.TILE_256x128, L.TILE_G128x128, L.TILE_P256x128, L.TILE_PP256x128])
+@pytest.mark.parametrize("tile", [0, L.TILE_256x128, L.TILE_G128x128, L.TILE_P256x128, L.TILE_PP256x128, L.TILE_Q128x128])
 def test_gemm_temporal_conv_residual(tile):
     Bn, F_, Pp, Cc = 2, 5, 24, 64
     M = Bn * F_ * Pp
@@ -177,7 +182,7 @@ def test_gemm_temporal_conv_residual(tile):
     check(dev["out"], ref)
 
 
-@pytest.mark.parametrize("tile", [0, L.TILE_256x128, L.TILE_G128x128, L.TILE_P256x128, L.TILE_PP256x128])
+@pytest.mark.parametrize("tile", [0, L.TILE_256x128, L.TILE_G128x128, L.TILE_P256x128, L.TILE_PP256x128, L.TILE_Q128x128])
 @pytest.mark.parametrize("ks", [2, 5])
 def test_gemm_splitk(ks, tile):
     M, N, K = 200, 256, 1280

@@ -7,7 +7,7 @@ import torch
 from videomv_amd import _lib as L, ops
 
 BF = torch.bfloat16
-N160 = (L.TILE_128x160, L.TILE_256x160, L.TILE_G128x160, L.TILE_P256x160, L.TILE_PP256x160)
+N160 = (L.TILE_128x160, L.TILE_256x160, L.TILE_G128x160, L.TILE_P256x160, L.TILE_PP256x160, L.TILE_Q96x160)
 
 
 def bench(fn, reps=20):
@@ -63,10 +63,15 @@ def main():
             p = ops.gemm_params(M, N, segs, w, out, No, bias=b, geom=geom, tile=tile, workspace=stamps, **kw)
             ms = bench(lambda: S.gemm(p))
             line += f" t{tile}:{2.0 * M * N * K / ms / 1e9:7.1f}"
-            if stamps is not None and tile in (L.TILE_P256x128, L.TILE_P256x160):
+            if stamps is not None and tile in (L.TILE_P256x128, L.TILE_P256x160, L.TILE_Q128x128, L.TILE_Q96x160, L.TILE_PP256x128, L.TILE_PP256x160):
                 t = stamps.cpu().view(-1, 4)
                 t = t[t[:, 0] > 0]
-                if len(t):
+                if tile in (L.TILE_PP256x128, L.TILE_PP256x160):
+                    t = stamps.cpu().view(-1, 8)[:2]
+                    base = int(t[0, 0])
+                    line += "\n      PP stamps chunk 8 (grp0 / grp1: LOAD start, reads issued, DMA issued, waits done, barrier, MFMAs issued, wait, barrier):\n      " + \
+                            "\n      ".join(" ".join(f"{int(v) - base:6d}" for v in r) for r in t)
+                elif len(t):
                     base = int(t[0, 0])
                     rows = [" ".join(f"{int(v) - base:7d}" for v in r) for r in t[:6]]
                     line += "\n      stamps(block0; tile start / loop done / epi start / epi end, 100MHz ticks?):\n      " + "\n      ".join(rows)

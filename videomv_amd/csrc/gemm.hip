@@ -344,6 +344,16 @@ extern "C" int vmv_gemm_bf16(const VmvGemmParams* pp, void* stream) {
             rc = vmv_gemm_glds_launch(p, total_steps, VMV_TILE_256x160, st);
             if (rc == VMV_GLDS_UNSUPPORTED) rc = launch_cfg<4, 5>(p, total_steps, st);
             break;
+        case VMV_TILE_Q128x128:
+            rc = vmv_gemm_pglds_launch(p, total_steps, VMV_TILE_Q128x128, st);
+            if (rc == VMV_GLDS_UNSUPPORTED) rc = vmv_gemm_glds_launch(p, total_steps, VMV_TILE_256x128, st);
+            if (rc == VMV_GLDS_UNSUPPORTED) rc = launch_cfg<4, 4>(p, total_steps, st);
+            break;
+        case VMV_TILE_Q96x160:
+            rc = vmv_gemm_pglds_launch(p, total_steps, VMV_TILE_Q96x160, st);
+            if (rc == VMV_GLDS_UNSUPPORTED) rc = vmv_gemm_glds_launch(p, total_steps, VMV_TILE_256x160, st);
+            if (rc == VMV_GLDS_UNSUPPORTED) rc = launch_cfg<4, 5>(p, total_steps, st);
+            break;
         case VMV_TILE_P256x128:
             rc = vmv_gemm_pglds_launch(p, total_steps, VMV_TILE_P256x128, st);
             if (rc == VMV_GLDS_UNSUPPORTED) rc = vmv_gemm_glds_launch(p, total_steps, VMV_TILE_256x128, st);

@@ -189,23 +189,81 @@ __global__ __launch_bounds__(128 * WMW, WMW == 2 ? 2 : 1) void gemm_glds_kernel(
             if (grp == 1) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             int st = 0;
+            // ablate == 4: block 0 stamps s_memtime of its waves 0 and 4 at the phase edges of chunk 8 into p.workspace
+            unsigned long long* stamps = reinterpret_cast<unsigned long long*>(p.workspace);
+            auto stamp = [&](int t, int k) {
+                if constexpr (ablate == 4) {
+                    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wave & 3) == 0 && t == 8 && stamps)
+                        stamps[grp * 8 + k] = __builtin_readcyclecounter();
+                }
+            };
             for (int t = 0; t < nsteps; ++t) {
-                // LOAD(t)
-                if constexpr (ablate != 1) { read_frags(st, 0, a0, w0); read_frags(st, 1, a1, w1); }
+                // LOAD(t): the chunk's 2*(WM+WN) fragment reads INTERLEAVED with the LPT LDS-DMA pieces of chunk t+2, so that the
+                // LDS read port and the address/TA path work at the same time (issued back to back as two bursts they
+                // serialise: measured 430 + 560 cycles per wave against 740 cycles of MFMAs in the partner's phase).
+                stamp(t, 0);
                 int s2 = st + 2; if (s2 >= 3) s2 -= 3;
                 const bool more = issued < nsteps;
-                if (more) { if (ablate != 2) issue(s2); ++issued; }
+                {
+                    const VmvGemmSeg& sg = p.seg[more ? s : 0];
+                    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(sg.src), 0, SRD_RECORDS, SRD_FLAGS);
+                    const bool kvalid = !((kc + BK) > sg.k) || (kc + lsw * 8) < sg.k;      // k tail of a segment: zero fill
+                    unsigned char* abase = smem + s2 * Cfg::STAGE_BYTES + wave * 1024;
+                    unsigned char* wbase = smem + s2 * Cfg::STAGE_BYTES + Cfg::A_BYTES;
+                    const uint32_t a_so = (uint32_t)kc * 2u, w_so = (uint32_t)(koff + kc) * 2u;
+                    const u32x4_t* fa = reinterpret_cast<const u32x4_t*>(smem + st * Cfg::STAGE_BYTES) + (wave_m * 64 + frow) * 8;
+                    const u32x4_t* fw = reinterpret_cast<const u32x4_t*>(smem + st * Cfg::STAGE_BYTES + Cfg::A_BYTES) +
+                                        (wave_n * 16 * WN + frow) * 8;
+                    const int slot0 = fgrp ^ fswz, slot1 = (4 + fgrp) ^ fswz;
+                    constexpr int NRD = 2 * (WM + WN);
+                    auto read_one = [&](int r) {               // r: a0[0..WM), w0[0..WN), a1[..], w1[..]
+                        if (r < WM) a0[r] = __builtin_bit_cast(bf16x8_t, fa[r * 16 * 8 + slot0]);
+                        else if (r < WM + WN) w0[r - WM] = __builtin_bit_cast(bf16x8_t, fw[(r - WM) * 16 * 8 + slot0]);
+                        else if (r < 2 * WM + WN) a1[r - WM - WN] = __builtin_bit_cast(bf16x8_t, fa[(r - WM - WN) * 16 * 8 + slot1]);
+                        else w1[r - 2 * WM - WN] = __builtin_bit_cast(bf16x8_t, fw[(r - 2 * WM - WN) * 16 * 8 + slot1]);
+                    };
+                    int rd = 0;
+#pragma unroll
+                    for (int k = 0; k < Cfg::LPT; ++k) {
+                        if (more && ablate != 2) {
+                            if (k < Cfg::NAI) VMV_BLDS16(a_rsrc, abase + k * (NW * 1024), kvalid ? avo[k] : OOB, a_so);
+                            else VMV_BLDS16(w_rsrc, wbase + wgrp[k - Cfg::NAI] * 1024, kvalid ? wvo[k - Cfg::NAI] : OOB, w_so);
+                        }
+                        const int upto = (NRD * (k + 1)) / Cfg::LPT;
+                        if constexpr (ablate != 1) {
+#pragma unroll
+                            for (int r = 0; r < NRD; ++r) if (r >= rd && r < upto) read_one(r);
+                        }
+                        rd = upto;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    stamp(t, 1);
+                    if (more) {                                // advance the K walk
+                        kc += BK;
+                        if (kc >= sg.k) {
+                            koff += sg.k; ++s; kc = 0;
+                            if (s < p.nseg) enter_segment();
+                        }
+                        ++issued;
+                    }
+                }
+                stamp(t, 2);
                 if (grp == 1) { if (more) wait_vmcnt<Cfg::LPT>(); else wait_vmcnt<0>(); }
                 __builtin_amdgcn_s_waitcnt(0xc07f);
+                stamp(t, 3);
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
+                stamp(t, 4);
                 // MATRIX(t)
                 if constexpr (ablate != 1) { mma(a0, w0); mma(a1, w1); }
                 __builtin_amdgcn_sched_barrier(0);
+                stamp(t, 5);
                 if (grp == 0) { if (more) wait_vmcnt<Cfg::LPT>(); else wait_vmcnt<0>(); }
+                stamp(t, 6);
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+                stamp(t, 7);
                 st = st + 1 == 3 ? 0 : st + 1;
             }
             if (grp == 0) __builtin_amdgcn_s_barrier();
@@ -394,6 +452,7 @@ int launch_glds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
         case 1: rc = go(std::integral_constant<int, 1>{}); break;
         case 2: rc = go(std::integral_constant<int, 2>{}); break;
         case 3: rc = go(std::integral_constant<int, 3>{}); break;
+        case 4: rc = go(std::integral_constant<int, 4>{}); break;
         case 5: rc = go(std::integral_constant<int, 5>{}); break;
         case 6: rc = go(std::integral_constant<int, 6>{}); break;
         default: rc = go(std::integral_constant<int, 0>{}); break;

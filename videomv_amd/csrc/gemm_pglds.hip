@@ -24,29 +24,36 @@ using namespace vmv_gemm;
 
 namespace {
 
-// 8 waves (4 along M x 2 along N), wave tile 16*WM x 16*WN, block tile 64*WM x 32*WN, 3-stage ring
-template <int WM_, int WN>
+// NWM x 2 waves (NWM = 4: one block per CU, 3-stage ring; NWM = 2: two blocks per CU, 2-stage ring), wave tile
+// 16*WM x 16*WN, block tile 16*WM*NWM x 32*WN
+template <int NWM, int WM_, int WN>
 struct PgCfg {
-    static constexpr int NW = 8, NT = 512;
-    static constexpr int BM = 64 * WM_;
+    static constexpr int NW = 2 * NWM, NT = 64 * NW;
+    static constexpr int STAGES = NWM == 4 ? 3 : 2;
+    static constexpr int BM = 16 * WM_ * NWM;
     static constexpr int BN = 32 * WN;
     static constexpr int A_BYTES = BM * 128;
     static constexpr int W_BYTES = BN * 128;
     static constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
-    static constexpr int LDS_BYTES = 3 * STAGE_BYTES;
-    static constexpr int NAI = BM / 64;                    // A wave-instructions per wave per chunk (8 rows each)
-    static constexpr int NWI = (BN / 8 + 7) / 8;
+    static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
+    static constexpr int NAI = BM / (8 * NW);              // A wave-instructions per wave per chunk (8 rows each)
+    static constexpr int NWI = (BN / 8 + NW - 1) / NW;
     static constexpr int LPT = NAI + NWI;
+    static constexpr int STRIPS = 512 * NW;                // per-wave bias strips behind the ring
+    static constexpr int LDS_LIMIT = (NWM == 4 ? 160 : 80) * 1024;
+    static constexpr bool DEDICATED = LDS_BYTES + STRIPS + NW * 2816 <= LDS_LIMIT;     // slabs behind the strips
+    static constexpr int LDS_TOTAL = LDS_BYTES + STRIPS + (DEDICATED ? NW * 2816 : 0);
+    static_assert(BM % (8 * NW) == 0, "A rows split evenly over the waves");
 };
 
-template <int WM, int WN, int ablate>
-__global__ __launch_bounds__(512) void gemm_pglds_kernel(const VmvGemmParams p, const int tiles_n, const int total_steps,
+template <int NWM, int WM, int WN, int ablate>
+__global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel(const VmvGemmParams p, const int tiles_n, const int total_steps,
                                                          const int nitems) {
-    using Cfg = PgCfg<WM, WN>;
+    using Cfg = PgCfg<NWM, WM, WN>;
     constexpr int BN = Cfg::BN;
     constexpr int BM = Cfg::BM;
     constexpr int NW = Cfg::NW;
-    constexpr int S = 3;
+    constexpr int S = Cfg::STAGES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -259,8 +266,8 @@ __global__ __launch_bounds__(512) void gemm_pglds_kernel(const VmvGemmParams p, 
         constexpr int NR = (NU + 63) / 64;
         if (lane < 4 * WN) *reinterpret_cast<f32x4_t*>(bias_lds + 4 * lane) = bias_hold;
         asm volatile("" ::: "memory");
-        constexpr bool DEDICATED = Cfg::LDS_BYTES + 4096 + 8 * 2816 <= 160 * 1024;
-        unsigned char* slab = DEDICATED ? smem + Cfg::LDS_BYTES + 4096 + wave * 2816 : slot_base + wave * 4096;   // 16 rows x RB <= 2816 B
+        unsigned char* slab = Cfg::DEDICATED ? smem + Cfg::LDS_BYTES + Cfg::STRIPS + wave * 2816
+                                             : slot_base + wave * 4096;                       // 16 rows x RB <= 2816 B
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
             const int m = mbase + 16 * i;
@@ -373,14 +380,17 @@ __global__ __launch_bounds__(512) void gemm_pglds_kernel(const VmvGemmParams p, 
         stamp(0);
         // ---- tile prologue: chunk `consumed` must be visible to every wave
         if (first) {
-            if (pro == 3) wait_vmcnt<2 * Cfg::LPT>(); else if (pro == 2) wait_vmcnt<Cfg::LPT>(); else wait_vmcnt<0>();
+            if (pro == 3) wait_vmcnt<(S == 3 ? 2 : 0) * Cfg::LPT>(); else if (pro == 2) wait_vmcnt<Cfg::LPT>(); else wait_vmcnt<0>();
         }   // (later tiles: everything issued so far was waited for before the previous epilogue)
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();             // also: every wave has left the previous epilogue's slab
         asm volatile("" ::: "memory");
-        if (!first && issued < total) { issue_one(); ++issued; }      // the refill that the epilogue's slab delayed
+        if (!Cfg::DEDICATED && !first && issued < total) { issue_one(); ++issued; }   // the refill that the epilogue's slab delayed
         if constexpr (ablate != 1) read_frags(st, 0, a0, w0);
-        bool known_landed = !first;               // chunk consumed+1 was waited for before the previous epilogue
+        // chunk consumed+1: with the 3-stage ring it was waited for before the previous epilogue; with the 2-stage ring it
+        // was issued right before that epilogue, so exactly the epilogue's stores are younger than it
+        bool known_landed = !first && S == 3;
+        const int younger_stores = (!first && S == 2 && staged) ? WM * (geglu ? (16 * WN + 63) / 64 : (32 * WN + 63) / 64) : 0;
         int m0, n0;
         item_tile(item, m0, n0);
         for (int t = 0; t + 1 < total_steps; ++t) {
@@ -391,7 +401,9 @@ __global__ __launch_bounds__(512) void gemm_pglds_kernel(const VmvGemmParams p, 
             }
             const int stn = st + 1 == S ? 0 : st + 1;
             if (!known_landed) {                  // chunk consumed+1 landed (mine); one younger chunk may stay in flight
-                if (issued - consumed >= 3) wait_vmcnt<Cfg::LPT>(); else wait_vmcnt<0>();
+                if (S == 3 && issued - consumed >= 3) wait_vmcnt<(S == 3 ? 1 : 0) * Cfg::LPT>();
+                else if (S == 2 && t == 0 && younger_stores > 0) wait_vmcnt_rt(younger_stores);
+                else wait_vmcnt<0>();
             }
             known_landed = false;
             __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -428,6 +440,8 @@ __global__ __launch_bounds__(512) void gemm_pglds_kernel(const VmvGemmParams p, 
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (Cfg::DEDICATED && issued < total) { issue_one(); ++issued; }     // slabs are outside the ring: refill at once
+        asm volatile("" ::: "memory");
         stamp(2);
         if (geglu) epilogue(m0, n0, slab_slot, std::true_type{}); else epilogue(m0, n0, slab_slot, std::false_type{});
         zero_acc();
@@ -437,59 +451,53 @@ __global__ __launch_bounds__(512) void gemm_pglds_kernel(const VmvGemmParams p, 
     }
 }
 
-template <int WM, int WN>
+template <int NWM, int WM, int WN>
 int launch_pglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
-    using Cfg = PgCfg<WM, WN>;
-    constexpr int PG_EXTRA = (Cfg::LDS_BYTES + 4096 + 8 * 2816 <= 160 * 1024) ? 8 * 2816 : 0;
-    static_assert(Cfg::LPT == 6 || Cfg::LPT == 7, "wait_vmcnt literals");
-    static_assert(8 * 4096 <= Cfg::STAGE_BYTES && 16 * (16 * WN * 2 + 16) <= 4096, "per-wave slabs fit in one ring slot");
-    static_assert(Cfg::LDS_BYTES + 8 * 512 <= 160 * 1024 && 16 * WN * 4 <= 512, "bias strips fit behind the ring");
+    using Cfg = PgCfg<NWM, WM, WN>;
+    static_assert(Cfg::LPT >= 6 && Cfg::LPT <= 9 && (Cfg::STAGES == 2 || 2 * Cfg::LPT <= 14), "wait_vmcnt literals");
+    static_assert(Cfg::DEDICATED || (Cfg::NW * 4096 <= Cfg::STAGE_BYTES), "per-wave slabs fit in one ring slot");
+    static_assert(16 * (16 * WN * 2 + 16) <= 2816 && 16 * WN * 4 <= 512 && Cfg::LDS_TOTAL <= Cfg::LDS_LIMIT, "LDS budget");
     const int tiles_m = (p.M + Cfg::BM - 1) / Cfg::BM;
     const int tiles_n = (p.N + Cfg::BN - 1) / Cfg::BN;
     const int nitems = tiles_m * tiles_n;
     static int ncu = 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        int dev = 0;
+    if (ncu == 0) {
+        int dev = 0, n = 0;
         hipError_t e = hipGetDevice(&dev);
-        if (e == hipSuccess) e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pglds_kernel<WM, WN, 0>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES + 4096 + PG_EXTRA);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pglds_kernel<WM, WN, 1>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES + 4096 + PG_EXTRA);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pglds_kernel<WM, WN, 2>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES + 4096 + PG_EXTRA);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pglds_kernel<WM, WN, 3>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES + 4096 + PG_EXTRA);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pglds_kernel<WM, WN, 7>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES + 4096 + PG_EXTRA);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pglds_kernel<WM, WN, 8>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES + 4096 + PG_EXTRA);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pglds_kernel<WM, WN, 4>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES + 4096 + PG_EXTRA);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         if (e != hipSuccess) return (int)e;
-        if (ncu < 8) ncu = 8;
-        ncu &= ~7;                                   // whole XCD groups: item & 7 == block & 7 in every round
-        attr_set = true;
+        if (n < 8) n = 8;
+        ncu = n & ~7;                                // whole XCD groups: item & 7 == block & 7 in every round
     }
     static int ablate = -1;
     if (ablate < 0) { const char* e = getenv("VMV_GEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
-    const int G = nitems < ncu ? nitems : ncu;
+    const int slots = ncu * (NWM == 4 ? 1 : 2);
+    const int G = nitems < slots ? nitems : slots;
     dim3 grid(G, 1, 1);
-    if (ablate == 8)
-        hipLaunchKernelGGL((gemm_pglds_kernel<WM, WN, 8>), grid, dim3(512), Cfg::LDS_BYTES + 4096 + PG_EXTRA, st, p, tiles_n, total_steps, nitems);
-    else if (ablate == 7)
-        hipLaunchKernelGGL((gemm_pglds_kernel<WM, WN, 7>), grid, dim3(512), Cfg::LDS_BYTES + 4096 + PG_EXTRA, st, p, tiles_n, total_steps, nitems);
-    else if (ablate == 4)
-        hipLaunchKernelGGL((gemm_pglds_kernel<WM, WN, 4>), grid, dim3(512), Cfg::LDS_BYTES + 4096 + PG_EXTRA, st, p, tiles_n, total_steps, nitems);
-    else if (ablate == 3)
-        hipLaunchKernelGGL((gemm_pglds_kernel<WM, WN, 3>), grid, dim3(512), Cfg::LDS_BYTES + 4096 + PG_EXTRA, st, p, tiles_n, total_steps, nitems);
-    else if (ablate == 2)
-        hipLaunchKernelGGL((gemm_pglds_kernel<WM, WN, 2>), grid, dim3(512), Cfg::LDS_BYTES + 4096 + PG_EXTRA, st, p, tiles_n, total_steps, nitems);
-    else if (ablate == 1)
-        hipLaunchKernelGGL((gemm_pglds_kernel<WM, WN, 1>), grid, dim3(512), Cfg::LDS_BYTES + 4096 + PG_EXTRA, st, p, tiles_n, total_steps, nitems);
-    else
-        hipLaunchKernelGGL((gemm_pglds_kernel<WM, WN, 0>), grid, dim3(512), Cfg::LDS_BYTES + 4096 + PG_EXTRA, st, p, tiles_n, total_steps, nitems);
+    auto go = [&](auto tag) -> int {
+        constexpr int AB = decltype(tag)::value;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pglds_kernel<NWM, WM, WN, AB>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_TOTAL);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((gemm_pglds_kernel<NWM, WM, WN, AB>), grid, dim3(Cfg::NT), Cfg::LDS_TOTAL, st, p, tiles_n, total_steps,
+                           nitems);
+        return VMV_OK;
+    };
+    int rc;
+    switch (ablate) {
+        case 1: rc = go(std::integral_constant<int, 1>{}); break;
+        case 2: rc = go(std::integral_constant<int, 2>{}); break;
+        case 3: rc = go(std::integral_constant<int, 3>{}); break;
+        case 4: rc = go(std::integral_constant<int, 4>{}); break;
+        case 7: rc = go(std::integral_constant<int, 7>{}); break;
+        case 8: rc = go(std::integral_constant<int, 8>{}); break;
+        default: rc = go(std::integral_constant<int, 0>{}); break;
+    }
+    if (rc != VMV_OK) return rc;
     return vmv_launch_status();
 }
 
@@ -508,10 +516,15 @@ int vmv_gemm_pglds_launch(const VmvGemmParams& p, int total_steps, int tile, hip
     // the epilogue addresses out / residual through buffer descriptors too (32-bit byte offsets)
     if ((long)(p.M + 256) * p.ldo * (p.out_fp32 ? 4 : 2) >= (1L << 31) - 65536) return VMV_GLDS_UNSUPPORTED;
     if (p.residual && (long)(p.M + 256) * p.ldr * 2 >= (1L << 31) - 65536) return VMV_GLDS_UNSUPPORTED;
-    if (tile == VMV_TILE_P256x128) return launch_pglds<4, 4>(p, total_steps, st);
+    if (tile == VMV_TILE_P256x128) return launch_pglds<4, 4, 4>(p, total_steps, st);
+    if (tile == VMV_TILE_Q128x128) return launch_pglds<2, 4, 4>(p, total_steps, st);
+    if (tile == VMV_TILE_Q96x160) {
+        if (p.epilogue == VMV_EPI_GEGLU) return VMV_EINVAL;
+        return launch_pglds<2, 3, 5>(p, total_steps, st);
+    }
     if (tile == VMV_TILE_P256x160) {
         if (p.epilogue == VMV_EPI_GEGLU) return VMV_EINVAL;
-        return launch_pglds<3, 5>(p, total_steps, st);     // 192 x 160: the 160-wide wave tile needs 20 fewer accumulators
+        return launch_pglds<4, 3, 5>(p, total_steps, st);  // 192 x 160: the 160-wide wave tile needs 20 fewer accumulators
     }
     return VMV_EINVAL;
 }
