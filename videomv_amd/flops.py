@@ -8,6 +8,27 @@ def gemm_flops(p) -> float:
     return 2.0 * p.M * p.N * p.ktot
 
 
+def gemm_bytes(p) -> float:
+    """Algorithmic (compulsory) HBM bytes of one implicit-GEMM launch: every distinct source read once (an im2col tap
+    or a temporal shift re-reads rows that are already counted), the weights once, the residual once, the output once."""
+    seen, b = set(), 0.0
+    for i in range(p.nseg):
+        sg = p.seg[i]
+        if sg.src in seen:
+            continue
+        seen.add(sg.src)
+        rows = p.M
+        if sg.mode == L.SEG_SPATIAL and p.OH > 0:
+            rows = (p.M // (p.OH * p.OW)) * p.IH * p.IW
+        b += 2.0 * rows * sg.k
+    n_out = p.N // 2 if p.epilogue == L.EPI_GEGLU else p.N
+    b += 2.0 * p.N * p.ktot
+    b += (4.0 if p.out_fp32 else 2.0) * p.M * n_out
+    if p.residual:
+        b += 2.0 * p.M * n_out
+    return b
+
+
 def attn_flops(p) -> float:
     return 4.0 * p.n_outer * p.heads * p.Nq * p.Nk * 64
 
