@@ -244,6 +244,81 @@ def camera_case():
     save_file({"camera_data": cam.reshape(1, 24, 16).contiguous()}, os.path.join(GOLD, "camera_24.safetensors"))
 
 
+LGM_TINY = dict(down_channels=(64, 512, 1024), down_attention=(False, True, True), mid_attention=True,
+                up_channels=(1024, 512, 64), up_attention=(True, True, False))
+
+
+def lgm_case():
+    """LGM branch (core/unet.py, core/models.py forward_gaussians, core/utils.py get_rays) from the imported reference:
+    a 3-level U-Net whose attention levels have head_dim 32 and 64 (the two the full model uses), the Gaussian
+    activations, the ray helper, and the key manifest of the full 'big' model."""
+    import dataclasses
+    from .lgm_ref import LgmCfg, lgm_unet_param_shapes
+    ns = shim.load_lgm_reference()
+    cfg = LgmCfg(**LGM_TINY)
+    shapes = lgm_unet_param_shapes(cfg)
+    ref = ns.unet.UNet(9, 14, down_channels=cfg.down_channels, down_attention=cfg.down_attention,
+                       mid_attention=cfg.mid_attention, up_channels=cfg.up_channels, up_attention=cfg.up_attention).eval()
+    ref_sd = ref.state_dict()
+    assert list(ref_sd.keys()) == list(shapes.keys()), "LGM U-Net manifest order mismatch"
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), (k, v.shape, shapes[k])
+    sd = random_state_dict(shapes, 2468)
+    ref.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(97)
+    x = torch.randn(4, 9, 32, 32, generator=g)
+    taps = {}
+
+    def hook(key):
+        def fn(mod, inp, out):
+            taps[key] = (out[0] if isinstance(out, tuple) else out).detach().clone()
+        return fn
+    for i, b in enumerate(ref.down_blocks):
+        b.register_forward_hook(hook(f"down_blocks.{i}"))
+    ref.mid_block.register_forward_hook(hook("mid_block"))
+    for i, b in enumerate(ref.up_blocks):
+        b.register_forward_hook(hook(f"up_blocks.{i}"))
+    with torch.no_grad():
+        out = ref(x)
+    tensors = {"x": x, "out": out.contiguous()}
+    for k in ("down_blocks.2", "mid_block"):
+        tensors["tap." + k] = taps[k].contiguous()
+    save_file(tensors, os.path.join(GOLD, "lgm_unet_tiny.safetensors"),
+              metadata={"cfg": json.dumps(LGM_TINY), "seed": "2468", "weights_checksum": str(checksum(sd))})
+    # forward_gaussians (U-Net + 1x1 conv + activations) through the reference LGM class
+    opt = dataclasses.replace(ns.options.config_defaults["big"], down_channels=cfg.down_channels,
+                              down_attention=cfg.down_attention, mid_attention=cfg.mid_attention,
+                              up_channels=cfg.up_channels, up_attention=cfg.up_attention, input_size=32, splat_size=32,
+                              output_size=64, lambda_lpips=0.0)
+    lgm = ns.models.LGM(opt).eval()
+    lsd = {("unet." + k): v for k, v in sd.items()}
+    gc = torch.Generator().manual_seed(5)
+    lsd["conv.weight"] = (torch.randn(14, 14, 1, 1, generator=gc) * 0.3).bfloat16().float()
+    lsd["conv.bias"] = (torch.randn(14, generator=gc) * 0.1).bfloat16().float()
+    assert set(lgm.state_dict().keys()) == set(lsd.keys())
+    lgm.load_state_dict(lsd, strict=True)
+    with torch.no_grad():
+        gauss = lgm.forward_gaussians(x.unsqueeze(0))
+    save_file({"images": x.unsqueeze(0).contiguous(), "gaussians": gauss.contiguous(), "conv.weight": lsd["conv.weight"],
+               "conv.bias": lsd["conv.bias"]}, os.path.join(GOLD, "lgm_gaussians_tiny.safetensors"),
+              metadata={"cfg": json.dumps(LGM_TINY), "seed": "2468"})
+    # rays of two poses
+    poses = torch.eye(4).repeat(2, 1, 1)
+    poses[0, :3, 3] = torch.tensor([0.0, 0.0, 1.5])
+    c, s_ = 0.8, 0.6
+    poses[1, :3, :3] = torch.tensor([[c, 0.0, s_], [0.0, 1.0, 0.0], [-s_, 0.0, c]])
+    poses[1, :3, 3] = torch.tensor([0.9, 0.2, 1.2])
+    ro, rd = zip(*[ns.utils.get_rays(poses[i], 8, 12, 39.6) for i in range(2)])
+    save_file({"poses": poses, "rays_o": torch.stack(ro).contiguous(), "rays_d": torch.stack(rd).contiguous()},
+              os.path.join(GOLD, "lgm_rays.safetensors"))
+    # key manifest of the full model as the UNet registers it (unet_t2v.py:267-274: self.lgm_big = LGM(opt))
+    big = ns.models.LGM(dataclasses.replace(ns.options.config_defaults["big"], lambda_lpips=0.0))
+    man = {k: list(v.shape) for k, v in big.state_dict().items()}
+    with open(os.path.join(GOLD, "manifest_lgm_big.json"), "w") as f:
+        json.dump({"n_keys": len(man), "n_params": int(sum(v.numel() for v in big.state_dict().values())), "shapes": man}, f)
+    print("lgm: golden written;", len(man), "keys,", sum(v.numel() for v in big.state_dict().values()), "params")
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ns = shim.load_reference()
@@ -257,6 +332,7 @@ def main():
     manifest_case(ns)
     camera_case()
     i2v_case(ns)
+    lgm_case()
 
 
 if __name__ == "__main__":

@@ -127,8 +127,18 @@ def install():
     fsnn.__path__ = []
     _mod("fairscale.nn.checkpoint", checkpoint_wrapper=lambda m, *a, **kw: m)
     _mod("easydict", EasyDict=_AttrDict)
-    _mod("tyro")
-    _mod("kiui")
+    ty = _mod("tyro")
+    ty.__path__ = []
+    ty.extras = _mod("tyro.extras", subcommand_type_from_defaults=lambda *a, **kw: None)
+    ki = _mod("kiui")
+    ki.__path__ = []
+
+    def safe_normalize(x, eps=1e-20):       # kiui.op.safe_normalize (third-party, absent): x / max(|x|, sqrt(eps))
+        return x / torch.sqrt(torch.clamp(torch.sum(x * x, -1, keepdim=True), min=eps))
+
+    ki.op = _mod("kiui.op", safe_normalize=safe_normalize)
+    ki.lpips = _mod("kiui.lpips", LPIPS=type("LPIPS", (torch.nn.Module,), {}))
+    _mod("roma")
     _mod("pynvml")
 
     if REF_ROOT not in sys.path:
@@ -138,6 +148,22 @@ def install():
     _pkg("tools.modules.unet", os.path.join(REF_ROOT, "tools", "modules", "unet"))
     _pkg("tools.modules.diffusions", os.path.join(REF_ROOT, "tools", "modules", "diffusions"))
     _installed = True
+
+
+def load_lgm_reference():
+    """core.unet / core.attention / core.options / core.utils / core.models of the reference (the LGM branch).
+    ``core.gs`` needs the absent third-party rasteriser, so a placeholder with an inert ``GaussianRenderer`` is
+    registered in its place: only ``LGM.forward_gaussians`` (U-Net + activations) is exercised."""
+    install()
+    import importlib
+
+    _mod("core.gs", GaussianRenderer=lambda opt: None)
+    ns = types.SimpleNamespace()
+    ns.unet = importlib.import_module("core.unet")
+    ns.options = importlib.import_module("core.options")
+    ns.utils = importlib.import_module("core.utils")
+    ns.models = importlib.import_module("core.models")
+    return ns
 
 
 def load_reference():

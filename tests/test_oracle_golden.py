@@ -143,3 +143,40 @@ def test_vae_encoder_matches_reference(golden_dir):
     sd = random_state_dict(vae_encoder_param_shapes(ch=32), 91)
     assert checksum(sd) == pytest.approx(float(g["weights_checksum"][0]), rel=1e-12)
     assert _rel(vae_encode_moments(sd, g["img"]), g["moments"]) < 1e-5
+
+
+def test_lgm_unet_and_gaussians_match_reference_golden(golden_dir):
+    """LGM branch (the pinned part): oracle U-Net vs the imported core.unet.UNet output and two block taps,
+    forward_gaussians vs core.models.LGM.forward_gaussians, get_rays vs core.utils.get_rays (all 1e-5 relative)."""
+    import json
+    from safetensors import safe_open
+    from safetensors.torch import load_file
+    from oracle.lgm_ref import LgmCfg, lgm_unet_param_shapes, lgm_unet_forward, forward_gaussians, get_rays
+    from oracle.weights import random_state_dict
+    path = os.path.join(golden_dir, "lgm_unet_tiny.safetensors")
+    g = load_file(path)
+    with safe_open(path, "pt") as f:
+        meta = f.metadata()
+    c = json.loads(meta["cfg"])
+    cfg = LgmCfg(**{k: tuple(v) if isinstance(v, list) else v for k, v in c.items()})
+    sd = random_state_dict(lgm_unet_param_shapes(cfg), int(meta["seed"]))
+    taps = {}
+    out = lgm_unet_forward(sd, cfg, g["x"], taps=taps)
+    assert _rel(out, g["out"]) < 1e-5, _rel(out, g["out"])
+    for k in ("down_blocks.2", "mid_block"):
+        assert _rel(taps[k], g["tap." + k]) < 1e-5, k
+    gg = load_file(os.path.join(golden_dir, "lgm_gaussians_tiny.safetensors"))
+    lsd = {("unet." + k): v for k, v in sd.items()}
+    lsd["conv.weight"], lsd["conv.bias"] = gg["conv.weight"], gg["conv.bias"]
+    gauss = forward_gaussians(lsd, cfg, gg["images"])
+    assert gauss.shape == gg["gaussians"].shape
+    assert _rel(gauss, gg["gaussians"]) < 1e-5
+    gr = load_file(os.path.join(golden_dir, "lgm_rays.safetensors"))
+    for i in range(2):
+        o, d = get_rays(gr["poses"][i], 8, 12, 39.6)
+        assert torch.allclose(o, gr["rays_o"][i], atol=1e-6) and torch.allclose(d, gr["rays_d"][i], atol=1e-6)
+    with open(os.path.join(golden_dir, "manifest_lgm_big.json")) as f:
+        man = json.load(f)
+    big = {("unet." + k): list(v) for k, v in lgm_unet_param_shapes(LgmCfg()).items()}
+    big["conv.weight"], big["conv.bias"] = [14, 14, 1, 1], [14]
+    assert big == man["shapes"] and man["n_params"] == 415042848
