@@ -91,7 +91,8 @@ typedef struct {
     int32_t ksplit;
     float* workspace;
     int32_t tile;            /* 0 = auto; else VMV_TILE_* to force a configuration                 */
-    int32_t _pad;
+    float res_scale;         /* the residual is added as res_scale * residual; 0 means 1 (LGM's (x + res) * sqrt(.5),
+                                core/unet.py:99,49, with the weights pre-scaled on the host)                    */
 } VmvGemmParams;
 
 #define VMV_TILE_AUTO     0
@@ -238,6 +239,12 @@ int vmv_i2v_temporal_adapter(const void* in, int ld_in, void* out, int ld_out, c
 /* nn.AdaptiveAvgPool2d((OH,OW)) on channels-last rows: in [n*IH*IW][ld] -> out [n*OH*OW][ldo], C % 8 == 0 */
 int vmv_adaptive_avgpool_rows(const void* in, int ld, void* out, int ldo, int n, int C, int IH, int IW, int OH, int OW,
                               void* stream);
+
+/* LGM Gaussian activations (core/models.py:37-43,102-112): raw fp32 rows [n][ld >= 14] -> out [n][14] =
+ * (pos.clamp(-1,1) x3, sigmoid(opacity), 0.1*softplus(scale) x3, rotation x4, 0.5*tanh(rgb)+0.5 x3).  The reference applies
+ * F.normalize with its default dim=1 to the [B, N, 4] rotation block, i.e. each quaternion COMPONENT is divided by
+ * max(L2 norm over the n Gaussians, 1e-12) — reproduced as is.  workspace: >= 1024 floats (deterministic two-pass sum). */
+int vmv_gaussian_activation(const float* raw, int ld, float* out, int n, float* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Block permute-copy (frame-sharded sampling, DESIGN.md §8: packs / unpacks the all-to-all buffers that switch an

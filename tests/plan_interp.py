@@ -71,7 +71,7 @@ def gemm(p: L.GemmParams):
     if p.act == L.ACT_SILU:
         acc = torch.nn.functional.silu(acc)
     if p.residual:
-        acc = acc + _rows(p.residual, M, p.ldr)[:, :No].float()
+        acc = acc + (p.res_scale if p.res_scale != 0.0 else 1.0) * _rows(p.residual, M, p.ldr)[:, :No].float()
     out = _rows(p.out, M, p.ldo, "f32" if p.out_fp32 else "bf16")
     out[:, :No] = acc if p.out_fp32 else acc.to(torch.bfloat16)
 
@@ -222,6 +222,14 @@ def posterior_sample(moments_rows, ld, noise, z, scale):
     z.copy_(scale * (mean + torch.exp(0.5 * logvar) * noise))
 
 
+def gaussian_activation(raw, ld, out, n, workspace):
+    x = raw.view(-1, ld)[:n, :14].float()
+    rot = x[:, 7:11]
+    rot = rot / rot.norm(dim=0, keepdim=True).clamp_min(1e-12)
+    out.view(-1, 14)[:n] = torch.cat([x[:, 0:3].clamp(-1, 1), torch.sigmoid(x[:, 3:4]),
+                                      0.1 * torch.nn.functional.softplus(x[:, 4:7]), rot, 0.5 * torch.tanh(x[:, 11:14]) + 0.5], dim=1)
+
+
 def _p(t):
     return t if isinstance(t, int) else t.data_ptr()
 
@@ -288,5 +296,5 @@ def install(monkeypatch):
     monkeypatch.setattr(ops.Stream, "_go", _go)
     monkeypatch.setattr(ops.Stream, "run", run)
     for name in ("latent_to_rows", "latent_to_rows_keep", "rows_to_nchw", "emb_combine_silu", "sinusoidal", "cfg_ddim_step",
-                 "i2v_temporal_adapter", "adaptive_avgpool_rows", "posterior_sample"):
+                 "i2v_temporal_adapter", "adaptive_avgpool_rows", "posterior_sample", "gaussian_activation"):
         monkeypatch.setattr(ops, name, globals()[name])

@@ -159,3 +159,39 @@ def test_vae_encoder_plan_matches_reference_golden(monkeypatch, golden_dir):
     torch.manual_seed(5)
     noise = torch.randn(2, 4, 8, 9)
     assert rel_l2(z, posterior_sample(g["moments"], noise, 0.18215)) < 2e-2
+
+
+def test_lgm_plan_matches_oracle_and_reference_golden(monkeypatch, golden_dir):
+    """SURVEY a16 (the pinned part): the recorded LGM plan (ResnetBlocks with folded skip_scale, MVAttention on the flash
+    path at head_dim 64 and on the GEMM/softmax/GEMM path at head_dim 32, Gaussian activations incl. the dim=1 normalize)
+    executed by the interpreter vs the oracle taps and the imported reference's Gaussians.  bf16 storage: rel-L2 <= 3e-2
+    on the taps / raw features; activated Gaussians <= 2e-2."""
+    import json
+    from safetensors import safe_open
+    from safetensors.torch import load_file
+    plan_interp.install(monkeypatch)
+    from videomv_amd.lgm import LgmEngine, LgmOptions, lgm_param_shapes
+    from oracle.lgm_ref import LgmCfg, lgm_unet_param_shapes, lgm_unet_forward
+    path = os.path.join(golden_dir, "lgm_unet_tiny.safetensors")
+    with safe_open(path, "pt") as f:
+        meta = f.metadata()
+    c = {k: tuple(v) if isinstance(v, list) else v for k, v in json.loads(meta["cfg"]).items()}
+    gg = load_file(os.path.join(golden_dir, "lgm_gaussians_tiny.safetensors"))
+    cfg = LgmCfg(**c)
+    opt = LgmOptions(**c, input_size=32, splat_size=32, output_size=64)
+    sd = random_state_dict(lgm_unet_param_shapes(cfg), int(meta["seed"]))
+    lsd = {("unet." + k): v for k, v in sd.items()}
+    lsd["conv.weight"], lsd["conv.bias"] = gg["conv.weight"], gg["conv.bias"]
+    assert {k: tuple(v.shape) for k, v in lsd.items()} == lgm_param_shapes(opt)
+    images = gg["images"][0]
+    taps_ref = {}
+    lgm_unet_forward(sd, cfg, images, taps=taps_ref)
+    taps = {}
+    eng = LgmEngine(opt, lsd, 32, 32, torch.device("cpu"), taps=taps)
+    gauss = eng.forward_gaussians(images)
+    for key, (act, h, w) in taps.items():
+        mine = act.tensor().float().view(4, h, w, act.C).permute(0, 3, 1, 2)
+        assert mine.shape == taps_ref[key].shape, key
+        assert rel_l2(mine, taps_ref[key]) < 3e-2, (key, rel_l2(mine, taps_ref[key]))
+    assert gauss.shape == gg["gaussians"][0].shape
+    assert rel_l2(gauss, gg["gaussians"][0]) < 2e-2, rel_l2(gauss, gg["gaussians"][0])

@@ -419,3 +419,19 @@ def test_i2v_frontend_kernels():
     rows = torch.full((2 * 3 * 30, 8), 7.0, dtype=BF, device="cuda")
     ops.latent_to_rows_keep(lat.cuda(), rows, 8, 2)
     assert torch.equal(rows.cpu(), rows_ref) and float(rows[:, 4:].float().min()) == 7.0
+
+
+def test_gaussian_activation_matches_reference_semantics():
+    """vmv_gaussian_activation vs the torch expressions of core/models.py:37-43 (incl. F.normalize's default dim=1)."""
+    n = 5000
+    raw = torch.randn(n, 16, generator=g(11)) * 2.0
+    raw[:5, 4:7] = 25.0                      # softplus threshold branch
+    ref = torch.zeros(n, 14)
+    I.gaussian_activation(raw.clone(), 16, ref, n, None)
+    out = torch.zeros(n, 14, device="cuda")
+    ops.gaussian_activation(raw.cuda(), 16, out, n, torch.zeros(1024, device="cuda"))
+    torch.cuda.synchronize()
+    assert torch.allclose(out.cpu(), ref, rtol=2e-5, atol=2e-6), float((out.cpu() - ref).abs().max())
+    x = raw[:, :14]
+    exp_rot = torch.nn.functional.normalize(x[None, :, 7:11])[0]          # the reference call: default dim=1 on [B, N, 4]
+    assert torch.allclose(out.cpu()[:, 7:11], exp_rot, rtol=2e-5, atol=2e-6)

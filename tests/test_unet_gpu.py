@@ -273,3 +273,25 @@ def test_vae_encode_matches_reference_golden(golden_dir):
     torch.manual_seed(5)
     noise = torch.randn(2, 4, 8, 9)
     assert rel_l2(z, posterior_sample(g["moments"], noise, 0.18215)) < 2e-2
+
+
+def test_lgm_gaussians_match_reference_golden(golden_dir):
+    """SURVEY a16 (pinned part) on the GPU: LgmEngine (HIP plan) vs the imported reference's LGM.forward_gaussians on
+    the 3-level golden net (attention at head_dim 32 via GEMM/softmax/GEMM and head_dim 64 via the flash kernel).
+    Tolerance: activated Gaussians rel-L2 <= 2.5e-2 (bf16 storage of the U-Net activations)."""
+    from videomv_amd.lgm import LgmEngine, LgmOptions
+    from oracle.lgm_ref import LgmCfg, lgm_unet_param_shapes
+    path = os.path.join(golden_dir, "lgm_unet_tiny.safetensors")
+    with safe_open(path, "pt") as f:
+        meta = f.metadata()
+    c = {k: tuple(v) if isinstance(v, list) else v for k, v in json.loads(meta["cfg"]).items()}
+    gg = load_file(os.path.join(golden_dir, "lgm_gaussians_tiny.safetensors"))
+    sd = random_state_dict(lgm_unet_param_shapes(LgmCfg(**c)), int(meta["seed"]))
+    lsd = {("unet." + k): v for k, v in sd.items()}
+    lsd["conv.weight"], lsd["conv.bias"] = gg["conv.weight"], gg["conv.bias"]
+    eng = LgmEngine(LgmOptions(**c, input_size=32, splat_size=32, output_size=64), lsd, 32, 32, torch.device("cuda", 0))
+    gauss = eng.forward_gaussians(gg["images"][0].cuda())
+    torch.cuda.synchronize()
+    assert torch.isfinite(gauss).all()
+    e = rel_l2(gauss, gg["gaussians"][0])
+    assert e < 2.5e-2, e

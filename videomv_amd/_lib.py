@@ -36,7 +36,7 @@ class GemmParams(C.Structure):
                 ("stride", C.c_int32), ("ups", C.c_int32),
                 ("F", C.c_int32), ("P", C.c_int32),
                 ("ksplit", C.c_int32), ("workspace", C.c_void_p),
-                ("tile", C.c_int32), ("_pad", C.c_int32)]
+                ("tile", C.c_int32), ("res_scale", C.c_float)]
 
 
 class GroupNormParams(C.Structure):
@@ -94,6 +94,7 @@ SYMBOLS = {
     "vmv_attention_bf16": (C.c_int, [C.POINTER(AttnParams), _P]),
     "vmv_softmax_rows": (C.c_int, [C.POINTER(SoftmaxParams), _P]),
     "vmv_permute_copy": (C.c_int, [C.POINTER(CopyParams), _P]),
+    "vmv_gaussian_activation": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P]),
     "vmv_latent_to_rows": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "vmv_latent_to_rows_keep": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "vmv_i2v_temporal_adapter": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),

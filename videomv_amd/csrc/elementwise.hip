@@ -39,6 +39,54 @@ __global__ void latent_to_rows_keep_kernel(const float* __restrict__ x, uint16_t
     }
 }
 
+// LGM Gaussian head.  Pass 1: per-block sums of squares of the 4 rotation components (fixed order: strided rows per
+// thread, then a tree over the block) -> workspace[block][4].  Pass 2: every block folds the <= 256 partials in the same
+// order, then applies the activations to its rows.
+__global__ __launch_bounds__(256) void gauss_rot_sumsq_kernel(const float* __restrict__ raw, int ld, int n, float* __restrict__ ws) {
+    __shared__ float sh[4][256];
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float* r = raw + i * ld + 7;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[c] += r[c] * r[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sh[c][threadIdx.x] = s[c];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sh[c][threadIdx.x] += sh[c][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) ws[blockIdx.x * 4 + threadIdx.x] = sh[threadIdx.x][0];
+}
+
+__global__ __launch_bounds__(256) void gauss_activation_kernel(const float* __restrict__ raw, int ld, float* __restrict__ out,
+                                                               int n, const float* __restrict__ ws, int nparts) {
+    __shared__ float inv[4];
+    if (threadIdx.x < 4) {
+        float t = 0.f;
+        for (int b = 0; b < nparts; ++b) t += ws[b * 4 + threadIdx.x];
+        inv[threadIdx.x] = 1.0f / fmaxf(sqrtf(t), 1e-12f);
+    }
+    __syncthreads();
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = raw + i * ld;
+    float* o = out + i * 14;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = fminf(fmaxf(r[c], -1.f), 1.f);
+    o[3] = 1.0f / (1.0f + expf(-r[3]));
+#pragma unroll
+    for (int c = 4; c < 7; ++c) o[c] = 0.1f * (r[c] > 20.f ? r[c] : log1pf(expf(r[c])));      // F.softplus (threshold 20)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[7 + c] = r[7 + c] * inv[c];
+#pragma unroll
+    for (int c = 11; c < 14; ++c) o[c] = 0.5f * tanhf(r[c]) + 0.5f;
+}
+
 // dst (contiguous [n0][n1][n2][inner16] of 16-byte vectors) <- src with per-axis strides: both sides move whole
 // channel rows, so every lane does 16-byte loads and stores and consecutive lanes touch consecutive vectors.
 __global__ __launch_bounds__(256) void permute_copy_kernel(const VmvCopyParams p, const long total) {
@@ -250,6 +298,17 @@ inline int grid_for(long n, int block = 256, int cap = 8192) {
 }
 
 }  // namespace
+
+extern "C" int vmv_gaussian_activation(const float* raw, int ld, float* out, int n, float* workspace, void* stream) {
+    if (!raw || !out || !workspace) return VMV_ENULL;
+    if (n <= 0 || ld < 14) return VMV_EINVAL;
+    int blocks = (n + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(gauss_rot_sumsq_kernel, dim3(blocks), dim3(256), 0, st, raw, ld, n, workspace);
+    hipLaunchKernelGGL(gauss_activation_kernel, dim3((n + 255) / 256), dim3(256), 0, st, raw, ld, out, n, workspace, blocks);
+    return vmv_launch_status();
+}
 
 extern "C" int vmv_permute_copy(const VmvCopyParams* pp, void* stream) {
     if (!pp) return VMV_ENULL;

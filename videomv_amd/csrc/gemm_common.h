@@ -53,7 +53,8 @@ VMV_DEV void epilogue_store(const VmvGemmParams& p, int m, int n, f32x4_t v, f32
     if (p.act == VMV_ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
     if (p.residual) {
         const u32x2_t r = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const uint16_t*>(p.residual) + (size_t)m * p.ldr + no);
-        v.x += bf16_lo(r.x); v.y += bf16_hi(r.x); v.z += bf16_lo(r.y); v.w += bf16_hi(r.y);
+        const float rs = p.res_scale != 0.f ? p.res_scale : 1.f;
+        v.x += rs * bf16_lo(r.x); v.y += rs * bf16_hi(r.x); v.z += rs * bf16_lo(r.y); v.w += rs * bf16_hi(r.y);
     }
     if (p.out_fp32) {
         *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + no) = v;

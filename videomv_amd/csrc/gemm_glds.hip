@@ -404,6 +404,7 @@ __global__ __launch_bounds__(128 * WMW, WMW == 2 ? 2 : 1) void gemm_glds_kernel(
         const int U = out_w >> 3;                                // 16-byte units per tile row
         uint16_t* outp = reinterpret_cast<uint16_t*>(p.out);
         const uint16_t* resp = reinterpret_cast<const uint16_t*>(p.residual);
+        const float rs = p.res_scale != 0.f ? p.res_scale : 1.f;
         for (int idx = tid; idx < GL_BM * U; idx += Cfg::NT) {
             const int r = idx / U, u = idx - r * U;
             const int m = m0 + r, n = n_out0 + u * 8;
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(128 * WMW, WMW == 2 ? 2 : 1) void gemm_glds_kernel(
                 float a[8], b[8];
                 unpack8(v, a); unpack8(rr, b);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) a[e] += b[e];
+                for (int e = 0; e < 8; ++e) a[e] += rs * b[e];
                 v = pack8(a);
             }
             *reinterpret_cast<u32x4_t*>(outp + (size_t)m * p.ldo + n) = v;

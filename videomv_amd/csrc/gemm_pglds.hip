@@ -198,6 +198,7 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, SRD_RECORDS, SRD_FLAGS);
     const __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual), 0, SRD_RECORDS, SRD_FLAGS);
     const bool has_res = staged && p.residual != nullptr;
+    const float res_scale = p.res_scale != 0.f ? p.res_scale : 1.f;
     auto unit_offsets = [&](int m0, int n0, int i, int r, int ld, auto geglu_tag) -> uint32_t {
         // byte offset (relative to the group's scalar base) of 16-byte unit `lane + 64 r` of row group i, or OOB
         constexpr bool GEGLU = decltype(geglu_tag)::value;
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
                     float a[8], b[8];
                     unpack8(v, a); unpack8(resv[i & 1][r], b);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) a[e] += b[e];
+                    for (int e = 0; e < 8; ++e) a[e] += res_scale * b[e];
                     v = pack8(a);
                 }
                 if constexpr (ablate != 7)

@@ -1,0 +1,344 @@
+"""LGM branch of VideoMV on the gfx950 kernels: the multi-view U-Net that turns 4 decoded views (+ Pluecker rays) into
+pixel-aligned 3-D Gaussians (reference ``core/unet.py``, ``core/models.py:87-113``, registered inside the video UNet as
+``self.lgm_big``, ``tools/modules/unet/unet_t2v.py:125-129``).
+
+``LgmEngine`` records the forward as a plan of C-ABI launches over channels-last bf16 rows ``[V*H*W, C]`` like the
+other engines: ResnetBlock = GN+SiLU -> conv3x3 -> GN+SiLU -> conv3x3 (+1x1 shortcut folded into the K loop), with the
+block's ``(x + res) * skip_scale`` folded into pre-scaled weights and ``res_scale``; the decoder's ``torch.cat`` is a
+segment list; down = stride-2 conv, up = nearest-x2 folded into the conv's gather.  MVAttention attends over the
+V*H*W tokens of a sample with 16 heads: head_dim 64 (1024-channel levels) runs on the flash kernel, head_dim 32 (512
+channels, 4096 tokens) as QK^T GEMM -> row softmax -> PV GEMM per head (K heads gathered head-major by
+``vmv_permute_copy``, V^T produced directly by a GEMM with the roles of weights and activations swapped).
+The Gaussian activations run in ``vmv_gaussian_activation``; nothing here computes in PyTorch.
+"""
+import dataclasses
+import math
+from typing import Dict, Tuple
+
+import torch
+
+from . import _lib as L
+from . import ops
+from . import packing as P
+from .unet_engine import Pool, Act, BF16
+
+
+@dataclasses.dataclass
+class LgmOptions:
+    """The fields of ``core/options.py`` (``config_defaults['big']``) that inference reads."""
+    in_channels: int = 9
+    out_channels: int = 14
+    down_channels: Tuple[int, ...] = (64, 128, 256, 512, 1024, 1024)
+    down_attention: Tuple[bool, ...] = (False, False, False, True, True, True)
+    mid_attention: bool = True
+    up_channels: Tuple[int, ...] = (1024, 1024, 512, 256, 128)
+    up_attention: Tuple[bool, ...] = (True, True, True, False, False)
+    layers_per_block: int = 2
+    num_heads: int = 16
+    num_frames: int = 4
+    skip_scale: float = math.sqrt(0.5)
+    input_size: int = 256
+    splat_size: int = 128
+    output_size: int = 512
+    fovy: float = 39.6
+    znear: float = 0.5
+    zfar: float = 2.5
+
+
+def _res_shapes(p, cin, cout):
+    s = [(f"{p}.norm1.weight", (cin,)), (f"{p}.norm1.bias", (cin,)),
+         (f"{p}.conv1.weight", (cout, cin, 3, 3)), (f"{p}.conv1.bias", (cout,)),
+         (f"{p}.norm2.weight", (cout,)), (f"{p}.norm2.bias", (cout,)),
+         (f"{p}.conv2.weight", (cout, cout, 3, 3)), (f"{p}.conv2.bias", (cout,))]
+    if cin != cout:
+        s += [(f"{p}.shortcut.weight", (cout, cin, 1, 1)), (f"{p}.shortcut.bias", (cout,))]
+    return s
+
+
+def _attn_shapes(p, c):
+    return [(f"{p}.norm.weight", (c,)), (f"{p}.norm.bias", (c,)), (f"{p}.attn.qkv.weight", (3 * c, c)),
+            (f"{p}.attn.proj.weight", (c, c)), (f"{p}.attn.proj.bias", (c,))]
+
+
+def lgm_param_shapes(o: LgmOptions) -> Dict[str, tuple]:
+    """state-dict manifest of ``LGM`` (``unet.*`` + ``conv.*``) in registration order; equals
+    tests/golden/manifest_lgm_big.json for the default options."""
+    s = [("conv_in.weight", (o.down_channels[0], o.in_channels, 3, 3)), ("conv_in.bias", (o.down_channels[0],))]
+    cout, nd, nu = o.down_channels[0], len(o.down_channels), len(o.up_channels)
+    for i in range(nd):
+        cin, cout = cout, o.down_channels[i]
+        for j in range(o.layers_per_block):
+            s += _res_shapes(f"down_blocks.{i}.nets.{j}", cin if j == 0 else cout, cout)
+        if o.down_attention[i]:
+            for j in range(o.layers_per_block):
+                s += _attn_shapes(f"down_blocks.{i}.attns.{j}", cout)
+        if i != nd - 1:
+            s += [(f"down_blocks.{i}.downsample.weight", (cout, cout, 3, 3)), (f"down_blocks.{i}.downsample.bias", (cout,))]
+    cm = o.down_channels[-1]
+    s += _res_shapes("mid_block.nets.0", cm, cm) + _res_shapes("mid_block.nets.1", cm, cm)
+    if o.mid_attention:
+        s += _attn_shapes("mid_block.attns.0", cm)
+    cout = o.up_channels[0]
+    for i in range(nu):
+        cin, cout = cout, o.up_channels[i]
+        cskip = o.down_channels[max(-2 - i, -nd)]
+        nl = o.layers_per_block + 1
+        for j in range(nl):
+            s += _res_shapes(f"up_blocks.{i}.nets.{j}", (cin if j == 0 else cout) + (cskip if j == nl - 1 else cout), cout)
+        if o.up_attention[i]:
+            for j in range(nl):
+                s += _attn_shapes(f"up_blocks.{i}.attns.{j}", cout)
+        if i != nu - 1:
+            s += [(f"up_blocks.{i}.upsample.weight", (cout, cout, 3, 3)), (f"up_blocks.{i}.upsample.bias", (cout,))]
+    s += [("norm_out.weight", (o.up_channels[-1],)), ("norm_out.bias", (o.up_channels[-1],)),
+          ("conv_out.weight", (o.out_channels, o.up_channels[-1], 3, 3)), ("conv_out.bias", (o.out_channels,))]
+    d = {("unet." + k): v for k, v in s}
+    d["conv.weight"], d["conv.bias"] = (14, 14, 1, 1), (14,)
+    return d
+
+
+class LgmEngine:
+    """Plan for ``LGM.forward_gaussians`` of ONE sample: images [V, 9, H, W] -> gaussians fp32 [V*S*S, 14]."""
+
+    def __init__(self, opt: LgmOptions, sd: Dict[str, torch.Tensor], H: int, W: int, device, taps=None):
+        self.o, self.V, self.H, self.W, self.device = opt, opt.num_frames, H, W, device
+        self.pool = Pool(device)
+        self.S = ops.Stream(record=True)
+        self._gnws = torch.empty(4 << 20, dtype=torch.float32, device=device)
+        self._keep = []
+        self.taps = taps
+        self.wt: Dict[str, torch.Tensor] = {}
+        self._pack(sd)
+        self._build()
+
+    # ------------------------------------------------------------------ weights
+    def _pack(self, sd):
+        dev, w, k = self.device, self.wt, self.o.skip_scale
+        u = lambda key: sd["unet." + key]
+
+        def norm(p):
+            w[p + ".weight"], w[p + ".bias"] = P.f32(u(p + ".weight"), dev), P.f32(u(p + ".bias"), dev)
+
+        def conv(p):
+            w[p + ".weight"], w[p + ".bias"] = P.pack_conv3x3(u(p + ".weight"), dev), P.pack_bias(u(p + ".bias"), dev)
+
+        def res(p):
+            norm(p + ".norm1"); conv(p + ".conv1"); norm(p + ".norm2")
+            w2 = u(p + ".conv2.weight")
+            b2 = u(p + ".conv2.bias").float()
+            w2p = w2.permute(0, 2, 3, 1).reshape(w2.shape[0], -1)
+            if ("unet." + p + ".shortcut.weight") in sd:          # 1x1 shortcut joins conv2's K loop
+                w2p = torch.cat([w2p, u(p + ".shortcut.weight").reshape(w2.shape[0], -1)], dim=1)
+                b2 = b2 + u(p + ".shortcut.bias").float()
+            w[p + ".conv2.weight"] = P.pack_linear(w2p * k, dev)   # (conv2 + shortcut) * skip_scale
+            w[p + ".conv2.bias"] = P.pack_bias(b2 * k, dev)
+
+        def attn(p):
+            norm(p + ".norm")
+            qkv = u(p + ".attn.qkv.weight")
+            C = qkv.shape[1]
+            w[p + ".qkv"] = P.pack_linear(qkv, dev)
+            w[p + ".wv"] = P.pack_linear(qkv[2 * C:], dev)          # rows of W_v: the A operand of the V^T GEMM (head_dim 32)
+            w[p + ".proj.weight"] = P.pack_linear(u(p + ".attn.proj.weight") * k, dev)
+            w[p + ".proj.bias"] = P.pack_bias(u(p + ".attn.proj.bias").float() * k, dev)
+
+        o = self.o
+        nd, nu = len(o.down_channels), len(o.up_channels)
+        conv("conv_in")
+        for i in range(nd):
+            for j in range(o.layers_per_block):
+                res(f"down_blocks.{i}.nets.{j}")
+                if o.down_attention[i]:
+                    attn(f"down_blocks.{i}.attns.{j}")
+            if i != nd - 1:
+                conv(f"down_blocks.{i}.downsample")
+        res("mid_block.nets.0"); res("mid_block.nets.1")
+        if o.mid_attention:
+            attn("mid_block.attns.0")
+        for i in range(nu):
+            for j in range(o.layers_per_block + 1):
+                res(f"up_blocks.{i}.nets.{j}")
+                if o.up_attention[i]:
+                    attn(f"up_blocks.{i}.attns.{j}")
+            if i != nu - 1:
+                conv(f"up_blocks.{i}.upsample")
+        norm("norm_out"); conv("conv_out")
+        w["final.weight"] = P.pack_linear(sd["conv.weight"].reshape(14, 14), dev)      # LGM.conv (1x1), K padded 14 -> 16
+        w["final.bias"] = P.pack_bias(sd["conv.bias"], dev)
+
+    # ------------------------------------------------------------------ helpers
+    def act(self, rows, C, dtype=BF16):
+        return Act(self.pool.get(rows * C * (2 if dtype == BF16 else 4)), rows, C, dtype)
+
+    def rel(self, a):
+        if self.taps is None:
+            self.pool.put(a.buf)
+
+    def _gemm(self, label, M, segs, W, out, ldo=None, bias=None, N=None, **kw):
+        Wt = self.wt[W] if isinstance(W, str) else W
+        if N is None:
+            N = Wt.shape[0]
+        self.S.gemm(ops.gemm_params(M, N, segs, Wt, out.ptr if isinstance(out, Act) else out,
+                                    ldo if ldo is not None else out.C, bias=bias, **kw), label)
+
+    def _gn(self, label, srcs, hw, key, silu) -> Act:
+        rows = srcs[0].rows
+        C0 = srcs[0].C
+        C1 = srcs[1].C if len(srcs) > 1 else 0
+        y = self.act(rows, C0 + C1)
+        assert ops.gn_partial_floats(rows, hw, C0 + C1) <= self._gnws.numel()
+        self.S.groupnorm(ops.gn_params(srcs[0].ptr, C0, C0, rows, hw, self._gnws, self.wt[key + ".weight"],
+                                       self.wt[key + ".bias"], 1e-5, silu, y.ptr, C0 + C1,
+                                       x1=srcs[1].ptr if C1 else None, ld1=C1, C1=C1), label)
+        return y
+
+    def _res(self, p, srcs, h, w) -> Act:
+        """srcs = [x] or [x, skip] (channel concat, never materialised)."""
+        T = srcs[0].rows
+        geom = ops.Geom(OH=h, OW=w, IH=h, IW=w)
+        cout = self.wt[p + ".conv1.weight"].shape[0]
+        h0 = self._gn(p + ".norm1", srcs, h * w, p + ".norm1", True)
+        h1 = self.act(T, cout)
+        self._gemm(p + ".conv1", T, ops.conv3x3_segs([(h0.ptr, h0.C, h0.C)]), p + ".conv1.weight", h1,
+                   bias=self.wt[p + ".conv1.bias"], geom=geom)
+        self.rel(h0)
+        h2 = self._gn(p + ".norm2", [h1], h * w, p + ".norm2", True)
+        self.rel(h1)
+        y = self.act(T, cout)
+        segs = ops.conv3x3_segs([(h2.ptr, h2.C, h2.C)])
+        cin = sum(s.C for s in srcs)
+        if cin != cout:
+            segs += ops.linear_segs([(s.ptr, s.C, s.C) for s in srcs])
+            self._gemm(p + ".conv2+shortcut", T, segs, p + ".conv2.weight", y, bias=self.wt[p + ".conv2.bias"], geom=geom)
+        else:           # identity shortcut: (conv2(h) + x) * k = k*conv2(h) + k*x
+            self._gemm(p + ".conv2", T, segs, p + ".conv2.weight", y, bias=self.wt[p + ".conv2.bias"], geom=geom,
+                       residual=srcs[0].ptr, ldr=srcs[0].C, res_scale=self.o.skip_scale)
+        self.rel(h2)
+        return y
+
+    def _attn(self, p, x: Act, h, w) -> Act:
+        o = self.o
+        C, T = x.C, x.rows                         # T = V*h*w tokens of the one sample
+        heads = o.num_heads
+        hd = C // heads
+        hn = self._gn(p + ".norm", [x], h * w, p + ".norm", False)
+        qkv = self.act(T, 3 * C)
+        self._gemm(p + ".qkv", T, ops.linear_segs([(hn.ptr, C, C)]), p + ".qkv", qkv)
+        ao = self.act(T, C)
+        if hd == 64:
+            self.rel(hn)
+            m = lambda: ops.seq_map(0, 0, 3 * C, inner=1)
+            self.S.attention(ops.attn_params(qkv.ptr, qkv.ptr + 2 * C, qkv.ptr + 4 * C, ao.ptr, m(), m(), m(),
+                                             ops.seq_map(0, 0, C, inner=1), 1, heads, T, T, hd ** -0.5), p + ".attn")
+        else:
+            if hd % 8 or T % 8:
+                raise NotImplementedError("LGM attention: head_dim and token count must be multiples of 8")
+            # V^T[c][j] = sum_k Wv[c][k] hn[j][k]  -> [C][T]; K gathered head-major [heads][T][hd]
+            vT = self.act(C, T)
+            self._gemm(p + ".vT", C, ops.linear_segs([(self.wt[p + ".wv"].data_ptr(), C, C)]), hn.ptr, vT, ldo=T, N=T)
+            self.rel(hn)
+            kh = self.act(heads * T, hd)
+            self.S.copy(ops.copy_params(qkv.ptr + 2 * C, kh.ptr, heads, T, 1, hd // 8, hd // 8, 3 * C // 8), p + ".k_heads")
+            sc = self.act(T, T, torch.float32)
+            pr = self.act(T, T)
+            for hh in range(heads):
+                self._gemm(f"{p}.qk[{hh}]", T, ops.linear_segs([(qkv.ptr + 2 * hh * hd, 3 * C, hd)]), kh.ptr + 2 * hh * T * hd,
+                           sc, ldo=T, out_fp32=True, N=T)
+                self.S.softmax(ops.softmax_params(sc.ptr, T, pr.ptr, T, T, T, hd ** -0.5), f"{p}.softmax[{hh}]")
+                self._gemm(f"{p}.pv[{hh}]", T, ops.linear_segs([(pr.ptr, T, T)]), vT.ptr + 2 * hh * hd * T,
+                           ao.ptr + 2 * hh * hd, ldo=C, N=hd)
+            for a in (vT, kh, sc, pr):
+                self.rel(a)
+        self.rel(qkv)
+        y = self.act(T, C)
+        self._gemm(p + ".proj", T, ops.linear_segs([(ao.ptr, C, C)]), p + ".proj.weight", y, bias=self.wt[p + ".proj.bias"],
+                   residual=x.ptr, ldr=C, res_scale=o.skip_scale)
+        self.rel(ao)
+        return y
+
+    # ------------------------------------------------------------------ plan
+    def _build(self):
+        o, V, dev = self.o, self.V, self.device
+        h, w = self.H, self.W
+        nd, nu = len(o.down_channels), len(o.up_channels)
+        self.cin_pad = (o.in_channels + 7) // 8 * 8
+        self.x_rows = torch.zeros(V * h * w, self.cin_pad, dtype=BF16, device=dev)
+        x = self.act(V * h * w, o.down_channels[0])
+        self._gemm("conv_in", x.rows, ops.conv3x3_segs([(self.x_rows.data_ptr(), self.cin_pad, self.cin_pad)]),
+                   "conv_in.weight", x, bias=self.wt["conv_in.bias"], geom=ops.Geom(OH=h, OW=w, IH=h, IW=w))
+        xss = [(x, h, w)]                              # skip stack: activations stay alive until the decoder pops them
+        for i in range(nd):
+            for j in range(o.layers_per_block):
+                y = self._res(f"down_blocks.{i}.nets.{j}", [x], h, w)
+                if o.down_attention[i]:
+                    y2 = self._attn(f"down_blocks.{i}.attns.{j}", y, h, w)
+                    self.rel(y)
+                    y = y2
+                x = y
+                xss.append((x, h, w))
+            if i != nd - 1:
+                oh, ow = (h + 1) // 2, (w + 1) // 2
+                p = f"down_blocks.{i}.downsample"
+                y = self.act(V * oh * ow, x.C)
+                self._gemm(p, y.rows, ops.conv3x3_segs([(x.ptr, x.C, x.C)]), p + ".weight", y, bias=self.wt[p + ".bias"],
+                           geom=ops.Geom(OH=oh, OW=ow, IH=h, IW=w, stride=2))
+                x, h, w = y, oh, ow
+                xss.append((x, h, w))
+            if self.taps is not None:
+                self.taps[f"down_blocks.{i}"] = (x, h, w)
+        y = self._res("mid_block.nets.0", [x], h, w)       # x itself is the top of the skip stack: not released here
+        if o.mid_attention:
+            y2 = self._attn("mid_block.attns.0", y, h, w)
+            self.rel(y)
+            y = y2
+        x = self._res("mid_block.nets.1", [y], h, w)
+        self.rel(y)
+        if self.taps is not None:
+            self.taps["mid_block"] = (x, h, w)
+        for i in range(nu):
+            nl = o.layers_per_block + 1
+            for j in range(nl):
+                skip, sh, sw = xss.pop()
+                assert (sh, sw) == (h, w), (sh, sw, h, w)
+                y = self._res(f"up_blocks.{i}.nets.{j}", [x, skip], h, w)
+                self.rel(x)
+                self.rel(skip)
+                if o.up_attention[i]:
+                    y2 = self._attn(f"up_blocks.{i}.attns.{j}", y, h, w)
+                    self.rel(y)
+                    y = y2
+                x = y
+            if i != nu - 1:
+                p = f"up_blocks.{i}.upsample"
+                y = self.act(V * 4 * h * w, x.C)
+                self._gemm(p, y.rows, ops.conv3x3_segs([(x.ptr, x.C, x.C)]), p + ".weight", y, bias=self.wt[p + ".bias"],
+                           geom=ops.Geom(OH=2 * h, OW=2 * w, IH=h, IW=w, ups=1))
+                self.rel(x)
+                x, h, w = y, 2 * h, 2 * w
+            if self.taps is not None:
+                self.taps[f"up_blocks.{i}"] = (x, h, w)
+        assert not xss, "skip stack not consumed"
+        hn = self._gn("norm_out", [x], h * w, "norm_out", True)
+        self.rel(x)
+        T = V * h * w
+        self.S_out, self.T_out = h, T
+        self._u14 = torch.zeros(T, 16, dtype=BF16, device=dev)         # conv_out: 14 channels at row pitch 16 (the K of
+        u14 = Act(self._u14.view(torch.uint8).view(-1), T, 16)         # the final 1x1); the packed weight's 2 pad rows give 0
+        self._gemm("conv_out", T, ops.conv3x3_segs([(hn.ptr, hn.C, hn.C)]), "conv_out.weight", u14, ldo=16,
+                   bias=self.wt["conv_out.bias"], geom=ops.Geom(OH=h, OW=w, IH=h, IW=w))
+        self.rel(hn)
+        self.raw_rows = torch.zeros(T, 16, dtype=torch.float32, device=dev)
+        self._gemm("final_1x1", T, ops.linear_segs([(u14.ptr, 16, 16)]), "final.weight", self.raw_rows.data_ptr(), ldo=16,
+                   bias=self.wt["final.bias"], out_fp32=True)
+        self.gaussians = torch.zeros(T, 14, dtype=torch.float32, device=dev)
+        self._act_ws = torch.zeros(1024, dtype=torch.float32, device=dev)
+
+    # ------------------------------------------------------------------ run
+    def forward_gaussians(self, images: torch.Tensor) -> torch.Tensor:
+        """images [V, 9, H, W] fp32 on device -> gaussians [V*S*S, 14] fp32 (pos, opacity, scale, rotation, rgb)."""
+        V, Cc, H, W = images.shape
+        assert (V, H, W) == (self.V, self.H, self.W) and Cc == self.o.in_channels
+        ops.latent_to_rows(images.reshape(V, Cc, 1, H, W).contiguous(), self.x_rows, self.cin_pad, 1)
+        self.S.run()
+        ops.gaussian_activation(self.raw_rows, 16, self.gaussians, self.T_out, self._act_ws)
+        return self.gaussians

@@ -54,7 +54,7 @@ class Geom:
 
 def gemm_params(M, N, segs: Sequence[Seg], W, out, ldo, bias=None, rowvec=None, rowvec_div=1, rowvec_ld=0,
                 residual=None, ldr=0, epilogue=L.EPI_NONE, act=L.ACT_NONE, out_fp32=False, geom: Optional[Geom] = None,
-                ksplit=0, workspace=None, tile=L.TILE_AUTO) -> L.GemmParams:
+                ksplit=0, workspace=None, tile=L.TILE_AUTO, res_scale=0.0) -> L.GemmParams:
     p = L.GemmParams()
     p.M, p.N, p.nseg = int(M), int(N), len(segs)
     if len(segs) > L.VMV_MAX_SEGS:
@@ -72,7 +72,7 @@ def gemm_params(M, N, segs: Sequence[Seg], W, out, ldo, bias=None, rowvec=None, 
     p.out, p.ldo = _ptr(out), int(ldo)
     g = geom or Geom()
     p.OH, p.OW, p.IH, p.IW, p.stride, p.ups, p.F, p.P = g.OH, g.OW, g.IH, g.IW, g.stride, g.ups, g.F, g.P
-    p.ksplit, p.workspace, p.tile = int(ksplit), _ptr(workspace), tile
+    p.ksplit, p.workspace, p.tile, p.res_scale = int(ksplit), _ptr(workspace), tile, float(res_scale)
     return p
 
 
@@ -250,6 +250,11 @@ def posterior_sample(moments_rows, ld, noise, z, scale):
     n, zc, H, W = z.shape
     L.check(L.load().vmv_posterior_sample(moments_rows.data_ptr(), ld, noise.data_ptr(), z.data_ptr(), n, zc, H * W,
                                           float(scale), _stream_ptr()), "posterior_sample")
+
+
+def gaussian_activation(raw, ld, out, n, workspace):
+    L.check(L.load().vmv_gaussian_activation(raw.data_ptr(), int(ld), out.data_ptr(), int(n), workspace.data_ptr(),
+                                             _stream_ptr()), "gaussian_activation")
 
 
 def emb_combine_silu(temb, cam, out, rows, Cc, rows_per_t, cam_rows):
