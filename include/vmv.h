@@ -32,7 +32,8 @@ extern "C" {
 #define VMV_ABI_VERSION   1
 int vmv_abi_version(void);
 /* sizeof() of the argument blocks, so a foreign-language binding can verify its struct layout:
- * which = VMV_OP_* (GN_STATS/GN_APPLY share a block), 100 = VmvDdimParams, 101 = VmvGemmSeg, 102 = VmvSeqMap */
+ * which = VMV_OP_* (GN_STATS/GN_APPLY share a block), 100 = VmvDdimParams, 101 = VmvGemmSeg, 102 = VmvSeqMap,
+ * 103 = VmvGsParams */
 int vmv_sizeof(int which);
 /* human-readable text for a code returned by any launcher (VMV_E* or hipError_t) */
 const char* vmv_error_string(int code);
@@ -245,6 +246,41 @@ int vmv_adaptive_avgpool_rows(const void* in, int ld, void* out, int ldo, int n,
  * F.normalize with its default dim=1 to the [B, N, 4] rotation block, i.e. each quaternion COMPONENT is divided by
  * max(L2 norm over the n Gaussians, 1e-12) — reproduced as is.  workspace: >= 1024 floats (deterministic two-pass sum). */
 int vmv_gaussian_activation(const float* raw, int ld, float* out, int n, float* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Forward Gaussian-splatting rasteriser of the LGM refinement branch.  Replaces the reference's use of the third-party
+ * extension diff_gaussian_rasterization (core/gs.py:7-10,57-83: GaussianRasterizationSettings(sh_degree=0, bg, tanfov,
+ * viewmatrix, projmatrix) + rasterizer(means3D, colors_precomp, opacities, scales, rotations)); one view per call pair.
+ * All buffers are caller-owned device memory.  Two calls because the number of (tile, Gaussian) instances is data
+ * dependent: vmv_gs_preprocess fills the per-Gaussian arrays and `offsets` (inclusive scan of tiles_touched; the host
+ * reads offsets[N-1] = num_rendered and sizes keys/vals), vmv_gs_render bins, sorts (rocprim radix sort), and blends.
+ * out_color [3][size][size] is clamped to [0,1] (core/gs.py:84), out_alpha [size][size] (optional) = sum alpha*T.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* gaussians;      /* [N][14]: pos 3, opacity 1, scale 3, rotation (r,x,y,z) 4 — used as given —, rgb 3 */
+    int32_t N;
+    int32_t size;                /* square image, pixels */
+    const float* view;           /* [16] row-major 4x4, row-vector convention (p @ M): cam_view        */
+    const float* view_proj;      /* [16]                                            : cam_view_proj   */
+    float tan_half_fov;
+    float bg[3];
+    float* depth;                /* [N]   preprocess outputs */
+    float* xy;                   /* [N][2] */
+    float* conic_opacity;        /* [N][4] */
+    int32_t* rect;               /* [N][4] tile rectangle x0,y0,x1,y1 */
+    uint32_t* tiles_touched;     /* [N] */
+    uint32_t* offsets;           /* [N] inclusive scan */
+    void* scan_temp; size_t scan_temp_bytes;
+    uint64_t* keys; uint64_t* keys_sorted;      /* [num_rendered] */
+    uint32_t* vals; uint32_t* vals_sorted;      /* [num_rendered] */
+    int32_t num_rendered; int32_t _pad;
+    void* sort_temp; size_t sort_temp_bytes;
+    uint32_t* ranges;            /* [tiles][2] */
+    float* out_color; float* out_alpha;
+} VmvGsParams;
+int vmv_gs_workspace_bytes(int n_gaussians, int n_instances, size_t* scan_bytes, size_t* sort_bytes);
+int vmv_gs_preprocess(const VmvGsParams* p, void* stream);
+int vmv_gs_render(const VmvGsParams* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Block permute-copy (frame-sharded sampling, DESIGN.md §8: packs / unpacks the all-to-all buffers that switch an

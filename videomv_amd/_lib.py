@@ -46,6 +46,16 @@ class GroupNormParams(C.Structure):
                 ("eps", C.c_float), ("silu", C.c_int32), ("y", C.c_void_p), ("ldy", C.c_int32), ("fold_ranks", C.c_int32)]
 
 
+class GsParams(C.Structure):
+    _fields_ = [("gaussians", C.c_void_p), ("N", C.c_int32), ("size", C.c_int32), ("view", C.c_void_p),
+                ("view_proj", C.c_void_p), ("tan_half_fov", C.c_float), ("bg", C.c_float * 3),
+                ("depth", C.c_void_p), ("xy", C.c_void_p), ("conic_opacity", C.c_void_p), ("rect", C.c_void_p),
+                ("tiles_touched", C.c_void_p), ("offsets", C.c_void_p), ("scan_temp", C.c_void_p),
+                ("scan_temp_bytes", C.c_size_t), ("keys", C.c_void_p), ("keys_sorted", C.c_void_p), ("vals", C.c_void_p),
+                ("vals_sorted", C.c_void_p), ("num_rendered", C.c_int32), ("_pad", C.c_int32), ("sort_temp", C.c_void_p),
+                ("sort_temp_bytes", C.c_size_t), ("ranges", C.c_void_p), ("out_color", C.c_void_p), ("out_alpha", C.c_void_p)]
+
+
 class CopyParams(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("n0", C.c_int32), ("n1", C.c_int32), ("n2", C.c_int32),
                 ("inner16", C.c_int32), ("ss0", C.c_int64), ("ss1", C.c_int64), ("ss2", C.c_int64)]
@@ -95,6 +105,9 @@ SYMBOLS = {
     "vmv_softmax_rows": (C.c_int, [C.POINTER(SoftmaxParams), _P]),
     "vmv_permute_copy": (C.c_int, [C.POINTER(CopyParams), _P]),
     "vmv_gaussian_activation": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P]),
+    "vmv_gs_workspace_bytes": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "vmv_gs_preprocess": (C.c_int, [C.POINTER(GsParams), _P]),
+    "vmv_gs_render": (C.c_int, [C.POINTER(GsParams), _P]),
     "vmv_latent_to_rows": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "vmv_latent_to_rows_keep": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "vmv_i2v_temporal_adapter": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
@@ -132,7 +145,7 @@ def load():
     if lib.vmv_abi_version() != 1:
         raise RuntimeError("libvmv_hip.so ABI version mismatch")
     for which, st in ((OP_GEMM, GemmParams), (OP_GN_STATS, GroupNormParams), (OP_LAYERNORM, LayerNormParams),
-                      (OP_ATTENTION, AttnParams), (OP_SOFTMAX, SoftmaxParams), (OP_COPY, CopyParams), (100, DdimParams), (101, GemmSeg), (102, SeqMap)):
+                      (OP_ATTENTION, AttnParams), (OP_SOFTMAX, SoftmaxParams), (OP_COPY, CopyParams), (103, GsParams), (100, DdimParams), (101, GemmSeg), (102, SeqMap)):
         if lib.vmv_sizeof(which) != C.sizeof(st):
             raise RuntimeError(f"struct layout drift for {st.__name__}: C {lib.vmv_sizeof(which)} vs ctypes "
                                f"{C.sizeof(st)}")

@@ -44,6 +44,7 @@ extern "C" int vmv_sizeof(int which) {
         case 100: return (int)sizeof(VmvDdimParams);
         case 101: return (int)sizeof(VmvGemmSeg);
         case 102: return (int)sizeof(VmvSeqMap);
+        case 103: return (int)sizeof(VmvGsParams);
         default: return (int)op_size(which);
     }
 }

@@ -1,0 +1,94 @@
+"""``GaussianRenderer`` — the LGM branch's splatting renderer on the gfx950 rasteriser (``csrc/raster.hip``).
+
+Mirrors ``core/gs.py:16-94`` of the reference: ``render(gaussians [B,N,14], cam_view, cam_view_proj, cam_pos, bg_color)``
+-> ``{"image": [B,V,3,S,S] (clamped to [0,1]), "alpha": [B,V,1,S,S]}``, one rasterisation per (sample, view).  The
+reference delegates to the third-party ``diff_gaussian_rasterization`` extension, which is absent and unpinned; the
+kernels follow the published forward algorithm (oracle/gs_ref.py, parity unpinned — DESIGN.md §2).
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+from .ops import _stream_ptr
+
+
+class GaussianRenderer:
+    def __init__(self, output_size=512, fovy=39.6, znear=0.5, zfar=2.5):
+        self.size, self.fovy = int(output_size), float(fovy)
+        self.tan_half_fov = math.tan(0.5 * math.radians(self.fovy))
+        self.proj_matrix = torch.zeros(4, 4, dtype=torch.float32)          # core/gs.py:23-29
+        self.proj_matrix[0, 0] = 1 / self.tan_half_fov
+        self.proj_matrix[1, 1] = 1 / self.tan_half_fov
+        self.proj_matrix[2, 2] = (zfar + znear) / (zfar - znear)
+        self.proj_matrix[3, 2] = -(zfar * znear) / (zfar - znear)
+        self.proj_matrix[2, 3] = 1
+        self._buf = {}
+        self.last_num_rendered = []
+
+    def _buffers(self, N, device):
+        key = (N, str(device))
+        b = self._buf.get(key)
+        if b is None:
+            lib = L.load()
+            sb, so = C.c_size_t(0), C.c_size_t(0)
+            L.check(lib.vmv_gs_workspace_bytes(N, 1, C.byref(sb), C.byref(so)), "gs_workspace_bytes")
+            grid = (self.size + 15) // 16
+            f = lambda *shape, dt=torch.float32: torch.zeros(*shape, dtype=dt, device=device)
+            b = dict(depth=f(N), xy=f(N, 2), co=f(N, 4), rect=f(N, 4, dt=torch.int32), touched=f(N, dt=torch.int32),
+                     offsets=f(N, dt=torch.int32), scan=torch.zeros(max(int(sb.value), 16), dtype=torch.uint8, device=device),
+                     ranges=f(grid * grid, 2, dt=torch.int32), cap=0)
+            self._buf[key] = b
+        return b
+
+    def _grow(self, b, N, n, device):
+        if n <= b["cap"]:
+            return
+        cap = max(int(n * 1.25), 1 << 16)
+        sb, so = C.c_size_t(0), C.c_size_t(0)
+        L.check(L.load().vmv_gs_workspace_bytes(N, cap, C.byref(sb), C.byref(so)), "gs_workspace_bytes")
+        i64 = lambda: torch.zeros(cap, dtype=torch.int64, device=device)
+        i32 = lambda: torch.zeros(cap, dtype=torch.int32, device=device)
+        b.update(keys=i64(), keys_s=i64(), vals=i32(), vals_s=i32(), cap=cap,
+                 sort=torch.zeros(max(int(so.value), 16), dtype=torch.uint8, device=device))
+
+    @torch.no_grad()
+    def render(self, gaussians, cam_view, cam_view_proj, cam_pos=None, bg_color=None, scale_modifier=1):
+        if scale_modifier != 1:
+            raise NotImplementedError("scale_modifier != 1 is not a VideoMV configuration")
+        device = gaussians.device
+        B, V = cam_view.shape[:2]
+        N, S = gaussians.shape[1], self.size
+        lib = L.load()
+        bg = [1.0, 1.0, 1.0] if bg_color is None else [float(v) for v in bg_color.reshape(-1)[:3]]
+        images = torch.empty(B, V, 3, S, S, dtype=torch.float32, device=device)
+        alphas = torch.empty(B, V, 1, S, S, dtype=torch.float32, device=device)
+        buf = self._buffers(N, device)
+        self.last_num_rendered = []
+        for b in range(B):
+            g = gaussians[b].float().contiguous()
+            for v in range(V):
+                view = cam_view[b, v].float().contiguous().to(device)
+                vp = cam_view_proj[b, v].float().contiguous().to(device)
+                p = L.GsParams()
+                p.gaussians, p.N, p.size, p.view, p.view_proj = g.data_ptr(), N, S, view.data_ptr(), vp.data_ptr()
+                p.tan_half_fov = self.tan_half_fov
+                p.bg[0], p.bg[1], p.bg[2] = bg
+                p.depth, p.xy, p.conic_opacity, p.rect = (buf["depth"].data_ptr(), buf["xy"].data_ptr(), buf["co"].data_ptr(),
+                                                          buf["rect"].data_ptr())
+                p.tiles_touched, p.offsets = buf["touched"].data_ptr(), buf["offsets"].data_ptr()
+                p.scan_temp, p.scan_temp_bytes = buf["scan"].data_ptr(), buf["scan"].numel()
+                L.check(lib.vmv_gs_preprocess(C.byref(p), _stream_ptr()), "gs_preprocess")
+                n = int(buf["offsets"][N - 1].item())                       # the one host round trip per view
+                self.last_num_rendered.append(n)
+                self._grow(buf, N, n, device)
+                p.num_rendered = n
+                if n > 0:
+                    p.keys, p.keys_sorted, p.vals, p.vals_sorted = (buf["keys"].data_ptr(), buf["keys_s"].data_ptr(),
+                                                                    buf["vals"].data_ptr(), buf["vals_s"].data_ptr())
+                    p.sort_temp, p.sort_temp_bytes = buf["sort"].data_ptr(), buf["sort"].numel()
+                p.ranges = buf["ranges"].data_ptr()
+                p.out_color, p.out_alpha = images[b, v].data_ptr(), alphas[b, v].data_ptr()
+                L.check(lib.vmv_gs_render(C.byref(p), _stream_ptr()), "gs_render")
+        return {"image": images, "alpha": alphas}
