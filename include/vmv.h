@@ -241,6 +241,22 @@ int vmv_i2v_temporal_adapter(const void* in, int ld_in, void* out, int ld_out, c
 int vmv_adaptive_avgpool_rows(const void* in, int ld, void* out, int ldo, int n, int C, int IH, int IW, int OH, int OW,
                               void* stream);
 
+/* Glue of the LGM-refined sampling step (unet_t2v.py:404-433, diffusion_ddim.py:179-182,224-243).
+ * vmv_lgm_x0_views: z[v] = inv_scale * (c_recip * xt[:, :, idx[v]] - c_recipm1 * eps_branch[:, :, idx[v]]) for 4 views;
+ *   eps_rows fp32 [2*F*HW][ld] (branch-major), xt [1][C][F][HW], out [4][C][HW].
+ * vmv_lgm_pack_input: decoded VAE images [4][3][HW] in [-1,1] -> clamp(0.5*d+0.5, 0, 1) -> (x - mean)/std (ImageNet) into
+ *   out[:, 0:3], rays [4][6][HW] copied into out[:, 3:9]; out [4][9][HW].
+ * vmv_lgm_render_to_vae: rendered images [V][3][2S][2S] in [0,1] -> nearest down-sampling by 2 (F.interpolate) and
+ *   (x - 0.5) / 0.5; out [V][3][S][S].
+ * vmv_ddim_x0_step: x0 = u + guide * (c - u) (CFG on the two branches' latent_z), eps = (c_recip*xt - x0)/c_recipm1,
+ *   xt <- sqrt(a_prev) * x0 + sqrt(1 - a_prev) * eps, in place; all [n] floats. */
+int vmv_lgm_x0_views(const float* eps_rows, int ld, int branch, const float* xt, int C, int F, int HW, const int32_t* idx4,
+                     float c_recip, float c_recipm1, float inv_scale, float* out, void* stream);
+int vmv_lgm_pack_input(const float* decoded, const float* rays, float* out, int nviews, int HW, void* stream);
+int vmv_lgm_render_to_vae(const float* images, float* out, int nviews, int S, void* stream);
+int vmv_ddim_x0_step(const float* x0_cond, const float* x0_uncond, float* xt, long n, float guide, float c_recip,
+                     float c_recipm1, float a_prev, void* stream);
+
 /* LGM Gaussian activations (core/models.py:37-43,102-112): raw fp32 rows [n][ld >= 14] -> out [n][14] =
  * (pos.clamp(-1,1) x3, sigmoid(opacity), 0.1*softplus(scale) x3, rotation x4, 0.5*tanh(rgb)+0.5 x3).  The reference applies
  * F.normalize with its default dim=1 to the [B, N, 4] rotation block, i.e. each quaternion COMPONENT is divided by

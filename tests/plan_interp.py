@@ -222,6 +222,31 @@ def posterior_sample(moments_rows, ld, noise, z, scale):
     z.copy_(scale * (mean + torch.exp(0.5 * logvar) * noise))
 
 
+def lgm_x0_views(eps_rows, ld, branch, xt, idx4, c_recip, c_recipm1, inv_scale, out):
+    _, Cc, F_, H, W = xt.shape
+    e = eps_rows.view(-1, ld)[branch * F_ * H * W:(branch + 1) * F_ * H * W, :Cc].view(F_, H * W, Cc)
+    for v, f in enumerate(idx4):
+        out[v] = inv_scale * (c_recip * xt[0, :, f] - c_recipm1 * e[f].t().reshape(Cc, H, W))
+
+
+def lgm_pack_input(decoded, rays, out):
+    x = (decoded * 0.5 + 0.5).clamp(0, 1)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    out[:, 0:3] = (x - mean) / std
+    out[:, 3:9] = rays
+
+
+def lgm_render_to_vae(images, out):
+    out.copy_((images[:, :, ::2, ::2] - 0.5) / 0.5)
+
+
+def ddim_x0_step(x0_cond, x0_uncond, xt, guide, c_recip, c_recipm1, a_prev):
+    x0 = x0_uncond + guide * (x0_cond - x0_uncond)
+    eps = (c_recip * xt - x0) / c_recipm1
+    xt.copy_(math.sqrt(a_prev) * x0 + math.sqrt(1 - a_prev) * eps)
+
+
 def gaussian_activation(raw, ld, out, n, workspace):
     x = raw.view(-1, ld)[:n, :14].float()
     rot = x[:, 7:11]
@@ -292,9 +317,20 @@ def install(monkeypatch):
         self.plan = None
         self.keep, self.nops, self.labels, self.recorded = [], 0, [], []
 
+    from videomv_amd import gs as _gs
+
+    def render_cpu(self, gaussians, cam_view, cam_view_proj, cam_pos=None, bg_color=None, scale_modifier=1):
+        from oracle.gs_ref import render_views
+        bg = torch.ones(3) if bg_color is None else bg_color.float().cpu()
+        imgs, alphas = zip(*[render_views(gaussians[b].float().cpu(), cam_view[b].float().cpu(), cam_view_proj[b].float().cpu(),
+                                          self.size, self.fovy, bg) for b in range(gaussians.shape[0])])
+        return {"image": torch.stack(imgs), "alpha": torch.stack(alphas)}
+
+    monkeypatch.setattr(_gs.GaussianRenderer, "render", render_cpu)
     monkeypatch.setattr(ops.Stream, "__init__", init)
     monkeypatch.setattr(ops.Stream, "_go", _go)
     monkeypatch.setattr(ops.Stream, "run", run)
     for name in ("latent_to_rows", "latent_to_rows_keep", "rows_to_nchw", "emb_combine_silu", "sinusoidal", "cfg_ddim_step",
-                 "i2v_temporal_adapter", "adaptive_avgpool_rows", "posterior_sample", "gaussian_activation"):
+                 "i2v_temporal_adapter", "adaptive_avgpool_rows", "posterior_sample", "gaussian_activation", "lgm_x0_views", "lgm_pack_input", "lgm_render_to_vae",
+                 "ddim_x0_step"):
         monkeypatch.setattr(ops, name, globals()[name])

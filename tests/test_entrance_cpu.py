@@ -41,7 +41,7 @@ def test_entrance_four_views_two_steps(monkeypatch, tmp_path):
     argv = ["--cfg", "configs/t2v_infer.yaml", "--debug",
             "device", "cpu", "allow_random_init", "True", "num_views", "4", "ddim_timesteps", "2",
             "test_list_path", str(prompts), "log_dir", str(tmp_path / "out"),
-            "UNet.num_heads", "2", "UNet.num_res_blocks", "1", "UNet.dim_mult", "[1, 2]",
+            "UNet.num_heads", "2", "UNet.num_res_blocks", "1", "UNet.dim_mult", "[1, 2]", "UNet.use_lgm_refine", "False",
             "test_model", "none.pth"]
     cu = Config(load=True, argv=argv)
     cu.cfg_dict["UNet"]["dim"] = 64                               # tiny net for the CPU interpreter
@@ -78,7 +78,8 @@ def test_i2vgen_entrance_plumbing(monkeypatch, tmp_path):
     lst.write_text(f"{img_path}\n")
     argv = ["--cfg", "configs/i2vgen_xl_infer.yaml", "--debug", "device", "cpu", "allow_random_init", "True",
             "num_views", "4", "ddim_timesteps", "2", "test_list_path", str(lst), "log_dir", str(tmp_path / "out"),
-            "UNet.num_heads", "2", "UNet.num_res_blocks", "1", "UNet.dim_mult", "[1, 2]", "test_model", "none.pth"]
+            "UNet.num_heads", "2", "UNet.num_res_blocks", "1", "UNet.dim_mult", "[1, 2]", "UNet.use_lgm_refine", "False",
+            "test_model", "none.pth"]
     cu = Config(load=True, argv=argv)
     cu.cfg_dict["UNet"]["dim"] = 64
     cu.cfg_dict["UNet"]["attn_scales"] = [1.0, 0.5]
@@ -94,3 +95,37 @@ def test_i2vgen_entrance_plumbing(monkeypatch, tmp_path):
     blob = torch.load(os.path.join(cfg.log_dir, out[0]))
     assert blob["latent"].shape == (1, 4, 4, 8, 8) and blob["video"].shape == (1, 3, 4, 64, 64)
     assert torch.isfinite(blob["video"]).all()
+
+
+def test_entrance_lgm_refined_loop(monkeypatch, tmp_path):
+    """BASELINE configs[4] plumbing (use_lgm_refine=True, the YAML default): the second, LGM-refined DDIM loop — at step
+    index 20 each CFG branch's eps goes x0 -> 4 decoded views -> LGM Gaussians -> 4 renders (oracle rasteriser on CPU) ->
+    VAE-encoded latent_z, CFG on latent_z, DDIM update from x0 — writes the `_gs` output next to the plain one.
+    Tiny LGM (2 levels, head_dim 32) through the `lgm_opt` test hook; 21 DDIM steps so that index 20 exists."""
+    plan_interp.install(monkeypatch)
+    from videomv_amd.config import Config
+    from videomv_amd.registry import INFER_ENGINE
+    import videomv_amd.entrance  # noqa: F401
+    prompts = tmp_path / "prompts.txt"
+    prompts.write_text("a wooden chair\n")
+    argv = ["--cfg", "configs/t2v_infer.yaml", "--debug", "device", "cpu", "allow_random_init", "True", "num_views", "4",
+            "ddim_timesteps", "21", "test_list_path", str(prompts), "log_dir", str(tmp_path / "out"),
+            "UNet.num_heads", "2", "UNet.num_res_blocks", "1", "UNet.dim_mult", "[1]", "test_model", "none.pth"]
+    cu = Config(load=True, argv=argv)
+    assert cu.cfg_dict["UNet"]["use_lgm_refine"] is True
+    cu.cfg_dict["UNet"]["dim"] = 64
+    cu.cfg_dict["UNet"]["attn_scales"] = [1.0]
+    cu.cfg_dict["resolution"] = [64, 64]
+    cu.cfg_dict["lgm_opt"] = dict(down_channels=(32, 64), down_attention=(False, True), mid_attention=True,
+                                  up_channels=(64, 32), up_attention=(True, False), num_heads=2, input_size=64,
+                                  splat_size=64, output_size=128)
+    cu.cfg_dict["auto_encoder"] = {"type": "AutoencoderKL", "embed_dim": 4, "pretrained": "none.pth",
+                                   "ddconfig": {"double_z": True, "z_channels": 4, "resolution": 64, "in_channels": 3,
+                                                "out_ch": 3, "ch": 32, "ch_mult": [1, 2, 4, 4], "num_res_blocks": 2,
+                                                "attn_resolutions": [], "dropout": 0.0}}
+    cfg = INFER_ENGINE.build(dict(type=cu.TASK_TYPE), cfg_update=cu.cfg_dict)
+    outs = sorted(f for f in os.listdir(cfg.log_dir) if f.endswith(".pt"))
+    assert len(outs) == 2 and outs[1].endswith("_gs.pt")
+    plain, gs = (torch.load(os.path.join(cfg.log_dir, f)) for f in outs)
+    assert gs["latent"].shape == plain["latent"].shape == (1, 4, 4, 8, 8) and torch.isfinite(gs["video"]).all()
+    assert not torch.allclose(gs["latent"], plain["latent"])          # the refined steps changed the trajectory

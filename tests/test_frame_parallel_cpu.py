@@ -143,7 +143,7 @@ def _entrance_worker(rank, world, port, tmp, q):
         argv = ["--cfg", "configs/t2v_infer.yaml", "device", "cpu", "allow_random_init", "True", "num_views", "4",
                 "ddim_timesteps", "2", "test_list_path", os.path.join(tmp, "prompts.txt"), "log_dir", os.path.join(tmp, f"out{world}"),
                 "UNet.num_heads", "2", "UNet.num_res_blocks", "1", "UNet.dim_mult", "[1, 2]", "test_model", "none.pth",
-                "frame_parallel", "True"]
+                "UNet.use_lgm_refine", "False", "frame_parallel", "True"]
         cu = Config(load=True, argv=argv)
         cu.cfg_dict["UNet"]["dim"] = 64
         cu.cfg_dict["UNet"]["attn_scales"] = [1.0, 0.5]

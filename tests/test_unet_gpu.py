@@ -141,7 +141,7 @@ def test_inference_py_entry_on_gpu(tmp_path):
     prompts.write_text("a wooden chair\n")
     cmd = [sys.executable, "inference.py", "--cfg", "configs/t2v_infer.yaml", "--debug", "allow_random_init", "True",
            "num_views", "4", "ddim_timesteps", "2", "test_list_path", str(prompts), "log_dir", str(tmp_path / "out"),
-           "UNet.num_res_blocks", "1", "UNet.dim_mult", "[1, 2]", "test_model", "none.pth"]
+           "UNet.num_res_blocks", "1", "UNet.dim_mult", "[1, 2]", "UNet.use_lgm_refine", "False", "test_model", "none.pth"]
     r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     outdir = tmp_path / "out" / "p"
@@ -161,7 +161,7 @@ def test_inference_py_i2vgen_entry_on_gpu(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "inference.py", "--cfg", "configs/i2vgen_xl_infer.yaml", "--debug", "allow_random_init", "True",
            "num_views", "4", "ddim_timesteps", "4", "log_dir", str(tmp_path / "out"),
-           "UNet.num_res_blocks", "1", "UNet.dim_mult", "[1, 2]", "test_model", "none.pth"]
+           "UNet.num_res_blocks", "1", "UNet.dim_mult", "[1, 2]", "UNet.use_lgm_refine", "False", "test_model", "none.pth"]
     r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     outdir = tmp_path / "out" / "test_images"

@@ -39,6 +39,57 @@ __global__ void latent_to_rows_keep_kernel(const float* __restrict__ x, uint16_t
     }
 }
 
+__global__ void lgm_x0_views_kernel(const float* __restrict__ eps, int ld, int branch, const float* __restrict__ xt, int C,
+                                    int F, long HW, int i0, int i1, int i2, int i3, float cr, float crm1, float inv_scale,
+                                    float* __restrict__ out) {
+    const long total = 4L * C * HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i % HW;
+        const int c = (int)((i / HW) % C);
+        const int v = (int)(i / (HW * C));
+        const int f = v == 0 ? i0 : (v == 1 ? i1 : (v == 2 ? i2 : i3));
+        const float e = eps[(((long)branch * F + f) * HW + pix) * ld + c];
+        out[i] = inv_scale * (cr * xt[((long)c * F + f) * HW + pix] - crm1 * e);
+    }
+}
+
+__global__ void lgm_pack_input_kernel(const float* __restrict__ dec, const float* __restrict__ rays, float* __restrict__ out,
+                                      int nviews, long HW) {
+    const long total = (long)nviews * 9 * HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i % HW;
+        const int c = (int)((i / HW) % 9);
+        const long v = i / (HW * 9);
+        if (c < 3) {
+            const float mean = c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f);
+            const float stdv = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
+            const float x = fminf(1.f, fmaxf(0.f, dec[(v * 3 + c) * HW + pix] * 0.5f + 0.5f));
+            out[i] = (x - mean) / stdv;
+        } else {
+            out[i] = rays[(v * 6 + (c - 3)) * HW + pix];
+        }
+    }
+}
+
+__global__ void lgm_render_to_vae_kernel(const float* __restrict__ img, float* __restrict__ out, int nviews, int S) {
+    const long total = (long)nviews * 3 * S * S;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % S), y = (int)((i / S) % S);
+        const long vc = i / ((long)S * S);
+        out[i] = (img[(vc * 2 * S + 2 * y) * 2 * S + 2 * x] - 0.5f) / 0.5f;
+    }
+}
+
+__global__ void ddim_x0_step_kernel(const float* __restrict__ xc, const float* __restrict__ xu, float* __restrict__ xt, long n,
+                                    float guide, float cr, float crm1, float a_prev) {
+    const float sa = sqrtf(a_prev), sb = sqrtf(1.0f - a_prev);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float x0 = xu[i] + guide * (xc[i] - xu[i]);
+        const float eps = (cr * xt[i] - x0) / crm1;
+        xt[i] = sa * x0 + sb * eps;
+    }
+}
+
 // LGM Gaussian head.  Pass 1: per-block sums of squares of the 4 rotation components (fixed order: strided rows per
 // thread, then a tree over the block) -> workspace[block][4].  Pass 2: every block folds the <= 256 partials in the same
 // order, then applies the activations to its rows.
@@ -298,6 +349,42 @@ inline int grid_for(long n, int block = 256, int cap = 8192) {
 }
 
 }  // namespace
+
+extern "C" int vmv_lgm_x0_views(const float* eps_rows, int ld, int branch, const float* xt, int C, int F, int HW,
+                                const int32_t* idx4, float c_recip, float c_recipm1, float inv_scale, float* out, void* stream) {
+    if (!eps_rows || !xt || !idx4 || !out) return VMV_ENULL;
+    if (ld < C || C <= 0 || F <= 0 || HW <= 0 || branch < 0) return VMV_EINVAL;
+    for (int v = 0; v < 4; ++v) if (idx4[v] < 0 || idx4[v] >= F) return VMV_ERANGE;
+    hipLaunchKernelGGL(lgm_x0_views_kernel, dim3(grid_for(4L * C * HW)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       eps_rows, ld, branch, xt, C, F, (long)HW, idx4[0], idx4[1], idx4[2], idx4[3], c_recip, c_recipm1,
+                       inv_scale, out);
+    return vmv_launch_status();
+}
+
+extern "C" int vmv_lgm_pack_input(const float* decoded, const float* rays, float* out, int nviews, int HW, void* stream) {
+    if (!decoded || !rays || !out) return VMV_ENULL;
+    if (nviews <= 0 || HW <= 0) return VMV_EINVAL;
+    hipLaunchKernelGGL(lgm_pack_input_kernel, dim3(grid_for((long)nviews * 9 * HW)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), decoded, rays, out, nviews, (long)HW);
+    return vmv_launch_status();
+}
+
+extern "C" int vmv_lgm_render_to_vae(const float* images, float* out, int nviews, int S, void* stream) {
+    if (!images || !out) return VMV_ENULL;
+    if (nviews <= 0 || S <= 0) return VMV_EINVAL;
+    hipLaunchKernelGGL(lgm_render_to_vae_kernel, dim3(grid_for((long)nviews * 3 * S * S)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), images, out, nviews, S);
+    return vmv_launch_status();
+}
+
+extern "C" int vmv_ddim_x0_step(const float* x0_cond, const float* x0_uncond, float* xt, long n, float guide, float c_recip,
+                                float c_recipm1, float a_prev, void* stream) {
+    if (!x0_cond || !x0_uncond || !xt) return VMV_ENULL;
+    if (n <= 0 || c_recipm1 == 0.0f) return VMV_EINVAL;
+    hipLaunchKernelGGL(ddim_x0_step_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x0_cond,
+                       x0_uncond, xt, n, guide, c_recip, c_recipm1, a_prev);
+    return vmv_launch_status();
+}
 
 extern "C" int vmv_gaussian_activation(const float* raw, int ld, float* out, int n, float* workspace, void* stream) {
     if (!raw || !out || !workspace) return VMV_ENULL;

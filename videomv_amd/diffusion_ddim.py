@@ -93,23 +93,38 @@ class DiffusionDDIM(object):
         return xt
 
     @torch.no_grad()
+    def ddim_step_lgm(self, xt, step, unet, cond_kwargs, uncond_kwargs, guide_scale, stride, autoencoder):
+        """One LGM-refined step: each CFG branch's eps goes through predicted x0 -> 4 decoded views -> LGM Gaussians ->
+        24 renders -> VAE-encoded latent_z (unet_t2v.py:404-433); CFG is applied to the two latent_z, the result is taken
+        as x0 (diffusion_ddim.py:157-160,179-182) and the DDIM update follows from it (:233-243)."""
+        t = torch.full((xt.shape[0],), int(step), dtype=torch.long, device=xt.device)
+        eng, eps_rows = unet.forward_cfg_rows(xt, self._scale_timesteps(t), cond_kwargs, uncond_kwargs)
+        k = self.step_scalars(int(step), stride)
+        ref = unet.lgm_refiner(xt.device)
+        # predicted x0 of each branch: eps form (unet_t2v.py:405) or v form (unet_i2vgen.py:441-442), following the MODEL
+        ca, cb = (k["c_sqrt_ac"], k["c_sqrt_1mac"]) if getattr(unet, "lgm_vpred", False) else (k["c_recip"], k["c_recipm1"])
+        z = [ref.latent_z(eps_rows, eng.out_pad, br, xt, ca, cb, autoencoder, dict(kw["gs_data"]))
+             for br, kw in enumerate((cond_kwargs, uncond_kwargs))]
+        ops.ddim_x0_step(z[0], z[1], xt, float(guide_scale), k["c_recip"], k["c_recipm1"], k["a_prev"])
+        return xt
+
+    @torch.no_grad()
     def ddim_sample_loop(self, noise, model, autoencoder=None, model_kwargs={}, clamp=None, percentile=None,
                          condition_fn=None, guide_scale=None, ddim_timesteps=20, eta=0.0):
-        if autoencoder is not None:
-            raise NotImplementedError("LGM-refined sampling (autoencoder=...) is a later row of SURVEY §8(f)")
         b = noise.size(0)
         steps = self.ddim_steps(ddim_timesteps)
         stride = self.num_timesteps // ddim_timesteps
         unet = _unwrap(model)
         fused = (hasattr(unet, "forward_cfg_rows") and guide_scale is not None and isinstance(model_kwargs, list)
-                 and len(model_kwargs) == 2 and autoencoder is None and clamp is None and percentile is None
+                 and len(model_kwargs) == 2 and clamp is None and percentile is None
                  and condition_fn is None and eta == 0.0 and b == 1 and self.mean_type in ('eps', 'v')
                  and noise.is_cuda)
         if not fused:
             xt = noise
             for idx, step in enumerate(steps):
                 t = torch.full((b,), int(step), dtype=torch.long, device=xt.device)
-                xt, _ = self.ddim_sample(xt, t, model, None, model_kwargs, clamp, percentile, condition_fn, guide_scale,
+                ae = autoencoder if idx in (20, 30, 40) else None          # diffusion_ddim.py:254-257
+                xt, _ = self.ddim_sample(xt, t, model, ae, model_kwargs, clamp, percentile, condition_fn, guide_scale,
                                          ddim_timesteps, eta)
             return xt
         assert self.var_type.startswith('fixed'), "learned variance doubles the UNet out channels: not a VideoMV config"
@@ -119,8 +134,13 @@ class DiffusionDDIM(object):
             noise = noise[:, :, comm.rank * fl:(comm.rank + 1) * fl]
         xt = noise.detach().clone().float().contiguous()      # updated in place by the fused kernel
         kc, ku = model_kwargs
+        if autoencoder is not None and comm is not None:
+            raise NotImplementedError("LGM-refined sampling is not combined with frame-parallel execution")
         for idx, step in enumerate(steps):
-            self.ddim_step_hip(xt, int(step), unet, kc, ku, guide_scale, stride)
+            if autoencoder is not None and idx in (20, 30, 40):      # LGM-refined steps (diffusion_ddim.py:254-256)
+                self.ddim_step_lgm(xt, int(step), unet, kc, ku, guide_scale, stride, autoencoder)
+            else:
+                self.ddim_step_hip(xt, int(step), unet, kc, ku, guide_scale, stride)
         if comm is not None:
             from .unet_t2v import gather_frames
             xt = gather_frames(comm, xt)
@@ -132,21 +152,27 @@ class DiffusionDDIM(object):
                     guide_scale=None, ddim_timesteps=20, eta=0.0):
         """One DDIM step for an arbitrary callable ``model`` (API compatibility; the HIP UNet never takes this
         route inside ``ddim_sample_loop``).  All samples of a call share one timestep, as in the reference loop."""
-        if autoencoder is not None or condition_fn is not None or percentile is not None:
-            raise NotImplementedError("LGM refinement / classifier guidance / percentile clipping are not on the built path")
+        if condition_fn is not None or percentile is not None:
+            raise NotImplementedError("classifier guidance / percentile clipping are not on the built path")
         if eta != 0.0:
             raise NotImplementedError("stochastic DDIM (eta > 0) is not used by VideoMV")
         step = int(t.reshape(-1)[0])
         ts = self._scale_timesteps(t)
+        tabs = dict(autoencoder=autoencoder, sqrt_alphas_cumprod=self.sqrt_alphas_cumprod,
+                    sqrt_one_minus_alphas_cumprod=self.sqrt_one_minus_alphas_cumprod,
+                    sqrt_recip_alphas_cumprod=self.sqrt_recip_alphas_cumprod,
+                    sqrt_recipm1_alphas_cumprod=self.sqrt_recipm1_alphas_cumprod) if autoencoder is not None else {}
         if guide_scale is None:
             pred = model(xt, ts, **model_kwargs)
         else:
             assert isinstance(model_kwargs, list) and len(model_kwargs) == 2
-            cond, uncond = model(xt, ts, **model_kwargs[0]), model(xt, ts, **model_kwargs[1])
+            cond, uncond = model(xt, ts, **tabs, **model_kwargs[0]), model(xt, ts, **tabs, **model_kwargs[1])
             pred = uncond + guide_scale * (cond - uncond)
         k = {n: torch.tensor(v, dtype=xt.dtype, device=xt.device)
              for n, v in self.step_scalars(step, self.num_timesteps // ddim_timesteps).items()}
-        if self.mean_type == 'eps':
+        if autoencoder is not None:
+            x0 = pred                       # the model returned latent_z (diffusion_ddim.py:179-182)
+        elif self.mean_type == 'eps':
             x0 = k["c_recip"] * xt - k["c_recipm1"] * pred
         elif self.mean_type == 'v':
             x0 = k["c_sqrt_ac"] * xt - k["c_sqrt_1mac"] * pred

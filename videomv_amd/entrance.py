@@ -100,9 +100,10 @@ def worker(gpu, cfg, cfg_update):
                   prefix_filter='first_stage_model.')
     autoencoder.eval()
     unet_cfg = dict(cfg.UNet)
-    if unet_cfg.get('use_lgm_refine'):
-        logging.info("use_lgm_refine=True: the LGM-refined second loop is not built yet; running the plain loop only")
-        unet_cfg['use_lgm_refine'] = False
+    use_lgm = bool(unet_cfg.get('use_lgm_refine')) and not fpar
+    unet_cfg['use_lgm_refine'] = use_lgm
+    if use_lgm and cfg.get('lgm_opt'):              # (not a reference key: shrinks the LGM for CPU plumbing tests)
+        unet_cfg['lgm_opt'] = _plain(dict(cfg.lgm_opt))
     model = MODEL.build(unet_cfg)
     _load_weights(model, cfg.get('test_model'), cfg.allow_random_init, "UNet")
     model.eval()
@@ -130,6 +131,16 @@ def worker(gpu, cfg, cfg_update):
         x0, video = sample_views(model, diffusion, autoencoder, noise, y_words.to(device), zero_y_negative.to(device),
                                  camera_data, guide_scale=cfg.guide_scale, ddim_timesteps=int(cfg.ddim_timesteps),
                                  decoder_bs=int(cfg.decoder_bs), scale_factor=cfg.scale_factor)
+        x0_gs = video_gs = None
+        if use_lgm:       # second, LGM-refined loop from the SAME noise (inference_text2video_entrance.py:267-279,302-311)
+            from .lgm import prepare_gs_data
+            from .pipeline import decode_views
+            gs_data = prepare_gs_data(camera_data, model.lgm_opt)
+            kw = [dict(y=y_words.to(device), camera_data=camera_data, gs_data=gs_data),
+                  dict(y=zero_y_negative.to(device), camera_data=camera_data, gs_data=gs_data)]
+            x0_gs = diffusion.ddim_sample_loop(noise=noise, model=model, autoencoder=autoencoder, model_kwargs=kw,
+                                               guide_scale=cfg.guide_scale, ddim_timesteps=int(cfg.ddim_timesteps), eta=0.0)
+            video_gs = decode_views(autoencoder, x0_gs, int(cfg.decoder_bs), cfg.scale_factor)
         if fpar and cfg.rank != 0:          # every rank holds the gathered views; rank 0 writes them
             continue
         cap_name = re.sub(r'[^\w\s]', '', caption).replace(' ', '_')
@@ -137,6 +148,9 @@ def worker(gpu, cfg, cfg_update):
         path = osp.join(cfg.log_dir, stem + '.pt')
         torch.save({'latent': x0.cpu(), 'video': video.cpu(), 'caption': caption}, path)
         _save_contact_sheet(video.cpu(), osp.join(cfg.log_dir, stem + '.png'), cfg.mean, cfg.std)
+        if video_gs is not None:                     # the reference's second file: <name>_gs
+            torch.save({'latent': x0_gs.cpu(), 'video': video_gs.cpu(), 'caption': caption}, osp.join(cfg.log_dir, stem + '_gs.pt'))
+            _save_contact_sheet(video_gs.cpu(), osp.join(cfg.log_dir, stem + '_gs.png'), cfg.mean, cfg.std)
         logging.info('Save views to %s' % path)
         outputs.append(path)
     logging.info('Congratulations! The inference is completed!')
@@ -210,9 +224,9 @@ def worker_i2v(gpu, cfg, cfg_update):
                   prefix_filter='first_stage_model.')
     autoencoder.eval()
     unet_cfg = dict(cfg.UNet)
-    if unet_cfg.get('use_lgm_refine'):
-        logging.info("use_lgm_refine=True: the LGM-refined second loop is not built yet; running the plain loop only")
-        unet_cfg['use_lgm_refine'] = False
+    use_lgm = bool(unet_cfg.get('use_lgm_refine'))
+    if use_lgm and cfg.get('lgm_opt'):              # (not a reference key: shrinks the LGM for CPU plumbing tests)
+        unet_cfg['lgm_opt'] = _plain(dict(cfg.lgm_opt))
     model = MODEL.build(unet_cfg)
     _load_weights(model, cfg.get('test_model'), cfg.allow_random_init, "UNet")
     model.eval()
@@ -256,6 +270,15 @@ def worker_i2v(gpu, cfg, cfg_update):
         path = osp.join(cfg.log_dir, stem + '.pt')
         torch.save({'latent': x0.cpu(), 'video': video.cpu(), 'image': line}, path)
         _save_contact_sheet(video.cpu(), osp.join(cfg.log_dir, stem + '.png'), cfg.mean, cfg.std)
+        if use_lgm:       # second, LGM-refined loop from the same noise (inference_i2vgen_entrance.py:281-292)
+            from .lgm import prepare_gs_data
+            gs_data = prepare_gs_data(camera_data, model.lgm_opt)
+            kw_gs = [dict(k, gs_data=gs_data) for k in kw]
+            x0_gs = diffusion.ddim_sample_loop(noise=noise, model=model, autoencoder=autoencoder, model_kwargs=kw_gs,
+                                               guide_scale=cfg.guide_scale, ddim_timesteps=int(cfg.ddim_timesteps), eta=0.0)
+            video_gs = decode_views(autoencoder, x0_gs, int(cfg.decoder_bs), cfg.scale_factor)
+            torch.save({'latent': x0_gs.cpu(), 'video': video_gs.cpu(), 'image': line}, osp.join(cfg.log_dir, stem + '_gs.pt'))
+            _save_contact_sheet(video_gs.cpu(), osp.join(cfg.log_dir, stem + '_gs.png'), cfg.mean, cfg.std)
         logging.info('Save views to %s' % path)
         outputs.append(path)
     logging.info('Congratulations! The inference is completed!')

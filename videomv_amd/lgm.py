@@ -342,3 +342,86 @@ class LgmEngine:
         self.S.run()
         ops.gaussian_activation(self.raw_rows, 16, self.gaussians, self.T_out, self._act_ws)
         return self.gaussians
+
+
+# --------------------------------------------------------------------------------------------- cameras / rays (host, once per prompt)
+def get_rays(pose, h, w, fovy):
+    """core/utils.py:10-43 (OpenGL convention): origins and unit directions [h, w, 3] of a camera-to-world pose."""
+    x, y = torch.meshgrid(torch.arange(w), torch.arange(h), indexing="xy")
+    x, y = x.flatten().to(pose.dtype), y.flatten().to(pose.dtype)
+    focal = h * 0.5 / math.tan(0.5 * math.radians(fovy))
+    dirs = torch.stack([(x - w * 0.5 + 0.5) / focal, -(y - h * 0.5 + 0.5) / focal, -torch.ones_like(x)], dim=-1)
+    rays_d = dirs @ pose[:3, :3].transpose(0, 1)
+    rays_o = pose[:3, 3].unsqueeze(0).expand_as(rays_d)
+    rays_d = rays_d / torch.sqrt(torch.clamp((rays_d * rays_d).sum(-1, keepdim=True), min=1e-20))
+    return rays_o.reshape(h, w, 3), rays_d.reshape(h, w, 3)
+
+
+def prepare_gs_data(camera_data: torch.Tensor, opt: LgmOptions = None) -> dict:
+    """camera_data [1, T, 16] (the UNet's camera condition) -> gs_data = dict(input [1,T,6,S,S] Pluecker rays, cam_view,
+    cam_view_proj [1,T,4,4], cam_pos [1,T,3]) exactly as the entrance builds it
+    (tools/inferences/inference_text2video_entrance.py:198-235), conventions included."""
+    opt = opt or LgmOptions()
+    T = camera_data.shape[1]
+    cam = camera_data.detach().cpu().clone().reshape(T, 4, 4).contiguous().float()
+    cam[:, 1] *= -1
+    cam[:, [1, 2]] = cam[:, [2, 1]]
+    cam[:, :3, 1:3] *= -1
+    dist = float(torch.sqrt(cam[0, 0, 3] ** 2 + cam[0, 1, 3] ** 2 + cam[0, 2, 3] ** 2))
+    transform = torch.tensor([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, dist], [0, 0, 0, 1]], dtype=torch.float32) @ torch.inverse(cam[0])
+    poses = transform.unsqueeze(0) @ cam
+    rays = []
+    for i in range(T):
+        o, d = get_rays(poses[i], opt.input_size, opt.input_size, opt.fovy)
+        rays.append(torch.cat([torch.cross(o, d, dim=-1), d], dim=-1))
+    rays = torch.stack(rays, dim=0).permute(0, 3, 1, 2).contiguous()
+    tan = math.tan(0.5 * math.radians(opt.fovy))
+    proj = torch.zeros(4, 4)
+    proj[0, 0] = proj[1, 1] = 1 / tan
+    proj[2, 2] = (opt.zfar + opt.znear) / (opt.zfar - opt.znear)
+    proj[3, 2] = -(opt.zfar * opt.znear) / (opt.zfar - opt.znear)
+    proj[2, 3] = 1
+    poses = poses.clone()
+    poses[:, :3, 1:3] *= -1
+    view = torch.inverse(poses).transpose(1, 2)
+    return dict(input=rays.unsqueeze(0), cam_view=view.unsqueeze(0), cam_view_proj=(view @ proj).unsqueeze(0),
+                cam_pos=(-poses[:, :3, 3]).unsqueeze(0))
+
+
+class LgmRefiner:
+    """The ``autoencoder is not None`` branch of ``UNetSD_T2VBase.forward`` (unet_t2v.py:404-433) for ONE branch of ONE
+    sample: predicted x0 of 4 views -> VAE decode -> LGM Gaussians -> 24 renders -> VAE encode -> latent_z."""
+
+    def __init__(self, opt: LgmOptions, lgm_state: Dict[str, torch.Tensor], device, bg_color=0.5):
+        from .gs import GaussianRenderer
+        self.opt, self.device, self.bg_color = opt, device, float(bg_color)
+        self.engine = LgmEngine(opt, lgm_state, opt.input_size, opt.input_size, device)
+        self.renderer = GaussianRenderer(opt.output_size, opt.fovy, opt.znear, opt.zfar)
+        S = opt.input_size
+        self.z4 = None
+        self.inp = torch.zeros(opt.num_frames, 9, S, S, dtype=torch.float32, device=device)
+
+    @torch.no_grad()
+    def latent_z(self, eps_rows, ld, branch, xt, c_recip, c_recipm1, autoencoder, gs_data, scale_factor=0.18215):
+        """x0 = c_recip * xt - c_recipm1 * pred  (eps-prediction: sqrt(1/a), sqrt(1/a - 1); v-prediction: sqrt(a), sqrt(1-a))."""
+        _, Cc, F_, h, w = xt.shape
+        idxs = [0, 6, 12, 18] if F_ == 24 else [i * F_ // 4 for i in range(4)]          # unet_t2v.py:409 (F = 24)
+        if self.z4 is None or self.z4.shape[-2:] != (h, w):
+            self.z4 = torch.zeros(4, Cc, h, w, dtype=torch.float32, device=self.device)
+        ops.lgm_x0_views(eps_rows, ld, branch, xt, idxs, c_recip, c_recipm1, 1.0 / scale_factor, self.z4)
+        decoded = autoencoder.decode(self.z4)                                           # [4, 3, S, S] in [-1, 1]
+        S = self.opt.input_size
+        if decoded.shape[-1] != S or decoded.shape[-2] != S:
+            raise ValueError(f"LGM expects {S}x{S} decoded views (latent {S // 8}x{S // 8}), got {tuple(decoded.shape[-2:])}")
+        rays = gs_data["input"][0, idxs].to(self.device, torch.float32).contiguous()
+        ops.lgm_pack_input(decoded.contiguous(), rays, self.inp)
+        gaussians = self.engine.forward_gaussians(self.inp)
+        bg = torch.full((3,), self.bg_color, dtype=torch.float32, device=self.device)   # LGM.infer bg_color_factor
+        out = self.renderer.render(gaussians.unsqueeze(0), gs_data["cam_view"].to(self.device), gs_data["cam_view_proj"].to(self.device),
+                                   None, bg_color=bg)
+        images = out["image"][0]                                                        # [T, 3, 2S, 2S]
+        T = images.shape[0]
+        small = torch.empty(T, 3, images.shape[-1] // 2, images.shape[-1] // 2, dtype=torch.float32, device=self.device)
+        ops.lgm_render_to_vae(images.contiguous(), small)
+        z = autoencoder.encode_firsr_stage(small, scale_factor)                         # [T, C, h, w]
+        return z.reshape(1, T, z.shape[1], z.shape[2], z.shape[3]).permute(0, 2, 1, 3, 4).contiguous()

@@ -252,6 +252,30 @@ def posterior_sample(moments_rows, ld, noise, z, scale):
                                           float(scale), _stream_ptr()), "posterior_sample")
 
 
+def lgm_x0_views(eps_rows, ld, branch, xt, idx4, c_recip, c_recipm1, inv_scale, out):
+    _, Cc, F_, H, W = xt.shape
+    ia = (C.c_int32 * 4)(*[int(i) for i in idx4])
+    L.check(L.load().vmv_lgm_x0_views(eps_rows.data_ptr(), int(ld), int(branch), xt.data_ptr(), Cc, F_, H * W, ia,
+                                      float(c_recip), float(c_recipm1), float(inv_scale), out.data_ptr(), _stream_ptr()),
+            "lgm_x0_views")
+
+
+def lgm_pack_input(decoded, rays, out):
+    n, _, H, W = decoded.shape
+    L.check(L.load().vmv_lgm_pack_input(decoded.data_ptr(), rays.data_ptr(), out.data_ptr(), n, H * W, _stream_ptr()),
+            "lgm_pack_input")
+
+
+def lgm_render_to_vae(images, out):
+    n, _, S, _ = out.shape
+    L.check(L.load().vmv_lgm_render_to_vae(images.data_ptr(), out.data_ptr(), n, S, _stream_ptr()), "lgm_render_to_vae")
+
+
+def ddim_x0_step(x0_cond, x0_uncond, xt, guide, c_recip, c_recipm1, a_prev):
+    L.check(L.load().vmv_ddim_x0_step(x0_cond.data_ptr(), x0_uncond.data_ptr(), xt.data_ptr(), xt.numel(), float(guide),
+                                      float(c_recip), float(c_recipm1), float(a_prev), _stream_ptr()), "ddim_x0_step")
+
+
 def gaussian_activation(raw, ld, out, n, workspace):
     L.check(L.load().vmv_gaussian_activation(raw.data_ptr(), int(ld), out.data_ptr(), int(n), workspace.data_ptr(),
                                              _stream_ptr()), "gaussian_activation")

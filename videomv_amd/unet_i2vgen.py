@@ -22,7 +22,7 @@ from . import _lib as L
 from . import ops
 from . import packing as P
 from .unet_engine import UNetEngine, param_shapes, BF16
-from .unet_t2v import _Holder, _ZERO_INIT_SUFFIXES
+from .unet_t2v import LgmMixin, _Holder, _ZERO_INIT_SUFFIXES
 
 
 def i2v_extra_shapes(arch: dict, concat_dim: int, num_tokens: int, y_dim: int) -> Dict[str, tuple]:
@@ -144,14 +144,17 @@ class I2VFrontEnd:
 
 
 @MODEL.register_class()
-class UNetSD_I2VGen(nn.Module):
+class UNetSD_I2VGen(nn.Module, LgmMixin):
+    lgm_bg_color = 0.7            # unet_i2vgen.py:458
+    lgm_vpred = True              # unet_i2vgen.py:441-442
+
     def __init__(self, config=None, in_dim=4, dim=512, y_dim=512, context_dim=512, hist_dim=156, concat_dim=8,
                  dim_condition=4, out_dim=6, num_tokens=4, dim_mult=[1, 2, 3, 4], num_heads=None, head_dim=64,
                  num_res_blocks=3, attn_scales=[1 / 2, 1 / 4, 1 / 8], use_scale_shift_norm=True, dropout=0.1,
                  temporal_attn_times=1, temporal_attention=True, use_checkpoint=False, use_image_dataset=False,
                  use_sim_mask=False, training=True, inpainting=True, camera_dim=16, use_fps_condition=False,
                  use_camera_condition=False, use_lgm_refine=False, p_all_zero=0.1, p_all_keep=0.1, zero_y=None,
-                 adapter_transformer_layers=1, **kwargs):
+                 adapter_transformer_layers=1, lgm_opt=None, **kwargs):
         super().__init__()
         concat_dim = in_dim                           # the reference overrides the argument (unet_i2vgen.py:93)
         if concat_dim != 4 or adapter_transformer_layers != 1:
@@ -182,10 +185,12 @@ class UNetSD_I2VGen(nn.Module):
                 child = _Holder()
                 self.add_module(head, child)
             child.add(rest, nn.Parameter(v, requires_grad=False))
+        self._init_lgm(use_lgm_refine, lgm_opt)
         self._engines, self._front = {}, {}
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
 
     def _invalidate(self):
+        self._lgm = None
         self._engines.clear()
         self._front.clear()
 
@@ -210,8 +215,10 @@ class UNetSD_I2VGen(nn.Module):
                 local_image=None, camera_data=None, masked=None, fps=None, video_mask=None, focus_present_mask=None,
                 prob_focus_present=0., mask_last_frame_num=0, **kwargs):
         assert self.inpainting or masked is None, 'inpainting is not supported'
-        if autoencoder is not None or (self.use_lgm_refine and x0 is not None):
-            raise NotImplementedError("LGM refinement branch is not built yet (SURVEY §8f)")
+        if self.use_lgm_refine and x0 is not None:
+            raise NotImplementedError("training-time LGM branch (unet_i2vgen.py:406-436)")
+        if autoencoder is not None and not self.use_lgm_refine:
+            raise ValueError("autoencoder=... needs a model built with use_lgm_refine=True")
         if local_image is None or image is None or y is None or fps is None:
             raise ValueError("UNetSD_I2VGen needs y, image, local_image and fps")
         b, c, f, h, w = x.shape
@@ -221,7 +228,11 @@ class UNetSD_I2VGen(nn.Module):
         front.run(eng, self._first_frame(local_image).to(dev), y.to(dev).float(), image.to(dev).float(), fps)
         eng.set_camera(camera_data.to(dev) if (camera_data is not None and self.use_camera_condition) else None)
         eng.forward_rows(x.float(), t.to(dev))
-        return eng.eps_ncfhw()
+        if autoencoder is None:
+            return eng.eps_ncfhw()
+        return self._lgm_branch(eng, x, t, autoencoder, gs_data, dict(
+            sqrt_alphas_cumprod=sqrt_alphas_cumprod, sqrt_one_minus_alphas_cumprod=sqrt_one_minus_alphas_cumprod,
+            sqrt_recip_alphas_cumprod=sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod=sqrt_recipm1_alphas_cumprod))
 
     @torch.no_grad()
     def forward_cfg_rows(self, xt, t, cond_kwargs, uncond_kwargs):

@@ -10,8 +10,9 @@ What differs by design: there is no PyTorch math in ``forward``.  Parameters are
 operands on first use and the whole forward is a recorded plan of HIP launches (``unet_engine.UNetEngine``).
 If the HIP library is missing, construction of the engine raises — there is no CPU fallback.
 
-The LGM refinement branch (``autoencoder is not None`` / ``use_lgm_refine``, unet_t2v.py:404-433) is a
-"next" row of SURVEY §8(f) and raises ``NotImplementedError``.
+The LGM refinement branch (``autoencoder is not None``, unet_t2v.py:404-433; ``use_lgm_refine=True`` registers the
+``lgm_big.*`` parameters, :125-129) runs on ``lgm.LgmRefiner``; only its training-time variant (``x0 is not None``,
+:370-400, which needs ground-truth renders and the LGM losses) raises ``NotImplementedError``.
 """
 import math
 from typing import Dict, Optional
@@ -41,6 +42,56 @@ class _Holder(nn.Module):
         child.add(rest, param)
 
 
+class LgmMixin:
+    """``self.lgm_big = LGM(config_defaults['big'])`` of the video UNets (unet_t2v.py:125-129, unet_i2vgen.py:108-112): the
+    376 ``lgm_big.*`` parameters (415 M) and the inference branch that returns latent_z instead of eps."""
+    lgm_bg_color = 0.5            # LGM.infer(bg_color_factor): 0.5 for T2V (models.py:115), 0.7 for I2VGen (unet_i2vgen.py:458)
+    lgm_vpred = False             # x0 from eps (unet_t2v.py:405) or from v (unet_i2vgen.py:441-442)
+
+    def _init_lgm(self, use_lgm_refine, lgm_opt):
+        self.lgm_opt, self._lgm = None, None
+        if not use_lgm_refine:
+            return
+        from .lgm import LgmOptions, lgm_param_shapes
+        self.lgm_opt = LgmOptions(**lgm_opt) if isinstance(lgm_opt, dict) else (lgm_opt or LgmOptions())
+        for key, shape in lgm_param_shapes(self.lgm_opt).items():
+            if len(shape) == 1:
+                v = torch.zeros(shape) if key.endswith(".bias") else torch.ones(shape)
+            else:
+                fan_in = 1
+                for d in shape[1:]:
+                    fan_in *= d
+                v = torch.empty(shape).normal_(0.0, 1.0 / math.sqrt(fan_in))
+            head, _, rest = ("lgm_big." + key).partition(".")
+            child = self._modules.get(head)
+            if child is None:
+                child = _Holder()
+                self.add_module(head, child)
+            child.add(rest, nn.Parameter(v, requires_grad=False))
+
+    def lgm_refiner(self, device):
+        if not self.use_lgm_refine:
+            raise ValueError("model was built with use_lgm_refine=False")
+        if self._lgm is None:
+            from .lgm import LgmRefiner
+            sd = {k[len("lgm_big."):]: v.detach() for k, v in self.state_dict().items() if k.startswith("lgm_big.")}
+            self._lgm = LgmRefiner(self.lgm_opt, sd, device, bg_color=self.lgm_bg_color)
+        return self._lgm
+
+    def _lgm_branch(self, eng, x, t, autoencoder, gs_data, tables):
+        """eps / v rows of ONE sample in ``eng`` -> latent_z (the value forward() returns when ``autoencoder`` is given)."""
+        if x.shape[0] != 1:
+            raise ValueError("the LGM branch handles one sample per call (the reference's gs_data has batch 1)")
+        step = int(t.reshape(-1)[0])
+        a, b = ("sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod") if self.lgm_vpred else \
+               ("sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod")
+        if tables.get(a) is None or tables.get(b) is None:
+            raise ValueError(f"the LGM branch needs the schedule tables {a} / {b}")
+        ca, cb = float(tables[a][step].to(torch.float32)), float(tables[b][step].to(torch.float32))
+        return self.lgm_refiner(x.device).latent_z(eng.eps_rows, eng.out_pad, 0, x.float().contiguous(), ca, cb, autoencoder,
+                                                   dict(gs_data))
+
+
 def gather_frames(comm, x_local: torch.Tensor) -> torch.Tensor:
     """[b, c, F/R, h, w] per rank -> [b, c, F, h, w] on every rank (frame-parallel sampling)."""
     x_local = x_local.contiguous()
@@ -50,14 +101,14 @@ def gather_frames(comm, x_local: torch.Tensor) -> torch.Tensor:
 
 
 @MODEL.register_class()
-class UNetSD_T2VBase(nn.Module):
+class UNetSD_T2VBase(nn.Module, LgmMixin):
     def __init__(self, config=None, in_dim=4, dim=512, y_dim=512, context_dim=512, hist_dim=156, dim_condition=4,
                  out_dim=6, num_tokens=4, dim_mult=[1, 2, 3, 4], num_heads=None, head_dim=64, camera_dim=16,
                  num_res_blocks=3, attn_scales=[1 / 2, 1 / 4, 1 / 8], use_scale_shift_norm=True, dropout=0.1,
                  temporal_attn_times=1, temporal_attention=True, use_checkpoint=False, use_image_dataset=False,
                  use_sim_mask=False, training=True, inpainting=True, use_fps_condition=False,
                  use_camera_condition=False, use_lgm_refine=False, p_all_zero=0.1, p_all_keep=0.1, zero_y=None,
-                 adapter_transformer_layers=1, **kwargs):
+                 adapter_transformer_layers=1, lgm_opt=None, **kwargs):
         super().__init__()
         if not temporal_attention:
             raise NotImplementedError("temporal_attention=False is not a VideoMV configuration")
@@ -88,6 +139,7 @@ class UNetSD_T2VBase(nn.Module):
                     fan_in *= d
                 v = torch.empty(shape).normal_(0.0, 1.0 / math.sqrt(fan_in))
             self._add_param(key, nn.Parameter(v, requires_grad=False))
+        self._init_lgm(use_lgm_refine, lgm_opt)
         self._engines: Dict[tuple, UNetEngine] = {}
         self.frame_comm = None        # comm.FrameComm: frame-parallel execution over the ranks of one sample
         self._weights_version = 0
@@ -102,6 +154,7 @@ class UNetSD_T2VBase(nn.Module):
         child.add(rest, param)
 
     def _invalidate(self):
+        self._lgm = None
         self._engines.clear()
         self._weights_version += 1
 
@@ -131,8 +184,10 @@ class UNetSD_T2VBase(nn.Module):
                 masked=None, camera_data=None, video_mask=None, focus_present_mask=None, prob_focus_present=0.,
                 mask_last_frame_num=0, **kwargs):
         assert self.inpainting or masked is None, 'inpainting is not supported'
-        if autoencoder is not None or (self.use_lgm_refine and x0 is not None):
-            raise NotImplementedError("LGM refinement branch (unet_t2v.py:404-433) is not built yet (SURVEY §8f)")
+        if self.use_lgm_refine and x0 is not None:
+            raise NotImplementedError("training-time LGM branch (unet_t2v.py:370-400: ground-truth renders + LGM losses)")
+        if autoencoder is not None and not self.use_lgm_refine:
+            raise ValueError("autoencoder=... needs a model built with use_lgm_refine=True")
         b, c, f, h, w = x.shape
         dev = x.device
         if y is None:
@@ -148,7 +203,12 @@ class UNetSD_T2VBase(nn.Module):
         eng.set_camera(camera_data if self.use_camera_condition else None)
         if self.frame_comm is None:
             eng.forward_rows(x.float(), t.to(dev))
-            return eng.eps_ncfhw()
+            if autoencoder is None:
+                return eng.eps_ncfhw()
+            # LGM branch: eps -> x0 of 4 views -> LGM -> 24 renders -> latent_z (returned in place of eps)
+            return self._lgm_branch(eng, x, t, autoencoder, gs_data, dict(
+                sqrt_alphas_cumprod=sqrt_alphas_cumprod, sqrt_one_minus_alphas_cumprod=sqrt_one_minus_alphas_cumprod,
+                sqrt_recip_alphas_cumprod=sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod=sqrt_recipm1_alphas_cumprod))
         comm = self.frame_comm                    # whole sample in, whole sample out: run this rank's frames, gather
         fl = f // comm.world
         eng.forward_rows(x[:, :, comm.rank * fl:(comm.rank + 1) * fl].float().contiguous(), t.to(dev))
