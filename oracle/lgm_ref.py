@@ -218,3 +218,25 @@ def gs_data_from_camera(camera_data, cfg: LgmCfg = LgmCfg()):
     view = torch.inverse(poses).transpose(1, 2)
     return dict(input=rays.unsqueeze(0), cam_view=view.unsqueeze(0), cam_view_proj=(view @ proj).unsqueeze(0),
                 cam_pos=(-poses[:, :3, 3]).unsqueeze(0))
+
+
+@torch.no_grad()
+def lgm_latent_z(lgm_sd, cfg: LgmCfg, vae_sd, z4, rays4, cam_view, cam_view_proj, noise, bg=0.5, scale_factor=0.18215,
+                 vae_kw=None):
+    """The whole ``autoencoder is not None`` branch of the video UNet for one CFG branch (unet_t2v.py:404-433), composed from
+    the oracle pieces: z4 [4,C,h,w] (predicted x0 / 0.18215 of the 4 input views) -> VAE decode -> [0,1] clamp, ImageNet
+    normalise, cat with the Pluecker rays -> Gaussians -> render all views (bg colour ``bg``), clamp -> nearest /2 ->
+    (x-0.5)/0.5 -> VAE encode moments -> ``scale_factor * (mean + std * noise)`` -> latent_z [1,C,T,h,w]."""
+    from .vae_ref import vae_decode, vae_encode_moments, posterior_sample
+    from .gs_ref import render_views
+    vae_kw = vae_kw or {}
+    dec = vae_decode(vae_sd, z4, **vae_kw)
+    x = (dec * 0.5 + 0.5).clamp(0, 1)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    images = torch.cat([(x - mean) / std, rays4], dim=1).unsqueeze(0)
+    gauss = forward_gaussians(lgm_sd, cfg, images)[0]
+    imgs, _ = render_views(gauss, cam_view, cam_view_proj, cfg.output_size, cfg.fovy, torch.full((3,), float(bg)))
+    small = (imgs[:, :, ::2, ::2] - 0.5) / 0.5
+    z = posterior_sample(vae_encode_moments(vae_sd, small, **vae_kw), noise, scale_factor)
+    return z.unsqueeze(0).permute(0, 2, 1, 3, 4).contiguous()
