@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--dump-ops", type=str, default="", help="write the per-launch timing table to this file")
     ap.add_argument("--no-frame-parallel", action="store_true", help="N > 1: skip the frame-parallel (one sample over all GPUs) leg")
     ap.add_argument("--frame-parallel-budget", type=float, default=300.0, help="seconds before the watchdog abandons that leg")
+    ap.add_argument("--no-lgm", action="store_true", help="skip the LGM-refined sample (BASELINE configs[4])")
     ap.add_argument("--no-sample", action="store_true", help="skip the (untimed-region) full 50-step + VAE-decode sample")
     args = ap.parse_args()
     H, W = (int(v) for v in args.latent.split("x"))
@@ -318,6 +319,43 @@ def main():
                       samples_per_s=round(1.0 / (t3 - t1), 5), video_shape=list(vid.shape),
                       finite=bool(torch.isfinite(vid).all() and torch.isfinite(x0_lat).all()))
 
+    # ---- BASELINE configs[4]: one LGM-refined sample at the reference's own 256-px shape (latent 24x32x32): 50 DDIM steps,
+    #      of which steps 20/30/40 send each CFG branch through VAE decode (4 views) -> LGM U-Net (415 M) -> 65 536
+    #      Gaussians -> 24 renders at 512^2 -> VAE encode (24 views); full-size LGM, random weights
+    lgm = None
+    if rank == 0 and world == 1 and not args.no_sample and not args.no_lgm:
+        from videomv_amd.lgm import prepare_gs_data
+        from videomv_amd.camera import entrance_camera_data
+        with torch.device(dev):
+            model_l = MODEL.build(dict(type="UNetSD_T2VBase", y_dim=1024, use_camera_condition=True, use_lgm_refine=True, **FULL))
+        randomize_(model_l, 1234)
+        model_l.eval()
+        cam_l = entrance_camera_data(24, elevation=15, camera_distance=2.0)
+        gs_data = prepare_gs_data(cam_l, model_l.lgm_opt)
+        gl = torch.Generator(device=dev).manual_seed(11)
+        noise_l = torch.randn(1, 4, 24, 32, 32, generator=gl, device=dev)
+        kw_l = [dict(y=y, camera_data=cam_l, gs_data=gs_data), dict(y=y0, camera_data=cam_l, gs_data=gs_data)]
+        xl = noise_l.clone()
+        dif.ddim_step_hip(xl, steps[0], model_l, kw_l[0], kw_l[1], 9.0, stride)          # warm-up: plans, VAE engines, LGM
+        dif.ddim_step_lgm(xl, steps[1], model_l, kw_l[0], kw_l[1], 9.0, stride, vae)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        dif.ddim_step_lgm(xl, steps[2], model_l, kw_l[0], kw_l[1], 9.0, stride, vae)
+        torch.cuda.synchronize()
+        t_lgm_step = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        x0_l = dif.ddim_sample_loop(noise=noise_l, model=model_l, autoencoder=vae, model_kwargs=kw_l, guide_scale=9.0,
+                                    ddim_timesteps=50, eta=0.0)
+        torch.cuda.synchronize()
+        t_loop = time.perf_counter() - t1
+        ref_l = model_l.lgm_refiner(dev)
+        lgm = dict(workload="t2v + use_lgm_refine=True, latent 24x32x32, 50 DDIM steps, LGM at step indices 20/30/40 "
+                            "(2 branches each): LGM 'big' 415 M params, 65 536 Gaussians, 24 renders at 512x512 per branch",
+                   ddim50_lgm_seconds=round(t_loop, 4), lgm_refined_step_ms=round(1000 * t_lgm_step, 2),
+                   instances_per_view=int(sum(ref_l.renderer.last_num_rendered) / max(1, len(ref_l.renderer.last_num_rendered))),
+                   finite=bool(torch.isfinite(x0_l).all()))
+        del model_l
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cores = os.cpu_count() or 1
@@ -340,7 +378,7 @@ def main():
 
     if rank == 0:
         out = headline()
-        out.update({"sample_24view": sample, "frame_parallel": fpar, "cpu_baseline": cpu})
+        out.update({"sample_24view": sample, "lgm_refined_sample": lgm, "frame_parallel": fpar, "cpu_baseline": cpu})
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

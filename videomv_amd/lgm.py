@@ -317,7 +317,8 @@ class LgmEngine:
                 x, h, w = y, 2 * h, 2 * w
             if self.taps is not None:
                 self.taps[f"up_blocks.{i}"] = (x, h, w)
-        assert not xss, "skip stack not consumed"
+        for leftover, _, _ in xss:            # the 'big' U-Net is asymmetric (5 decoder levels for 6 encoder levels): the
+            self.rel(leftover)                # shallowest skips are simply unused, as in the reference (core/unet.py:306-310)
         hn = self._gn("norm_out", [x], h * w, "norm_out", True)
         self.rel(x)
         T = V * h * w
