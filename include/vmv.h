@@ -137,6 +137,11 @@ typedef struct {
     int32_t fold_ranks;    /* 0/1: `partial` holds this launch's sums.  R > 1 (frame-sharded 5-D norms): apply
                               folds `partial` = [R][nstat][nchunk][32][2] — the all-gathered sums of R equally sized shards of
                               each stat group — and normalises by R * rows_per_stat rows.  Ignored by _stats.            */
+    /* Optional pre-folded statistics (long stat groups: the all-frame norms have up to 256 chunks, which every apply block
+     * would otherwise re-fold).  With `totals` set, _stats follows up with a one-block-per-stat fold of that group's chunks,
+     * in fixed order, into totals[stat][32][2]; _apply then reads totals instead of partial: [nstat][32][2], or
+     * [R][nstat][32][2] gathered when fold_ranks = R > 1.                                                                  */
+    float* totals;
 } VmvGroupNormParams;
 
 int vmv_groupnorm_stats(const VmvGroupNormParams* p, void* stream);

@@ -95,6 +95,8 @@ def groupnorm_stats(p: L.GroupNormParams):
         blk = xg[:, c * p.chunk_rows:(c + 1) * p.chunk_rows]
         part[:, c, :, 0] = blk.sum(dim=(1, 3))
         part[:, c, :, 1] = (blk * blk).sum(dim=(1, 3))
+    if p.totals:
+        _view(p.totals, nstat * 64, "f32").view(nstat, 32, 2).copy_(part.sum(dim=1))
 
 
 def groupnorm(p: L.GroupNormParams):
@@ -103,7 +105,10 @@ def groupnorm(p: L.GroupNormParams):
     nstat = p.rows // p.rows_per_stat
     nchunk = (p.rows_per_stat + p.chunk_rows - 1) // p.chunk_rows
     R = max(1, p.fold_ranks)
-    part = _view(p.partial, R * nstat * nchunk * 64, "f32").view(R, nstat, nchunk, 32, 2).double().sum(dim=(0, 2))
+    if p.totals:
+        part = _view(p.totals, R * nstat * 64, "f32").view(R, nstat, 32, 2).double().sum(dim=0)
+    else:
+        part = _view(p.partial, R * nstat * nchunk * 64, "f32").view(R, nstat, nchunk, 32, 2).double().sum(dim=(0, 2))
     n = float(p.rows_per_stat) * (Cc // 32) * R
     mean = part[..., 0] / n
     var = (part[..., 1] / n - mean * mean).clamp_min(0.0)

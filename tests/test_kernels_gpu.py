@@ -231,6 +231,22 @@ def test_groupnorm(rows, rps, C0, C1, silu, eps):
     check(dev["y"], cpu["y"], tol_l2=5e-3, tol_max=1.5e-2)
 
 
+@pytest.mark.parametrize("rows,rps,Cc,silu", [(2 * 61440, 61440, 320, True), (2 * 960, 960, 1280, False), (3 * 500, 500, 64, True)])
+def test_groupnorm_prefolded_totals(rows, rps, Cc, silu):
+    """Long stat groups (the all-frame norms): a one-block fold after the stats writes totals[stat][32][2]; apply reads
+    the totals.  Must equal the plain two-launch path bit for bit (same fold order)."""
+    x = rnd((rows, Cc), 21, 1.3).cuda() + 0.1
+    gamma, beta = (1 + 0.1 * torch.randn(Cc, generator=g(3))).cuda(), (0.1 * torch.randn(Cc, generator=g(4))).cuda()
+    part = torch.zeros(ops.gn_partial_floats(rows, rps, Cc) + 64, device="cuda")
+    tot = torch.zeros(64 * 64, device="cuda")
+    y0, y1 = torch.zeros(rows, Cc, dtype=BF, device="cuda"), torch.zeros(rows, Cc, dtype=BF, device="cuda")
+    S = ops.Stream(record=False)
+    S.groupnorm(ops.gn_params(x, Cc, Cc, rows, rps, part, gamma, beta, 1e-5, silu, y0, Cc))
+    S.groupnorm(ops.gn_params(x, Cc, Cc, rows, rps, part, gamma, beta, 1e-5, silu, y1, Cc, totals=tot))
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+
+
 @pytest.mark.parametrize("R,B,rps_loc,Cc", [(2, 2, 96, 320), (8, 2, 15, 1280), (4, 1, 640, 64)])
 def test_groupnorm_sharded_statistics(R, B, rps_loc, Cc):
     """Frame-parallel 5-D norm: R ranks each hold rps_loc rows of every stat group; stats per shard, partial sums gathered
@@ -254,6 +270,18 @@ def test_groupnorm_sharded_statistics(R, B, rps_loc, Cc):
     torch.cuda.synchronize()
     got = torch.cat([y.view(B, rps_loc, Cc) for y in ys], dim=1)
     check(got, ref.to(BF), tol_l2=5e-3, tol_max=3e-2)
+    # the same through pre-folded totals: every "rank" folds its own chunks, the [R][B][32][2] totals are "gathered"
+    tot_all = torch.zeros(R * B * 64, device="cuda")
+    ys2 = [torch.zeros(B * rps_loc, Cc, dtype=BF, device="cuda") for _ in range(R)]
+    for r in range(R):
+        S.groupnorm_stats(ops.gn_params(xd[r], Cc, Cc, B * rps_loc, rps_loc, part_all, gd, bd, 1e-5, True, ys2[r], Cc,
+                                        totals=tot_all[r * B * 64:]))
+    for r in range(R):
+        S.groupnorm_apply(ops.gn_params(xd[r], Cc, Cc, B * rps_loc, rps_loc, part_all, gd, bd, 1e-5, True, ys2[r], Cc,
+                                        fold_ranks=R, totals=tot_all))
+    torch.cuda.synchronize()
+    got2 = torch.cat([y.view(B, rps_loc, Cc) for y in ys2], dim=1)
+    check(got2, ref.to(BF), tol_l2=5e-3, tol_max=3e-2)
 
 
 def test_permute_copy_matches_torch():

@@ -43,7 +43,8 @@ class GroupNormParams(C.Structure):
     _fields_ = [("x", C.c_void_p), ("x1", C.c_void_p), ("ld", C.c_int32), ("ld1", C.c_int32),
                 ("C0", C.c_int32), ("C1", C.c_int32), ("rows", C.c_int32), ("rows_per_stat", C.c_int32),
                 ("chunk_rows", C.c_int32), ("partial", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
-                ("eps", C.c_float), ("silu", C.c_int32), ("y", C.c_void_p), ("ldy", C.c_int32), ("fold_ranks", C.c_int32)]
+                ("eps", C.c_float), ("silu", C.c_int32), ("y", C.c_void_p), ("ldy", C.c_int32), ("fold_ranks", C.c_int32),
+                ("totals", C.c_void_p)]
 
 
 class GsParams(C.Structure):

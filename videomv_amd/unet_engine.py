@@ -213,7 +213,9 @@ class UNetEngine:
         self._keepalive = []
         self._ws = None
         self._gnws = torch.empty(4 << 20, dtype=torch.float32, device=device)
-        self._gnws_all = torch.empty((4 << 20) * self.R, dtype=torch.float32, device=device) if comm is not None else None
+        # pre-folded statistics of the all-frame norms: [nstat][32][2] per rank (+ the gathered [R][nstat][32][2]), tickets
+        self._gn_tot = torch.zeros(64 * 64, dtype=torch.float32, device=device)
+        self._gn_tot_all = torch.zeros(64 * 64 * self.R, dtype=torch.float32, device=device) if comm is not None else None
         self.taps = taps            # optional dict: prefix -> Act (buffers are then never recycled)
         self.n_t = n_t
         self.dim = cfg["dim"]
@@ -371,20 +373,22 @@ class UNetEngine:
         y = self.act(rows, C)
         nfl = ops.gn_partial_floats(rows, rows_per_stat, C)
         assert nfl <= self._gnws.numel()
-        kw = dict(x1=srcs[1].ptr if C1 else None, ld1=srcs[1].C if C1 else 0, C1=C1)
-        if self.comm is None or not all_frames:
-            p = ops.gn_params(srcs[0].ptr, srcs[0].C, C0, rows, rows_per_stat, self._gnws, self.w[wkey + ".weight"],
-                              self.w[wkey + ".bias"], eps, silu, y.ptr, C, **kw)
-            self.S.groupnorm(p, label)
+        nstat = rows // rows_per_stat
+        base = dict(x1=srcs[1].ptr if C1 else None, ld1=srcs[1].C if C1 else 0, C1=C1)
+        args = (srcs[0].ptr, srcs[0].C, C0, rows, rows_per_stat, self._gnws, self.w[wkey + ".weight"], self.w[wkey + ".bias"],
+                eps, silu, y.ptr, C)
+        if not all_frames:
+            self.S.groupnorm(ops.gn_params(*args, **base), label)
             return y
-        p = ops.gn_params(srcs[0].ptr, srcs[0].C, C0, rows, rows_per_stat, self._gnws, self.w[wkey + ".weight"],
-                          self.w[wkey + ".bias"], eps, silu, y.ptr, C, **kw)
-        self.S.groupnorm_stats(p, label)
-        loc, allr = self._gnws[:nfl], self._gnws_all[: nfl * self.R]
+        # all-frame norm: up to 256 chunks per stat group -> a one-block fold after the stats folds them once (pre-folded totals)
+        assert nstat <= 64
+        if self.comm is None:
+            self.S.groupnorm(ops.gn_params(*args, totals=self._gn_tot, **base), label)
+            return y
+        self.S.groupnorm_stats(ops.gn_params(*args, totals=self._gn_tot, **base), label)
+        loc, allr = self._gn_tot[: nstat * 64], self._gn_tot_all[: nstat * 64 * self.R]
         self._break(lambda: self.comm.all_gather(allr, loc))
-        p2 = ops.gn_params(srcs[0].ptr, srcs[0].C, C0, rows, rows_per_stat, self._gnws_all, self.w[wkey + ".weight"],
-                           self.w[wkey + ".bias"], eps, silu, y.ptr, C, fold_ranks=self.R, **kw)
-        self.S.groupnorm_apply(p2, label)
+        self.S.groupnorm_apply(ops.gn_params(*args, totals=self._gn_tot_all, fold_ranks=self.R, **base), label)
         return y
 
     # ------------------------------------------------------------------ frame-parallel layout switches
