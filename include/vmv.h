@@ -111,6 +111,9 @@ typedef struct {
 #define VMV_TILE_PP256x160 12
 #define VMV_TILE_Q128x128 13   /* persistent, 4 waves, 2-stage ring, TWO blocks per CU (gemm_pglds.hip) */
 #define VMV_TILE_Q96x160  14
+#define VMV_TILE_S256x128 15   /* persistent, wave-specialised: 8 MFMA waves + 4 LDS-DMA loader waves (gemm_sglds.hip) */
+#define VMV_TILE_S192x160 16
+#define VMV_TILE_S256x160 17
 
 int vmv_gemm_bf16(const VmvGemmParams* p, void* stream);
 

@@ -50,9 +50,10 @@ class Case:
         return {k: (v.clone().to(dev).contiguous() if isinstance(v, torch.Tensor) else v) for k, v in self.t.items()}
 
 
-def run_gemm(build, case, out_keys=("out",)):
+def run_gemm(build, case, out_keys=("out",), cpu_ref=True):
     cpu = case.on("cpu")
-    I.gemm(build(cpu))
+    if cpu_ref:                       # (the big multi-tile cases check against torch ops instead of the slow interpreter)
+        I.gemm(build(cpu))
     dev = case.on("cuda")
     S = ops.Stream(record=False)
     S.gemm(build(dev), "test")
@@ -82,7 +83,14 @@ def run_gemm(build, case, out_keys=("out",)):
                                         (300, 320, 64, L.TILE_Q96x160), (257, 128, 192, L.TILE_Q128x128),
                                         (513, 200, 72, L.TILE_Q128x128), (2000, 1280, 1280, L.TILE_Q96x160),
                                         (70000, 320, 320, L.TILE_Q96x160), (70000, 384, 128, L.TILE_Q128x128),
-                                        (66000, 160, 64, L.TILE_Q96x160)])
+                                        (66000, 160, 64, L.TILE_Q96x160),
+                                        (640, 640, 640, L.TILE_S256x128), (1000, 960, 320, L.TILE_S192x160),
+                                        (300, 320, 64, L.TILE_S192x160), (257, 128, 192, L.TILE_S256x128),
+                                        (513, 200, 72, L.TILE_S256x128), (2000, 1280, 1280, L.TILE_S192x160),
+                                        (70000, 320, 320, L.TILE_S192x160), (70000, 384, 128, L.TILE_S256x128),
+                                        (66000, 160, 64, L.TILE_S192x160), (1000, 960, 320, L.TILE_S256x160),
+                                        (70000, 320, 320, L.TILE_S256x160), (2000, 1280, 1280, L.TILE_S256x160),
+                                        (66000, 100, 72, L.TILE_S256x160)])
 def test_gemm_linear_bias(M, N, K, tile):
     c = Case(a=rnd((M, K), 1), w=rnd((N, K), 2, K ** -0.5), b=torch.randn(N, generator=g(3)), out=torch.zeros(M, N, dtype=BF))
 
@@ -92,7 +100,7 @@ def test_gemm_linear_bias(M, N, K, tile):
     check(dev["out"], cpu["out"])
 
 
-@pytest.mark.parametrize("tile", [0, L.TILE_256x160, L.TILE_G128x160, L.TILE_P256x160, L.TILE_PP256x160, L.TILE_Q96x160])
+@pytest.mark.parametrize("tile", [0, L.TILE_256x160, L.TILE_G128x160, L.TILE_P256x160, L.TILE_PP256x160, L.TILE_Q96x160, L.TILE_S192x160, L.TILE_S256x160])
 def test_gemm_fp32_out_rowvec_act_residual(tile):
     M, N, K = 384, 320, 128
     c = Case(a=rnd((M, K), 1), w=rnd((N, K), 2, K ** -0.5), b=torch.randn(N, generator=g(3)),
@@ -106,7 +114,7 @@ def test_gemm_fp32_out_rowvec_act_residual(tile):
     check(dev["out"], cpu["out"], tol_l2=1e-3, tol_max=2e-3)
 
 
-@pytest.mark.parametrize("tile", [0, L.TILE_256x128, L.TILE_G128x128, L.TILE_P256x128, L.TILE_PP256x128, L.TILE_Q128x128])
+@pytest.mark.parametrize("tile", [0, L.TILE_256x128, L.TILE_G128x128, L.TILE_P256x128, L.TILE_PP256x128, L.TILE_Q128x128, L.TILE_S256x128])
 def test_gemm_geglu(tile):
     M, I2, K = 200, 512, 128        # 2*I = 512 rows -> 256 outputs
     w = rnd((I2, K), 2, K ** -0.5)
@@ -124,7 +132,7 @@ def test_gemm_geglu(tile):
     check(dev["out"], x * torch.nn.functional.gelu(gate))
 
 
-@pytest.mark.parametrize("tile", [0, L.TILE_256x128, L.TILE_G128x128, L.TILE_P256x128, L.TILE_PP256x128, L.TILE_Q128x128])
+@pytest.mark.parametrize("tile", [0, L.TILE_256x128, L.TILE_G128x128, L.TILE_P256x128, L.TILE_PP256x128, L.TILE_Q128x128, L.TILE_S256x128, L.TILE_S192x160, L.TILE_S256x160])
 @pytest.mark.parametrize("stride,ups,two_src,skip", [(1, 0, False, False), (2, 0, False, False), (1, 1, False, False),
                                                      (1, 0, True, True)])
 def test_gemm_conv3x3(stride, ups, two_src, skip, tile):
@@ -163,7 +171,7 @@ def test_gemm_conv3x3(stride, ups, two_src, skip, tile):
     check(dev["out"], ref.permute(0, 2, 3, 1).reshape(M, N))
 
 
-@pytest.mark.parametrize("tile", [0, L.TILE_256x128, L.TILE_G128x128, L.TILE_P256x128, L.TILE_PP256x128, L.TILE_Q128x128])
+@pytest.mark.parametrize("tile", [0, L.TILE_256x128, L.TILE_G128x128, L.TILE_P256x128, L.TILE_PP256x128, L.TILE_Q128x128, L.TILE_S256x128, L.TILE_S192x160, L.TILE_S256x160])
 def test_gemm_temporal_conv_residual(tile):
     Bn, F_, Pp, Cc = 2, 5, 24, 64
     M = Bn * F_ * Pp
@@ -182,7 +190,7 @@ def test_gemm_temporal_conv_residual(tile):
     check(dev["out"], ref)
 
 
-@pytest.mark.parametrize("tile", [0, L.TILE_256x128, L.TILE_G128x128, L.TILE_P256x128, L.TILE_PP256x128, L.TILE_Q128x128])
+@pytest.mark.parametrize("tile", [0, L.TILE_256x128, L.TILE_G128x128, L.TILE_P256x128, L.TILE_PP256x128, L.TILE_Q128x128, L.TILE_S256x128, L.TILE_S192x160, L.TILE_S256x160])
 @pytest.mark.parametrize("ks", [2, 5])
 def test_gemm_splitk(ks, tile):
     M, N, K = 200, 256, 1280
@@ -194,6 +202,64 @@ def test_gemm_splitk(ks, tile):
                                residual=t["res"], ldr=N, ksplit=ks, workspace=t["ws"], tile=tile)
     cpu, dev = run_gemm(build, c)
     check(dev["out"], cpu["out"])
+
+
+@pytest.mark.parametrize("tile", [L.TILE_S256x128, L.TILE_S192x160, L.TILE_S256x160, L.TILE_256x160])
+def test_gemm_conv3x3_many_tiles(tile):
+    """>= 2 tiles per persistent block (M = 2*24*40*64/2 rows), residual + per-image row vector, two sources + 1x1 skip."""
+    n, IH, IW, C0, C1, N = 24, 40, 64, 64, 32, 320
+    Cin = C0 + C1
+    M = n * IH * IW
+    wt = torch.randn(N, Cin, 3, 3, generator=g(2)) * (9 * Cin) ** -0.5
+    ws = torch.randn(N, Cin, generator=g(7)) * Cin ** -0.5
+    wp = torch.cat([wt.permute(0, 2, 3, 1).reshape(N, -1), ws], dim=1)
+    c = Case(x0=rnd((M, C0), 1), x1=rnd((M, C1), 4), w=wp.to(BF), b=torch.randn(N, generator=g(3)),
+             rv=torch.randn(n, N, generator=g(8)), out=torch.zeros(M, N, dtype=BF))
+
+    def build(t):
+        srcs = [(t["x0"], C0, C0), (t["x1"], C1, C1)]
+        return ops.gemm_params(M, N, ops.conv3x3_segs(srcs) + ops.linear_segs(srcs), t["w"], t["out"], N, bias=t["b"],
+                               rowvec=t["rv"], rowvec_div=IH * IW, rowvec_ld=N,
+                               geom=ops.Geom(OH=IH, OW=IW, IH=IH, IW=IW), tile=tile)
+    cpu, dev = run_gemm(build, c, cpu_ref=False)
+    x = torch.cat([cpu["x0"].float(), cpu["x1"].float()], dim=1)
+    img = x.view(n, IH, IW, Cin).permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(img, wt.to(BF).float(), cpu["b"], padding=1)
+    ref = ref + torch.nn.functional.conv2d(img, ws.to(BF).float()[:, :, None, None]) + cpu["rv"][:, :, None, None]
+    check(dev["out"], ref.permute(0, 2, 3, 1).reshape(M, N))
+
+
+@pytest.mark.parametrize("tile", [L.TILE_S256x128, L.TILE_S192x160, L.TILE_S256x160])
+def test_gemm_temporal_conv_many_tiles(tile):
+    Bn, F_, Pp, Cc = 2, 24, 1280, 320
+    M = Bn * F_ * Pp
+    wt = torch.randn(Cc, Cc, 3, 1, 1, generator=g(2)) * (3 * Cc) ** -0.5
+    c = Case(x=rnd((M, Cc), 1), w=P.pack_tconv(wt, "cpu"), b=torch.randn(Cc, generator=g(3)), res=rnd((M, Cc), 5),
+             out=torch.zeros(M, Cc, dtype=BF))
+
+    def build(t):
+        return ops.gemm_params(M, Cc, ops.temporal_segs(t["x"], Cc, Cc), t["w"], t["out"], Cc, bias=t["b"],
+                               geom=ops.Geom(F=F_, P=Pp), residual=t["res"], ldr=Cc, tile=tile)
+    cpu, dev = run_gemm(build, c, cpu_ref=False)
+    x5 = cpu["x"].float().view(Bn, F_, Pp, Cc).permute(0, 3, 1, 2)[..., None]
+    ref = torch.nn.functional.conv3d(x5, wt.to(BF).float(), cpu["b"], padding=(1, 0, 0))
+    ref = ref[..., 0].permute(0, 2, 3, 1).reshape(M, Cc) + cpu["res"].float()
+    check(dev["out"], ref)
+
+
+def test_gemm_geglu_many_tiles():
+    M, I2, K = 70000, 1280, 320
+    w = rnd((I2, K), 2, K ** -0.5)
+    b = torch.randn(I2, generator=g(3))
+    c = Case(a=rnd((M, K), 1), w=P.geglu_interleave(w), b=P.geglu_interleave(b), out=torch.zeros(M, I2 // 2, dtype=BF))
+
+    def build(t):
+        return ops.gemm_params(M, I2, ops.linear_segs([(t["a"], K, K)]), t["w"], t["out"], I2 // 2, bias=t["b"],
+                               epilogue=L.EPI_GEGLU, tile=L.TILE_S256x128)
+    cpu, dev = run_gemm(build, c, cpu_ref=False)
+    h = cpu["a"].float() @ w.float().t() + b
+    x, gate = h.chunk(2, dim=-1)
+    check(dev["out"], x * torch.nn.functional.gelu(gate))
 
 
 def test_gemm_rejects_bad_arguments():

@@ -7,7 +7,7 @@ import torch
 from videomv_amd import _lib as L, ops
 
 BF = torch.bfloat16
-N160 = (L.TILE_128x160, L.TILE_256x160, L.TILE_G128x160, L.TILE_P256x160, L.TILE_PP256x160, L.TILE_Q96x160)
+N160 = (L.TILE_128x160, L.TILE_256x160, L.TILE_G128x160, L.TILE_P256x160, L.TILE_PP256x160, L.TILE_Q96x160, L.TILE_S192x160, L.TILE_S256x160)
 
 
 def bench(fn, reps=20):
@@ -35,7 +35,10 @@ def main():
         ("conv L1 640->640", M1, 640, 640, "conv"), ("tcnv L1 640", M1, 640, 640, "tconv"),
         ("conv L2 1280", M2, 1280, 1280, "conv"),
     ]
+    flt = os.environ.get("VMV_BENCH_SHAPES", "")
     for name, M, N, C, kind in shapes:
+        if flt and not any(f in name for f in flt.split(",")):
+            continue
         x = torch.randn(M, C, device=dev).to(BF)
         kw = {}
         No = N
@@ -59,7 +62,7 @@ def main():
         for tile in tiles:
             if tile in N160 and (N % 160 or kind == "geglu"):
                 line += "      -    "; continue
-            stamps = torch.zeros(4 * 64, dtype=torch.int64, device=dev) if os.environ.get("VMV_GEMM_ABLATE") in ("4", "7", "8") else None
+            stamps = torch.zeros(8 * 64, dtype=torch.int64, device=dev) if os.environ.get("VMV_GEMM_ABLATE") in ("4", "7", "8") else None
             p = ops.gemm_params(M, N, segs, w, out, No, bias=b, geom=geom, tile=tile, workspace=stamps, **kw)
             ms = bench(lambda: S.gemm(p))
             line += f" t{tile}:{2.0 * M * N * K / ms / 1e9:7.1f}"
@@ -74,7 +77,12 @@ def main():
                 elif len(t):
                     base = int(t[0, 0])
                     rows = [" ".join(f"{int(v) - base:7d}" for v in r) for r in t[:6]]
-                    line += "\n      stamps(block0; tile start / loop done / epi start / epi end, 100MHz ticks?):\n      " + "\n      ".join(rows)
+                    line += "\n      stamps(block0; tile start / loop done / epi start / epi end):\n      " + "\n      ".join(rows)
+            if stamps is not None and tile in (L.TILE_S256x128, L.TILE_S192x160, L.TILE_S256x160):
+                t = stamps.cpu().view(-1, 8)[:int(os.environ.get("VMV_STAMP_ROWS", "40"))]
+                base = int(t[0, 0])
+                line += "\n   chunk: loader[before wait, after wait, after B, after issue]  mfma[before B, after B]\n   " + \
+                        "\n   ".join(f"{i:3d}: " + " ".join(f"{int(v) - base:7d}" for v in r[:6]) for i, r in enumerate(t))
         print(line, flush=True)
 
 

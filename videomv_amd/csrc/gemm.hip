@@ -21,6 +21,7 @@ using namespace vmv_gemm;
 
 int vmv_gemm_glds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st);   // gemm_glds.hip
 int vmv_gemm_pglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st);  // gemm_pglds.hip
+int vmv_gemm_sglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st);  // gemm_sglds.hip
 
 namespace {
 
@@ -275,6 +276,17 @@ int pick_tile(const VmvGemmParams& p, int total_steps) {
     if (gemm_policy() >= 1 && p.ksplit > 1 && p.M > 64 && (best == VMV_TILE_128x128 || best == VMV_TILE_128x160))
         // split-K (small-M levels): the 4-wave LDS-DMA kernel instead of the register-staged one (same 128-row tiles)
         best = best == VMV_TILE_128x128 ? VMV_TILE_G128x128 : VMV_TILE_G128x160;
+    if (gemm_policy() >= 3 && p.ksplit <= 1 && !geglu && p.N % 160 == 0) {
+        // wave-specialised persistent kernel (gemm_sglds.hip): 8 MFMA waves + 4 loader waves per CU.  Measured against every
+        // other variant (tools/gemm_bench.py) it wins wherever its static round-robin over the 256 CUs is
+        // balanced: +15-25 % on the L0 convs / temporal convs, +3-10 % on the L0 / L1 linears; it loses when the tile count
+        // leaves the last round mostly empty (L2: 320 tiles = 1.25 rounds).
+        const long items = (long)((p.M + 191) / 192) * (p.N / 160);
+        const long rounds = (items + 255) / 256;
+        bool any_gather = false;
+        for (int i = 0; i < p.nseg; ++i) any_gather = any_gather || p.seg[i].mode != VMV_SEG_LINEAR;
+        if (items >= 256 && (double)items / (double)(rounds * 256) >= 0.8 && (gemm_policy() == 3 || any_gather)) return VMV_TILE_S192x160;
+    }
     if (gemm_policy() >= 1 && p.ksplit <= 1 && (best == VMV_TILE_128x128 || best == VMV_TILE_128x160)) {
         // the 256-row kernel runs one block per CU: use it when its grid still fills the 256 CUs well
         const int bn = best == VMV_TILE_128x128 ? 128 : 160;
@@ -329,7 +341,8 @@ extern "C" int vmv_gemm_bf16(const VmvGemmParams* pp, void* stream) {
     if ((long)p.M * (long)maxld >= (1L << 31) || (long)p.N * (long)p.ktot >= (1L << 31)) return VMV_ERANGE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc;
-    switch (pick_tile(p, total_steps)) {
+    const int picked = pick_tile(p, total_steps);
+    switch (picked) {
         case VMV_TILE_128x128: rc = launch_cfg<4, 4>(p, total_steps, st); break;
         case VMV_TILE_128x160:
             if (p.epilogue == VMV_EPI_GEGLU) return VMV_EINVAL;
@@ -342,6 +355,17 @@ extern "C" int vmv_gemm_bf16(const VmvGemmParams* pp, void* stream) {
             break;
         case VMV_TILE_256x160:
             rc = vmv_gemm_glds_launch(p, total_steps, VMV_TILE_256x160, st);
+            if (rc == VMV_GLDS_UNSUPPORTED) rc = launch_cfg<4, 5>(p, total_steps, st);
+            break;
+        case VMV_TILE_S256x128:
+            rc = vmv_gemm_sglds_launch(p, total_steps, VMV_TILE_S256x128, st);
+            if (rc == VMV_GLDS_UNSUPPORTED) rc = vmv_gemm_glds_launch(p, total_steps, VMV_TILE_256x128, st);
+            if (rc == VMV_GLDS_UNSUPPORTED) rc = launch_cfg<4, 4>(p, total_steps, st);
+            break;
+        case VMV_TILE_S192x160:
+        case VMV_TILE_S256x160:
+            rc = vmv_gemm_sglds_launch(p, total_steps, picked, st);
+            if (rc == VMV_GLDS_UNSUPPORTED) rc = vmv_gemm_glds_launch(p, total_steps, VMV_TILE_256x160, st);
             if (rc == VMV_GLDS_UNSUPPORTED) rc = launch_cfg<4, 5>(p, total_steps, st);
             break;
         case VMV_TILE_Q128x128:

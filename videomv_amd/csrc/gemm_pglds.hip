@@ -46,9 +46,9 @@ struct PgCfg {
     static_assert(BM % (8 * NW) == 0, "A rows split evenly over the waves");
 };
 
-template <int NWM, int WM, int WN, int ablate>
+template <int NWM, int WM, int WN, int ablate, bool IL>
 __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel(const VmvGemmParams p, const int tiles_n, const int total_steps,
-                                                         const int nitems) {
+                                                         const int nitems, const int panel_order) {
     using Cfg = PgCfg<NWM, WM, WN>;
     constexpr int BN = Cfg::BN;
     constexpr int BM = Cfg::BM;
@@ -65,7 +65,18 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
 
     auto item_tile = [&](int v, int& m0, int& n0) {      // XCD-aware bijection item -> tile (see gemm_glds.hip)
         const int q = nitems >> 3, r = nitems & 7;
-        const int xcd = v & 7, idx = v >> 3;
+        const int xcd = v & 7;
+        int idx = v >> 3;
+        if (panel_order) {
+            // Panels of 8 tile rows (8 * tiles_n consecutive tiles of this XCD's range): CU j of the XCD (idx = 32 round + j)
+            // keeps row j % 8 for the whole panel and walks its columns 4 at a time with the three CUs that share the row, so
+            // an A tile is fetched from HBM once per panel and re-read from L2 by the following rounds — in plain order every
+            // round of an XCD starts on fresh rows and each chunk of every tile waits for an HBM miss.
+            const int qx = q + (xcd < r ? 1 : 0);
+            const int P = 8 * tiles_n;
+            const int pb = (idx / P) * P, l = idx - pb;
+            if (pb + P <= qx) idx = pb + (l & 7) * tiles_n + (l >> 3);
+        }
         const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
         const int tn = logical % tiles_n;
         m0 = (logical / tiles_n) * BM;
@@ -112,27 +123,38 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
         L_left = total_steps;
         enter_segment();
     };
-    auto issue_one = [&]() {                 // LDS-DMA the loader's next chunk into ring slot `islot`
+    // One chunk = LPT wave-instructions ("pieces": NAI of A, then NWI of W).  issue_one() sends them in a burst; the
+    // interleaved main loop (IL) sends them one at a time between MFMAs, half a chunk per MFMA phase: the texture path
+    // accepts one 1-KB wave-instruction every ~26 cycles per CU (tools/experiments/lds_dma_rate.hip: 91 GB/s per CU with 8
+    // waves), so a burst of 8 x LPT instructions after a barrier parks every wave in its issue slot for ~500 cycles with
+    // the MFMA pipes idle.
+    struct ChunkCtx {
+        __amdgpu_buffer_rsrc_t a_rsrc;
+        unsigned char* abase;
+        unsigned char* wbase;
+        uint32_t a_so, w_so;
+        bool kall;           // lane's 16 bytes lie inside the segment's K range
+    };
+    auto chunk_ctx = [&]() -> ChunkCtx {
         const VmvGemmSeg& sg = p.seg[s];
-        const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(sg.src), 0, SRD_RECORDS, SRD_FLAGS);
-        const bool ktail = (kc + BK) > sg.k;
-        const bool kvalid = (kc + lsw * 8) < sg.k;
-        unsigned char* abase = smem + islot * Cfg::STAGE_BYTES + wave * 1024;
-        unsigned char* wbase = smem + islot * Cfg::STAGE_BYTES + Cfg::A_BYTES;
-        const uint32_t a_so = (uint32_t)kc * 2u, w_so = (uint32_t)(koff + kc) * 2u;
+        ChunkCtx c;
+        c.a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(sg.src), 0, SRD_RECORDS, SRD_FLAGS);
+        c.kall = (kc + BK) <= sg.k || (kc + lsw * 8) < sg.k;
+        c.abase = smem + islot * Cfg::STAGE_BYTES + wave * 1024;
+        c.wbase = smem + islot * Cfg::STAGE_BYTES + Cfg::A_BYTES;
+        c.a_so = (uint32_t)kc * 2u;
+        c.w_so = (uint32_t)(koff + kc) * 2u;
+        return c;
+    };
+    auto issue_piece = [&](const ChunkCtx& c, const int q) {      // q: compile-time after unrolling
         if constexpr (ablate != 2) {
-            if (!ktail) {
-#pragma unroll
-                for (int i = 0; i < Cfg::NAI; ++i) VMV_BLDS16(a_rsrc, abase + i * (NW * 1024), avo[i], a_so);
-#pragma unroll
-                for (int j = 0; j < Cfg::NWI; ++j) VMV_BLDS16(w_rsrc, wbase + wgrp[j] * 1024, wvo[j], w_so);
-            } else {
-#pragma unroll
-                for (int i = 0; i < Cfg::NAI; ++i) VMV_BLDS16(a_rsrc, abase + i * (NW * 1024), kvalid ? avo[i] : OOB, a_so);
-#pragma unroll
-                for (int j = 0; j < Cfg::NWI; ++j) VMV_BLDS16(w_rsrc, wbase + wgrp[j] * 1024, kvalid ? wvo[j] : OOB, w_so);
-            }
+            if (q < Cfg::NAI) VMV_BLDS16(c.a_rsrc, c.abase + q * (NW * 1024), c.kall ? avo[q < Cfg::NAI ? q : 0] : OOB, c.a_so);
+            else VMV_BLDS16(w_rsrc, c.wbase + wgrp[q >= Cfg::NAI ? q - Cfg::NAI : 0] * 1024,
+                            c.kall ? wvo[q >= Cfg::NAI ? q - Cfg::NAI : 0] : OOB, c.w_so);
         }
+    };
+    auto advance_chunk = [&]() {
+        const VmvGemmSeg& sg = p.seg[s];
         islot = islot + 1 == S ? 0 : islot + 1;
         kc += BK;
         --L_left;
@@ -144,6 +166,12 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
             L_item += G;
             if (L_item < nitems) setup_item(L_item);
         }
+    };
+    auto issue_one = [&]() {                 // LDS-DMA the loader's next chunk into ring slot `islot` (burst)
+        const ChunkCtx c = chunk_ctx();
+#pragma unroll
+        for (int q = 0; q < Cfg::LPT; ++q) issue_piece(c, q);
+        advance_chunk();
     };
 
     // ------------------------------------------------------------------ MFMA side
@@ -176,6 +204,37 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
                 acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
     };
 
+    // One MFMA phase of the interleaved loop: the WM*WN MFMAs on (af, wf), with the WM+WN fragment reads of the NEXT phase
+    // (slot_n, kk_n -> afn, wfn) and pieces [Q0, Q1) of the chunk being loaded spread evenly between them.
+    constexpr int NM = WM * WN, NRD = WM + WN;
+    auto phase = [&](const bf16x8_t (&af)[WM], const bf16x8_t (&wf)[WN], bf16x8_t (&afn)[WM], bf16x8_t (&wfn)[WN],
+                     const int slot_n, const int kk_n, const bool dma, const ChunkCtx& cx, auto q0_tag, auto q1_tag) {
+        constexpr int Q0 = decltype(q0_tag)::value, Q1 = decltype(q1_tag)::value, ND = Q1 - Q0;
+        const u32x4_t* a = reinterpret_cast<const u32x4_t*>(smem + slot_n * Cfg::STAGE_BYTES) + (wave_m * 16 * WM + frow) * 8;
+        const u32x4_t* w = reinterpret_cast<const u32x4_t*>(smem + slot_n * Cfg::STAGE_BYTES + Cfg::A_BYTES) +
+                           (wave_n * 16 * WN + frow) * 8;
+        const int slot = (kk_n * 4 + fgrp) ^ fswz;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int j = m / WM, i = m % WM;
+            if constexpr (ablate != 1) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < NRD; ++r)
+                if (((2 * r + 1) * NM) / (2 * NRD) == m) {
+                    if constexpr (ablate != 1) {
+                        if (r < WM) afn[r < WM ? r : 0] = __builtin_bit_cast(bf16x8_t, a[(r < WM ? r : 0) * 16 * 8 + slot]);
+                        else wfn[r >= WM ? r - WM : 0] = __builtin_bit_cast(bf16x8_t, w[(r >= WM ? r - WM : 0) * 16 * 8 + slot]);
+                    }
+                }
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+                if (((2 * d + 1) * NM) / (2 * ND) == m) {
+                    if (dma) issue_piece(cx, Q0 + d);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
     // ------------------------------------------------------------------ per-wave epilogue through a private LDS slab
     const bool geglu = p.epilogue == VMV_EPI_GEGLU;
     const int N_out = geglu ? p.N / 2 : p.N;
@@ -193,7 +252,10 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
     // bias: staged per wave in the 512 B it owns behind the ring (keeps 4*WN registers out of the tile's last MFMAs);
     // residual: two 16-row groups in flight, refilled as soon as a group has been added to its rows
     float* bias_lds = reinterpret_cast<float*>(smem + S * Cfg::STAGE_BYTES + wave * 512);
-    u32x4_t resv[2][NR_MAX];
+    u32x4_t resv[2][NR_MAX];                  // residual: two 16-row groups in flight
+    u32x4_t sd_prev[NR_MAX];                  // store data of the last 16-row group written (see the epilogue)
+#pragma unroll
+    for (int r = 0; r < NR_MAX; ++r) sd_prev[r] = u32x4_t{0u, 0u, 0u, 0u};
     f32x4_t bias_hold = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, SRD_RECORDS, SRD_FLAGS);
     const __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual), 0, SRD_RECORDS, SRD_FLAGS);
@@ -332,6 +394,14 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_sched_barrier(0);
+            // Store-data discipline (found with gemm_sglds.hip, where 168 registers make the allocator reuse registers at
+            // once): an LDS read that RETURNS into a pending buffer_store's data registers corrupts the store when the store
+            // path is backed up.  So store data is always a VALU-written copy (`sd`), never an LDS-read destination, and the
+            // previous group's `sd` is kept alive (fake use) until this group's LDS reads — bias strip, slab — have returned.
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                if (i > 0) asm volatile("" ::"v"(sd_prev[r]));
+            u32x4_t sd[NR];
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 u32x4_t v = vout[r];
@@ -342,17 +412,29 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
                     for (int e = 0; e < 8; ++e) a[e] += res_scale * b[e];
                     v = pack8(a);
                 }
-                if constexpr (ablate != 7)
-                    __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, unit_offsets(m0, n0, i, r, p.ldo, geglu_tag), sb, 0);
-                else if (v.x == 0x12345u) bias_lds[lane] = 1.f;          // (keep the value alive)
+                asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                             : "=&v"(sd[r].x), "=&v"(sd[r].y), "=&v"(sd[r].z), "=&v"(sd[r].w)
+                             : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
             }
+            // The slot just consumed is refilled (group i + 2) BEFORE this group's stores: vmcnt retires in order, so a load
+            // issued behind stores can only be waited for together with them (a full write round trip).
             asm volatile("" ::: "memory");
-            if (has_res && i + 2 < WM) {                      // refill the slot just consumed with group i + 2
+            if (has_res && i + 2 < WM) {
                 const uint32_t sr = group_base(m0, n0, i + 2, p.ldr, geglu_tag);
 #pragma unroll
                 for (int r = 0; r < NR; ++r)
                     resv[i & 1][r] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, unit_offsets(m0, n0, i + 2, r, p.ldr, geglu_tag), sr, 0);
             }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                if constexpr (ablate != 7)
+                    __builtin_amdgcn_raw_buffer_store_b128(sd[r], out_rsrc, unit_offsets(m0, n0, i, r, p.ldo, geglu_tag), sb, 0);
+                else if (sd[r].x == 0x12345u) bias_lds[lane] = 1.f;          // (keep the value alive)
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r) sd_prev[r] = sd[r];
+            asm volatile("" ::: "memory");
         }
     };
 
@@ -368,6 +450,8 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
     int st = 0;                       // ring slot of the next chunk to consume
     bool first = true;
     bf16x8_t a0[WM], w0[WN], a1[WM], w1[WN];
+    bool pending = false;             // IL: the second half of a chunk's pieces is still to be issued
+    ChunkCtx cx = chunk_ctx();
     // ablate == 4 (experiments): block 0, wave 0 stamps s_memtime at {tile start, main loop done, epilogue start, epilogue
     // end} into p.workspace (uint64 x 4 per tile)
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(p.workspace);
@@ -388,12 +472,45 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
         asm volatile("" ::: "memory");
         if (!Cfg::DEDICATED && !first && issued < total) { issue_one(); ++issued; }   // the refill that the epilogue's slab delayed
         if constexpr (ablate != 1) read_frags(st, 0, a0, w0);
+        if (!first) {                             // the previous tile's last store data stays alive until these reads returned
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+            for (int r = 0; r < NR_MAX; ++r) asm volatile("" ::"v"(sd_prev[r]));
+        }
         // chunk consumed+1: with the 3-stage ring it was waited for before the previous epilogue; with the 2-stage ring it
         // was issued right before that epilogue, so exactly the epilogue's stores are younger than it
         bool known_landed = !first && S == 3;
         const int younger_stores = (!first && S == 2 && staged) ? WM * (geglu ? (16 * WN + 63) / 64 : (32 * WN + 63) / 64) : 0;
         int m0, n0;
         item_tile(item, m0, n0);
+        if constexpr (IL) {
+            constexpr int H0 = Cfg::LPT / 2;
+            using QA = std::integral_constant<int, 0>;
+            using QB = std::integral_constant<int, H0>;
+            using QC = std::integral_constant<int, Cfg::LPT>;
+            for (int t = 0; t + 1 < total_steps; ++t) {
+                phase(a0, w0, a1, w1, st, 1, pending, cx, QB{}, QC{});           // + second half of the chunk in flight
+                if (pending) { advance_chunk(); ++issued; pending = false; }
+                const int stn = st + 1 == S ? 0 : st + 1;
+                if (!known_landed) {
+                    if (issued - consumed >= 3) wait_vmcnt<Cfg::LPT>(); else wait_vmcnt<0>();
+                }
+                known_landed = false;
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_s_barrier();         // slot st is free, chunk consumed+1 is visible
+                asm volatile("" ::: "memory");
+                pending = issued < total;
+                if (pending) cx = chunk_ctx();
+                phase(a1, w1, a0, w0, stn, 0, pending, cx, QA{}, QB{});          // + first half of the next refill
+                st = stn;
+                ++consumed;
+            }
+            if (pending) {                            // tile boundary: the rest of the refill goes out in one piece
+#pragma unroll
+                for (int q = H0; q < Cfg::LPT; ++q) issue_piece(cx, q);
+                advance_chunk(); ++issued; pending = false;
+            }
+        } else
         for (int t = 0; t + 1 < total_steps; ++t) {
             if constexpr (ablate != 1) {
                 read_frags(st, 1, a1, w1);
@@ -472,21 +589,31 @@ int launch_pglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
     }
     static int ablate = -1;
     if (ablate < 0) { const char* e = getenv("VMV_GEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
+    static int order_env = -1;
+    if (order_env < 0) { const char* e = getenv("VMV_GEMM_ORDER"); order_env = e ? atoi(e) : 0; }
     const int slots = ncu * (NWM == 4 ? 1 : 2);
     const int G = nitems < slots ? nitems : slots;
     dim3 grid(G, 1, 1);
-    auto go = [&](auto tag) -> int {
+    const int order = (order_env == 1 && G == 256 && NWM == 4) ? 1 : 0;       // (the panel map assumes 32 single-block CUs per XCD)
+    static int il_env = -1;
+    if (il_env < 0) { const char* e = getenv("VMV_GEMM_IL"); il_env = e ? atoi(e) : 0; }
+    auto go_il = [&](auto tag, auto il_tag) -> int {
         constexpr int AB = decltype(tag)::value;
+        constexpr bool IL = decltype(il_tag)::value;
         static bool attr_set = false;
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pglds_kernel<NWM, WM, WN, AB>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pglds_kernel<NWM, WM, WN, AB, IL>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_TOTAL);
             if (e != hipSuccess) return (int)e;
             attr_set = true;
         }
-        hipLaunchKernelGGL((gemm_pglds_kernel<NWM, WM, WN, AB>), grid, dim3(Cfg::NT), Cfg::LDS_TOTAL, st, p, tiles_n, total_steps,
-                           nitems);
+        hipLaunchKernelGGL((gemm_pglds_kernel<NWM, WM, WN, AB, IL>), grid, dim3(Cfg::NT), Cfg::LDS_TOTAL, st, p, tiles_n, total_steps,
+                           nitems, order);
         return VMV_OK;
+    };
+    auto go = [&](auto tag) -> int {
+        if constexpr (NWM == 4) { if (il_env == 1) return go_il(tag, std::true_type{}); }
+        return go_il(tag, std::false_type{});
     };
     int rc;
     switch (ablate) {
