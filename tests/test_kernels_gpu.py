@@ -300,7 +300,7 @@ def test_groupnorm(rows, rps, C0, C1, silu, eps):
 @pytest.mark.parametrize("rows,rps,Cc,silu", [(2 * 61440, 61440, 320, True), (2 * 960, 960, 1280, False), (3 * 500, 500, 64, True)])
 def test_groupnorm_prefolded_totals(rows, rps, Cc, silu):
     """Long stat groups (the all-frame norms): a one-block fold after the stats writes totals[stat][32][2]; apply reads
-    the totals.  Must equal the plain two-launch path bit for bit (same fold order)."""
+    the totals.  Same statistics as the plain two-launch path up to fp32 summation order (a different fixed order)."""
     x = rnd((rows, Cc), 21, 1.3).cuda() + 0.1
     gamma, beta = (1 + 0.1 * torch.randn(Cc, generator=g(3))).cuda(), (0.1 * torch.randn(Cc, generator=g(4))).cuda()
     part = torch.zeros(ops.gn_partial_floats(rows, rps, Cc) + 64, device="cuda")
@@ -310,7 +310,11 @@ def test_groupnorm_prefolded_totals(rows, rps, Cc, silu):
     S.groupnorm(ops.gn_params(x, Cc, Cc, rows, rps, part, gamma, beta, 1e-5, silu, y0, Cc))
     S.groupnorm(ops.gn_params(x, Cc, Cc, rows, rps, part, gamma, beta, 1e-5, silu, y1, Cc, totals=tot))
     torch.cuda.synchronize()
-    assert torch.equal(y0, y1)
+    check(y1, y0.float().cpu(), tol_l2=1e-4, tol_max=2e-2)                  # (<= 1 bf16 ulp where the rounding flips)
+    y2 = torch.zeros_like(y1)
+    S.groupnorm(ops.gn_params(x, Cc, Cc, rows, rps, part, gamma, beta, 1e-5, silu, y2, Cc, totals=tot))
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2)                                           # deterministic
 
 
 @pytest.mark.parametrize("R,B,rps_loc,Cc", [(2, 2, 96, 320), (8, 2, 15, 1280), (4, 1, 640, 64)])

@@ -34,6 +34,9 @@ def main():
         ("conv L0 320->320", M0, 320, 320, "conv"), ("tcnv L0 320", M0, 320, 320, "tconv"),
         ("conv L1 640->640", M1, 640, 640, "conv"), ("tcnv L1 640", M1, 640, 640, "tconv"),
         ("conv L2 1280", M2, 1280, 1280, "conv"),
+        ("conv L3 1280", 1920, 1280, 1280, "conv"), ("conv L3 2560->1280", 1920, 1280, 2560, "conv"),
+        ("tcnv L3 1280", 1920, 1280, 1280, "tconv"), ("down L3 N1280 K5120", 1920, 1280, 5120, "linres"),
+        ("lin+res L3 N1280 K1280", 1920, 1280, 1280, "linres"),
     ]
     flt = os.environ.get("VMV_BENCH_SHAPES", "")
     for name, M, N, C, kind in shapes:
@@ -48,7 +51,7 @@ def main():
                 kw["epilogue"] = L.EPI_GEGLU; No = N // 2
         elif kind == "conv":
             K = 9 * C; segs = ops.conv3x3_segs([(x, C, C)])
-            hw = {M0: (40, 64), M1: (20, 32), M2: (10, 16)}[M]
+            hw = {M0: (40, 64), M1: (20, 32), M2: (10, 16), 1920: (5, 8)}[M]
             geom = ops.Geom(OH=hw[0], OW=hw[1], IH=hw[0], IW=hw[1])
         else:
             K = 3 * C; segs = ops.temporal_segs(x, C, C); geom = ops.Geom(F=24, P=M // 48)
@@ -63,6 +66,10 @@ def main():
             if tile in N160 and (N % 160 or kind == "geglu"):
                 line += "      -    "; continue
             stamps = torch.zeros(8 * 64, dtype=torch.int64, device=dev) if os.environ.get("VMV_GEMM_ABLATE") in ("4", "7", "8") else None
+            ks = int(os.environ.get("VMV_BENCH_KSPLIT", "0"))
+            if ks > 1:
+                stamps = torch.zeros(ks * M * N, device=dev)
+                kw["ksplit"] = ks
             p = ops.gemm_params(M, N, segs, w, out, No, bias=b, geom=geom, tile=tile, workspace=stamps, **kw)
             ms = bench(lambda: S.gemm(p))
             line += f" t{tile}:{2.0 * M * N * K / ms / 1e9:7.1f}"

@@ -77,14 +77,17 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const VmvGroupNormParams 
 // Pre-fold for long stat groups (the all-frame norms, up to 256 chunks): one block per stat group folds the chunks in
 // fixed order into totals[stat][32][2] — a ~3 us launch instead of every apply block re-reading nchunk * 64 floats.
 // (A last-block ticket inside gn_stats was measured 2.3x slower: the release fence per block costs more than this launch.)
-__global__ __launch_bounds__(256) void gn_fold_kernel(const VmvGroupNormParams p, const int nchunk) {
+__global__ __launch_bounds__(1024) void gn_fold_kernel(const VmvGroupNormParams p, const int nchunk) {
+    // 32 lanes per group; every lane sums its chunks (independent loads, all in flight at once), then a fixed-order
+    // shuffle tree: deterministic, ~2 memory round trips in total
     const int tid = threadIdx.x, stat = blockIdx.x;
-    const int g = tid >> 3, sub = tid & 7;
+    const int g = tid >> 5, sub = tid & 31;
     float s = 0.f, q = 0.f;
-    const float* pp = p.partial + ((long)stat * nchunk * 32 + g) * 2;
-    for (int c = sub; c < nchunk; c += 8) { s += pp[(long)c * 64]; q += pp[(long)c * 64 + 1]; }
+    const float2* pp = reinterpret_cast<const float2*>(p.partial) + (long)stat * nchunk * 32 + g;
+#pragma unroll 8
+    for (int c = sub; c < nchunk; c += 32) { const float2 v = pp[(long)c * 32]; s += v.x; q += v.y; }
 #pragma unroll
-    for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    for (int o = 1; o < 32; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
     if (sub == 0) { p.totals[((long)stat * 32 + g) * 2] = s; p.totals[((long)stat * 32 + g) * 2 + 1] = q; }
 }
 
@@ -313,7 +316,7 @@ extern "C" int vmv_groupnorm_stats(const VmvGroupNormParams* pp, void* stream) {
     const size_t shbytes = (size_t)2 * RPP * C * sizeof(float);
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, nstat), dim3(256), shbytes, reinterpret_cast<hipStream_t>(stream), p, nchunk);
     if (p.totals)
-        hipLaunchKernelGGL(gn_fold_kernel, dim3(nstat), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, nchunk);
+        hipLaunchKernelGGL(gn_fold_kernel, dim3(nstat), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), p, nchunk);
     return vmv_launch_status();
 }
 
