@@ -17,6 +17,7 @@
 //   WPP = 1: every wave owns a whole short problem (Nq <= 32, e.g. the 24-frame temporal attention) with a
 //            private 16-KB stage.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -27,8 +28,11 @@ VMV_DEV int k_swz(int key) { return (((key >> 3) & 3) << 1) | ((key >> 1) & 1); 
 
 constexpr float NEG_BIG = -1.0e30f;
 
-template <int WPP>
-__global__ __launch_bounds__(256) void attn_kernel(const VmvAttnParams p, const int nproblems) {
+// QT = 16-query tiles per wave (QT = 4: 64 queries per wave, 256 per block — every K / V fragment read from LDS and
+// every staged K / V tile then serves twice the MFMAs; the LDS port, shared by all the blocks of a CU, is what bounds the
+// 128-query version at long sequences)
+template <int WPP, int QT>
+__global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, const int nproblems) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -39,7 +43,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const VmvAttnParams p, const 
     int o, h, q0;
     bool wvalid = true;
     if constexpr (WPP == 4) {
-        o = blockIdx.z; h = blockIdx.y; q0 = (blockIdx.x * 4 + wave) * 32;
+        o = blockIdx.z; h = blockIdx.y; q0 = (blockIdx.x * 4 + wave) * (16 * QT);
     } else {
         const int pidx = blockIdx.x * 4 + wave;
         wvalid = pidx < nproblems;
@@ -58,9 +62,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const VmvAttnParams p, const 
     // per stage: K tile [64 keys][8 slots] in 16-B units (8 KB) then V^T tile [64 d][64 keys] bf16 (8 KB)
 
     // ---- Q fragments (B operand): row q0 + 16*qt + u, k-slot kk*32 + 8*g
-    bf16x8_t qf[2][2];
+    bf16x8_t qf[QT][2];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         const int q = q0 + qt * 16 + u;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -70,15 +74,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const VmvAttnParams p, const 
         }
     }
 
-    f32x4_t oacc[2][4];
-    float m_run[2], l_run[2];
+    f32x4_t oacc[QT][4];
+    float m_run[QT], l_run[QT];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         m_run[qt] = NEG_BIG; l_run[qt] = 0.f;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) oacc[qt][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
-    const float sc = p.scale * 1.44269504088896341f;   // exp2 domain
+    const float sc = p.scale * 1.44269504088896341f;   // exp2 domain (> 0)
 
     const int ntile = (p.Nk + 63) >> 6;
     // K/V staging.  WPP = 4: two LDS stages; the next tile's global loads are issued BEFORE the current tile's MFMAs
@@ -152,66 +156,85 @@ __global__ __launch_bounds__(256) void attn_kernel(const VmvAttnParams p, const 
             Ks = Ksd; Vt = Vtd;
         }
 
-        // ---- S^T tiles
-        f32x4_t s[2][4];
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) s[qt][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        // ---- S^T tiles (two query tiles at a time: the K fragments stay in registers for all QT of them) + online softmax
+        bf16x8_t kf[4][2];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int krow = 32 * (t >> 1) + 8 * (u >> 2) + 4 * (t & 1) + (u & 3);
             const int ksw = k_swz(krow);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, Ks[krow * 8 + ((kk * 4 + g) ^ ksw)]);
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt)
-                    s[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][kk], s[qt][t], 0, 0, 0);
-            }
+            for (int kk = 0; kk < 2; ++kk) kf[t][kk] = __builtin_bit_cast(bf16x8_t, Ks[krow * 8 + ((kk * 4 + g) ^ ksw)]);
         }
-        // ---- online softmax (per lane: query u, 16 keys of this tile)
-        bf16x8_t pf[2][2];
+        bf16x8_t pf[QT][2];
+        const bool partial = key0 + 64 > p.Nk;                 // uniform
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            float mx = NEG_BIG;
+        for (int qp = 0; qp < QT / 2; ++qp) {
+            f32x4_t s[2][4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int kb = key0 + 32 * (t >> 1) + 8 * g + 4 * (t & 1);
+            for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float val = (kb + r < p.Nk) ? s[qt][t][r] * sc : NEG_BIG;
-                    s[qt][t][r] = val;
-                    mx = fmaxf(mx, val);
+                for (int t = 0; t < 4; ++t) s[q2][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int q2 = 0; q2 < 2; ++q2)
+                        s[q2][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][kk], qf[2 * qp + q2][kk], s[q2][t], 0, 0, 0);
+            // ---- online softmax (per lane: query u, 16 keys of this tile).  The softmax VALU work, not the 32 MFMAs, bounds a
+            //      tile (16 quarter-rate v_exp per query tile alone cost as much as the tile's MFMAs), so it is kept minimal:
+            //      the running max is tracked on the RAW scores (scale > 0) and the scale is folded into one FMA per score,
+            //      exp2((s - m) * sc) = exp2(fma(s, sc, -m * sc)); key masking runs only on a partial last tile; the
+            //      accumulator rescale is skipped while no lane of the wave sees a new maximum.
+    #pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) {
+                const int qt = 2 * qp + q2;
+                if (partial) {
+    #pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int kb = key0 + 32 * (t >> 1) + 8 * g + 4 * (t & 1);
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (kb + r >= p.Nk) s[q2][t][r] = NEG_BIG;
+                    }
                 }
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[qt], mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
-            m_run[qt] = m_new;
-            float psum = 0.f;
-            float pv[4][4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(s[qt][t][r] - m_new);
-                    pv[t][r] = e;
-                    psum += e;
+                float mx = fmaxf(fmaxf(s[q2][0][0], s[q2][0][1]), fmaxf(s[q2][0][2], s[q2][0][3]));
+    #pragma unroll
+                for (int t = 1; t < 4; ++t)
+                    mx = fmaxf(mx, fmaxf(fmaxf(s[q2][t][0], s[q2][t][1]), fmaxf(s[q2][t][2], s[q2][t][3])));
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_old = m_run[qt];
+                const float m_new = fmaxf(m_old, mx);
+                const float nm = -m_new * sc;
+                float psum = 0.f;
+                float pv[4][4];
+    #pragma unroll
+                for (int t = 0; t < 4; ++t) {
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[q2][t][r], sc, nm));
+                        pv[t][r] = e;
+                        psum += e;
+                    }
                 }
-            }
-            l_run[qt] = l_run[qt] * alpha + psum;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) oacc[qt][dt] *= alpha;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                u32x4_t w;
-                w.x = pack_bf16x2(pv[2 * kk][0], pv[2 * kk][1]);
-                w.y = pack_bf16x2(pv[2 * kk][2], pv[2 * kk][3]);
-                w.z = pack_bf16x2(pv[2 * kk + 1][0], pv[2 * kk + 1][1]);
-                w.w = pack_bf16x2(pv[2 * kk + 1][2], pv[2 * kk + 1][3]);
-                pf[qt][kk] = __builtin_bit_cast(bf16x8_t, w);
+                if (__builtin_amdgcn_ballot_w64(m_new != m_old) != 0ull) {          // some query of this wave has a new maximum
+                    const float alpha = __builtin_amdgcn_exp2f((m_old - m_new) * sc);
+                    m_run[qt] = m_new;
+                    l_run[qt] *= alpha;
+    #pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) oacc[qt][dt] *= alpha;
+                }
+                l_run[qt] += psum;
+    #pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    u32x4_t w;
+                    w.x = pack_bf16x2(pv[2 * kk][0], pv[2 * kk][1]);
+                    w.y = pack_bf16x2(pv[2 * kk][2], pv[2 * kk][3]);
+                    w.z = pack_bf16x2(pv[2 * kk + 1][0], pv[2 * kk + 1][1]);
+                    w.w = pack_bf16x2(pv[2 * kk + 1][2], pv[2 * kk + 1][3]);
+                    pf[qt][kk] = __builtin_bit_cast(bf16x8_t, w);
+                }
             }
         }
         // ---- O^T += V^T P^T
@@ -224,7 +247,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const VmvAttnParams p, const 
             for (int kk = 0; kk < 2; ++kk) {
                 const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, Vt16[d * 8 + ((kk * 4 + g) ^ fsl)]);
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt)
+                for (int qt = 0; qt < QT; ++qt)
                     oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][kk], oacc[qt][dt], 0, 0, 0);
             }
         }
@@ -236,7 +259,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const VmvAttnParams p, const 
 
     // ---- normalise and store: lane owns O[q = q0 + 16 qt + u][d = 16 dt + 4 g + 0..3]
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         float l = l_run[qt];
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
@@ -274,15 +297,21 @@ extern "C" int vmv_attention_bf16(const VmvAttnParams* pp, void* stream) {
         const int nproblems = p.n_outer * p.heads;
         static bool attr1 = false;
         if (!attr1) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<1>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<1, 2>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
             if (e != hipSuccess) return (int)e;
             attr1 = true;
         }
-        hipLaunchKernelGGL((attn_kernel<1>), dim3((nproblems + 3) / 4), dim3(256), 65536, st, p, nproblems);
+        hipLaunchKernelGGL((attn_kernel<1, 2>), dim3((nproblems + 3) / 4), dim3(256), 65536, st, p, nproblems);
     } else {
         if (p.n_outer > 65535 || p.heads > 65535) return VMV_ERANGE;
-        hipLaunchKernelGGL((attn_kernel<4>), dim3((p.Nq + 127) / 128, p.heads, p.n_outer), dim3(256), 32768, st, p, 0);
+        static int qt_env = -1;
+        if (qt_env < 0) { const char* e = getenv("VMV_ATTN_QT"); qt_env = e ? atoi(e) : 0; }
+        // 256-query blocks when that still leaves >= 2 blocks per CU and the key loop is long enough to matter
+        const long blocks256 = (long)((p.Nq + 255) / 256) * p.heads * p.n_outer;
+        const bool big = qt_env == 4 || (qt_env == 0 && p.Nk >= 512 && blocks256 >= 512 && (p.Nq % 256 == 0 || p.Nq >= 2048));
+        if (big) hipLaunchKernelGGL((attn_kernel<4, 4>), dim3((p.Nq + 255) / 256, p.heads, p.n_outer), dim3(256), 32768, st, p, 0);
+        else hipLaunchKernelGGL((attn_kernel<4, 2>), dim3((p.Nq + 127) / 128, p.heads, p.n_outer), dim3(256), 32768, st, p, 0);
     }
     return vmv_launch_status();
 }
