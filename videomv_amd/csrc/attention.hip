@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
     // ---- staging group
     constexpr int NT = (WPP == 4) ? 256 : 64;
     const int stid = (WPP == 4) ? tid : lane;
-    unsigned char* region = smem_raw + ((WPP == 4) ? 0 : wave * 16384);
+    unsigned char* region = smem_raw + ((WPP == 4) ? 0 : wave * 8192);       // WPP = 1: a private V^T stage per wave
     // per stage: K tile [64 keys][8 slots] in 16-B units (8 KB) then V^T tile [64 d][64 keys] bf16 (8 KB)
 
     // ---- Q fragments (B operand): row q0 + 16*qt + u, k-slot kk*32 + 8*g
@@ -106,6 +106,17 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
             }
         }
     };
+    auto write_vt = [&](uint16_t* Vtd, int idx, const u32x4_t& vv) {
+        const int row = idx >> 3, slot = idx & 7;
+        const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = slot * 8 + j;
+            const int fk = ((slot ^ (((slot & 1) << 2) | (j >> 1))) & 7) << 3;   // = 8*(((d>>3)^(d>>1))&7)
+            const uint16_t val = (j & 1) ? (uint16_t)(w[j >> 1] >> 16) : (uint16_t)(w[j >> 1] & 0xffffu);
+            Vtd[d * 64 + (row ^ fk)] = val;
+        }
+    };
     auto write_piece = [&](u32x4_t* Ksd, uint16_t* Vtd, int idx, const u32x4_t& kv, const u32x4_t& vv) {
         const int row = idx >> 3, slot = idx & 7;
         Ksd[row * 8 + (slot ^ k_swz(row))] = kv;
@@ -140,20 +151,26 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
             Ks = reinterpret_cast<const u32x4_t*>(region + (kt & 1) * 16384);
             Vt = reinterpret_cast<const uint16_t*>(region + (kt & 1) * 16384 + 8192);
         } else {
-            u32x4_t* Ksd = reinterpret_cast<u32x4_t*>(region);
-            uint16_t* Vtd = reinterpret_cast<uint16_t*>(region + 8192);
-            __syncthreads();   // previous tile's fragment reads are done
-            for (int idx = stid; idx < 512; idx += NT) {
+            // One short problem per wave (the 24-frame temporal attention: HBM-bound).  Only V^T goes through LDS — the K
+            // fragments are 16 contiguous bytes of a key row and are loaded straight into registers below — so a wave
+            // needs 8 KB instead of 16 (5 blocks per CU instead of 2), and the stage is private: no block barriers, the
+            // wave's own LDS instructions execute in order.
+            uint16_t* Vtd = reinterpret_cast<uint16_t*>(region);
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // previous tile's fragment reads are done
+            asm volatile("" ::: "memory");
+            u32x4_t vvr[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = stid + i * NT;
                 const int key = key0 + (idx >> 3);
-                u32x4_t kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-                if (wvalid && key < p.Nk) {
-                    kv = *reinterpret_cast<const u32x4_t*>(kp + (long)key * p.km.s_row + (idx & 7) * 8);
-                    vv = *reinterpret_cast<const u32x4_t*>(vp + (long)key * p.vm.s_row + (idx & 7) * 8);
-                }
-                write_piece(Ksd, Vtd, idx, kv, vv);
+                vvr[i] = u32x4_t{0u, 0u, 0u, 0u};
+                if (wvalid && key < p.Nk) vvr[i] = *reinterpret_cast<const u32x4_t*>(vp + (long)key * p.vm.s_row + (idx & 7) * 8);
             }
-            __syncthreads();
-            Ks = Ksd; Vt = Vtd;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) write_vt(Vtd, stid + i * NT, vvr[i]);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            asm volatile("" ::: "memory");
+            Ks = nullptr; Vt = Vtd;
         }
 
         // ---- S^T tiles (two query tiles at a time: the K fragments stay in registers for all QT of them) + online softmax
@@ -163,7 +180,16 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
             const int krow = 32 * (t >> 1) + 8 * (u >> 2) + 4 * (t & 1) + (u & 3);
             const int ksw = k_swz(krow);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) kf[t][kk] = __builtin_bit_cast(bf16x8_t, Ks[krow * 8 + ((kk * 4 + g) ^ ksw)]);
+            for (int kk = 0; kk < 2; ++kk) {
+                if constexpr (WPP == 4) {
+                    kf[t][kk] = __builtin_bit_cast(bf16x8_t, Ks[krow * 8 + ((kk * 4 + g) ^ ksw)]);
+                } else {
+                    u32x4_t kv = {0u, 0u, 0u, 0u};
+                    const int key = key0 + krow;
+                    if (wvalid && key < p.Nk) kv = *reinterpret_cast<const u32x4_t*>(kp + (long)key * p.km.s_row + kk * 32 + g * 8);
+                    kf[t][kk] = __builtin_bit_cast(bf16x8_t, kv);
+                }
+            }
         }
         bf16x8_t pf[QT][2];
         const bool partial = key0 + 64 > p.Nk;                 // uniform
@@ -298,11 +324,11 @@ extern "C" int vmv_attention_bf16(const VmvAttnParams* pp, void* stream) {
         static bool attr1 = false;
         if (!attr1) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<1, 2>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 32768);
             if (e != hipSuccess) return (int)e;
             attr1 = true;
         }
-        hipLaunchKernelGGL((attn_kernel<1, 2>), dim3((nproblems + 3) / 4), dim3(256), 65536, st, p, nproblems);
+        hipLaunchKernelGGL((attn_kernel<1, 2>), dim3((nproblems + 3) / 4), dim3(256), 32768, st, p, nproblems);
     } else {
         if (p.n_outer > 65535 || p.heads > 65535) return VMV_ERANGE;
         static int qt_env = -1;
