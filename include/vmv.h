@@ -94,6 +94,13 @@ typedef struct {
     int32_t tile;            /* 0 = auto; else VMV_TILE_* to force a configuration                 */
     float res_scale;         /* the residual is added as res_scale * residual; 0 means 1 (LGM's (x + res) * sqrt(.5),
                                 core/unet.py:99,49, with the weights pre-scaled on the host)                    */
+    /* LayerNorm folded into the GEMM (BasicTransformerBlock: norm -> Linear, util.py:520-546).  For y = W LN(x) + b with
+     * LN(x) = (x - mean) * rstd * gamma + beta the host packs W' = W diag(gamma), bias' = b + W beta and
+     * colsum[n] = sum_k W'[n][k] (of the bf16-rounded W'), the GEMM runs on the RAW rows, and the epilogue computes
+     *     rstd[m] * (acc[m][n] - mean[m] * colsum[n]) + bias'[n]
+     * with rowstat = fp32 [M][2] (mean, rstd) from vmv_layernorm(stats_out).  Linear segments only, no split-K.       */
+    const float* rowstat;
+    const float* colsum;     /* fp32 [N] (pre-GEGLU numbering), required with rowstat */
 } VmvGemmParams;
 
 #define VMV_TILE_AUTO     0
@@ -158,6 +165,8 @@ typedef struct {
     int32_t rows, C;       /* C % 8 == 0, C <= 2048 */
     float eps;
     int32_t _pad;
+    float* stats_out;      /* optional fp32 [rows][2]: write (mean, rstd) per row INSTEAD of y (y, gamma, beta may be NULL):
+                              the statistics pass of a LayerNorm folded into its consumer GEMM (VmvGemmParams.rowstat) */
 } VmvLayerNormParams;
 int vmv_layernorm(const VmvLayerNormParams* p, void* stream);
 

@@ -57,6 +57,9 @@ def gemm(p: L.GemmParams):
     A = torch.cat(cols, dim=1)
     W = _rows(p.W, N, p.ktot).float()
     acc = A @ W.t()
+    if p.rowstat:          # LayerNorm folded into the GEMM: rstd[m] * (acc - mean[m] * colsum[n])
+        st = _view(p.rowstat, 2 * M, "f32").view(M, 2)
+        acc = (acc - st[:, :1] * _view(p.colsum, N, "f32")[None, :]) * st[:, 1:2]
     if p.bias:
         acc = acc + _view(p.bias, N, "f32")
     if p.epilogue == L.EPI_GEGLU:
@@ -131,6 +134,11 @@ def permute_copy(p: L.CopyParams):
 
 def layernorm(p: L.LayerNormParams):
     x = _rows(p.x, p.rows, p.ldx)[:, : p.C].float()
+    if p.stats_out:        # statistics only: (mean, rstd) per row
+        mean = x.mean(dim=1)
+        rstd = torch.rsqrt(x.var(dim=1, unbiased=False) + p.eps)
+        _view(p.stats_out, 2 * p.rows, "f32").view(p.rows, 2).copy_(torch.stack([mean, rstd], dim=1))
+        return
     y = torch.nn.functional.layer_norm(x, (p.C,), _view(p.gamma, p.C, "f32"), _view(p.beta, p.C, "f32"), p.eps)
     _rows(p.y, p.rows, p.ldy)[:, : p.C] = y.to(torch.bfloat16)
 

@@ -394,6 +394,60 @@ def test_layernorm(rows, Cc):
     check(dev["y"], cpu["y"], tol_l2=5e-3, tol_max=1.5e-2)
 
 
+@pytest.mark.parametrize("rows,Cc", [(300, 320), (1000, 640), (77, 1280)])
+def test_layernorm_stats_out(rows, Cc):
+    """(mean, rstd) per row — the statistics pass of a LayerNorm folded into its consumer GEMM."""
+    x = (rnd((rows, Cc), 1, 2.0).float() + 0.3).to(BF).cuda()
+    st = torch.zeros(rows, 2, device="cuda")
+    ops.Stream(record=False).layernorm(ops.ln_params(x, Cc, None, 0, None, None, rows, Cc, 1e-5, stats_out=st))
+    torch.cuda.synchronize()
+    xf = x.float()
+    ref = torch.stack([xf.mean(dim=1), torch.rsqrt(xf.var(dim=1, unbiased=False) + 1e-5)], dim=1)
+    assert torch.allclose(st, ref, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("M,N,K,geglu,tile", [(300, 960, 320, False, 0), (1000, 640, 640, False, L.TILE_P256x160),
+                                               (70000, 320, 320, False, 0), (513, 1280, 320, True, 0),
+                                               (70000, 1280, 320, True, L.TILE_P256x128), (257, 128, 192, False, L.TILE_128x128),
+                                               (300, 512, 64, True, L.TILE_128x128), (2000, 3840, 1280, False, 0)])
+def test_gemm_layernorm_folded(M, N, K, geglu, tile):
+    """y = Linear(LayerNorm(x)) as ONE GEMM on the raw rows (packing.fold_layernorm + rowstat / colsum epilogue) against
+    the unfused definition, x with a large per-row offset (mean / sigma ~ 3) to exercise the cancellation."""
+    x = (rnd((M, K), 1, 1.5).float() + 4.0 * torch.randn(M, 1, generator=g(9))).to(BF)
+    w = torch.randn(N, K, generator=g(2)) * K ** -0.5
+    b = torch.randn(N, generator=g(3))
+    gamma, beta = 1 + 0.2 * torch.randn(K, generator=g(4)), 0.2 * torch.randn(K, generator=g(5))
+    wf, bf, cs = P.fold_layernorm(w, b, gamma, beta)
+    if geglu:
+        wf, bf, cs = P.geglu_interleave(wf), P.geglu_interleave(bf), P.geglu_interleave(cs)
+    No = N // 2 if geglu else N
+    xd = x.cuda()
+    st = torch.zeros(M, 2, device="cuda")
+    out = torch.zeros(M, No, dtype=BF, device="cuda")
+    S = ops.Stream(record=False)
+    S.layernorm(ops.ln_params(xd, K, None, 0, None, None, M, K, 1e-5, stats_out=st))
+    S.gemm(ops.gemm_params(M, N, ops.linear_segs([(xd, K, K)]), wf.cuda(), out, No, bias=bf.cuda(), rowstat=st, colsum=cs.cuda(),
+                           epilogue=L.EPI_GEGLU if geglu else L.EPI_NONE, tile=tile))
+    torch.cuda.synchronize()
+    ln = torch.nn.functional.layer_norm(x.float(), (K,), gamma, beta, 1e-5)
+    h = ln @ w.t() + b
+    if geglu:
+        a, gate = h.chunk(2, dim=-1)
+        h = a * torch.nn.functional.gelu(gate)
+    check(out, h, tol_l2=6e-3, tol_max=2e-2)
+
+
+def test_gemm_layernorm_folded_rejects_split_k_and_gathers():
+    import ctypes as C
+    lib = L.load()
+    x = rnd((256, 128), 1).cuda(); w = rnd((128, 128), 2).cuda(); o = torch.zeros(256, 128, dtype=BF, device="cuda")
+    st = torch.zeros(256, 2, device="cuda"); cs = torch.zeros(128, device="cuda"); ws = torch.zeros(2 * 256 * 128, device="cuda")
+    p = ops.gemm_params(256, 128, ops.linear_segs([(x, 128, 128)]), w, o, 128, rowstat=st, colsum=cs, ksplit=2, workspace=ws)
+    assert lib.vmv_gemm_bf16(C.byref(p), None) == -1          # VMV_EINVAL
+    p = ops.gemm_params(256, 128, ops.linear_segs([(x, 128, 128)]), w, o, 128, rowstat=st)
+    assert lib.vmv_gemm_bf16(C.byref(p), None) == -3          # VMV_ENULL
+
+
 # ------------------------------------------------------------------------------------------------- attention
 def _attn_case(kind, B, F_, HW, heads, Lc=77, seed=1):
     inner = heads * 64

@@ -37,7 +37,7 @@ class GemmParams(C.Structure):
                 ("stride", C.c_int32), ("ups", C.c_int32),
                 ("F", C.c_int32), ("P", C.c_int32),
                 ("ksplit", C.c_int32), ("workspace", C.c_void_p),
-                ("tile", C.c_int32), ("res_scale", C.c_float)]
+                ("tile", C.c_int32), ("res_scale", C.c_float), ("rowstat", C.c_void_p), ("colsum", C.c_void_p)]
 
 
 class GroupNormParams(C.Structure):
@@ -66,7 +66,7 @@ class CopyParams(C.Structure):
 class LayerNormParams(C.Structure):
     _fields_ = [("x", C.c_void_p), ("ldx", C.c_int32), ("y", C.c_void_p), ("ldy", C.c_int32),
                 ("gamma", C.c_void_p), ("beta", C.c_void_p), ("rows", C.c_int32), ("C", C.c_int32),
-                ("eps", C.c_float), ("_pad", C.c_int32)]
+                ("eps", C.c_float), ("_pad", C.c_int32), ("stats_out", C.c_void_p)]
 
 
 class SeqMap(C.Structure):

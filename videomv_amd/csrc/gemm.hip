@@ -341,7 +341,17 @@ extern "C" int vmv_gemm_bf16(const VmvGemmParams* pp, void* stream) {
     if ((long)p.M * (long)maxld >= (1L << 31) || (long)p.N * (long)p.ktot >= (1L << 31)) return VMV_ERANGE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc;
-    const int picked = pick_tile(p, total_steps);
+    if (p.rowstat) {       // LayerNorm-folded GEMM: implemented by the persistent kernel's epilogue and the generic one
+        if (!p.colsum) return VMV_ENULL;
+        if ((((uintptr_t)p.rowstat) & 7) || !vmv_aligned16(p.colsum)) return VMV_EALIGN;
+        if (p.ksplit > 1) return VMV_EINVAL;
+        for (int s = 0; s < p.nseg; ++s) if (p.seg[s].mode != VMV_SEG_LINEAR) return VMV_EINVAL;
+    }
+    int picked = pick_tile(p, total_steps);
+    if (p.rowstat && picked != VMV_TILE_P256x128 && picked != VMV_TILE_P256x160 && picked != VMV_TILE_Q128x128 &&
+        picked != VMV_TILE_Q96x160 && picked != VMV_TILE_128x128 && picked != VMV_TILE_128x160 && picked != VMV_TILE_128x64 &&
+        picked != VMV_TILE_64x64)
+        picked = (p.epilogue != VMV_EPI_GEGLU && p.N % 160 == 0) ? VMV_TILE_P256x160 : VMV_TILE_P256x128;
     switch (picked) {
         case VMV_TILE_128x128: rc = launch_cfg<4, 4>(p, total_steps, st); break;
         case VMV_TILE_128x160:
@@ -370,22 +380,22 @@ extern "C" int vmv_gemm_bf16(const VmvGemmParams* pp, void* stream) {
             break;
         case VMV_TILE_Q128x128:
             rc = vmv_gemm_pglds_launch(p, total_steps, VMV_TILE_Q128x128, st);
-            if (rc == VMV_GLDS_UNSUPPORTED) rc = vmv_gemm_glds_launch(p, total_steps, VMV_TILE_256x128, st);
+            if (rc == VMV_GLDS_UNSUPPORTED && !p.rowstat) rc = vmv_gemm_glds_launch(p, total_steps, VMV_TILE_256x128, st);
             if (rc == VMV_GLDS_UNSUPPORTED) rc = launch_cfg<4, 4>(p, total_steps, st);
             break;
         case VMV_TILE_Q96x160:
             rc = vmv_gemm_pglds_launch(p, total_steps, VMV_TILE_Q96x160, st);
-            if (rc == VMV_GLDS_UNSUPPORTED) rc = vmv_gemm_glds_launch(p, total_steps, VMV_TILE_256x160, st);
+            if (rc == VMV_GLDS_UNSUPPORTED && !p.rowstat) rc = vmv_gemm_glds_launch(p, total_steps, VMV_TILE_256x160, st);
             if (rc == VMV_GLDS_UNSUPPORTED) rc = launch_cfg<4, 5>(p, total_steps, st);
             break;
         case VMV_TILE_P256x128:
             rc = vmv_gemm_pglds_launch(p, total_steps, VMV_TILE_P256x128, st);
-            if (rc == VMV_GLDS_UNSUPPORTED) rc = vmv_gemm_glds_launch(p, total_steps, VMV_TILE_256x128, st);
+            if (rc == VMV_GLDS_UNSUPPORTED && !p.rowstat) rc = vmv_gemm_glds_launch(p, total_steps, VMV_TILE_256x128, st);
             if (rc == VMV_GLDS_UNSUPPORTED) rc = launch_cfg<4, 4>(p, total_steps, st);
             break;
         case VMV_TILE_P256x160:
             rc = vmv_gemm_pglds_launch(p, total_steps, VMV_TILE_P256x160, st);
-            if (rc == VMV_GLDS_UNSUPPORTED) rc = vmv_gemm_glds_launch(p, total_steps, VMV_TILE_256x160, st);
+            if (rc == VMV_GLDS_UNSUPPORTED && !p.rowstat) rc = vmv_gemm_glds_launch(p, total_steps, VMV_TILE_256x160, st);
             if (rc == VMV_GLDS_UNSUPPORTED) rc = launch_cfg<4, 5>(p, total_steps, st);
             break;
         case VMV_TILE_PP256x128:

@@ -36,6 +36,15 @@ VMV_DEV int seg_row_offset(const VmvGemmParams& p, const VmvGemmSeg& sg, const R
 // g = gate accumulators (GEGLU only).  `n` indexes W rows (pre-GEGLU numbering).
 VMV_DEV void epilogue_store(const VmvGemmParams& p, int m, int n, f32x4_t v, f32x4_t g) {
     if (m >= p.M || n >= p.N) return;
+    if (p.rowstat) {       // LayerNorm folded into this GEMM (vmv.h): rstd * (acc - mean * colsum[n])
+        const float2 ms = *reinterpret_cast<const float2*>(p.rowstat + (size_t)m * 2);
+        const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(p.colsum + n);
+        v = (v - c0 * ms.x) * ms.y;
+        if (p.epilogue == VMV_EPI_GEGLU) {
+            const f32x4_t c1 = *reinterpret_cast<const f32x4_t*>(p.colsum + n + 16);
+            g = (g - c1 * ms.x) * ms.y;
+        }
+    }
     if (p.bias) {
         const f32x4_t b = *reinterpret_cast<const f32x4_t*>(p.bias + n);
         v += b;

@@ -477,6 +477,7 @@ int launch_glds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
 
 // Called by vmv_gemm_bf16 (gemm.hip) after argument validation.  The split-K reduce pass stays in gemm.hip.
 int vmv_gemm_glds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st) {
+    if (p.rowstat) return VMV_GLDS_UNSUPPORTED;          // LayerNorm-folded GEMMs: gemm_pglds.hip / gemm.hip epilogues only
     // 32-bit byte offsets through buffer descriptors: every operand must span < 2 GiB
     long maxrows = p.M;
     if (p.OH > 0) { const long src_rows = (long)(p.M / (p.OH * p.OW) + 1) * p.IH * p.IW; if (src_rows > maxrows) maxrows = src_rows; }

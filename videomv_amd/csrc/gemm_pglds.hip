@@ -39,7 +39,8 @@ struct PgCfg {
     static constexpr int NAI = BM / (8 * NW);              // A wave-instructions per wave per chunk (8 rows each)
     static constexpr int NWI = (BN / 8 + NW - 1) / NW;
     static constexpr int LPT = NAI + NWI;
-    static constexpr int STRIPS = 512 * NW;                // per-wave bias strips behind the ring
+    static constexpr int STRIP = 640;                      // per wave: 16*WN bias values + 16*WN column sums (folded LayerNorm)
+    static constexpr int STRIPS = STRIP * NW;              // per-wave strips behind the ring
     static constexpr int LDS_LIMIT = (NWM == 4 ? 160 : 80) * 1024;
     static constexpr bool DEDICATED = LDS_BYTES + STRIPS + NW * 2816 <= LDS_LIMIT;     // slabs behind the strips
     static constexpr int LDS_TOTAL = LDS_BYTES + STRIPS + (DEDICATED ? NW * 2816 : 0);
@@ -251,12 +252,14 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
     constexpr int NR_MAX = (16 * (OWC_MAX / 8) + 63) / 64;
     // bias: staged per wave in the 512 B it owns behind the ring (keeps 4*WN registers out of the tile's last MFMAs);
     // residual: two 16-row groups in flight, refilled as soon as a group has been added to its rows
-    float* bias_lds = reinterpret_cast<float*>(smem + S * Cfg::STAGE_BYTES + wave * 512);
+    float* bias_lds = reinterpret_cast<float*>(smem + S * Cfg::STAGE_BYTES + wave * Cfg::STRIP);
+    float* csum_lds = bias_lds + 16 * WN;                  // colsum strip (LayerNorm folded into this GEMM: vmv.h)
     u32x4_t resv[2][NR_MAX];                  // residual: two 16-row groups in flight
     u32x4_t sd_prev[NR_MAX];                  // store data of the last 16-row group written (see the epilogue)
 #pragma unroll
     for (int r = 0; r < NR_MAX; ++r) sd_prev[r] = u32x4_t{0u, 0u, 0u, 0u};
     f32x4_t bias_hold = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    f32x4_t csum_hold = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, SRD_RECORDS, SRD_FLAGS);
     const __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual), 0, SRD_RECORDS, SRD_FLAGS);
     const bool has_res = staged && p.residual != nullptr;
@@ -290,6 +293,10 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
             const int n = n0 + wave_n * 16 * WN + 4 * lane;
             bias_hold = f32x4_t{0.f, 0.f, 0.f, 0.f};
             if (p.bias && lane < 4 * WN && n < p.N) bias_hold = *reinterpret_cast<const f32x4_t*>(p.bias + n);
+            if (p.rowstat) {
+                csum_hold = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                if (lane < 4 * WN && n < p.N) csum_hold = *reinterpret_cast<const f32x4_t*>(p.colsum + n);
+            }
         }
         if (has_res) {
 #pragma unroll
@@ -328,6 +335,9 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
         constexpr int NU = 16 * UW;                           // units per 16-row group
         constexpr int NR = (NU + 63) / 64;
         if (lane < 4 * WN) *reinterpret_cast<f32x4_t*>(bias_lds + 4 * lane) = bias_hold;
+        if (p.rowstat && lane < 4 * WN) *reinterpret_cast<f32x4_t*>(csum_lds + 4 * lane) = csum_hold;
+        float2 ms_next = make_float2(0.f, 0.f);
+        if (p.rowstat) ms_next = *reinterpret_cast<const float2*>(p.rowstat + (size_t)(mbase < p.M ? mbase : 0) * 2);
         asm volatile("" ::: "memory");
         unsigned char* slab = Cfg::DEDICATED ? smem + Cfg::LDS_BYTES + Cfg::STRIPS + wave * 2816
                                              : slot_base + wave * 4096;                       // 16 rows x RB <= 2816 B
@@ -347,6 +357,16 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
                 }
             }
             // Two phases, separated for the scheduler: (A) bias reads + math for every column tile, (B) the slab writes.
+            // LayerNorm folded into this GEMM (vmv.h): acc <- rstd[m] * (acc - mean[m] * colsum[n]); the row's two statistics
+            // and the columns' sums are L2-resident fp32 (read per 16-row group, only on this path)
+            if (p.rowstat) {       // (column sums from the wave's LDS strip, like the bias; this group's row statistics were
+                                   //  requested one group ahead)
+                const float2 ms = ms_next;
+                if (i + 1 < WM) ms_next = *reinterpret_cast<const float2*>(p.rowstat + (size_t)(m + 16 < p.M ? m + 16 : 0) * 2);
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[j][i] = (acc[j][i] - *reinterpret_cast<const f32x4_t*>(csum_lds + 16 * j + 4 * fgrp) * ms.x) * ms.y;
+            }
             u32x2_t packed[WN];
 #pragma unroll
             for (int j = 0; j < WN; ++j) {

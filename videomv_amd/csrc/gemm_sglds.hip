@@ -577,7 +577,7 @@ int launch_sglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
 
 // Called by vmv_gemm_bf16 (gemm.hip) after argument validation; split-K shapes stay on the non-persistent kernels.
 int vmv_gemm_sglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st) {
-    if (p.ksplit > 1) return VMV_GLDS_UNSUPPORTED;
+    if (p.ksplit > 1 || p.rowstat) return VMV_GLDS_UNSUPPORTED;
     long maxrows = p.M;
     if (p.OH > 0) { const long src_rows = (long)(p.M / (p.OH * p.OW) + 1) * p.IH * p.IW; if (src_rows > maxrows) maxrows = src_rows; }
     for (int i = 0; i < p.nseg; ++i)

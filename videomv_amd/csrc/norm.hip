@@ -234,6 +234,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const VmvLayerNormParams
     for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
     const float rstd = rsqrtf(q / (float)p.C + p.eps);
     if (!live) return;
+    if (p.stats_out) {                                   // statistics pass of a LayerNorm folded into its consumer GEMM
+        if (sub == 0) *reinterpret_cast<float2*>(p.stats_out + row * 2) = make_float2(mean, rstd);
+        return;
+    }
     uint16_t* y = reinterpret_cast<uint16_t*>(p.y) + row * p.ldy;
 #pragma unroll
     for (int it = 0; it < LN_MAX_IT; ++it) {
@@ -342,11 +346,13 @@ extern "C" int vmv_groupnorm_apply(const VmvGroupNormParams* pp, void* stream) {
 extern "C" int vmv_layernorm(const VmvLayerNormParams* pp, void* stream) {
     if (!pp) return VMV_ENULL;
     const VmvLayerNormParams& p = *pp;
-    if (!p.x || !p.y || !p.gamma || !p.beta) return VMV_ENULL;
+    if (!p.x) return VMV_ENULL;
+    if (!p.stats_out && (!p.y || !p.gamma || !p.beta)) return VMV_ENULL;
     if (p.rows <= 0 || p.C <= 0 || (p.C & 7)) return VMV_EINVAL;
     if (p.C > LN_MAX_IT * 64 * 8) return VMV_ERANGE;
-    if (!vmv_aligned16(p.x) || !vmv_aligned16(p.y) || (p.ldx & 7) || (p.ldy & 7) || !vmv_aligned16(p.gamma) ||
-        !vmv_aligned16(p.beta)) return VMV_EALIGN;
+    if (!vmv_aligned16(p.x) || (p.ldx & 7)) return VMV_EALIGN;
+    if (p.stats_out) { if (((uintptr_t)p.stats_out) & 7) return VMV_EALIGN; }
+    else if (!vmv_aligned16(p.y) || (p.ldy & 7) || !vmv_aligned16(p.gamma) || !vmv_aligned16(p.beta)) return VMV_EALIGN;
     const int CS = p.C >> 3;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     auto go = [&](auto lpr_tag) {

@@ -54,7 +54,7 @@ class Geom:
 
 def gemm_params(M, N, segs: Sequence[Seg], W, out, ldo, bias=None, rowvec=None, rowvec_div=1, rowvec_ld=0,
                 residual=None, ldr=0, epilogue=L.EPI_NONE, act=L.ACT_NONE, out_fp32=False, geom: Optional[Geom] = None,
-                ksplit=0, workspace=None, tile=L.TILE_AUTO, res_scale=0.0) -> L.GemmParams:
+                ksplit=0, workspace=None, tile=L.TILE_AUTO, res_scale=0.0, rowstat=None, colsum=None) -> L.GemmParams:
     p = L.GemmParams()
     p.M, p.N, p.nseg = int(M), int(N), len(segs)
     if len(segs) > L.VMV_MAX_SEGS:
@@ -73,6 +73,7 @@ def gemm_params(M, N, segs: Sequence[Seg], W, out, ldo, bias=None, rowvec=None, 
     g = geom or Geom()
     p.OH, p.OW, p.IH, p.IW, p.stride, p.ups, p.F, p.P = g.OH, g.OW, g.IH, g.IW, g.stride, g.ups, g.F, g.P
     p.ksplit, p.workspace, p.tile, p.res_scale = int(ksplit), _ptr(workspace), tile, float(res_scale)
+    p.rowstat, p.colsum = _ptr(rowstat), _ptr(colsum)
     return p
 
 
@@ -101,10 +102,12 @@ def gn_partial_floats(rows, rows_per_stat, C, chunk_rows=None) -> int:
     return (rows // rows_per_stat) * nchunk * 64
 
 
-def ln_params(x, ldx, y, ldy, gamma, beta, rows, Cc, eps=1e-5) -> L.LayerNormParams:
+def ln_params(x, ldx, y, ldy, gamma, beta, rows, Cc, eps=1e-5, stats_out=None) -> L.LayerNormParams:
+    """stats_out: fp32 [rows][2] — write (mean, rstd) per row instead of y (LayerNorm folded into its consumer GEMM)."""
     p = L.LayerNormParams()
     p.x, p.ldx, p.y, p.ldy, p.gamma, p.beta = _ptr(x), int(ldx), _ptr(y), int(ldy), _ptr(gamma), _ptr(beta)
     p.rows, p.C, p.eps = int(rows), int(Cc), float(eps)
+    p.stats_out = _ptr(stats_out)
     return p
 
 

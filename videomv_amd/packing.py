@@ -61,6 +61,19 @@ def geglu_interleave(t: torch.Tensor) -> torch.Tensor:
     return torch.cat([x, g], dim=1).reshape((two_i,) + rest)
 
 
+def fold_layernorm(w: torch.Tensor, b, gamma: torch.Tensor, beta: torch.Tensor):
+    """LayerNorm folded into the Linear that consumes it (include/vmv.h, VmvGemmParams.rowstat): for
+    y = W LN(x) + b, LN(x) = (x - mean) * rstd * gamma + beta, returns (W', b', colsum) with W' = W diag(gamma) already
+    rounded to bf16 (what the GEMM multiplies), b' = b + W beta and colsum[n] = sum_k W'[n][k] of the ROUNDED W' (so that
+    the epilogue's  rstd * (acc - mean * colsum)  cancels exactly what the MFMAs accumulated)."""
+    w = w.reshape(w.shape[0], -1).float()
+    wf = (w * gamma.float()[None, :]).to(BF16)
+    bf = w @ beta.float()
+    if b is not None:
+        bf = bf + b.float()
+    return wf, bf, wf.float().sum(dim=1)
+
+
 def pack_bias(b: torch.Tensor, device, n_pad_to=4) -> torch.Tensor:
     b = b.reshape(-1).float()
     pad = (-b.shape[0]) % n_pad_to

@@ -12,6 +12,7 @@ per block follows ``ResBlock._forward`` (util.py:703-730), ``TemporalConvBlock_v
 ``BasicTransformerBlock.forward`` (:536-540) and ``MemoryEfficientCrossAttention.forward`` (:230-268).
 """
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -221,6 +222,9 @@ class UNetEngine:
         self.dim = cfg["dim"]
         self.E = self.dim * 4
         self.inp, self.mid, self.outb = block_plan(cfg)
+        # LayerNorm -> Linear pairs of the transformer blocks run as ONE GEMM on the raw rows + a statistics pass (vmv.h,
+        # VmvGemmParams.rowstat): saves writing and re-reading LN(x) (VMV_FOLD_LN=0 keeps the two-kernel form)
+        self.fold_ln = os.environ.get("VMV_FOLD_LN", "1") != "0"
         self._pack(weights)
         self._static_inputs()
         self._build()
@@ -240,19 +244,34 @@ class UNetEngine:
             w[key + ".weight"] = P.f32(sd[key + ".weight"], dev)
             w[key + ".bias"] = P.f32(sd[key + ".bias"], dev)
 
+        def folded(key, wt, b, nkey, geglu=False):
+            """LayerNorm `nkey` folded into the Linear (wt, b): `key`.ln.{weight,bias,colsum} (packing.fold_layernorm)."""
+            if not self.fold_ln:
+                return
+            wf, bf, cs = P.fold_layernorm(wt, b, sd[nkey + ".weight"], sd[nkey + ".bias"])
+            if geglu:
+                wf, bf, cs = P.geglu_interleave(wf), P.geglu_interleave(bf), P.geglu_interleave(cs)
+            w[key + ".ln.weight"] = P.pack_linear(wf, dev)
+            w[key + ".ln.bias"] = P.pack_bias(bf, dev)
+            w[key + ".ln.colsum"] = P.pack_bias(cs, dev)
+
         def tblock(p):
             for a in ("attn1", "attn2"):
                 q = sd[f"{p}.{a}.to_q.weight"]
                 k = sd[f"{p}.{a}.to_k.weight"]
                 v = sd[f"{p}.{a}.to_v.weight"]
+                nk = "norm1" if a == "attn1" else "norm2"
                 if k.shape[1] == q.shape[1]:   # self-attention: fused QKV
                     w[f"{p}.{a}.qkv"] = P.pack_linear(torch.cat([q, k, v], dim=0), dev)
+                    folded(f"{p}.{a}.qkv", torch.cat([q, k, v], dim=0), None, f"{p}.{nk}")
                 else:                          # cross-attention: Q on tokens, fused KV on the context
                     w[f"{p}.{a}.q"] = P.pack_linear(q, dev)
+                    folded(f"{p}.{a}.q", q, None, f"{p}.{nk}")
                     w[f"{p}.{a}.kv"] = P.pack_linear(torch.cat([k, v], dim=0), dev)
                 lin(f"{p}.{a}.to_out.0")
             w[f"{p}.ff.net.0.proj.weight"] = P.pack_linear(P.geglu_interleave(sd[f"{p}.ff.net.0.proj.weight"]), dev)
             w[f"{p}.ff.net.0.proj.bias"] = P.pack_bias(P.geglu_interleave(sd[f"{p}.ff.net.0.proj.bias"]), dev)
+            folded(f"{p}.ff.net.0.proj", sd[f"{p}.ff.net.0.proj.weight"], sd[f"{p}.ff.net.0.proj.bias"], f"{p}.norm3", geglu=True)
             lin(f"{p}.ff.net.2")
             for n in ("norm1", "norm2", "norm3"):
                 norm(f"{p}.{n}")
@@ -342,7 +361,7 @@ class UNetEngine:
     def _gemm(self, label, M, N, segs, wkey, out: Act, bias=None, geom=None, **kw):
         """N is informational: the launch always covers every (4-padded) row of the packed weight."""
         W = self.w[wkey]
-        ks, ws = self._ksplit(M, W.shape[0], segs)
+        ks, ws = (0, None) if kw.get("rowstat") else self._ksplit(M, W.shape[0], segs)      # (folded-LN GEMMs: no split-K)
         p = ops.gemm_params(M, W.shape[0], segs, W, out.ptr, out.C, bias=bias, geom=geom, ksplit=ks, workspace=ws, **kw)
         self.S.gemm(p, label)
 
@@ -424,6 +443,21 @@ class UNetEngine:
         self.release(send); self.release(recv)
         return y
 
+    def _ln_linear(self, label, x: Act, nkey, N, wkey, out: Act, bias=None, **kw):
+        """out = Linear(LayerNorm(x)).  Folded: row statistics (mean, rstd) + one GEMM on the raw rows whose epilogue
+        applies them (weights pre-multiplied by gamma, beta folded into the bias: packing.fold_layernorm)."""
+        if not self.fold_ln:
+            ln = self._ln(label + ".ln", x, nkey)
+            self._gemm(label, x.rows, N, ops.linear_segs([(ln.ptr, ln.C, ln.C)]), wkey, out, bias=bias, **kw)
+            self.release(ln)
+            return
+        base = wkey[:-len(".weight")] if wkey.endswith(".weight") else wkey
+        st = self.act(x.rows, 2, dtype=torch.float32)
+        self.S.layernorm(ops.ln_params(x.ptr, x.C, None, 0, None, None, x.rows, x.C, 1e-5, stats_out=st.ptr), label + ".lnstat")
+        self._gemm(label, x.rows, N, ops.linear_segs([(x.ptr, x.C, x.C)]), base + ".ln.weight", out,
+                   bias=self.w[base + ".ln.bias"], rowstat=st.ptr, colsum=self.w[base + ".ln.colsum"], **kw)
+        self.release(st)
+
     def _ln(self, label, x: Act, wkey) -> Act:
         y = self.act(x.rows, x.C)
         self.S.layernorm(ops.ln_params(x.ptr, x.C, y.ptr, y.C, self.w[wkey + ".weight"], self.w[wkey + ".bias"],
@@ -494,10 +528,8 @@ class UNetEngine:
         Nq = F if temporal else hw
 
         def self_attn(tag, x: Act, normkey) -> Act:
-            ln = self._ln(f"{p}.{normkey}", x, f"{p}.{normkey}")
             qkv = self.act(T, 3 * inner)
-            self._gemm(f"{p}.{tag}.qkv", T, 3 * inner, ops.linear_segs([(ln.ptr, ln.C, ln.C)]), f"{p}.{tag}.qkv", qkv)
-            self.release(ln)
+            self._ln_linear(f"{p}.{tag}.qkv", x, f"{p}.{normkey}", 3 * inner, f"{p}.{tag}.qkv", qkv)
             ao = self.act(T, inner)
             ld = 3 * inner
             self.S.attention(ops.attn_params(qkv.ptr, qkv.ptr + 2 * inner, qkv.ptr + 4 * inner, ao.ptr,
@@ -511,10 +543,8 @@ class UNetEngine:
             return y
 
         def cross_attn(tag, x: Act, normkey) -> Act:
-            ln = self._ln(f"{p}.{normkey}", x, f"{p}.{normkey}")
             q = self.act(T, inner)
-            self._gemm(f"{p}.{tag}.q", T, inner, ops.linear_segs([(ln.ptr, ln.C, ln.C)]), f"{p}.{tag}.q", q)
-            self.release(ln)
+            self._ln_linear(f"{p}.{tag}.q", x, f"{p}.{normkey}", inner, f"{p}.{tag}.q", q)
             Lc = self.L
             kv = self.act(B * Lc, 2 * inner)
             cd = self.ctx_rows.shape[1]
@@ -534,11 +564,9 @@ class UNetEngine:
         a1 = self_attn("attn1", a, "norm1")
         a2 = cross_attn("attn2", a1, "norm2") if cross_ctx else self_attn("attn2", a1, "norm2")
         self.release(a1)
-        ln = self._ln(f"{p}.norm3", a2, f"{p}.norm3")
         ff = self.act(T, 4 * inner)
-        self._gemm(f"{p}.ff.geglu", T, 8 * inner, ops.linear_segs([(ln.ptr, ln.C, ln.C)]), f"{p}.ff.net.0.proj.weight", ff,
-                   bias=self.w[f"{p}.ff.net.0.proj.bias"], epilogue=L.EPI_GEGLU)
-        self.release(ln)
+        self._ln_linear(f"{p}.ff.geglu", a2, f"{p}.norm3", 8 * inner, f"{p}.ff.net.0.proj.weight", ff,
+                        bias=self.w[f"{p}.ff.net.0.proj.bias"], epilogue=L.EPI_GEGLU)
         a3 = self.act(T, inner)
         self._gemm(f"{p}.ff.down", T, inner, ops.linear_segs([(ff.ptr, ff.C, ff.C)]), f"{p}.ff.net.2.weight", a3,
                    bias=self.w[f"{p}.ff.net.2.bias"], residual=a2.ptr, ldr=a2.C)
