@@ -59,6 +59,52 @@ def test_recorded_plan_matches_oracle(monkeypatch):
     assert rel_l2(eps, eps_ref) < 2e-2, rel_l2(eps, eps_ref)
 
 
+@pytest.mark.parametrize("fold", ["0", "1"])
+def test_layernorm_folding_is_equivalent(monkeypatch, fold):
+    """VMV_FOLD_LN: LayerNorm -> Linear as one GEMM on the raw rows (statistics pass + rowstat / colsum epilogue,
+    packing.fold_layernorm) or as two launches — both within the oracle bound, and the folded plan has no LN(x) buffer."""
+    plan_interp.install(monkeypatch)
+    monkeypatch.setenv("VMV_FOLD_LN", fold)
+    from videomv_amd import _lib as L
+    from videomv_amd.unet_engine import UNetEngine
+    ocfg = UNetCfg(**{k: v for k, v in CFG.items() if k in {f.name for f in dataclasses.fields(UNetCfg)}})
+    sd = random_state_dict(unet_param_shapes(ocfg), 7)
+    for k in list(sd):                      # non-trivial gamma / beta so that the fold is actually exercised
+        if ".norm1." in k or ".norm2." in k or ".norm3." in k:
+            sd[k] = sd[k] + 0.3 * torch.randn(sd[k].shape, generator=torch.Generator().manual_seed(len(k)))
+    B, F_, H, W, Lc = 2, 3, 8, 8, 5
+    x, t, y, cam = _inputs(B, F_, H, W, Lc, seed=11)
+    eps_ref = unet_forward(sd, ocfg, x, t, y, cam)
+    eng = UNetEngine(CFG, sd, B, F_, H, W, Lc, torch.device("cpu"), n_t=B)
+    eng.set_context(y)
+    eng.set_camera(cam)
+    eng.forward_rows(x, t)
+    assert rel_l2(eng.eps_ncfhw(), eps_ref) < 2e-2
+    lns = [p for op, p in eng.S.recorded if op == L.OP_LAYERNORM]
+    folded = [p for op, p in eng.S.recorded if op == L.OP_GEMM and p.rowstat]
+    if fold == "1":
+        assert lns and all(p.stats_out and not p.y for p in lns) and len(folded) == len(lns)
+    else:
+        assert lns and all(p.y and not p.stats_out for p in lns) and not folded
+
+
+def test_fold_layernorm_identity():
+    """packing.fold_layernorm: rstd * (W' x - mean * colsum) + b' == W LN(x) + b in exact arithmetic (fp64 here, with the
+    bf16-rounded W' on both sides)."""
+    from videomv_amd import packing as P
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(37, 64, generator=g, dtype=torch.float64) * 1.7 + 2.5
+    w, b = torch.randn(48, 64, generator=g), torch.randn(48, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(64, generator=g), 0.2 * torch.randn(64, generator=g)
+    wf, bf, cs = P.fold_layernorm(w, b, gamma, beta)
+    mean = x.mean(dim=1, keepdim=True)
+    rstd = torch.rsqrt(x.var(dim=1, unbiased=False, keepdim=True) + 1e-5)
+    got = rstd * (x @ wf.double().t() - mean * cs.double()[None, :]) + bf.double()
+    w_eff = wf.double() / gamma.double()[None, :]                       # the weight the rounded W' stands for
+    ref = ((x - mean) * rstd * gamma.double() + beta.double()) @ w_eff.t() + b.double() + (w.double() - w_eff) @ beta.double()
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-5)       # (b', colsum are fp32 sums)
+
+
 def test_pooled_buffers_give_same_result_as_unpooled(monkeypatch):
     """Buffer recycling must not alias a live tensor: pooled run == run with recycling disabled (taps mode)."""
     plan_interp.install(monkeypatch)
