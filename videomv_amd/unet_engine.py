@@ -261,15 +261,19 @@ class UNetEngine:
                 k = sd[f"{p}.{a}.to_k.weight"]
                 v = sd[f"{p}.{a}.to_v.weight"]
                 nk = "norm1" if a == "attn1" else "norm2"
+                # (with the LayerNorm folded in, only the folded copy of a consumer's weight is packed)
                 if k.shape[1] == q.shape[1]:   # self-attention: fused QKV
-                    w[f"{p}.{a}.qkv"] = P.pack_linear(torch.cat([q, k, v], dim=0), dev)
+                    if not self.fold_ln:
+                        w[f"{p}.{a}.qkv"] = P.pack_linear(torch.cat([q, k, v], dim=0), dev)
                     folded(f"{p}.{a}.qkv", torch.cat([q, k, v], dim=0), None, f"{p}.{nk}")
                 else:                          # cross-attention: Q on tokens, fused KV on the context
-                    w[f"{p}.{a}.q"] = P.pack_linear(q, dev)
+                    if not self.fold_ln:
+                        w[f"{p}.{a}.q"] = P.pack_linear(q, dev)
                     folded(f"{p}.{a}.q", q, None, f"{p}.{nk}")
                     w[f"{p}.{a}.kv"] = P.pack_linear(torch.cat([k, v], dim=0), dev)
                 lin(f"{p}.{a}.to_out.0")
-            w[f"{p}.ff.net.0.proj.weight"] = P.pack_linear(P.geglu_interleave(sd[f"{p}.ff.net.0.proj.weight"]), dev)
+            if not self.fold_ln:
+                w[f"{p}.ff.net.0.proj.weight"] = P.pack_linear(P.geglu_interleave(sd[f"{p}.ff.net.0.proj.weight"]), dev)
             w[f"{p}.ff.net.0.proj.bias"] = P.pack_bias(P.geglu_interleave(sd[f"{p}.ff.net.0.proj.bias"]), dev)
             folded(f"{p}.ff.net.0.proj", sd[f"{p}.ff.net.0.proj.weight"], sd[f"{p}.ff.net.0.proj.bias"], f"{p}.norm3", geglu=True)
             lin(f"{p}.ff.net.2")
