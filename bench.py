@@ -2,11 +2,12 @@
 """bench.py — denoise-steps/s of the HIP hot path on MI355X (BASELINE.json metric).
 
 One "step" = one DDIM denoising step of the t2v sampler on one 24-view sample:
-    [cond | uncond] UNetSD_T2VBase pass (full-size: dim 320, 1.413 B params, bf16 storage / fp32 accumulate)
+    [cond | uncond] UNetSD_T2VBase pass (full-size: dim 320, 1.413 B params, 16-bit storage (VMV_DTYPE: fp16 default | bf16) / fp32 accumulate)
     + classifier-free guidance + x0 + DDIM update                      (diffusion_ddim.py:149-160,192-195,233-243)
 Workload (BASELINE.json configs[1]): t2v_infer.yaml shape, 24 views, 320x512 px = latent [1,4,24,40,64], 77 text
 tokens, guide 9.0, linear_sd schedule, 50-step timestep list (981..1) cycled over the timed steps.
-Synthetic data: seeded randn latents / text features, real orbit cameras replaced by randn [1,24,16]; random-init
+Synthetic data: seeded randn latents / text features, the entrance's real orbit cameras (get_camera 24 x elevation 15,
+distance 2.0 + the row flips: videomv_amd/camera.py); random-init
 weights of the reference architecture with the zero-inits re-randomised (no checkpoint ships).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): every rank denoises its OWN sample — replicas,
@@ -141,7 +142,8 @@ def main():
     noise = torch.randn(1, 4, args.frames, H, W, generator=g, device=dev)
     y = torch.randn(1, 77, 1024, generator=g, device=dev)
     y0 = torch.randn(1, 77, 1024, generator=g, device=dev)
-    cam = torch.randn(1, args.frames, 16, generator=g, device=dev)
+    from videomv_amd.camera import entrance_camera_data
+    cam = entrance_camera_data(args.frames, elevation=15, camera_distance=2.0).to(dev)   # the entrance's real orbit cameras (§8d)
     steps = [int(s) for s in dif.ddim_steps(50)]
     stride = 1000 // 50
     xt = noise.clone()
@@ -235,7 +237,7 @@ def main():
         return {"metric": "denoise-steps/sec, t2v 320x512x24 (latent 24x%dx%d), CFG 9.0, 50-step DDIM schedule" % (H, W),
                "value": round(steps_per_s, 4), "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded randn latents/text/cameras; random-init "
+               "vs_baseline": None, "dtype": L.elem_name(), "data": "synthetic (seeded randn latents/text, real orbit cameras; random-init "
                "weights, zero-inits re-randomised)",
                "config": {"workload": f"t2v_infer.yaml UNetSD_T2VBase 1.413B, 24 views, latent {H}x{W}, 77 ctx tokens, "
                                       f"1 sample per GPU (cond+uncond batched)", "parallelism": f"replicas x{world}"},
@@ -264,7 +266,7 @@ def main():
             gs = torch.Generator(device=dev).manual_seed(11)       # the SAME sample on every rank
             noise_s = torch.randn(1, 4, args.frames, H, W, generator=gs, device=dev)
             ys, y0s = torch.randn(1, 77, 1024, generator=gs, device=dev), torch.randn(1, 77, 1024, generator=gs, device=dev)
-            cams = torch.randn(1, args.frames, 16, generator=gs, device=dev)
+            cams = cam
             fl = args.frames // world
             xs = noise_s[:, :, rank * fl:(rank + 1) * fl].clone().contiguous()
             kc, ku = dict(y=ys, camera_data=cams), dict(y=y0s, camera_data=cams)

@@ -11,8 +11,8 @@
  *     so calls are hipGraph-capturable and thread-safe across streams;
  *   - returns 0 on success, a negative VMV_E* code for argument violations (reported, never asserted), or the
  *     positive hipError_t of a failed launch.
- * Activations are channels-last "rows": a [rows, C] bf16 matrix whose row index enumerates (batch, frame, y, x)
- * (see DESIGN.md §3); weights are bf16 [N][K] (output-channel major, reduction contiguous).
+ * Activations are channels-last "rows": a [rows, C] elem (fp16 | bf16, vmv_elem_type()) matrix whose row index enumerates (batch, frame, y, x)
+ * (see DESIGN.md §3); weights are elem [N][K] (output-channel major, reduction contiguous).
  */
 #ifndef VMV_H
 #define VMV_H
@@ -29,8 +29,15 @@ extern "C" {
 #define VMV_ENULL        -3   /* required pointer is NULL */
 #define VMV_ERANGE       -4   /* size outside what the kernel supports */
 
-#define VMV_ABI_VERSION   1
+#define VMV_ABI_VERSION   2
 int vmv_abi_version(void);
+/* The 16-bit storage / MFMA operand type ("elem") this build of the library computes in.  The same sources are
+ * compiled once per type: libvmv_hip_f16.so (VMV_ELEM_F16: IEEE fp16 — the default; the reference's own half mode,
+ * `use_fp16` + autocast, configs/i2vgen_xl_infer.yaml) and libvmv_hip_bf16.so (VMV_ELEM_BF16).  Every "elem" pointer
+ * below is an array of that type; accumulation, statistics and softmax are fp32 in both builds. */
+#define VMV_ELEM_F16      0
+#define VMV_ELEM_BF16     1
+int vmv_elem_type(void);
 /* sizeof() of the argument blocks, so a foreign-language binding can verify its struct layout:
  * which = VMV_OP_* (GN_STATS/GN_APPLY share a block), 100 = VmvDdimParams, 101 = VmvGemmSeg, 102 = VmvSeqMap,
  * 103 = VmvGsParams */
@@ -55,7 +62,7 @@ const char* vmv_error_string(int code);
 #define VMV_SEG_TEMPORAL 2   /* m -> (b, f, p); source row m + d0*P if 0 <= f+d0 < F else zero */
 
 typedef struct {
-    const void* src;     /* bf16 rows; row stride `ld` elements                                  */
+    const void* src;     /* elem rows; row stride `ld` elements                                  */
     int32_t ld;          /* elements; multiple of 8                                              */
     int32_t k;           /* channels taken from each source row (multiple of 8)                   */
     int32_t mode;        /* VMV_SEG_*                                                            */
@@ -73,15 +80,15 @@ typedef struct {
     int32_t nseg;
     int32_t ktot;            /* = sum of seg.k = row stride of W                                   */
     VmvGemmSeg seg[VMV_MAX_SEGS];
-    const void* W;           /* bf16 [N][ktot]                                                     */
+    const void* W;           /* elem [N][ktot]                                                     */
     const float* bias;       /* [N] or NULL                                                        */
     const float* rowvec;     /* optional [M / rowvec_div][rowvec_ld] fp32 added per row group (time embedding) */
     int32_t rowvec_div, rowvec_ld;
-    const void* residual;    /* optional bf16 [M][ldr] added last                                  */
+    const void* residual;    /* optional elem [M][ldr] added last                                  */
     int32_t ldr;
     int32_t epilogue;        /* VMV_EPI_*                                                          */
     int32_t act;             /* VMV_ACT_* applied after bias/rowvec, before residual               */
-    int32_t out_fp32;        /* 0: bf16 output, 1: fp32 output                                     */
+    int32_t out_fp32;        /* 0: elem output, 1: fp32 output                                     */
     void* out;               /* [M][ldo]                                                           */
     int32_t ldo;
     /* geometry for SPATIAL segments */
@@ -96,7 +103,7 @@ typedef struct {
                                 core/unet.py:99,49, with the weights pre-scaled on the host)                    */
     /* LayerNorm folded into the GEMM (BasicTransformerBlock: norm -> Linear, util.py:520-546).  For y = W LN(x) + b with
      * LN(x) = (x - mean) * rstd * gamma + beta the host packs W' = W diag(gamma), bias' = b + W beta and
-     * colsum[n] = sum_k W'[n][k] (of the bf16-rounded W'), the GEMM runs on the RAW rows, and the epilogue computes
+     * colsum[n] = sum_k W'[n][k] (of the elem-rounded W'), the GEMM runs on the RAW rows, and the epilogue computes
      *     rstd[m] * (acc[m][n] - mean[m] * colsum[n]) + bias'[n]
      * with rowstat = fp32 [M][2] (mean, rstd) from vmv_layernorm(stats_out).  Linear segments only, no split-K.       */
     const float* rowstat;
@@ -122,7 +129,7 @@ typedef struct {
 #define VMV_TILE_S192x160 16
 #define VMV_TILE_S256x160 17
 
-int vmv_gemm_bf16(const VmvGemmParams* p, void* stream);
+int vmv_gemm(const VmvGemmParams* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * GroupNorm(32 groups) over row blocks + optional SiLU (torch group_norm + silu: util.py:329,649,673,1014,
@@ -131,7 +138,7 @@ int vmv_gemm_bf16(const VmvGemmParams* p, void* stream);
  * (SURVEY F9).  Two launches: partial sums (deterministic, no atomics), then normalise(+SiLU).
  * ---------------------------------------------------------------------------------------------------- */
 typedef struct {
-    const void* x;         /* bf16 [rows][ld]   (second source x1 optional: channels [C0, C0+C1) )  */
+    const void* x;         /* elem [rows][ld]   (second source x1 optional: channels [C0, C0+C1) )  */
     const void* x1;
     int32_t ld, ld1;
     int32_t C0, C1;        /* C = C0 + C1, C % 32 == 0, (C/32) % 2 == 0, C0 % 8 == 0               */
@@ -142,7 +149,7 @@ typedef struct {
     const float* beta;     /* [C] */
     float eps;
     int32_t silu;          /* 1: y = silu(gn(x)) */
-    void* y;               /* bf16 [rows][ldy] */
+    void* y;               /* elem [rows][ldy] */
     int32_t ldy;
     int32_t fold_ranks;    /* 0/1: `partial` holds this launch's sums.  R > 1 (frame-sharded 5-D norms): apply
                               folds `partial` = [R][nstat][nchunk][32][2] — the all-gathered sums of R equally sized shards of
@@ -157,7 +164,7 @@ typedef struct {
 int vmv_groupnorm_stats(const VmvGroupNormParams* p, void* stream);
 int vmv_groupnorm_apply(const VmvGroupNormParams* p, void* stream);
 
-/* LayerNorm over the channel axis of [rows][C] bf16 (nn.LayerNorm, eps 1e-5: util.py:528-530) */
+/* LayerNorm over the channel axis of [rows][C] elem (nn.LayerNorm, eps 1e-5: util.py:528-530) */
 typedef struct {
     const void* x; int32_t ldx;
     void* y; int32_t ldy;
@@ -170,11 +177,11 @@ typedef struct {
 } VmvLayerNormParams;
 int vmv_layernorm(const VmvLayerNormParams* p, void* stream);
 
-/* Row softmax: p[r][c] = softmax_c(scale * s[r][c]), fp32 scores -> bf16 probabilities.  Used by the VAE decoder's
+/* Row softmax: p[r][c] = softmax_c(scale * s[r][c]), fp32 scores -> elem probabilities.  Used by the VAE decoder's
  * single-head, 512-wide attention (AttnBlock, autoencoder.py:366-390), which runs as GEMM -> softmax -> GEMM. */
 typedef struct {
     const float* s; int32_t lds;
-    void* p; int32_t ldp;          /* bf16 */
+    void* p; int32_t ldp;          /* elem */
     int32_t rows, n;               /* n % 4 == 0 */
     float scale;
     int32_t _pad;
@@ -196,7 +203,7 @@ typedef struct {
 } VmvSeqMap;
 
 typedef struct {
-    const void* q; const void* k; const void* v; void* o;   /* bf16 */
+    const void* q; const void* k; const void* v; void* o;   /* elem */
     VmvSeqMap qm, km, vm, om;
     int32_t n_outer;       /* number of q problems per head */
     int32_t kv_div;        /* kv problem index = o / kv_div */
@@ -204,20 +211,20 @@ typedef struct {
     int32_t Nq, Nk;
     float scale;
 } VmvAttnParams;
-int vmv_attention_bf16(const VmvAttnParams* p, void* stream);
+int vmv_attention(const VmvAttnParams* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Sampler glue kernels (DiffusionDDIM.p_mean_variance / ddim_sample: diffusion_ddim.py:157-160,192-195,233-243;
  * layout moves of unet_t2v.py:348,368; embeddings unet_t2v.py:326-335).
  * ---------------------------------------------------------------------------------------------------- */
-/* latent [nb_src][C][F][H][W] fp32 -> rows [nrep*nb_src*F*H*W][Cpad] bf16 (channels zero-padded to Cpad, the
+/* latent [nb_src][C][F][H][W] fp32 -> rows [nrep*nb_src*F*H*W][Cpad] elem (channels zero-padded to Cpad, the
  * whole volume written nrep times: the cond / uncond CFG branches see the same x_t) */
 int vmv_latent_to_rows(const float* x, void* rows, int nb_src, int C, int F, int H, int W, int Cpad, int nrep,
                        void* stream);
 /* same gather, but ONLY channels [0, C) of each ld-wide row are written (the rest of the row is left untouched): the
  * I2VGen input rows carry x_t in channels 0..3 and the step-invariant image `concat` in 4..7 (unet_i2vgen.py:383) */
 int vmv_latent_to_rows_keep(const float* x, void* rows, int nb, int C, int F, int H, int W, int ld, int nrep, void* stream);
-/* rows [n*HW][ld] (bf16 or fp32) -> image/latent [n][C][H][W] fp32 (C <= ld) */
+/* rows [n*HW][ld] (elem or fp32) -> image/latent [n][C][H][W] fp32 (C <= ld) */
 int vmv_rows_to_nchw(const void* rows, int rows_fp32, int ld, float* out, int n, int C, int HW, void* stream);
 
 typedef struct {
@@ -238,18 +245,18 @@ int vmv_cfg_ddim_step(const VmvDdimParams* p, void* stream);
  * moments rows fp32 [n*HW][ld] = (mean[zc] | logvar[zc]); z[n][zc][HW] = scale * (mean + exp(0.5*clamp(logvar,-30,20)) * noise) */
 int vmv_posterior_sample(const float* moments_rows, int ld, const float* noise, float* z, int n, int zc, int HW, float scale,
                          void* stream);
-/* e[r][c] = silu(temb[(r / rows_per_t)][c] + (cam ? cam[r % cam_rows][c] : 0)) -> bf16 [rows][C] */
+/* e[r][c] = silu(temb[(r / rows_per_t)][c] + (cam ? cam[r % cam_rows][c] : 0)) -> elem [rows][C] */
 int vmv_emb_combine_silu(const float* temb, const float* cam, void* out, int rows, int C, int rows_per_t,
                          int cam_rows, void* stream);
-/* sinusoidal timestep embedding (cos || sin), out fp32->bf16 [n][dim]  (util.py:177-189) */
-int vmv_sinusoidal(const float* t, void* out_bf16, int n, int dim, void* stream);
+/* sinusoidal timestep embedding (cos || sin), out fp32->elem [n][dim]  (util.py:177-189) */
+int vmv_sinusoidal(const float* t, void* out_elem, int n, int dim, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * I2VGen-XL front-end helpers (once per sample; unet_i2vgen.py:331-346, 156-162).
  * ---------------------------------------------------------------------------------------------------- */
 /* TransformerV2(depth 1, dim 4, heads 2, dim_head 4, mlp 16) over the F frames of every pixel (util.py:1091-1148):
  *   x = to_out(softmax(q k^T / 2) v) + x  with q,k,v = to_qkv(LayerNorm(x));   x = W2 gelu(W1 x + b1) + b2 + x
- * in: bf16 rows [F*HW][ld_in] (4 channels used); out: `scale` * result written to bf16 rows [nrep][F*HW][ld_out] at
+ * in: elem rows [F*HW][ld_in] (4 channels used); out: `scale` * result written to elem rows [nrep][F*HW][ld_out] at
  * channel offset 0 of `out` (pass out = base + 4 to fill channels 4..7).  w = packed fp32 parameter block:
  *   ln_g[4] ln_b[4] Wqkv[24][4] Wo[4][8] bo[4] W1[16][4] b1[16] W2[4][16] b2[4]   (288 floats). */
 int vmv_i2v_temporal_adapter(const void* in, int ld_in, void* out, int ld_out, const float* w, int F, int HW, int nrep,

@@ -14,15 +14,15 @@ from videomv_amd import _lib as L
 
 
 def _view(ptr, n, kind):
-    """Torch view of n elements at raw host address ptr. kind: 'bf16' | 'f32'."""
-    if kind == "bf16":
+    """Torch view of n elements at raw host address ptr. kind: 'elem' (the 16-bit type in use) | 'f32'."""
+    if kind == "elem":
         arr = np.ctypeslib.as_array((C.c_uint16 * n).from_address(ptr))
-        return torch.from_numpy(arr.view(np.int16)).view(torch.bfloat16)
+        return torch.from_numpy(arr.view(np.int16)).view(L.elem())
     arr = np.ctypeslib.as_array((C.c_float * n).from_address(ptr))
     return torch.from_numpy(arr)
 
 
-def _rows(ptr, nrows, ld, kind="bf16"):
+def _rows(ptr, nrows, ld, kind="elem"):
     return _view(ptr, nrows * ld, kind).view(nrows, ld)
 
 
@@ -75,8 +75,8 @@ def gemm(p: L.GemmParams):
         acc = torch.nn.functional.silu(acc)
     if p.residual:
         acc = acc + (p.res_scale if p.res_scale != 0.0 else 1.0) * _rows(p.residual, M, p.ldr)[:, :No].float()
-    out = _rows(p.out, M, p.ldo, "f32" if p.out_fp32 else "bf16")
-    out[:, :No] = acc if p.out_fp32 else acc.to(torch.bfloat16)
+    out = _rows(p.out, M, p.ldo, "f32" if p.out_fp32 else "elem")
+    out[:, :No] = acc if p.out_fp32 else acc.to(L.elem())
 
 
 def _gn_input(p):
@@ -120,14 +120,14 @@ def groupnorm(p: L.GroupNormParams):
     y = y * _view(p.gamma, Cc, "f32") + _view(p.beta, Cc, "f32")
     if p.silu:
         y = torch.nn.functional.silu(y)
-    _rows(p.y, p.rows, p.ldy)[:, :Cc] = y.to(torch.bfloat16)
+    _rows(p.y, p.rows, p.ldy)[:, :Cc] = y.to(L.elem())
 
 
 def permute_copy(p: L.CopyParams):
     """dst[i0][i1][i2][:] = src[i0*ss0 + i1*ss1 + i2*ss2 + :], 16-byte units (8 bf16)."""
     span = (p.n0 - 1) * p.ss0 + (p.n1 - 1) * p.ss1 + (p.n2 - 1) * p.ss2 + p.inner16
-    src = _view(p.src, span * 8, "bf16").view(torch.int16)
-    dst = _view(p.dst, p.n0 * p.n1 * p.n2 * p.inner16 * 8, "bf16").view(torch.int16)
+    src = _view(p.src, span * 8, "elem").view(torch.int16)
+    dst = _view(p.dst, p.n0 * p.n1 * p.n2 * p.inner16 * 8, "elem").view(torch.int16)
     v = torch.as_strided(src, (p.n0, p.n1, p.n2, p.inner16 * 8), (p.ss0 * 8, p.ss1 * 8, p.ss2 * 8, 1))
     dst.view(p.n0, p.n1, p.n2, p.inner16 * 8).copy_(v)
 
@@ -140,12 +140,12 @@ def layernorm(p: L.LayerNormParams):
         _view(p.stats_out, 2 * p.rows, "f32").view(p.rows, 2).copy_(torch.stack([mean, rstd], dim=1))
         return
     y = torch.nn.functional.layer_norm(x, (p.C,), _view(p.gamma, p.C, "f32"), _view(p.beta, p.C, "f32"), p.eps)
-    _rows(p.y, p.rows, p.ldy)[:, : p.C] = y.to(torch.bfloat16)
+    _rows(p.y, p.rows, p.ldy)[:, : p.C] = y.to(L.elem())
 
 
 def _seq_rows(ptr, mp, o, h, n):
     base = (o // mp.inner) * mp.s_outer + (o % mp.inner) * mp.s_inner + h * 64
-    flat = _view(ptr, int(base + (n - 1) * mp.s_row + 64), "bf16")
+    flat = _view(ptr, int(base + (n - 1) * mp.s_row + 64), "elem")
     idx = base + torch.arange(n)[:, None] * mp.s_row + torch.arange(64)[None, :]
     return flat, idx
 
@@ -158,14 +158,14 @@ def attention(p: L.AttnParams):
             vf, vi = _seq_rows(p.v, p.vm, o // p.kv_div, h, p.Nk)
             q, k, v = qf[qi].float(), kf[ki].float(), vf[vi].float()
             s = torch.softmax(q @ k.t() * p.scale, dim=-1)
-            out = (s @ v).to(torch.bfloat16)
+            out = (s @ v).to(L.elem())
             of, oi = _seq_rows(p.o, p.om, o, h, p.Nq)
             of[oi.reshape(-1)] = out.reshape(-1)
 
 
 def softmax_rows(p: L.SoftmaxParams):
     s = _rows(p.s, p.rows, p.lds, "f32")[:, : p.n]
-    _rows(p.p, p.rows, p.ldp)[:, : p.n] = torch.softmax(s * p.scale, dim=-1).to(torch.bfloat16)
+    _rows(p.p, p.rows, p.ldp)[:, : p.n] = torch.softmax(s * p.scale, dim=-1).to(L.elem())
 
 
 def run_recorded(recorded):
@@ -194,12 +194,12 @@ def latent_to_rows(x, rows, Cpad, nrep):
     r = x.permute(0, 2, 3, 4, 1).reshape(nb * F_ * H * W, Cc)
     full = torch.zeros(nb * F_ * H * W, Cpad)
     full[:, :Cc] = r
-    rows.copy_(full.repeat(nrep, 1).to(torch.bfloat16))
+    rows.copy_(full.repeat(nrep, 1).to(L.elem()))
 
 
 def latent_to_rows_keep(x, rows, ld, nrep):
     nb, Cc, F_, H, W = x.shape
-    r = x.permute(0, 2, 3, 4, 1).reshape(nb * F_ * H * W, Cc).to(torch.bfloat16)
+    r = x.permute(0, 2, 3, 4, 1).reshape(nb * F_ * H * W, Cc).to(L.elem())
     rows.view(nrep, nb * F_ * H * W, ld)[:, :, :Cc] = r[None]
 
 
@@ -214,8 +214,8 @@ def i2v_temporal_adapter(inp, ld_in, out_ptr, ld_out, w, F_, HW, nrep, scale):
     a = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) * 0.5, dim=-1) @ sp(v)
     y = a.permute(0, 2, 1, 3).reshape(HW, F_, 8) @ Wo.t() + bo + x
     z = Fn.gelu(y @ W1.t() + b1) @ W2.t() + b2 + y
-    res = (scale * z).permute(1, 0, 2).reshape(F_ * HW, 4).to(torch.bfloat16)
-    out = _view(_p(out_ptr), (nrep * F_ * HW - 1) * ld_out + 4, "bf16")
+    res = (scale * z).permute(1, 0, 2).reshape(F_ * HW, 4).to(L.elem())
+    out = _view(_p(out_ptr), (nrep * F_ * HW - 1) * ld_out + 4, "elem")
     idx = torch.arange(nrep * F_ * HW)[:, None] * ld_out + torch.arange(4)[None, :]
     out[idx.reshape(-1)] = res.repeat(nrep, 1).reshape(-1)
 
@@ -224,7 +224,7 @@ def adaptive_avgpool_rows(inp, ld, out, ldo, n, Cc, IH, IW, OH, OW):
     import torch.nn.functional as Fn
     x = _rows(_p(inp), n * IH * IW, ld)[:, :Cc].float().view(n, IH, IW, Cc).permute(0, 3, 1, 2)
     y = Fn.adaptive_avg_pool2d(x, (OH, OW)).permute(0, 2, 3, 1).reshape(n * OH * OW, Cc)
-    _rows(_p(out), n * OH * OW, ldo)[:, :Cc] = y.to(torch.bfloat16)
+    _rows(_p(out), n * OH * OW, ldo)[:, :Cc] = y.to(L.elem())
 
 
 def posterior_sample(moments_rows, ld, noise, z, scale):
@@ -282,14 +282,14 @@ def emb_combine_silu(temb, cam, out, rows, Cc, rows_per_t, cam_rows):
     v = temb[r // rows_per_t]
     if cam is not None:
         v = v + cam[r % cam_rows]
-    out.copy_(torch.nn.functional.silu(v).to(torch.bfloat16))
+    out.copy_(torch.nn.functional.silu(v).to(L.elem()))
 
 
 def sinusoidal(t, out, n, dim):
     half = dim // 2
     freq = torch.pow(10000, -torch.arange(half).float() / half)
     s = torch.outer(t.float(), freq)
-    out.copy_(torch.cat([torch.cos(s), torch.sin(s)], dim=1).to(torch.bfloat16))
+    out.copy_(torch.cat([torch.cos(s), torch.sin(s)], dim=1).to(L.elem()))
 
 
 def cfg_ddim_step(eps_rows, ld, xt, guide_scale, c_recip, c_recipm1, c_sqrt_ac, c_sqrt_1mac, a_prev, v_pred=False,

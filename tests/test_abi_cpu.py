@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
-    assert lib.vmv_abi_version() == 1
+    assert lib.vmv_abi_version() == 2
 
 
 def test_struct_layouts_match_c():
@@ -35,15 +35,15 @@ def test_struct_layouts_match_c():
 
 def test_argument_validation_needs_no_gpu():
     lib = L.load()
-    a = torch.zeros(64, 64, dtype=torch.bfloat16)
+    a = torch.zeros(64, 64, dtype=L.elem())
     p = ops.gemm_params(64, 64, ops.linear_segs([(a, 64, 64)]), a, a, 64)
     p.N = 63
-    assert lib.vmv_gemm_bf16(C.byref(p), None) == -1
+    assert lib.vmv_gemm(C.byref(p), None) == -1
     p = ops.gemm_params(64, 64, ops.linear_segs([(a, 64, 64)]), None, a, 64)
-    assert lib.vmv_gemm_bf16(C.byref(p), None) == -3
+    assert lib.vmv_gemm(C.byref(p), None) == -3
     p = ops.gemm_params(64, 64, ops.linear_segs([(a.data_ptr() + 2, 64, 64)]), a, a, 64)
-    assert lib.vmv_gemm_bf16(C.byref(p), None) == -2
-    assert lib.vmv_gemm_bf16(None, None) == -3
+    assert lib.vmv_gemm(C.byref(p), None) == -2
+    assert lib.vmv_gemm(None, None) == -3
     assert b"VMV_EALIGN" in lib.vmv_error_string(-2)
     ln = ops.ln_params(a, 64, a, 64, None, None, 64, 64)
     assert lib.vmv_layernorm(C.byref(ln), None) == -3
@@ -54,7 +54,7 @@ def test_argument_validation_needs_no_gpu():
 def test_plan_records_and_sizes():
     lib = L.load()
     plan = lib.vmv_plan_create()
-    a = torch.zeros(64, 64, dtype=torch.bfloat16)
+    a = torch.zeros(64, 64, dtype=L.elem())
     p = ops.gemm_params(64, 64, ops.linear_segs([(a, 64, 64)]), a, a, 64)
     assert lib.vmv_plan_add(plan, L.OP_GEMM, C.byref(p), C.sizeof(p)) == 0
     assert lib.vmv_plan_add(plan, L.OP_GEMM, C.byref(p), C.sizeof(p) - 8) == -1     # wrong block size
@@ -65,6 +65,6 @@ def test_plan_records_and_sizes():
 
 def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(L, "_lib", None)
-    monkeypatch.setattr(L, "LIB_PATH", "/nonexistent/libvmv_hip.so")
+    monkeypatch.setattr(L, "lib_path", lambda: "/nonexistent/libvmv_hip_f16.so")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         L.load()

@@ -9,7 +9,7 @@ from videomv_amd import _lib as L
 from videomv_amd import ops, packing as P
 from tests import plan_interp as I
 
-BF = torch.bfloat16
+BF = L.elem()
 
 
 def g(seed):

@@ -16,7 +16,9 @@ from videomv_amd import ops, packing as P
 from tests import plan_interp as I
 
 pytestmark = pytest.mark.gpu
-BF = torch.bfloat16
+BF = L.elem()
+# fp16 carries 3 more significand bits than bf16: every storage-rounding tolerance below is stated for bf16 and tightened 8x for fp16
+TS = 1.0 if BF == torch.bfloat16 else 0.125
 
 
 def rel_l2(a, b):
@@ -29,7 +31,7 @@ def check(out_gpu, out_ref, tol_l2=4e-3, tol_max=1e-2):
     scale = float(b.abs().max().clamp_min(1e-6))
     e_max = float((a - b).abs().max()) / scale
     e_l2 = rel_l2(a, b)
-    assert e_l2 < tol_l2 and e_max < tol_max, (e_l2, e_max)
+    assert e_l2 < tol_l2 * TS and e_max < tol_max * TS, (e_l2, e_max, TS)
 
 
 def g(seed):
@@ -268,11 +270,11 @@ def test_gemm_rejects_bad_arguments():
     import ctypes as C
     p = ops.gemm_params(64, 64, ops.linear_segs([(t["a"], 64, 64)]), t["w"], t["out"], 64)
     p.N = 63
-    assert lib.vmv_gemm_bf16(C.byref(p), None) == -1          # VMV_EINVAL
+    assert lib.vmv_gemm(C.byref(p), None) == -1          # VMV_EINVAL
     p = ops.gemm_params(64, 64, ops.linear_segs([(t["a"].data_ptr() + 2, 64, 64)]), t["w"], t["out"], 64)
-    assert lib.vmv_gemm_bf16(C.byref(p), None) == -2          # VMV_EALIGN
+    assert lib.vmv_gemm(C.byref(p), None) == -2          # VMV_EALIGN
     p = ops.gemm_params(64, 64, ops.linear_segs([(t["a"], 64, 64)]), None, t["out"], 64)
-    assert lib.vmv_gemm_bf16(C.byref(p), None) == -3          # VMV_ENULL
+    assert lib.vmv_gemm(C.byref(p), None) == -3          # VMV_ENULL
 
 
 # ------------------------------------------------------------------------------------------------- norms
@@ -443,9 +445,9 @@ def test_gemm_layernorm_folded_rejects_split_k_and_gathers():
     x = rnd((256, 128), 1).cuda(); w = rnd((128, 128), 2).cuda(); o = torch.zeros(256, 128, dtype=BF, device="cuda")
     st = torch.zeros(256, 2, device="cuda"); cs = torch.zeros(128, device="cuda"); ws = torch.zeros(2 * 256 * 128, device="cuda")
     p = ops.gemm_params(256, 128, ops.linear_segs([(x, 128, 128)]), w, o, 128, rowstat=st, colsum=cs, ksplit=2, workspace=ws)
-    assert lib.vmv_gemm_bf16(C.byref(p), None) == -1          # VMV_EINVAL
+    assert lib.vmv_gemm(C.byref(p), None) == -1          # VMV_EINVAL
     p = ops.gemm_params(256, 128, ops.linear_segs([(x, 128, 128)]), w, o, 128, rowstat=st)
-    assert lib.vmv_gemm_bf16(C.byref(p), None) == -3          # VMV_ENULL
+    assert lib.vmv_gemm(C.byref(p), None) == -3          # VMV_ENULL
 
 
 # ------------------------------------------------------------------------------------------------- attention

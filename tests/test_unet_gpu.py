@@ -2,10 +2,11 @@
 (HIP plan) vs (a) the golden eps captured from the imported reference and (b) the oracle, plus the fused
 CFG + DDIM loop vs the oracle's loop.
 
-Tolerances (stated): the HIP path stores activations in bf16 (fp32 accumulate) while the reference /
-oracle are fp32: rel-L2(eps) <= 3e-2 per forward on these 9-19-block tiny nets with re-randomised weights
-(the CPU emulation of the same bf16 storage measures 1.6e-2), per-block taps <= 3e-2, x0 after a 3-step CFG-9
-DDIM loop rel-L2 <= 6e-2 (guidance scale 9 amplifies the eps error ~x9 on the cond-uncond difference)."""
+Tolerances = the ones SURVEY §8d states: rel-L2(eps) <= 1e-2 per forward, per-block taps <= 5e-3, x0 after a CFG-9 DDIM
+loop <= 2e-2, against the fp32 reference / oracle.  They hold for the default fp16 storage (11 significand bits; measured
+~2e-3 / ~2e-3 / ~4e-3).  With VMV_DTYPE=bf16 (8 bits) they CANNOT hold: the CPU emulation of the storage roundings
+(tools/experiments/prec_emul.py) gives 1.3e-2 per forward for bf16 everywhere and still 0.84e-2 / blocks 0.87e-2 with an
+fp32 residual stream, so the bf16 build is only held to 3e-2 / 3e-2 / 6e-2."""
 import dataclasses
 import json
 import os
@@ -20,6 +21,11 @@ from oracle.weights import random_state_dict, unet_param_shapes
 from oracle.ddim_ref import betas_for, DDIMTables, ddim_sample_loop
 
 pytestmark = pytest.mark.gpu
+
+from videomv_amd import _lib as _L  # noqa: E402
+FP16 = _L.elem_name() == "fp16"
+TOL_FWD, TOL_BLOCK, TOL_X0 = (1e-2, 5e-3, 2e-2) if FP16 else (3e-2, 3e-2, 6e-2)
+TOL_AUX = 5e-3 if FP16 else 2.5e-2          # VAE decode / encode, LGM Gaussians (not stated by §8d; same per-block bound)
 
 
 def rel_l2(a, b):
@@ -49,7 +55,7 @@ def test_unet_matches_reference_golden(golden_dir):
     eps = m(g["x"].cuda(), g["t"].cuda(), y=g["y"].cuda(), camera_data=g["camera_data"])   # camera stays on CPU (F14)
     assert eps.shape == g["eps"].shape and eps.dtype == torch.float32
     e = rel_l2(eps, g["eps"])
-    assert e < 3e-2, e
+    assert e < TOL_FWD, e
     # run-to-run bitwise determinism (no atomics anywhere on the path)
     eps2 = m(g["x"].cuda(), g["t"].cuda(), y=g["y"].cuda(), camera_data=g["camera_data"])
     assert torch.equal(eps, eps2)
@@ -81,7 +87,7 @@ def test_unet_blocks_match_oracle():
         mine = act.tensor().float().view(B * F_, h, w, act.C).permute(0, 3, 1, 2)
         report[key] = rel_l2(mine, taps_ref[key])
     report["eps"] = rel_l2(eng.eps_ncfhw(), eps_ref)
-    assert all(v < 3e-2 for v in report.values()), report
+    assert report["eps"] < TOL_FWD and all(v < TOL_BLOCK for v in report.values()), report
 
 
 def test_fused_cfg_ddim_loop_matches_oracle():
@@ -105,7 +111,7 @@ def test_fused_cfg_ddim_loop_matches_oracle():
     x_ref = ddim_sample_loop(noise.clone(), lambda xt, t, y, camera_data: unet_forward(sd, ocfg, xt, t, y, camera_data),
                              tb, [dict(y=y, camera_data=cam), dict(y=y0, camera_data=cam)], 9.0, ddim_timesteps=3)
     e = rel_l2(x_hip, x_ref)
-    assert e < 6e-2, e
+    assert e < TOL_X0, e
     # the reference-structured generic path (two forwards per step through forward()) must agree with the fused one
     x_gen = noise.cuda()
     for step in dif.ddim_steps(3):
@@ -115,7 +121,7 @@ def test_fused_cfg_ddim_loop_matches_oracle():
     #  factors for their different row counts, so fp32 accumulation order and hence isolated bf16 roundings differ; CFG 9
     #  over 3 steps amplifies that.  Both must sit within the oracle bound; their mutual distance is reported.)
     e_gen_ref, e_gen = rel_l2(x_gen, x_ref), rel_l2(x_gen, x_hip.cpu())
-    assert e_gen_ref < 6e-2 and e_gen < 6e-2, (e, e_gen_ref, e_gen)
+    assert e_gen_ref < TOL_X0 and e_gen < TOL_X0, (e, e_gen_ref, e_gen)
     print("fused-vs-oracle", e, "generic-vs-oracle", e_gen_ref, "generic-vs-fused", e_gen)
 
 
@@ -133,7 +139,7 @@ def test_vae_decode_matches_reference_golden(golden_dir):
     img = vae.decode(g["z"].cuda())
     assert img.shape == g["img"].shape
     e = rel_l2(img, g["img"])
-    assert e < 2e-2, e
+    assert e < TOL_AUX, e
 
 
 def test_inference_py_entry_on_gpu(tmp_path):
@@ -178,8 +184,7 @@ def test_inference_py_i2vgen_entry_on_gpu(tmp_path):
 
 
 def test_i2vgen_matches_reference_golden_and_vpred_loop(golden_dir):
-    """BASELINE configs[3] analogue: UNetSD_I2VGen on HIP vs the imported reference's output (tolerance 3e-2, bf16
-    storage), then the fused CFG + v-prediction DDIM loop (cosine schedule with zero terminal SNR, guide 6) vs the oracle."""
+    """BASELINE configs[3] analogue: UNetSD_I2VGen on HIP vs the imported reference's output (tolerance TOL_FWD), then the fused CFG + v-prediction DDIM loop (cosine schedule with zero terminal SNR, guide 6) vs the oracle."""
     from videomv_amd.registry import MODEL, DIFFUSION
     from oracle.unet_i2v_ref import i2v_param_shapes, unet_i2v_forward
     path = os.path.join(golden_dir, "unet_i2v_tiny.safetensors")
@@ -197,7 +202,7 @@ def test_i2vgen_matches_reference_golden_and_vpred_loop(golden_dir):
     out = m(g["x"].cuda(), g["t"].cuda(), y=g["y"].cuda(), image=g["image"].cuda(), local_image=g["local_image"].cuda(),
             fps=g["fps"].cuda(), camera_data=g["camera_data"])
     e = rel_l2(out, g["out"])
-    assert e < 3e-2, e
+    assert e < TOL_FWD, e
     dif = DIFFUSION.build(dict(type="DiffusionDDIM", schedule="cosine",
                                schedule_param=dict(num_timesteps=1000, cosine_s=0.008, zero_terminal_snr=True),
                                mean_type="v", var_type="fixed_small"))
@@ -222,14 +227,14 @@ def test_i2vgen_matches_reference_golden_and_vpred_loop(golden_dir):
                              ddim_timesteps=4, mean_type="v")
     assert torch.isfinite(x_hip).all()
     e2 = rel_l2(x_hip, x_ref)
-    assert e2 < 6e-2, e2
+    assert e2 < TOL_X0, e2
 
 
 def test_full_size_architecture_parity_small_latent():
     """The REAL architecture (dim 320, 1.413 B parameters, 28 blocks, heads 5/10/20) on a small latent (24 x 8 x 8) vs the
     fp32 oracle on the host: measures how the bf16 storage error accumulates over the full depth.
-    Stated tolerance: rel-L2(eps) <= 2.5e-2 per forward with fully random (non-zero-init) weights (measured 1.35e-2,
-    per-block 0.5e-2 .. 1.5e-2, saturating after the first encoder level)."""
+    Stated tolerance (§8d): rel-L2(eps) <= 1e-2, every block tap <= 5e-3, fully random (non-zero-init) weights (bf16 build:
+    measured 1.35e-2, per-block 0.5e-2 .. 1.5e-2, held to 3e-2)."""
     from videomv_amd.unet_engine import UNetEngine
     cfg = dict(in_dim=4, dim=320, context_dim=1024, out_dim=4, dim_mult=[1, 2, 4, 4], num_heads=8, head_dim=64,
                num_res_blocks=2, attn_scales=[1.0, 0.5, 0.25], camera_dim=16, use_camera_condition=True,
@@ -255,7 +260,7 @@ def test_full_size_architecture_parity_small_latent():
               for k, (a, h, w) in taps.items()}
     e = rel_l2(eng.eps_ncfhw(), eps_ref)
     print("full-size per-block rel-L2:", report, "eps:", e)
-    assert e < 2.5e-2, (e, report)
+    assert e < TOL_FWD and all(v < TOL_BLOCK for v in report.values()), (e, report)
 
 
 def test_vae_encode_matches_reference_golden(golden_dir):
@@ -272,12 +277,12 @@ def test_vae_encode_matches_reference_golden(golden_dir):
     vae.load_state_dict(sd, strict=False)
     post = vae.encode(g["img"].cuda())
     e = rel_l2(post.parameters, g["moments"])
-    assert e < 2e-2, e
+    assert e < TOL_AUX, e
     torch.manual_seed(5)
     z = vae.encode_firsr_stage(g["img"].cuda(), 0.18215)
     torch.manual_seed(5)
     noise = torch.randn(2, 4, 8, 9)
-    assert rel_l2(z, posterior_sample(g["moments"], noise, 0.18215)) < 2e-2
+    assert rel_l2(z, posterior_sample(g["moments"], noise, 0.18215)) < TOL_AUX
 
 
 def test_lgm_gaussians_match_reference_golden(golden_dir):
@@ -299,7 +304,7 @@ def test_lgm_gaussians_match_reference_golden(golden_dir):
     torch.cuda.synchronize()
     assert torch.isfinite(gauss).all()
     e = rel_l2(gauss, gg["gaussians"][0])
-    assert e < 2.5e-2, e
+    assert e < TOL_AUX, e
 
 
 def test_lgm_latent_z_matches_oracle_composition():

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from videomv_amd import _lib as L, ops
 
-BF = torch.bfloat16
+BF = L.elem()
 N160 = (L.TILE_128x160, L.TILE_256x160, L.TILE_G128x160, L.TILE_P256x160, L.TILE_PP256x160, L.TILE_Q96x160, L.TILE_S192x160, L.TILE_S256x160)
 
 

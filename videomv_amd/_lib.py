@@ -1,13 +1,43 @@
-"""ctypes binding of ``libvmv_hip.so`` (the C ABI declared in ``include/vmv.h``).
+"""ctypes binding of ``libvmv_hip_{f16,bf16}.so`` (the C ABI declared in ``include/vmv.h``).
 
 The structures below mirror the header field-for-field.  Loading fails loudly (``RuntimeError``) when the
 shared library is missing: there is NO CPU / PyTorch fallback for the hot path.
+
+The kernels are built once per 16-bit element type (storage + MFMA operands; fp32 accumulate in both).  A process uses
+ONE of them: ``VMV_DTYPE`` = ``fp16`` (default — 11 significand bits, what the stated parity tolerances need, and the
+reference's own half mode: ``use_fp16`` / autocast) or ``bf16``; ``set_elem()`` overrides it until the first ``load()``.
 """
 import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvmv_hip.so")
+_ELEM_NAMES = {"fp16": "f16", "f16": "f16", "float16": "f16", "half": "f16", "bf16": "bf16", "bfloat16": "bf16"}
+_elem = _ELEM_NAMES[os.environ.get("VMV_DTYPE", "fp16").lower()]
+ELEM_F16, ELEM_BF16 = 0, 1
+
+
+def set_elem(name: str):
+    """Choose the element type ("fp16" | "bf16") before the library is first loaded."""
+    global _elem
+    new = _ELEM_NAMES[str(name).lower()]
+    if _lib is not None and new != _elem:
+        raise RuntimeError(f"the {_elem} kernels are already loaded; set VMV_DTYPE / call set_elem() before first use")
+    _elem = new
+
+
+def elem_name() -> str:
+    """"fp16" | "bf16" """
+    return "fp16" if _elem == "f16" else "bf16"
+
+
+def elem():
+    """torch dtype of the 16-bit storage type of the loaded / selected library."""
+    import torch
+    return torch.float16 if _elem == "f16" else torch.bfloat16
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "lib", f"libvmv_hip_{_elem}.so")
 
 VMV_MAX_SEGS = 24
 SEG_LINEAR, SEG_SPATIAL, SEG_TEMPORAL = 0, 1, 2
@@ -97,13 +127,14 @@ class DdimParams(C.Structure):
 _P = C.c_void_p
 SYMBOLS = {
     "vmv_abi_version": (C.c_int, []),
+    "vmv_elem_type": (C.c_int, []),
     "vmv_sizeof": (C.c_int, [C.c_int]),
     "vmv_error_string": (C.c_char_p, [C.c_int]),
-    "vmv_gemm_bf16": (C.c_int, [C.POINTER(GemmParams), _P]),
+    "vmv_gemm": (C.c_int, [C.POINTER(GemmParams), _P]),
     "vmv_groupnorm_stats": (C.c_int, [C.POINTER(GroupNormParams), _P]),
     "vmv_groupnorm_apply": (C.c_int, [C.POINTER(GroupNormParams), _P]),
     "vmv_layernorm": (C.c_int, [C.POINTER(LayerNormParams), _P]),
-    "vmv_attention_bf16": (C.c_int, [C.POINTER(AttnParams), _P]),
+    "vmv_attention": (C.c_int, [C.POINTER(AttnParams), _P]),
     "vmv_softmax_rows": (C.c_int, [C.POINTER(SoftmaxParams), _P]),
     "vmv_permute_copy": (C.c_int, [C.POINTER(CopyParams), _P]),
     "vmv_gaussian_activation": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P]),
@@ -139,6 +170,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    LIB_PATH = lib_path()
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; "
@@ -148,8 +180,10 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the ABI drifted
         fn.restype = res
         fn.argtypes = args
-    if lib.vmv_abi_version() != 1:
-        raise RuntimeError("libvmv_hip.so ABI version mismatch")
+    if lib.vmv_abi_version() != 2:
+        raise RuntimeError(f"{LIB_PATH}: ABI version mismatch")
+    if lib.vmv_elem_type() != (ELEM_F16 if _elem == "f16" else ELEM_BF16):
+        raise RuntimeError(f"{LIB_PATH} was built for another element type")
     for which, st in ((OP_GEMM, GemmParams), (OP_GN_STATS, GroupNormParams), (OP_LAYERNORM, LayerNormParams),
                       (OP_ATTENTION, AttnParams), (OP_SOFTMAX, SoftmaxParams), (OP_COPY, CopyParams), (103, GsParams), (100, DdimParams), (101, GemmSeg), (102, SeqMap)):
         if lib.vmv_sizeof(which) != C.sizeof(st):

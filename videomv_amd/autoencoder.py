@@ -23,7 +23,7 @@ from .registry import AUTO_ENCODER
 from . import _lib as L
 from . import ops
 from . import packing as P
-from .unet_engine import Pool, Act, BF16
+from .unet_engine import Pool, Act
 from .unet_t2v import _Holder
 
 
@@ -131,8 +131,8 @@ class _VaeEngine:
 
 
     # ---- helpers
-    def act(self, rows, C, dtype=BF16):
-        return Act(self.pool.get(rows * C * (2 if dtype == BF16 else 4)), rows, C, dtype)
+    def act(self, rows, C, dtype=None):
+        return Act(self.pool.get(rows * C * (4 if dtype == torch.float32 else 2)), rows, C, dtype)
 
     def rel(self, a):
         self.pool.put(a.buf)
@@ -233,8 +233,8 @@ class VaeDecoderEngine(_VaeEngine):
         T = n * h * w
         zc = self.dd["z_channels"]
         self.zpad = (zc + 7) // 8 * 8
-        self.z_rows = torch.zeros(T, self.zpad, dtype=BF16, device=dev)
-        self.pq_rows = torch.zeros(T, self.zpad, dtype=BF16, device=dev)     # cols >= zc stay zero
+        self.z_rows = torch.zeros(T, self.zpad, dtype=L.elem(), device=dev)
+        self.pq_rows = torch.zeros(T, self.zpad, dtype=L.elem(), device=dev)     # cols >= zc stay zero
         self._gemm("post_quant", T, ops.linear_segs([(self.z_rows.data_ptr(), self.zpad, self.zpad)]),
                    "post_quant_conv.weight", self.pq_rows.data_ptr(), ldo=self.zpad, bias=self.wt["post_quant_conv.bias"])
         c_in = self.wt["decoder.conv_in.weight"].shape[0]
@@ -305,7 +305,7 @@ class VaeEncoderEngine(_VaeEngine):
         n, h, w, dev = self.n, self.h, self.w, self.device
         cin = self.dd["in_channels"]
         self.cpad = (cin + 7) // 8 * 8
-        self.x_rows = torch.zeros(n * h * w, self.cpad, dtype=BF16, device=dev)
+        self.x_rows = torch.zeros(n * h * w, self.cpad, dtype=L.elem(), device=dev)
         c0 = self.wt["encoder.conv_in.weight"].shape[0]
         x = self.act(n * h * w, c0)
         self._gemm("conv_in", n * h * w, ops.conv3x3_segs([(self.x_rows.data_ptr(), self.cpad, self.cpad)]),

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
     // per stage: K tile [64 keys][8 slots] in 16-B units (8 KB) then V^T tile [64 d][64 keys] bf16 (8 KB)
 
     // ---- Q fragments (B operand): row q0 + 16*qt + u, k-slot kk*32 + 8*g
-    bf16x8_t qf[QT][2];
+    elem8_t qf[QT][2];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         const int q = q0 + qt * 16 + u;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
         for (int kk = 0; kk < 2; ++kk) {
             u32x4_t v = {0u, 0u, 0u, 0u};
             if (wvalid && q < p.Nq) v = *reinterpret_cast<const u32x4_t*>(qp + (long)q * p.qm.s_row + kk * 32 + g * 8);
-            qf[qt][kk] = __builtin_bit_cast(bf16x8_t, v);
+            qf[qt][kk] = __builtin_bit_cast(elem8_t, v);
         }
     }
 
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
         }
 
         // ---- S^T tiles (two query tiles at a time: the K fragments stay in registers for all QT of them) + online softmax
-        bf16x8_t kf[4][2];
+        elem8_t kf[4][2];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int krow = 32 * (t >> 1) + 8 * (u >> 2) + 4 * (t & 1) + (u & 3);
@@ -182,16 +182,16 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 if constexpr (WPP == 4) {
-                    kf[t][kk] = __builtin_bit_cast(bf16x8_t, Ks[krow * 8 + ((kk * 4 + g) ^ ksw)]);
+                    kf[t][kk] = __builtin_bit_cast(elem8_t, Ks[krow * 8 + ((kk * 4 + g) ^ ksw)]);
                 } else {
                     u32x4_t kv = {0u, 0u, 0u, 0u};
                     const int key = key0 + krow;
                     if (wvalid && key < p.Nk) kv = *reinterpret_cast<const u32x4_t*>(kp + (long)key * p.km.s_row + kk * 32 + g * 8);
-                    kf[t][kk] = __builtin_bit_cast(bf16x8_t, kv);
+                    kf[t][kk] = __builtin_bit_cast(elem8_t, kv);
                 }
             }
         }
-        bf16x8_t pf[QT][2];
+        elem8_t pf[QT][2];
         const bool partial = key0 + 64 > p.Nk;                 // uniform
 #pragma unroll
         for (int qp = 0; qp < QT / 2; ++qp) {
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                     for (int q2 = 0; q2 < 2; ++q2)
-                        s[q2][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][kk], qf[2 * qp + q2][kk], s[q2][t], 0, 0, 0);
+                        s[q2][t] = VMV_MFMA16(kf[t][kk], qf[2 * qp + q2][kk], s[q2][t], 0, 0, 0);
             // ---- online softmax (per lane: query u, 16 keys of this tile).  The softmax VALU work, not the 32 MFMAs, bounds a
             //      tile (16 quarter-rate v_exp per query tile alone cost as much as the tile's MFMAs), so it is kept minimal:
             //      the running max is tracked on the RAW scores (scale > 0) and the scale is folded into one FMA per score,
@@ -255,11 +255,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
     #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     u32x4_t w;
-                    w.x = pack_bf16x2(pv[2 * kk][0], pv[2 * kk][1]);
-                    w.y = pack_bf16x2(pv[2 * kk][2], pv[2 * kk][3]);
-                    w.z = pack_bf16x2(pv[2 * kk + 1][0], pv[2 * kk + 1][1]);
-                    w.w = pack_bf16x2(pv[2 * kk + 1][2], pv[2 * kk + 1][3]);
-                    pf[qt][kk] = __builtin_bit_cast(bf16x8_t, w);
+                    w.x = pack_elem2(pv[2 * kk][0], pv[2 * kk][1]);
+                    w.y = pack_elem2(pv[2 * kk][2], pv[2 * kk][3]);
+                    w.z = pack_elem2(pv[2 * kk + 1][0], pv[2 * kk + 1][1]);
+                    w.w = pack_elem2(pv[2 * kk + 1][2], pv[2 * kk + 1][3]);
+                    pf[qt][kk] = __builtin_bit_cast(elem8_t, w);
                 }
             }
         }
@@ -271,10 +271,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
             const int fsl = ((d >> 3) ^ (d >> 1)) & 7;   // 8-key block swizzle of row d
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, Vt16[d * 8 + ((kk * 4 + g) ^ fsl)]);
+                const elem8_t vf = __builtin_bit_cast(elem8_t, Vt16[d * 8 + ((kk * 4 + g) ^ fsl)]);
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt)
-                    oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][kk], oacc[qt][dt], 0, 0, 0);
+                    oacc[qt][dt] = VMV_MFMA16(vf, pf[qt][kk], oacc[qt][dt], 0, 0, 0);
             }
         }
         if constexpr (WPP == 4) {
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
             for (int dt = 0; dt < 4; ++dt) {
                 const f32x4_t a = oacc[qt][dt] * inv;
                 u32x2_t w;
-                w.x = pack_bf16x2(a.x, a.y); w.y = pack_bf16x2(a.z, a.w);
+                w.x = pack_elem2(a.x, a.y); w.y = pack_elem2(a.z, a.w);
                 *reinterpret_cast<u32x2_t*>(orow + dt * 16) = w;
             }
         }
@@ -310,7 +310,7 @@ int map_ok(const VmvSeqMap& m) {
 
 }  // namespace
 
-extern "C" int vmv_attention_bf16(const VmvAttnParams* pp, void* stream) {
+extern "C" int vmv_attention(const VmvAttnParams* pp, void* stream) {
     if (!pp) return VMV_ENULL;
     const VmvAttnParams& p = *pp;
     if (!p.q || !p.k || !p.v || !p.o) return VMV_ENULL;

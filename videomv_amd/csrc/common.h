@@ -1,39 +1,53 @@
-// common.h — shared device helpers for the gfx950 kernels (wave64, bf16 storage / fp32 math).
+// common.h — shared device helpers for the gfx950 kernels (wave64, 16-bit storage (fp16 or bf16 per build) / fp32 math).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/vmv.h"
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
 
 #define VMV_DEV __device__ __forceinline__
 
-// bf16 <-> fp32 (round-to-nearest-even; NaN not expected on this path)
-VMV_DEV float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
-VMV_DEV float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
-// (gfx950 converts in hardware: one v_cvt_pk_bf16_f32 per pair instead of ~9 integer instructions)
-typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-VMV_DEV uint32_t pack_bf16x2(float lo, float hi) {
+// ---- the 16-bit storage / MFMA operand type of this build of the library (vmv.h: vmv_elem_type()).
+// The same sources are compiled twice: -DVMV_BUILD_BF16 -> libvmv_hip_bf16.so (bf16, 8 significand bits),
+// default -> libvmv_hip_f16.so (IEEE fp16, 11 significand bits; what the parity tolerances of DESIGN §6 are stated for).
+// Both convert in hardware on gfx950 (v_cvt_pk_{bf16,f16}_f32, round-to-nearest-even) and run the same-rate MFMA.
+#if defined(VMV_BUILD_BF16)
+#define VMV_ELEM_TYPE 1
+typedef __attribute__((ext_vector_type(8))) __bf16 elem8_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 elem2_t;
+#define VMV_MFMA16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+VMV_DEV float elem_lo(uint32_t w) { return __uint_as_float(w << 16); }
+VMV_DEV float elem_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+VMV_DEV float elem_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+#else
+#define VMV_ELEM_TYPE 0
+typedef __attribute__((ext_vector_type(8))) _Float16 elem8_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 elem2_t;
+#define VMV_MFMA16 __builtin_amdgcn_mfma_f32_16x16x32_f16
+VMV_DEV float elem_lo(uint32_t w) { return (float)__builtin_bit_cast(elem2_t, w).x; }
+VMV_DEV float elem_hi(uint32_t w) { return (float)__builtin_bit_cast(elem2_t, w).y; }
+VMV_DEV float elem_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+#endif
+VMV_DEV uint32_t pack_elem2(float lo, float hi) {
     const f32x2_t f = {lo, hi};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, elem2_t));
 }
-VMV_DEV uint32_t f32_to_bf16_bits(float f) { return pack_bf16x2(f, 0.f) & 0xffffu; }
-VMV_DEV float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+VMV_DEV uint32_t f32_to_elem_bits(float f) { return pack_elem2(f, 0.f) & 0xffffu; }
 
 VMV_DEV void unpack8(const u32x4_t& v, float* f) {
-    f[0] = bf16_lo(v.x); f[1] = bf16_hi(v.x);
-    f[2] = bf16_lo(v.y); f[3] = bf16_hi(v.y);
-    f[4] = bf16_lo(v.z); f[5] = bf16_hi(v.z);
-    f[6] = bf16_lo(v.w); f[7] = bf16_hi(v.w);
+    f[0] = elem_lo(v.x); f[1] = elem_hi(v.x);
+    f[2] = elem_lo(v.y); f[3] = elem_hi(v.y);
+    f[4] = elem_lo(v.z); f[5] = elem_hi(v.z);
+    f[6] = elem_lo(v.w); f[7] = elem_hi(v.w);
 }
 VMV_DEV u32x4_t pack8(const float* f) {
     u32x4_t v;
-    v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
-    v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
+    v.x = pack_elem2(f[0], f[1]); v.y = pack_elem2(f[2], f[3]);
+    v.z = pack_elem2(f[4], f[5]); v.w = pack_elem2(f[6], f[7]);
     return v;
 }
 

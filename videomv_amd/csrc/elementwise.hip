@@ -18,7 +18,7 @@ __global__ void latent_to_rows_kernel(const float* __restrict__ x, uint16_t* __r
             uint16_t* dst = rows + ((long)rep * per + i) * Cpad;
             for (int c = 0; c < Cpad; ++c) {
                 const float v = (c < C) ? x[(((long)b * C + c) * F + f) * HW + pix] : 0.f;
-                dst[c] = (uint16_t)f32_to_bf16_bits(v);
+                dst[c] = (uint16_t)f32_to_elem_bits(v);
             }
         }
     }
@@ -34,7 +34,7 @@ __global__ void latent_to_rows_keep_kernel(const float* __restrict__ x, uint16_t
         const int b = (int)(bf / F);
         for (int rep = 0; rep < nrep; ++rep) {
             uint16_t* dst = rows + ((long)rep * per + i) * ld;
-            for (int c = 0; c < C; ++c) dst[c] = (uint16_t)f32_to_bf16_bits(x[(((long)b * C + c) * F + f) * HW + pix]);
+            for (int c = 0; c < C; ++c) dst[c] = (uint16_t)f32_to_elem_bits(x[(((long)b * C + c) * F + f) * HW + pix]);
         }
     }
 }
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void i2v_temporal_adapter_kernel(const uint16_
     if (act) {
         const uint16_t* src = in + ((long)lane * HW + pix) * ld_in;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) x[c] = bf16_to_f32(src[c]);
+        for (int c = 0; c < 4; ++c) x[c] = elem_to_f32(src[c]);
     }
     // LayerNorm over the 4 channels (eps 1e-5)
     const float mean = 0.25f * (x[0] + x[1] + x[2] + x[3]);
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void i2v_temporal_adapter_kernel(const uint16_
             float a = b2[c];
 #pragma unroll
             for (int k = 0; k < 16; ++k) a += W2[c * 16 + k] * hid[k];
-            r[c] = (uint16_t)f32_to_bf16_bits(scale * (a + y[c]));
+            r[c] = (uint16_t)f32_to_elem_bits(scale * (a + y[c]));
         }
         for (int rep = 0; rep < nrep; ++rep) {
             uint16_t* dst = out + (((long)rep * F + lane) * HW + pix) * ld_out;
@@ -259,8 +259,8 @@ __global__ void adaptive_avgpool_rows_kernel(const uint16_t* __restrict__ in, in
         const int x0 = (ox * IW) / OW, x1 = ((ox + 1) * IW + OW - 1) / OW;
         float s = 0.f;
         for (int yy = y0; yy < y1; ++yy)
-            for (int xx = x0; xx < x1; ++xx) s += bf16_to_f32(in[(((long)img * IH + yy) * IW + xx) * ld + c]);
-        out[(((long)img * OH + oy) * OW + ox) * ldo + c] = (uint16_t)f32_to_bf16_bits(s / (float)((y1 - y0) * (x1 - x0)));
+            for (int xx = x0; xx < x1; ++xx) s += elem_to_f32(in[(((long)img * IH + yy) * IW + xx) * ld + c]);
+        out[(((long)img * OH + oy) * OW + ox) * ldo + c] = (uint16_t)f32_to_elem_bits(s / (float)((y1 - y0) * (x1 - x0)));
     }
 }
 
@@ -274,7 +274,7 @@ __global__ void rows_to_nchw_kernel(const void* __restrict__ rows, int rows_fp32
         const long img = t / C;
         const long src = (img * HW + pix) * ld + c;
         out[i] = rows_fp32 ? reinterpret_cast<const float*>(rows)[src]
-                           : bf16_to_f32(reinterpret_cast<const uint16_t*>(rows)[src]);
+                           : elem_to_f32(reinterpret_cast<const uint16_t*>(rows)[src]);
     }
 }
 
@@ -321,7 +321,7 @@ __global__ void emb_combine_kernel(const float* __restrict__ temb, const float* 
         const int r = (int)(i / C), c = (int)(i % C);
         float v = temb[(long)(r / rows_per_t) * C + c];
         if (cam) v += cam[(long)(r % cam_rows) * C + c];
-        out[i] = (uint16_t)f32_to_bf16_bits(silu_f(v));
+        out[i] = (uint16_t)f32_to_elem_bits(silu_f(v));
     }
 }
 
@@ -337,7 +337,7 @@ __global__ void sinusoidal_kernel(const float* __restrict__ t, uint16_t* __restr
             const float a = t[r] * freq;
             v = c < half ? cosf(a) : sinf(a);   // cos first (util.py:186)
         }
-        out[i] = (uint16_t)f32_to_bf16_bits(v);
+        out[i] = (uint16_t)f32_to_elem_bits(v);
     }
 }
 
@@ -487,10 +487,10 @@ extern "C" int vmv_emb_combine_silu(const float* temb, const float* cam, void* o
     return vmv_launch_status();
 }
 
-extern "C" int vmv_sinusoidal(const float* t, void* out_bf16, int n, int dim, void* stream) {
-    if (!t || !out_bf16) return VMV_ENULL;
+extern "C" int vmv_sinusoidal(const float* t, void* out_elem, int n, int dim, void* stream) {
+    if (!t || !out_elem) return VMV_ENULL;
     if (n <= 0 || dim <= 0) return VMV_EINVAL;
     hipLaunchKernelGGL(sinusoidal_kernel, dim3(grid_for((long)n * dim)), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), t, reinterpret_cast<uint16_t*>(out_bf16), n, dim);
+                       reinterpret_cast<hipStream_t>(stream), t, reinterpret_cast<uint16_t*>(out_elem), n, dim);
     return vmv_launch_status();
 }

@@ -17,7 +17,7 @@
 #include "gemm_common.h"
 #include <cstdlib>
 
-using namespace vmv_gemm;
+using namespace vmvg;
 
 int vmv_gemm_glds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st);   // gemm_glds.hip
 int vmv_gemm_pglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st);  // gemm_pglds.hip
@@ -171,16 +171,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const VmvGemmParams p, const 
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int slot = (kk * 4 + fgrp) ^ fswz;
-            bf16x8_t af[WM], wf[WN];
+            elem8_t af[WM], wf[WN];
 #pragma unroll
-            for (int i = 0; i < WM; ++i) af[i] = __builtin_bit_cast(bf16x8_t, a[i * 16 * 8 + slot]);
+            for (int i = 0; i < WM; ++i) af[i] = __builtin_bit_cast(elem8_t, a[i * 16 * 8 + slot]);
 #pragma unroll
-            for (int j = 0; j < WN; ++j) wf[j] = __builtin_bit_cast(bf16x8_t, w[j * 16 * 8 + slot]);
+            for (int j = 0; j < WN; ++j) wf[j] = __builtin_bit_cast(elem8_t, w[j * 16 * 8 + slot]);
 #pragma unroll
             for (int j = 0; j < WN; ++j)
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+                    acc[j][i] = VMV_MFMA16(wf[j], af[i], acc[j][i], 0, 0, 0);
         }
         if (more) store_chunk(cur ^ 1);
         __syncthreads();
@@ -313,7 +313,7 @@ int pick_tile(const VmvGemmParams& p, int total_steps) {
 
 }  // namespace
 
-extern "C" int vmv_gemm_bf16(const VmvGemmParams* pp, void* stream) {
+extern "C" int vmv_gemm(const VmvGemmParams* pp, void* stream) {
     if (!pp) return VMV_ENULL;
     const VmvGemmParams& p = *pp;
     if (!p.W || !p.out) return VMV_ENULL;

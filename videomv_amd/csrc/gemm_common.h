@@ -3,7 +3,7 @@
 #pragma once
 #include "common.h"
 
-namespace vmv_gemm {
+namespace vmvg {
 
 constexpr int BK = 64;
 constexpr int VMV_GLDS_UNSUPPORTED = -100;   // internal: the LDS-DMA kernel cannot address these operands
@@ -63,16 +63,16 @@ VMV_DEV void epilogue_store(const VmvGemmParams& p, int m, int n, f32x4_t v, f32
     if (p.residual) {
         const u32x2_t r = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const uint16_t*>(p.residual) + (size_t)m * p.ldr + no);
         const float rs = p.res_scale != 0.f ? p.res_scale : 1.f;
-        v.x += rs * bf16_lo(r.x); v.y += rs * bf16_hi(r.x); v.z += rs * bf16_lo(r.y); v.w += rs * bf16_hi(r.y);
+        v.x += rs * elem_lo(r.x); v.y += rs * elem_hi(r.x); v.z += rs * elem_lo(r.y); v.w += rs * elem_hi(r.y);
     }
     if (p.out_fp32) {
         *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + no) = v;
     } else {
         u32x2_t o;
-        o.x = pack_bf16x2(v.x, v.y); o.y = pack_bf16x2(v.z, v.w);
+        o.x = pack_elem2(v.x, v.y); o.y = pack_elem2(v.z, v.w);
         *reinterpret_cast<u32x2_t*>(reinterpret_cast<uint16_t*>(p.out) + (size_t)m * p.ldo + no) = o;
     }
 }
 
 
-}  // namespace vmv_gemm
+}  // namespace vmvg

@@ -17,7 +17,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-using namespace vmv_gemm;
+using namespace vmvg;
 
 namespace {
 
@@ -152,25 +152,25 @@ __global__ __launch_bounds__(128 * WMW, WMW == 2 ? 2 : 1) void gemm_glds_kernel(
     // so every MFMA batch runs under the LDS reads of the next one (the lock-step "all waves read, then all waves
     // multiply" phases of a plain loop leave the matrix pipe idle during the LDS burst), and the barrier of chunk t+1
     // sits between two MFMA batches that need no LDS.
-    auto read_frags = [&](int slot_idx, int kk, bf16x8_t (&af)[WM], bf16x8_t (&wf)[WN]) {
+    auto read_frags = [&](int slot_idx, int kk, elem8_t (&af)[WM], elem8_t (&wf)[WN]) {
         const u32x4_t* a = reinterpret_cast<const u32x4_t*>(smem + slot_idx * Cfg::STAGE_BYTES) + (wave_m * 64 + frow) * 8;
         const u32x4_t* w = reinterpret_cast<const u32x4_t*>(smem + slot_idx * Cfg::STAGE_BYTES + Cfg::A_BYTES) +
                            (wave_n * 16 * WN + frow) * 8;
         const int slot = (kk * 4 + fgrp) ^ fswz;
 #pragma unroll
-        for (int i = 0; i < WM; ++i) af[i] = __builtin_bit_cast(bf16x8_t, a[i * 16 * 8 + slot]);
+        for (int i = 0; i < WM; ++i) af[i] = __builtin_bit_cast(elem8_t, a[i * 16 * 8 + slot]);
 #pragma unroll
-        for (int j = 0; j < WN; ++j) wf[j] = __builtin_bit_cast(bf16x8_t, w[j * 16 * 8 + slot]);
+        for (int j = 0; j < WN; ++j) wf[j] = __builtin_bit_cast(elem8_t, w[j * 16 * 8 + slot]);
     };
-    auto mma = [&](const bf16x8_t (&af)[WM], const bf16x8_t (&wf)[WN]) {
+    auto mma = [&](const elem8_t (&af)[WM], const elem8_t (&wf)[WN]) {
 #pragma unroll
         for (int j = 0; j < WN; ++j)
 #pragma unroll
             for (int i = 0; i < WM; ++i)
-                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+                acc[j][i] = VMV_MFMA16(wf[j], af[i], acc[j][i], 0, 0, 0);
     };
 
-    bf16x8_t a0[WM], w0[WN], a1[WM], w1[WN];
+    elem8_t a0[WM], w0[WN], a1[WM], w1[WN];
     if constexpr (PP) {
         // ---- ping-pong schedule (8 waves; waves w and w+4 share a SIMD).  Every chunk has a LOAD phase (fragment reads of
         //      chunk t + LDS-DMA issue of chunk t+2) and a MATRIX phase (its 40 MFMAs), separated by block barriers; the
@@ -217,10 +217,10 @@ __global__ __launch_bounds__(128 * WMW, WMW == 2 ? 2 : 1) void gemm_glds_kernel(
                     const int slot0 = fgrp ^ fswz, slot1 = (4 + fgrp) ^ fswz;
                     constexpr int NRD = 2 * (WM + WN);
                     auto read_one = [&](int r) {               // r: a0[0..WM), w0[0..WN), a1[..], w1[..]
-                        if (r < WM) a0[r] = __builtin_bit_cast(bf16x8_t, fa[r * 16 * 8 + slot0]);
-                        else if (r < WM + WN) w0[r - WM] = __builtin_bit_cast(bf16x8_t, fw[(r - WM) * 16 * 8 + slot0]);
-                        else if (r < 2 * WM + WN) a1[r - WM - WN] = __builtin_bit_cast(bf16x8_t, fa[(r - WM - WN) * 16 * 8 + slot1]);
-                        else w1[r - 2 * WM - WN] = __builtin_bit_cast(bf16x8_t, fw[(r - 2 * WM - WN) * 16 * 8 + slot1]);
+                        if (r < WM) a0[r] = __builtin_bit_cast(elem8_t, fa[r * 16 * 8 + slot0]);
+                        else if (r < WM + WN) w0[r - WM] = __builtin_bit_cast(elem8_t, fw[(r - WM) * 16 * 8 + slot0]);
+                        else if (r < 2 * WM + WN) a1[r - WM - WN] = __builtin_bit_cast(elem8_t, fa[(r - WM - WN) * 16 * 8 + slot1]);
+                        else w1[r - 2 * WM - WN] = __builtin_bit_cast(elem8_t, fw[(r - 2 * WM - WN) * 16 * 8 + slot1]);
                     };
                     int rd = 0;
 #pragma unroll
@@ -280,9 +280,9 @@ __global__ __launch_bounds__(128 * WMW, WMW == 2 ? 2 : 1) void gemm_glds_kernel(
             if (ablate != 1 && ablate != 5) read_frags(0, 0, a0, w0);
             else if (ablate == 5) {
 #pragma unroll
-                for (int i = 0; i < WM; ++i) { a0[i] = bf16x8_t{}; a1[i] = bf16x8_t{}; }
+                for (int i = 0; i < WM; ++i) { a0[i] = elem8_t{}; a1[i] = elem8_t{}; }
 #pragma unroll
-                for (int j = 0; j < WN; ++j) { w0[j] = bf16x8_t{}; w1[j] = bf16x8_t{}; }
+                for (int j = 0; j < WN; ++j) { w0[j] = elem8_t{}; w1[j] = elem8_t{}; }
             }
         }
         int st = 0;                                   // ring slot of chunk t
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(128 * WMW, WMW == 2 ? 2 : 1) void gemm_glds_kernel(
                     tc = (tc >> 5) * 16 + (tc & 15);
                 }
                 u32x2_t o;
-                o.x = pack_bf16x2(v.x, v.y); o.y = pack_bf16x2(v.z, v.w);
+                o.x = pack_elem2(v.x, v.y); o.y = pack_elem2(v.z, v.w);
                 *reinterpret_cast<u32x2_t*>(smem + (trow0 + 16 * i) * row_bytes + tc * 2) = o;
             }
         }
@@ -475,7 +475,7 @@ int launch_glds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
 
 }  // namespace
 
-// Called by vmv_gemm_bf16 (gemm.hip) after argument validation.  The split-K reduce pass stays in gemm.hip.
+// Called by vmv_gemm (gemm.hip) after argument validation.  The split-K reduce pass stays in gemm.hip.
 int vmv_gemm_glds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st) {
     if (p.rowstat) return VMV_GLDS_UNSUPPORTED;          // LayerNorm-folded GEMMs: gemm_pglds.hip / gemm.hip epilogues only
     // 32-bit byte offsets through buffer descriptors: every operand must span < 2 GiB

@@ -2,7 +2,7 @@
 #pragma once
 #include "gemm_common.h"
 
-namespace vmv_gemm {
+namespace vmvg {
 
 template <int WMW, int WN, int STAGES>
 struct GlCfg {
@@ -66,4 +66,4 @@ VMV_DEV void wait_vmcnt_rt(int n) {
     }
 }
 
-}  // namespace vmv_gemm
+}  // namespace vmvg

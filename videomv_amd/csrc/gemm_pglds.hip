@@ -20,7 +20,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-using namespace vmv_gemm;
+using namespace vmvg;
 
 namespace {
 
@@ -187,28 +187,28 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
     const int frow = lane & 15;
     const int fgrp = lane >> 4;
     const int fswz = (frow >> 1) & 7;
-    auto read_frags = [&](int slot_idx, int kk, bf16x8_t (&af)[WM], bf16x8_t (&wf)[WN]) {
+    auto read_frags = [&](int slot_idx, int kk, elem8_t (&af)[WM], elem8_t (&wf)[WN]) {
         const u32x4_t* a = reinterpret_cast<const u32x4_t*>(smem + slot_idx * Cfg::STAGE_BYTES) + (wave_m * 16 * WM + frow) * 8;
         const u32x4_t* w = reinterpret_cast<const u32x4_t*>(smem + slot_idx * Cfg::STAGE_BYTES + Cfg::A_BYTES) +
                            (wave_n * 16 * WN + frow) * 8;
         const int slot = (kk * 4 + fgrp) ^ fswz;
 #pragma unroll
-        for (int i = 0; i < WM; ++i) af[i] = __builtin_bit_cast(bf16x8_t, a[i * 16 * 8 + slot]);
+        for (int i = 0; i < WM; ++i) af[i] = __builtin_bit_cast(elem8_t, a[i * 16 * 8 + slot]);
 #pragma unroll
-        for (int j = 0; j < WN; ++j) wf[j] = __builtin_bit_cast(bf16x8_t, w[j * 16 * 8 + slot]);
+        for (int j = 0; j < WN; ++j) wf[j] = __builtin_bit_cast(elem8_t, w[j * 16 * 8 + slot]);
     };
-    auto mma = [&](const bf16x8_t (&af)[WM], const bf16x8_t (&wf)[WN]) {
+    auto mma = [&](const elem8_t (&af)[WM], const elem8_t (&wf)[WN]) {
 #pragma unroll
         for (int j = 0; j < WN; ++j)
 #pragma unroll
             for (int i = 0; i < WM; ++i)
-                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+                acc[j][i] = VMV_MFMA16(wf[j], af[i], acc[j][i], 0, 0, 0);
     };
 
     // One MFMA phase of the interleaved loop: the WM*WN MFMAs on (af, wf), with the WM+WN fragment reads of the NEXT phase
     // (slot_n, kk_n -> afn, wfn) and pieces [Q0, Q1) of the chunk being loaded spread evenly between them.
     constexpr int NM = WM * WN, NRD = WM + WN;
-    auto phase = [&](const bf16x8_t (&af)[WM], const bf16x8_t (&wf)[WN], bf16x8_t (&afn)[WM], bf16x8_t (&wfn)[WN],
+    auto phase = [&](const elem8_t (&af)[WM], const elem8_t (&wf)[WN], elem8_t (&afn)[WM], elem8_t (&wfn)[WN],
                      const int slot_n, const int kk_n, const bool dma, const ChunkCtx& cx, auto q0_tag, auto q1_tag) {
         constexpr int Q0 = decltype(q0_tag)::value, Q1 = decltype(q1_tag)::value, ND = Q1 - Q0;
         const u32x4_t* a = reinterpret_cast<const u32x4_t*>(smem + slot_n * Cfg::STAGE_BYTES) + (wave_m * 16 * WM + frow) * 8;
@@ -218,13 +218,13 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
             const int j = m / WM, i = m % WM;
-            if constexpr (ablate != 1) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+            if constexpr (ablate != 1) acc[j][i] = VMV_MFMA16(wf[j], af[i], acc[j][i], 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < NRD; ++r)
                 if (((2 * r + 1) * NM) / (2 * NRD) == m) {
                     if constexpr (ablate != 1) {
-                        if (r < WM) afn[r < WM ? r : 0] = __builtin_bit_cast(bf16x8_t, a[(r < WM ? r : 0) * 16 * 8 + slot]);
-                        else wfn[r >= WM ? r - WM : 0] = __builtin_bit_cast(bf16x8_t, w[(r >= WM ? r - WM : 0) * 16 * 8 + slot]);
+                        if (r < WM) afn[r < WM ? r : 0] = __builtin_bit_cast(elem8_t, a[(r < WM ? r : 0) * 16 * 8 + slot]);
+                        else wfn[r >= WM ? r - WM : 0] = __builtin_bit_cast(elem8_t, w[(r >= WM ? r - WM : 0) * 16 * 8 + slot]);
                     }
                 }
 #pragma unroll
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
                 }
                 if (p.rowvec) v += rv[j];
                 if (p.act == VMV_ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
-                packed[j].x = pack_bf16x2(v.x, v.y); packed[j].y = pack_bf16x2(v.z, v.w);
+                packed[j].x = pack_elem2(v.x, v.y); packed[j].y = pack_elem2(v.z, v.w);
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_sched_barrier(0);
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
     int consumed = 0;                 // chunks fully multiplied
     int st = 0;                       // ring slot of the next chunk to consume
     bool first = true;
-    bf16x8_t a0[WM], w0[WN], a1[WM], w1[WN];
+    elem8_t a0[WM], w0[WN], a1[WM], w1[WN];
     bool pending = false;             // IL: the second half of a chunk's pieces is still to be issued
     ChunkCtx cx = chunk_ctx();
     // ablate == 4 (experiments): block 0, wave 0 stamps s_memtime at {tile start, main loop done, epilogue start, epilogue
@@ -651,7 +651,7 @@ int launch_pglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
 
 }  // namespace
 
-// Called by vmv_gemm_bf16 (gemm.hip) after argument validation; split-K shapes stay on the non-persistent kernels.
+// Called by vmv_gemm (gemm.hip) after argument validation; split-K shapes stay on the non-persistent kernels.
 int vmv_gemm_pglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st) {
     if (p.ksplit > 1) return VMV_GLDS_UNSUPPORTED;
     for (int i = 0; i < p.nseg; ++i)

@@ -19,7 +19,7 @@
 #include <cstddef>
 #include <type_traits>
 
-using namespace vmv_gemm;
+using namespace vmvg;
 
 namespace {
 
@@ -251,26 +251,26 @@ __global__ __launch_bounds__(768, 3) void gemm_sglds_kernel(const VmvGemmParams 
     const int frow = lane & 15;
     const int fgrp = lane >> 4;
     const int fswz = (frow >> 1) & 7;
-    auto read_frags = [&](int slot_idx, int kk, bf16x8_t (&af)[WM], bf16x8_t (&wf)[WN]) {
+    auto read_frags = [&](int slot_idx, int kk, elem8_t (&af)[WM], elem8_t (&wf)[WN]) {
         const u32x4_t* a = reinterpret_cast<const u32x4_t*>(smem + slot_idx * Cfg::STAGE_BYTES) + (wave_m * 16 * WM + frow) * 8;
         const u32x4_t* w = reinterpret_cast<const u32x4_t*>(smem + slot_idx * Cfg::STAGE_BYTES + Cfg::A_BYTES) +
                            (wave_n * 16 * WN + frow) * 8;
         const int slot = (kk * 4 + fgrp) ^ fswz;
 #pragma unroll
-        for (int i = 0; i < WM; ++i) af[i] = __builtin_bit_cast(bf16x8_t, a[i * 16 * 8 + slot]);
+        for (int i = 0; i < WM; ++i) af[i] = __builtin_bit_cast(elem8_t, a[i * 16 * 8 + slot]);
 #pragma unroll
-        for (int j = 0; j < WN; ++j) wf[j] = __builtin_bit_cast(bf16x8_t, w[j * 16 * 8 + slot]);
+        for (int j = 0; j < WN; ++j) wf[j] = __builtin_bit_cast(elem8_t, w[j * 16 * 8 + slot]);
     };
-    auto mma = [&](const bf16x8_t (&af)[WM], const bf16x8_t (&wf)[WN]) {
+    auto mma = [&](const elem8_t (&af)[WM], const elem8_t (&wf)[WN]) {
 #pragma unroll
         for (int j = 0; j < WN; ++j)
 #pragma unroll
             for (int i = 0; i < WM; ++i)
-                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+                acc[j][i] = VMV_MFMA16(wf[j], af[i], acc[j][i], 0, 0, 0);
     };
     // one MFMA phase: the WM*WN MFMAs on (af, wf) with the WM+WN fragment reads of the next phase spread between them
     constexpr int NM = WM * WN, NRD = WM + WN;
-    auto phase = [&](const bf16x8_t (&af)[WM], const bf16x8_t (&wf)[WN], bf16x8_t (&afn)[WM], bf16x8_t (&wfn)[WN],
+    auto phase = [&](const elem8_t (&af)[WM], const elem8_t (&wf)[WN], elem8_t (&afn)[WM], elem8_t (&wfn)[WN],
                      const int slot_n, const int kk_n) {
         const u32x4_t* a = reinterpret_cast<const u32x4_t*>(smem + slot_n * Cfg::STAGE_BYTES) + (wave_m * 16 * WM + frow) * 8;
         const u32x4_t* w = reinterpret_cast<const u32x4_t*>(smem + slot_n * Cfg::STAGE_BYTES + Cfg::A_BYTES) +
@@ -279,12 +279,12 @@ __global__ __launch_bounds__(768, 3) void gemm_sglds_kernel(const VmvGemmParams 
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
             const int j = m / WM, i = m % WM;
-            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+            acc[j][i] = VMV_MFMA16(wf[j], af[i], acc[j][i], 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < NRD; ++r)
                 if (((2 * r + 1) * NM) / (2 * NRD) == m) {
-                    if (r < WM) afn[r < WM ? r : 0] = __builtin_bit_cast(bf16x8_t, a[(r < WM ? r : 0) * 16 * 8 + slot]);
-                    else wfn[r >= WM ? r - WM : 0] = __builtin_bit_cast(bf16x8_t, w[(r >= WM ? r - WM : 0) * 16 * 8 + slot]);
+                    if (r < WM) afn[r < WM ? r : 0] = __builtin_bit_cast(elem8_t, a[(r < WM ? r : 0) * 16 * 8 + slot]);
+                    else wfn[r >= WM ? r - WM : 0] = __builtin_bit_cast(elem8_t, w[(r >= WM ? r - WM : 0) * 16 * 8 + slot]);
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(768, 3) void gemm_sglds_kernel(const VmvGemmParams 
                 }
                 if (p.rowvec) v += rv[j];
                 if (p.act == VMV_ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
-                packed[j].x = pack_bf16x2(v.x, v.y); packed[j].y = pack_bf16x2(v.z, v.w);
+                packed[j].x = pack_elem2(v.x, v.y); packed[j].y = pack_elem2(v.z, v.w);
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_sched_barrier(0);
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(768, 3) void gemm_sglds_kernel(const VmvGemmParams 
     };
 
     // ------------------------------------------------------------------ chunk pipeline of the MFMA waves
-    bf16x8_t a0[WM], w0[WN], a1[WM], w1[WN];
+    elem8_t a0[WM], w0[WN], a1[WM], w1[WN];
     int st = 0;                                            // ring slot of the chunk being consumed
     int cdbg = 0;
     __builtin_amdgcn_s_barrier();                          // X0
@@ -575,7 +575,7 @@ int launch_sglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
 
 }  // namespace
 
-// Called by vmv_gemm_bf16 (gemm.hip) after argument validation; split-K shapes stay on the non-persistent kernels.
+// Called by vmv_gemm (gemm.hip) after argument validation; split-K shapes stay on the non-persistent kernels.
 int vmv_gemm_sglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st) {
     if (p.ksplit > 1 || p.rowstat) return VMV_GLDS_UNSUPPORTED;
     long maxrows = p.M;

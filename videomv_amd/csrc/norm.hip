@@ -287,8 +287,8 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const VmvSoftmaxParam
     for (int i = lane; i < n4; i += 64) {
         const f32x4_t v = *reinterpret_cast<const f32x4_t*>(s + 4 * i);
         u32x2_t w;
-        w.x = pack_bf16x2(__builtin_amdgcn_exp2f(v.x * sc - m2) * inv, __builtin_amdgcn_exp2f(v.y * sc - m2) * inv);
-        w.y = pack_bf16x2(__builtin_amdgcn_exp2f(v.z * sc - m2) * inv, __builtin_amdgcn_exp2f(v.w * sc - m2) * inv);
+        w.x = pack_elem2(__builtin_amdgcn_exp2f(v.x * sc - m2) * inv, __builtin_amdgcn_exp2f(v.y * sc - m2) * inv);
+        w.y = pack_elem2(__builtin_amdgcn_exp2f(v.z * sc - m2) * inv, __builtin_amdgcn_exp2f(v.w * sc - m2) * inv);
         *reinterpret_cast<u32x2_t*>(out + 4 * i) = w;
     }
 }

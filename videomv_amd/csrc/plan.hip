@@ -15,11 +15,11 @@ struct VmvPlan {
 namespace {
 int run_op(const VmvPlan::Op& o, void* stream) {
     switch (o.op) {
-        case VMV_OP_GEMM: return vmv_gemm_bf16(reinterpret_cast<const VmvGemmParams*>(o.args.data()), stream);
+        case VMV_OP_GEMM: return vmv_gemm(reinterpret_cast<const VmvGemmParams*>(o.args.data()), stream);
         case VMV_OP_GN_STATS: return vmv_groupnorm_stats(reinterpret_cast<const VmvGroupNormParams*>(o.args.data()), stream);
         case VMV_OP_GN_APPLY: return vmv_groupnorm_apply(reinterpret_cast<const VmvGroupNormParams*>(o.args.data()), stream);
         case VMV_OP_LAYERNORM: return vmv_layernorm(reinterpret_cast<const VmvLayerNormParams*>(o.args.data()), stream);
-        case VMV_OP_ATTENTION: return vmv_attention_bf16(reinterpret_cast<const VmvAttnParams*>(o.args.data()), stream);
+        case VMV_OP_ATTENTION: return vmv_attention(reinterpret_cast<const VmvAttnParams*>(o.args.data()), stream);
         case VMV_OP_SOFTMAX: return vmv_softmax_rows(reinterpret_cast<const VmvSoftmaxParams*>(o.args.data()), stream);
         case VMV_OP_COPY: return vmv_permute_copy(reinterpret_cast<const VmvCopyParams*>(o.args.data()), stream);
         default: return VMV_EINVAL;
@@ -39,6 +39,7 @@ size_t op_size(int op) {
 }  // namespace
 
 extern "C" int vmv_abi_version(void) { return VMV_ABI_VERSION; }
+extern "C" int vmv_elem_type(void) { return VMV_ELEM_TYPE; }
 extern "C" int vmv_sizeof(int which) {
     switch (which) {
         case 100: return (int)sizeof(VmvDdimParams);

@@ -20,7 +20,7 @@ import torch
 from . import _lib as L
 from . import ops
 from . import packing as P
-from .unet_engine import Pool, Act, BF16
+from .unet_engine import Pool, Act
 
 
 @dataclasses.dataclass
@@ -167,8 +167,8 @@ class LgmEngine:
         w["final.bias"] = P.pack_bias(sd["conv.bias"], dev)
 
     # ------------------------------------------------------------------ helpers
-    def act(self, rows, C, dtype=BF16):
-        return Act(self.pool.get(rows * C * (2 if dtype == BF16 else 4)), rows, C, dtype)
+    def act(self, rows, C, dtype=None):
+        return Act(self.pool.get(rows * C * (4 if dtype == torch.float32 else 2)), rows, C, dtype)
 
     def rel(self, a):
         if self.taps is None:
@@ -262,7 +262,7 @@ class LgmEngine:
         h, w = self.H, self.W
         nd, nu = len(o.down_channels), len(o.up_channels)
         self.cin_pad = (o.in_channels + 7) // 8 * 8
-        self.x_rows = torch.zeros(V * h * w, self.cin_pad, dtype=BF16, device=dev)
+        self.x_rows = torch.zeros(V * h * w, self.cin_pad, dtype=L.elem(), device=dev)
         x = self.act(V * h * w, o.down_channels[0])
         self._gemm("conv_in", x.rows, ops.conv3x3_segs([(self.x_rows.data_ptr(), self.cin_pad, self.cin_pad)]),
                    "conv_in.weight", x, bias=self.wt["conv_in.bias"], geom=ops.Geom(OH=h, OW=w, IH=h, IW=w))
@@ -323,7 +323,7 @@ class LgmEngine:
         self.rel(x)
         T = V * h * w
         self.S_out, self.T_out = h, T
-        self._u14 = torch.zeros(T, 16, dtype=BF16, device=dev)         # conv_out: 14 channels at row pitch 16 (the K of
+        self._u14 = torch.zeros(T, 16, dtype=L.elem(), device=dev)         # conv_out: 14 channels at row pitch 16 (the K of
         u14 = Act(self._u14.view(torch.uint8).view(-1), T, 16)         # the final 1x1); the packed weight's 2 pad rows give 0
         self._gemm("conv_out", T, ops.conv3x3_segs([(hn.ptr, hn.C, hn.C)]), "conv_out.weight", u14, ldo=16,
                    bias=self.wt["conv_out.bias"], geom=ops.Geom(OH=h, OW=w, IH=h, IW=w))

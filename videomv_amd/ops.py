@@ -174,7 +174,7 @@ class Stream:
             L.check(fn(C.byref(params), _stream_ptr()), label)
 
     def gemm(self, params, label="gemm"):
-        self._go(L.OP_GEMM, params, self.lib.vmv_gemm_bf16, label)
+        self._go(L.OP_GEMM, params, self.lib.vmv_gemm, label)
 
     def groupnorm(self, params, label="gn"):
         self._go(L.OP_GN_STATS, params, self.lib.vmv_groupnorm_stats, label + ".stats")
@@ -193,7 +193,7 @@ class Stream:
         self._go(L.OP_LAYERNORM, params, self.lib.vmv_layernorm, label)
 
     def attention(self, params, label="attn"):
-        self._go(L.OP_ATTENTION, params, self.lib.vmv_attention_bf16, label)
+        self._go(L.OP_ATTENTION, params, self.lib.vmv_attention, label)
 
     def softmax(self, params, label="softmax"):
         self._go(L.OP_SOFTMAX, params, self.lib.vmv_softmax_rows, label)

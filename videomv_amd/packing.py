@@ -1,4 +1,4 @@
-"""Weight repacking: reference state-dict tensors (fp32, PyTorch layouts) -> the bf16 ``[N][K]`` matrices the
+"""Weight repacking: reference state-dict tensors (fp32, PyTorch layouts) -> the 16-bit (``_lib.elem()``: fp16 | bf16) ``[N][K]`` matrices the
 implicit-GEMM kernel consumes (``include/vmv.h``).  Done once at load time on the host/device with torch
 tensor ops (pure data movement — no arithmetic of the hot path happens here).
 
@@ -12,7 +12,7 @@ N is zero-padded to a multiple of 4 (the epilogue stores 4 channels per lane).
 """
 import torch
 
-BF16 = torch.bfloat16
+from . import _lib as L
 
 
 def _pad_rows(w: torch.Tensor, mult=4) -> torch.Tensor:
@@ -29,7 +29,7 @@ def pack_linear(w: torch.Tensor, device) -> torch.Tensor:
     padk = (-k) % 8
     if padk:
         w = torch.cat([w, w.new_zeros(w.shape[0], padk)], dim=1)
-    return _pad_rows(w).to(device=device, dtype=BF16).contiguous()
+    return _pad_rows(w).to(device=device, dtype=L.elem()).contiguous()
 
 
 def pack_conv3x3(w: torch.Tensor, device) -> torch.Tensor:
@@ -39,14 +39,14 @@ def pack_conv3x3(w: torch.Tensor, device) -> torch.Tensor:
     if padc:
         w = torch.cat([w, w.new_zeros(n, padc, 3, 3)], dim=1)
     w = w.permute(0, 2, 3, 1).reshape(n, -1)
-    return _pad_rows(w).to(device=device, dtype=BF16).contiguous()
+    return _pad_rows(w).to(device=device, dtype=L.elem()).contiguous()
 
 
 def pack_tconv(w: torch.Tensor, device) -> torch.Tensor:
     n, c, kt, kh, kw = w.shape
     assert kt == 3 and kh == 1 and kw == 1
     w = w.reshape(n, c, 3).permute(0, 2, 1).reshape(n, 3 * c)
-    return _pad_rows(w).to(device=device, dtype=BF16).contiguous()
+    return _pad_rows(w).to(device=device, dtype=L.elem()).contiguous()
 
 
 def geglu_interleave(t: torch.Tensor) -> torch.Tensor:
@@ -64,10 +64,10 @@ def geglu_interleave(t: torch.Tensor) -> torch.Tensor:
 def fold_layernorm(w: torch.Tensor, b, gamma: torch.Tensor, beta: torch.Tensor):
     """LayerNorm folded into the Linear that consumes it (include/vmv.h, VmvGemmParams.rowstat): for
     y = W LN(x) + b, LN(x) = (x - mean) * rstd * gamma + beta, returns (W', b', colsum) with W' = W diag(gamma) already
-    rounded to bf16 (what the GEMM multiplies), b' = b + W beta and colsum[n] = sum_k W'[n][k] of the ROUNDED W' (so that
+    rounded to the element type (what the GEMM multiplies), b' = b + W beta and colsum[n] = sum_k W'[n][k] of the ROUNDED W' (so that
     the epilogue's  rstd * (acc - mean * colsum)  cancels exactly what the MFMAs accumulated)."""
     w = w.reshape(w.shape[0], -1).float()
-    wf = (w * gamma.float()[None, :]).to(BF16)
+    wf = (w * gamma.float()[None, :]).to(L.elem())
     bf = w @ beta.float()
     if b is not None:
         bf = bf + b.float()

@@ -21,7 +21,6 @@ from . import _lib as L
 from . import ops
 from . import packing as P
 
-BF16 = torch.bfloat16
 
 
 # --------------------------------------------------------------------------------------------- architecture
@@ -177,15 +176,15 @@ class Act:
     """A [rows, C] activation living in a pooled buffer."""
     __slots__ = ("buf", "rows", "C", "dtype")
 
-    def __init__(self, buf, rows, C, dtype=BF16):
-        self.buf, self.rows, self.C, self.dtype = buf, rows, C, dtype
+    def __init__(self, buf, rows, C, dtype=None):
+        self.buf, self.rows, self.C, self.dtype = buf, rows, C, dtype or L.elem()
 
     @property
     def ptr(self):
         return self.buf.data_ptr()
 
     def tensor(self) -> torch.Tensor:
-        esz = 2 if self.dtype == BF16 else 4
+        esz = 4 if self.dtype == torch.float32 else 2
         return self.buf[: self.rows * self.C * esz].view(self.dtype).view(self.rows, self.C)
 
 
@@ -336,26 +335,26 @@ class UNetEngine:
         dev, B, F, H, W = self.device, self.B, self.F, self.H, self.W
         self.T0 = B * F * H * W
         self.cin_pad = (self.cfg["in_dim"] + 7) // 8 * 8
-        self.x_rows = torch.zeros(self.T0, self.cin_pad, dtype=BF16, device=dev)
-        self.ctx_rows = torch.zeros(B * self.L, self.cfg["context_dim"], dtype=BF16, device=dev)
+        self.x_rows = torch.zeros(self.T0, self.cin_pad, dtype=L.elem(), device=dev)
+        self.ctx_rows = torch.zeros(B * self.L, self.cfg["context_dim"], dtype=L.elem(), device=dev)
         self.t_dev = torch.zeros(self.n_t, dtype=torch.float32, device=dev)
-        self.cam_rows = torch.zeros(B * F, (self.cfg.get("camera_dim", 16) + 7) // 8 * 8, dtype=BF16, device=dev)
+        self.cam_rows = torch.zeros(B * F, (self.cfg.get("camera_dim", 16) + 7) // 8 * 8, dtype=L.elem(), device=dev)
         self.eps_rows = torch.zeros(self.T0, self.out_pad, dtype=torch.float32, device=dev)
         # embedding scratch
-        self.sin_emb = torch.zeros(self.n_t, self.dim, dtype=BF16, device=dev)
-        self.te_hidden = torch.zeros(self.n_t, self.E, dtype=BF16, device=dev)
+        self.sin_emb = torch.zeros(self.n_t, self.dim, dtype=L.elem(), device=dev)
+        self.te_hidden = torch.zeros(self.n_t, self.E, dtype=L.elem(), device=dev)
         self.temb = torch.zeros(self.n_t, self.E, dtype=torch.float32, device=dev)
-        self.cam_hidden = torch.zeros(B * F, self.E, dtype=BF16, device=dev)
+        self.cam_hidden = torch.zeros(B * F, self.E, dtype=L.elem(), device=dev)
         self.cam_emb = torch.zeros(B * F, self.E, dtype=torch.float32, device=dev)
         self.n_cam_rows = F
-        self.emb_silu = torch.zeros(B * F, self.E, dtype=BF16, device=dev)
+        self.emb_silu = torch.zeros(B * F, self.E, dtype=L.elem(), device=dev)
         self.emb_out = torch.zeros(B * F, self.emb_total, dtype=torch.float32, device=dev)
         self.cam_valid = False
         self.extra_emb = None        # optional fp32 [n_t, E] added to the time embedding (I2VGen: fps_embedding)
 
     # ------------------------------------------------------------------ helpers
-    def act(self, rows, C, dtype=BF16) -> Act:
-        esz = 2 if dtype == BF16 else 4
+    def act(self, rows, C, dtype=None) -> Act:
+        esz = 4 if dtype == torch.float32 else 2
         return Act(self.pool.get(rows * C * esz), rows, C, dtype)
 
     def release(self, a: Act):
@@ -686,7 +685,7 @@ class UNetEngine:
     # ------------------------------------------------------------------ execution
     def set_context(self, y: torch.Tensor):
         """y [B, L, ctx] -> bf16 context rows (dtype cast only)."""
-        self.ctx_rows.copy_(y.reshape(self.B * self.L, -1).to(BF16))
+        self.ctx_rows.copy_(y.reshape(self.B * self.L, -1).to(L.elem()))
 
     def set_camera(self, camera_data: Optional[torch.Tensor]):
         """camera_data [b, F, 16] with b = 1 (shared by all branches) or b = B: the camera-embedding MLP
@@ -702,7 +701,7 @@ class UNetEngine:
             raise ValueError(f"camera_data has {n} rows, expected {self.F} or {self.B * self.F}")
         self.n_cam_rows = n
         self.cam_rows.zero_()
-        self.cam_rows[:n, : cam.shape[1]].copy_(cam.to(BF16))
+        self.cam_rows[:n, : cam.shape[1]].copy_(cam.to(L.elem()))
         S = ops.Stream(record=False)
         cd = self.cam_rows.shape[1]
         S.gemm(ops.gemm_params(n, self.E, ops.linear_segs([(self.cam_rows, cd, cd)]),

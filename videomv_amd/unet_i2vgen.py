@@ -21,7 +21,7 @@ from .registry import MODEL
 from . import _lib as L
 from . import ops
 from . import packing as P
-from .unet_engine import UNetEngine, param_shapes, BF16
+from .unet_engine import UNetEngine, param_shapes
 from .unet_t2v import LgmMixin, _Holder, _ZERO_INIT_SUFFIXES
 
 
@@ -74,7 +74,7 @@ class I2VFrontEnd:
     def _conv(self, S, x, cin, key, n, ih, iw, stride=1, silu=False):
         oh, ow = (ih + stride - 1) // stride, (iw + stride - 1) // stride
         W = self.w[key + ".weight"]
-        y = torch.empty(n * oh * ow, W.shape[0], dtype=BF16, device=self.dev)
+        y = torch.empty(n * oh * ow, W.shape[0], dtype=L.elem(), device=self.dev)
         S.gemm(ops.gemm_params(n * oh * ow, W.shape[0], ops.conv3x3_segs([(x, cin, cin)]), W, y, W.shape[0],
                                bias=self.w[key + ".bias"], act=L.ACT_SILU if silu else L.ACT_NONE,
                                geom=ops.Geom(OH=oh, OW=ow, IH=ih, IW=iw, stride=stride)), key)
@@ -83,11 +83,11 @@ class I2VFrontEnd:
 
     def _mlp(self, S, x_rows, key, out_fp32):
         n, k = x_rows.shape
-        hid = torch.empty(n, self.E, dtype=BF16, device=self.dev)
+        hid = torch.empty(n, self.E, dtype=L.elem(), device=self.dev)
         W0, W2 = self.w[key + ".0.weight"], self.w[key + ".2.weight"]
         S.gemm(ops.gemm_params(n, self.E, ops.linear_segs([(x_rows, k, k)]), W0, hid, self.E, bias=self.w[key + ".0.bias"],
                                act=L.ACT_SILU), key + ".0")
-        out = torch.empty(n, W2.shape[0], dtype=torch.float32 if out_fp32 else BF16, device=self.dev)
+        out = torch.empty(n, W2.shape[0], dtype=torch.float32 if out_fp32 else L.elem(), device=self.dev)
         S.gemm(ops.gemm_params(n, W2.shape[0], ops.linear_segs([(hid, self.E, self.E)]), W2, out, W2.shape[0],
                                bias=self.w[key + ".2.bias"], out_fp32=out_fp32), key + ".2")
         self._keep += [x_rows, hid, out]
@@ -103,8 +103,8 @@ class I2VFrontEnd:
         Ly = ys.shape[1]
         assert eng.L == Ly + 64 + self.num_tokens, "context length must be Ly + 64 local + num_tokens image tokens"
         ctx = eng.ctx_rows.view(B, eng.L, -1)
-        ctx[:, :Ly].copy_(ys.to(BF16))
-        img_tok = self._mlp(S, images.reshape(B, -1).to(BF16).contiguous(), "context_embedding", out_fp32=False)
+        ctx[:, :Ly].copy_(ys.to(L.elem()))
+        img_tok = self._mlp(S, images.reshape(B, -1).to(L.elem()).contiguous(), "context_embedding", out_fp32=False)
         ctx[:, Ly + 64:].copy_(img_tok.view(B, self.num_tokens, -1))
         ld = eng.cin_pad
         for b in range(B):
@@ -117,24 +117,24 @@ class I2VFrontEnd:
             seq[:, :, 0] = li
             for i in range(1, F):
                 seq[:, :, i] = i / (F - 1)
-            rows_a = torch.zeros(F * h * w, 8, dtype=BF16, device=dev)
+            rows_a = torch.zeros(F * h * w, 8, dtype=L.elem(), device=dev)
             ops.latent_to_rows_keep(seq, rows_a, 8, 1)
             a1, _, _ = self._conv(S, rows_a, 8, "local_image_concat.0", F, h, w, silu=True)
             a2, _, _ = self._conv(S, a1, a1.shape[1], "local_image_concat.2", F, h, w, silu=True)
             a3, _, _ = self._conv(S, a2, a2.shape[1], "local_image_concat.4", F, h, w)
             xr = eng.x_rows.view(B, -1, ld)[b]
             ops.i2v_temporal_adapter(a3, a3.shape[1], xr.data_ptr() + 8, ld, self.w["adapter"], F, h * w, 1, 2.0)
-            rows_l = torch.zeros(h * w, 8, dtype=BF16, device=dev)
+            rows_l = torch.zeros(h * w, 8, dtype=L.elem(), device=dev)
             ops.latent_to_rows_keep(li.reshape(1, 4, 1, h, w).contiguous(), rows_l, 8, 1)
             l1, _, _ = self._conv(S, rows_l, 8, "local_image_embedding.0", 1, h, w, silu=True)
-            l2 = torch.empty(32 * 32, l1.shape[1], dtype=BF16, device=dev)
+            l2 = torch.empty(32 * 32, l1.shape[1], dtype=L.elem(), device=dev)
             ops.adaptive_avgpool_rows(l1, l1.shape[1], l2, l2.shape[1], 1, l1.shape[1], h, w, 32, 32)
             l3, oh, ow = self._conv(S, l2, l2.shape[1], "local_image_embedding.3", 1, 32, 32, stride=2, silu=True)
             l4, oh, ow = self._conv(S, l3, l3.shape[1], "local_image_embedding.5", 1, oh, ow, stride=2)
             ctx[b, Ly:Ly + 64].copy_(l4.view(64, -1))
             self._keep += [seq, rows_a, rows_l, l2]
         t_f = fps.to(dev).float().reshape(-1)
-        sin = torch.empty(t_f.numel(), self.dim, dtype=BF16, device=dev)
+        sin = torch.empty(t_f.numel(), self.dim, dtype=L.elem(), device=dev)
         ops.sinusoidal(t_f, sin, t_f.numel(), self.dim)
         fe = self._mlp(S, sin, "fps_embedding", out_fp32=True)
         eng.extra_emb = fe if fe.shape[0] == eng.n_t else fe[:1].expand(eng.n_t, -1).contiguous()
