@@ -129,3 +129,50 @@ def test_entrance_lgm_refined_loop(monkeypatch, tmp_path):
     plain, gs = (torch.load(os.path.join(cfg.log_dir, f)) for f in outs)
     assert gs["latent"].shape == plain["latent"].shape == (1, 4, 4, 8, 8) and torch.isfinite(gs["video"]).all()
     assert not torch.allclose(gs["latent"], plain["latent"])          # the refined steps changed the trajectory
+
+
+def test_checkpoint_round_trip(monkeypatch, tmp_path, golden_dir):
+    """Real-checkpoint formats (inference_text2video_entrance.py:136-145, autoencoder.py:65-74): a UNet file
+    ``{'state_dict': ..., 'step': n}`` holding exactly the reference's 1484 keys loads with nothing missing / unexpected,
+    and a VAE file whose keys carry the ``first_stage_model.`` prefix among foreign keys loads through the entrance's
+    prefix filter and through ``AutoencoderKL.init_from_ckpt`` (strict)."""
+    import json
+    from videomv_amd.entrance import _load_weights
+    from videomv_amd.registry import MODEL, AUTO_ENCODER
+    import videomv_amd.unet_t2v, videomv_amd.autoencoder  # noqa: F401,E401
+    man = json.load(open(os.path.join(golden_dir, "manifest_unet_t2v_full.json")))
+    keys = man["keys"] if "keys" in man else man
+    assert len(keys) == 1484
+    # the full-size model on the meta device: key / shape bookkeeping only
+    with torch.device("meta"):
+        m = MODEL.build(dict(type="UNetSD_T2VBase", in_dim=4, dim=320, y_dim=1024, context_dim=1024, out_dim=4,
+                             dim_mult=[1, 2, 4, 4], num_heads=8, head_dim=64, num_res_blocks=2,
+                             attn_scales=[1.0, 0.5, 0.25], use_camera_condition=True, use_lgm_refine=False))
+    mine = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert mine == {k: tuple(v) for k, v in keys.items()}
+    # a small model through the real file formats
+    cfg = dict(in_dim=4, dim=64, y_dim=1024, context_dim=1024, out_dim=4, dim_mult=[1, 2], num_heads=2, head_dim=64,
+               num_res_blocks=1, attn_scales=[1.0, 0.5], use_camera_condition=True, use_lgm_refine=False)
+    src = MODEL.build(dict(type="UNetSD_T2VBase", **cfg))
+    g = torch.Generator().manual_seed(4)
+    sd = {k: torch.randn(v.shape, generator=g) for k, v in src.state_dict().items()}
+    path = tmp_path / "model_00001000.pth"
+    torch.save({"state_dict": sd, "step": 1000}, path)
+    dst = MODEL.build(dict(type="UNetSD_T2VBase", **cfg))
+    assert _load_weights(dst, str(path), False, "UNet")
+    assert all(torch.equal(v, sd[k]) for k, v in dst.state_dict().items()) and len(dst.state_dict()) == len(sd)
+    with pytest.raises(FileNotFoundError):
+        _load_weights(dst, str(tmp_path / "missing.pth"), False, "UNet")
+    dd = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 4, 4],
+              num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    vsrc = AUTO_ENCODER.build(dict(type="AutoencoderKL", ddconfig=dd, embed_dim=4))
+    vsd = {k: torch.randn(v.shape, generator=g) for k, v in vsrc.state_dict().items()}
+    blob = {"first_stage_model." + k: v for k, v in vsd.items()}
+    blob.update({"model.diffusion_model.foreign.weight": torch.zeros(3), "cond_stage_model.x": torch.zeros(1)})
+    vpath = tmp_path / "v2-1_512-ema-pruned.ckpt"
+    torch.save({"state_dict": blob}, vpath)
+    v1 = AUTO_ENCODER.build(dict(type="AutoencoderKL", ddconfig=dd, embed_dim=4))
+    assert _load_weights(v1, str(vpath), False, "autoencoder", prefix_filter="first_stage_model.")
+    assert all(torch.equal(v, vsd[k]) for k, v in v1.state_dict().items())
+    v2 = AUTO_ENCODER.build(dict(type="AutoencoderKL", ddconfig=dd, embed_dim=4, pretrained=str(vpath)))   # init_from_ckpt, strict
+    assert all(torch.equal(v, vsd[k]) for k, v in v2.state_dict().items())

@@ -134,6 +134,8 @@ class DiffusionDDIM(object):
             noise = noise[:, :, comm.rank * fl:(comm.rank + 1) * fl]
         xt = noise.detach().clone().float().contiguous()      # updated in place by the fused kernel
         kc, ku = model_kwargs
+        if hasattr(unet, "begin_sample"):
+            unet.begin_sample()                                # new sample: step-invariant conditioning is re-evaluated
         if autoencoder is not None and comm is not None:
             raise NotImplementedError("LGM-refined sampling is not combined with frame-parallel execution")
         for idx, step in enumerate(steps):

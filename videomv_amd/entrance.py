@@ -6,8 +6,9 @@ Kept: config layering (python defaults <- YAML/CLI dict-merge <- ``vldm_cfg`` ov
 (``state_dict``/``step`` wrapper, ``strict=False``), orbit ``camera_data``, latent noise shape
 ``[1, 4, max_frames, res_y/scale, res_x/scale]``, CFG kwargs pair, 50-step DDIM (``cfg.ddim_timesteps``, new key — the
 reference hard-codes 50 at :264), VAE decode in ``decoder_bs`` chunks, output naming.
-Different by design: launches go to ``libvmv_hip.so``; frames are written as a ``.pt`` tensor + PNG contact sheet (the
-mp4 writer is out of scope); the second, LGM-refined loop (:271-278) is skipped with a log line until that row is built.
+Different by design: launches go to ``libvmv_hip_{f16,bf16}.so`` (``hip_dtype`` config key / ``VMV_DTYPE``); frames are
+written as a ``.pt`` tensor + PNG contact sheet (the mp4 writer is out of scope); the second, LGM-refined loop (:271-278)
+runs when ``UNet.use_lgm_refine`` is set (not combined with ``frame_parallel``).
 """
 import logging
 import os
@@ -73,6 +74,9 @@ def worker(gpu, cfg, cfg_update):
         cfg = AttrDict(assign_signle_cfg(cfg, cfg_update, 'vldm_cfg'))
         merge_into(cfg, _plain(dict(cfg_update)))
     cfg.gpu, cfg.seed = gpu, int(cfg.seed)
+    if cfg.get('hip_dtype'):                        # (not a reference key) 16-bit storage type of the kernels: fp16 | bf16
+        from . import _lib
+        _lib.set_elem(cfg.hip_dtype)
     cfg.rank = cfg.pmi_rank
     # frame_parallel (not a reference key; BASELINE configs[2]): the ranks share ONE sample — same seed, F / N views each
     fpar = bool(cfg.get('frame_parallel', False)) and cfg.world_size > 1

@@ -283,6 +283,9 @@ class UNetEngine:
         self.has_cam = "camera_embedding.0.weight" in sd
         if self.has_cam:
             lin("camera_embedding.0"); lin("camera_embedding.2")
+        self.has_fps = self.cfg.get("use_fps_condition", False) and "fps_embedding.0.weight" in sd
+        if self.has_fps:
+            lin("fps_embedding.0"); lin("fps_embedding.2")
         emb_w, emb_b, self.emb_off = [], [], {}
         off = 0
         for blk in self.inp + [self.mid] + self.outb:
@@ -711,6 +714,27 @@ class UNetEngine:
                                self.w["camera_embedding.2.weight"], self.cam_emb, self.E,
                                bias=self.w["camera_embedding.2.bias"], out_fp32=True), "cam.2")
         self.cam_valid = True
+
+    def set_fps(self, fps: Optional[torch.Tensor]):
+        """fps [n_t] -> fps_embedding(sinusoidal(fps)) added to the time embedding (unet_t2v.py:155-161,323-324); constant
+        per sample, so it runs once here.  None (or a model without the MLP) leaves the time embedding alone."""
+        if not self.has_fps or fps is None:
+            self.extra_emb = None
+            return
+        f = fps.to(self.device).float().reshape(-1)[: self.n_t].contiguous()
+        if f.numel() != self.n_t:
+            f = f[:1].expand(self.n_t).contiguous()
+        S = ops.Stream(record=False)
+        sin = torch.empty(self.n_t, self.dim, dtype=L.elem(), device=self.device)
+        hid = torch.empty(self.n_t, self.E, dtype=L.elem(), device=self.device)
+        out = torch.empty(self.n_t, self.E, dtype=torch.float32, device=self.device)
+        ops.sinusoidal(f, sin, self.n_t, self.dim)
+        S.gemm(ops.gemm_params(self.n_t, self.E, ops.linear_segs([(sin, self.dim, self.dim)]), self.w["fps_embedding.0.weight"],
+                               hid, self.E, bias=self.w["fps_embedding.0.bias"], act=L.ACT_SILU), "fps.0")
+        S.gemm(ops.gemm_params(self.n_t, self.E, ops.linear_segs([(hid, self.E, self.E)]), self.w["fps_embedding.2.weight"],
+                               out, self.E, bias=self.w["fps_embedding.2.bias"], out_fp32=True), "fps.2")
+        self._fps_keep = (f, sin, hid)        # stream-ordered temporaries of the launches above
+        self.extra_emb = out
 
     def _embeddings(self):
         S = ops.Stream(record=False)

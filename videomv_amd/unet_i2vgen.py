@@ -22,7 +22,7 @@ from . import _lib as L
 from . import ops
 from . import packing as P
 from .unet_engine import UNetEngine, param_shapes
-from .unet_t2v import LgmMixin, _Holder, _ZERO_INIT_SUFFIXES
+from .unet_t2v import LgmMixin, _Holder, _ZERO_INIT_SUFFIXES, CondCache, same_for_both_branches
 
 
 def i2v_extra_shapes(arch: dict, concat_dim: int, num_tokens: int, y_dim: int) -> Dict[str, tuple]:
@@ -247,12 +247,20 @@ class UNetSD_I2VGen(nn.Module, LgmMixin):
             raise NotImplementedError("uncond branch without image tokens (use_zero_infer=False) has a shorter context")
         L_ctx = kc["y"].shape[1] + 64 + self.num_tokens
         eng, front = self._get(2, f, h, w, L_ctx, dev, n_t=1)
-        key = tuple(v.data_ptr() for v in (kc["y"], ku["y"], kc["image"], ku["image"], kc["local_image"]))
-        if getattr(eng, "_cond_key", None) != key:
+        same_for_both_branches("local_image", kc.get("local_image"), ku.get("local_image"))
+        same_for_both_branches("fps", kc.get("fps"), ku.get("fps"))
+        same_for_both_branches("camera_data", kc.get("camera_data"), ku.get("camera_data"))
+        cache = eng.__dict__.setdefault("_cond", CondCache())
+        if not cache.hit(kc["y"], ku["y"], kc["image"], ku["image"], kc["local_image"], kc["fps"], kc.get("camera_data")):
             li = self._first_frame(kc["local_image"]).to(dev)
             front.run(eng, torch.cat([li, li], dim=0), torch.cat([kc["y"], ku["y"]], dim=0).to(dev).float(),
                       torch.cat([kc["image"], ku["image"]], dim=0).to(dev).float(), kc["fps"][:1])
             cam = kc.get("camera_data")
             eng.set_camera(cam.to(dev) if (cam is not None and self.use_camera_condition) else None)
-            eng._cond_key = key
         return eng, eng.forward_rows(xt.float(), t.to(dev))
+
+    def begin_sample(self):
+        """Drop the per-sample conditioning caches (called by the sampler at the start of every ddim_sample_loop)."""
+        for eng in self._engines.values():
+            if "_cond" in eng.__dict__:
+                eng._cond.clear()

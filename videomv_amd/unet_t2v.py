@@ -100,6 +100,37 @@ def gather_frames(comm, x_local: torch.Tensor) -> torch.Tensor:
     return torch.cat(list(out.unbind(0)), dim=2)
 
 
+class CondCache:
+    """Step-invariant conditioning of the fused CFG pass (context rows, camera MLP, I2V image front-end) is evaluated once
+    per sample.  The cache key is the IDENTITY and in-place VERSION of the conditioning tensors, and the cache holds
+    strong references to them, so neither a freed-and-reallocated buffer (same address, new contents) nor an in-place
+    refill of the same tensor can be mistaken for the cached sample.  ``DiffusionDDIM.ddim_sample_loop`` additionally
+    drops it at the start of every sample (``begin_sample``)."""
+
+    def __init__(self):
+        self.key, self.refs = None, None
+
+    def hit(self, *tensors) -> bool:
+        key = tuple(None if t is None else (id(t), t._version) for t in tensors)
+        if key == self.key:
+            return True
+        self.key, self.refs = key, tensors
+        return False
+
+    def clear(self):
+        self.key, self.refs = None, None
+
+
+def same_for_both_branches(name, a, b):
+    """The fused pass evaluates shared conditioning once: the two model_kwargs dicts must agree on it (the reference
+    evaluates each branch with its own kwargs, diffusion_ddim.py:149-156)."""
+    if a is b:
+        return
+    if (a is None) != (b is None) or a.shape != b.shape or not torch.equal(a.to(b.device), b):
+        raise NotImplementedError(f"cond / uncond model_kwargs differ in `{name}`: not supported by the fused CFG pass "
+                                  f"(call model.forward per branch through DiffusionDDIM.ddim_sample instead)")
+
+
 @MODEL.register_class()
 class UNetSD_T2VBase(nn.Module, LgmMixin):
     def __init__(self, config=None, in_dim=4, dim=512, y_dim=512, context_dim=512, hist_dim=156, dim_condition=4,
@@ -112,8 +143,6 @@ class UNetSD_T2VBase(nn.Module, LgmMixin):
         super().__init__()
         if not temporal_attention:
             raise NotImplementedError("temporal_attention=False is not a VideoMV configuration")
-        if use_fps_condition:
-            raise NotImplementedError("use_fps_condition=True (I2VGen front-end) is a later row of SURVEY §8(f)")
         num_heads = num_heads if num_heads else dim // 32
         self.zero_y = zero_y
         self.in_dim, self.dim, self.y_dim, self.context_dim = in_dim, dim, y_dim, context_dim
@@ -201,6 +230,7 @@ class UNetSD_T2VBase(nn.Module, LgmMixin):
         eng = self.engine_for(b, f, h, w, y.shape[1], dev, n_t=b)
         eng.set_context(y.float())
         eng.set_camera(camera_data if self.use_camera_condition else None)
+        eng.set_fps(fps if self.use_fps_condition else None)
         if self.frame_comm is None:
             eng.forward_rows(x.float(), t.to(dev))
             if autoencoder is None:
@@ -219,11 +249,12 @@ class UNetSD_T2VBase(nn.Module, LgmMixin):
         """(Frame-parallel: ``xt`` holds THIS rank's frames only; camera_data / y stay whole-sample.)
         Both classifier-free-guidance branches in ONE pass (B = 2 rows blocks sharing x_t, so weights stream once
         per step instead of twice — SURVEY App. C).  ``cond_kwargs`` / ``uncond_kwargs`` are the two ``model_kwargs``
-        dicts of ``ddim_sample_loop`` (keys ``y``, ``camera_data``; ``fps`` is ignored as in the reference when
+        dicts of ``ddim_sample_loop`` (keys ``y``, ``camera_data``, ``fps`` — the latter ignored, as in the reference, when
         ``use_fps_condition`` is False).  Returns (engine, eps_rows fp32 [2*F*H*W, out_pad]); rows [0, F*H*W) are the
         conditional branch."""
         y_cond, y_uncond = cond_kwargs["y"], uncond_kwargs["y"]
         camera_data = cond_kwargs.get("camera_data", None)
+        cam_u = uncond_kwargs.get("camera_data", None)
         b, c, f, h, w = xt.shape
         if b != 1:
             raise ValueError("forward_cfg_rows handles one sample (the reference's noise is [1,4,F,h,w])")
@@ -231,9 +262,25 @@ class UNetSD_T2VBase(nn.Module, LgmMixin):
         if self.frame_comm is not None:
             f = f * self.frame_comm.world
         eng = self.engine_for(2, f, h, w, y_cond.shape[1], dev, n_t=1)
-        key = (y_cond.data_ptr(), y_uncond.data_ptr(), None if camera_data is None else camera_data.data_ptr())
-        if getattr(eng, "_cond_key", None) != key:      # context / camera are step-invariant: set once per sample
+        cache = eng.__dict__.setdefault("_cond", CondCache())
+        if not cache.hit(y_cond, y_uncond, camera_data, cam_u, cond_kwargs.get("fps")):      # context / camera are step-invariant: once per sample
+            cam = None
+            if self.use_camera_condition and (camera_data is not None or cam_u is not None):
+                if camera_data is None or cam_u is None:
+                    raise NotImplementedError("camera_data on only one CFG branch is not supported by the fused pass")
+                cam = camera_data.to(dev)
+                if cam_u is not camera_data and not (cam_u.shape == camera_data.shape and torch.equal(cam_u.to(dev), cam)):
+                    cam = torch.cat([cam.reshape(1, -1, cam.shape[-1]), cam_u.to(dev).reshape(1, -1, cam.shape[-1])], dim=0)
             eng.set_context(torch.cat([y_cond.to(dev).float(), y_uncond.to(dev).float()], dim=0))
-            eng.set_camera(camera_data.to(dev) if (camera_data is not None and self.use_camera_condition) else None)
-            eng._cond_key = key
+            eng.set_camera(cam)
+            fps = cond_kwargs.get("fps") if self.use_fps_condition else None
+            if fps is not None:
+                same_for_both_branches("fps", fps, uncond_kwargs.get("fps"))
+            eng.set_fps(fps)
         return eng, eng.forward_rows(xt.float(), t.to(dev))
+
+    def begin_sample(self):
+        """Drop the per-sample conditioning caches (called by the sampler at the start of every ddim_sample_loop)."""
+        for eng in self._engines.values():
+            if "_cond" in eng.__dict__:
+                eng._cond.clear()
