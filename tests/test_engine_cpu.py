@@ -316,3 +316,53 @@ def test_cfg_conditioning_cache_follows_the_tensors(monkeypatch):
     e_u = m(xt, t, y=y0, camera_data=cam_u)                           # reference-structured single-branch forward
     mine_u = rc[T:, :4].reshape(F_, H * W, 4).permute(2, 0, 1).reshape(1, 4, F_, H, W)
     assert rel_l2(mine_u, e_u) < 2e-3
+
+
+def test_shared_cfg_prefix_and_hoisted_context_kv(monkeypatch):
+    """B = 2 CFG pair: (a) everything before the first cross-attention is recorded once on one branch's rows and
+    replicated (share_prefix) — same eps as the plain B = 2 plan and as the oracle, fewer rows in the prefix GEMMs;
+    (b) K / V of the text tokens are not in the per-step plan at all: they sit in the context stream that set_context
+    runs once per sample (one GEMM on B*L rows per cross-attention layer)."""
+    plan_interp.install(monkeypatch)
+    from videomv_amd import _lib as L
+    from videomv_amd.unet_engine import UNetEngine
+    ocfg = UNetCfg(**{k: v for k, v in CFG.items() if k in {f.name for f in dataclasses.fields(UNetCfg)}})
+    sd = random_state_dict(unet_param_shapes(ocfg), 41)
+    B, F_, H, W, Lc = 2, 3, 8, 8, 5
+    g = torch.Generator().manual_seed(8)
+    x1 = torch.randn(1, 4, F_, H, W, generator=g)
+    y = torch.randn(B, Lc, 1024, generator=g)
+    cam = torch.randn(1, F_, 16, generator=g)
+    t = torch.tensor([501])
+    out = {}
+    for share in (False, True):
+        eng = UNetEngine(CFG, sd, B, F_, H, W, Lc, torch.device("cpu"), n_t=1, share_prefix=share)
+        eng.set_context(y)
+        eng.set_camera(cam)
+        eng.forward_rows(x1, t)
+        out[share] = (eng, eng.eps_ncfhw().clone())
+    e0, e1 = out[False][1], out[True][1]
+    ref = torch.cat([unet_forward(sd, ocfg, x1, t, y[b:b + 1], cam) for b in range(B)], dim=0)
+    assert rel_l2(e0, ref) < 1e-2 and rel_l2(e1, ref) < 1e-2
+    assert rel_l2(e1, e0) < 1e-3, rel_l2(e1, e0)
+    for share in (False, True):
+        eng = out[share][0]
+        labels = eng.S.labels
+        assert not any(l.endswith(".kv") for l in labels)                       # no context K/V GEMM per step
+        n_cross = sum(1 for blk in eng.inp + [eng.mid] + eng.outb for k, _, _ in blk if k == "st")
+        assert eng.Sctx.nops == n_cross and all(l.endswith(".kv") for l in eng.Sctx.labels)
+        assert all(p.M == B * Lc for _, p in eng.Sctx.recorded)
+    T = B * F_ * H * W
+    gm0 = [p.M for op, p in out[False][0].S.recorded if op == L.OP_GEMM]
+    gm1 = [p.M for op, p in out[True][0].S.recorded if op == L.OP_GEMM]
+    assert gm0.count(T // 2) == 0 and gm1.count(T // 2) >= 10                   # prefix GEMMs run on one branch's rows
+    assert sum(1 for l in out[True][0].S.labels if ".share." in l or l.startswith("share.")) == 3
+    # a context refill is picked up (K / V recomputed by set_context)
+    eng = out[True][0]
+    y2 = torch.randn(B, Lc, 1024, generator=g)
+    eng.set_context(y2)
+    eng.forward_rows(x1, t)
+    ref2 = torch.cat([unet_forward(sd, ocfg, x1, t, y2[b:b + 1], cam) for b in range(B)], dim=0)
+    assert rel_l2(eng.eps_ncfhw(), ref2) < 1e-2
+    with pytest.raises(ValueError):
+        eng.set_camera(torch.randn(B, F_, 16, generator=g))                    # per-branch cameras cannot share a prefix

@@ -27,6 +27,8 @@ def main():
     M0, M1, M2 = 122880, 30720, 7680
     shapes = [  # (name, M, N, C(=K per tap), kind)
         ("lin+res L0 N320 K320", M0, 320, 320, "linres"), ("qkv  L0 N960 K320", M0, 960, 320, "lin"),
+        ("lnqkv L0 N960 K320", M0, 960, 320, "lnlin"), ("lngeglu L0 N2560 K320", M0, 2560, 320, "lngeglu"),
+        ("lnqkv L1 N1920 K640", M1, 1920, 640, "lnlin"), ("lngeglu L1 N5120 K640", M1, 5120, 640, "lngeglu"),
         ("geglu L0 N2560 K320", M0, 2560, 320, "geglu"), ("down L0 N320 K1280", M0, 320, 1280, "linres"),
         ("lin+res L1 N640 K640", M1, 640, 640, "linres"), ("qkv  L1 N1920 K640", M1, 1920, 640, "lin"),
         ("geglu L1 N5120 K640", M1, 5120, 640, "geglu"), ("down L1 N640 K2560", M1, 640, 2560, "linres"),
@@ -45,9 +47,12 @@ def main():
         x = torch.randn(M, C, device=dev).to(BF)
         kw = {}
         No = N
-        if kind in ("lin", "linres", "geglu"):
+        if kind in ("lin", "linres", "geglu", "lnlin", "lngeglu"):
             K = C; segs = ops.linear_segs([(x, C, C)]); geom = None
-            if kind == "geglu":
+            if kind in ("lnlin", "lngeglu"):
+                kw["rowstat"] = torch.randn(M, 2, device=dev).abs() + 0.5
+                kw["colsum"] = torch.randn(N, device=dev)
+            if kind in ("geglu", "lngeglu"):
                 kw["epilogue"] = L.EPI_GEGLU; No = N // 2
         elif kind == "conv":
             K = 9 * C; segs = ops.conv3x3_segs([(x, C, C)])
@@ -63,7 +68,7 @@ def main():
             kw.update(residual=res, ldr=No)
         line = f"{name:24s}"
         for tile in tiles:
-            if tile in N160 and (N % 160 or kind == "geglu"):
+            if tile in N160 and (N % 160 or kind in ("geglu", "lngeglu")):
                 line += "      -    "; continue
             stamps = torch.zeros(8 * 64, dtype=torch.int64, device=dev) if os.environ.get("VMV_GEMM_ABLATE") in ("4", "7", "8") else None
             ks = int(os.environ.get("VMV_BENCH_KSPLIT", "0"))

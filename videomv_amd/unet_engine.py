@@ -191,13 +191,18 @@ class Act:
 # --------------------------------------------------------------------------------------------- the engine
 class UNetEngine:
     def __init__(self, cfg: dict, weights: Dict[str, torch.Tensor], B: int, F: int, H: int, W: int, L_ctx: int,
-                 device, n_t: int = 1, taps: Optional[dict] = None, comm=None):
+                 device, n_t: int = 1, taps: Optional[dict] = None, comm=None, share_prefix: bool = False):
         """weights: reference-named fp32 state dict (any device).  B = number of batched branches
         (2 = cond + uncond CFG pair sharing x_t), n_t = number of distinct timesteps rows (B // n_t branches
         share each).  F = number of frames of the whole sample.
 
         comm (``comm.FrameComm``) turns on frame-parallel execution: this rank owns frames
         [rank*F/R, (rank+1)*F/R); ``self.F`` is then the LOCAL frame count and ``self.Fg`` the sample's."""
+        # share_prefix: the B = 2 branches are a classifier-free-guidance pair on the SAME x_t, t, camera and fps, so every op
+        # before the first cross-attention (init conv + TemporalTransformer, the first ResBlock, the first SpatialTransformer up
+        # to and including its self-attention) sees identical inputs in both branches (SURVEY App. C): it is recorded once on
+        # B = 1 rows and its three live tensors are replicated (3 copies instead of ~1.1 TFLOP per step at 40x64)
+        self.share_prefix = bool(share_prefix) and B == 2 and n_t == 1 and comm is None
         self.comm = comm
         self.R = comm.world if comm is not None else 1
         self.rk = comm.rank if comm is not None else 0
@@ -206,10 +211,12 @@ class UNetEngine:
             raise ValueError(f"{F} frames do not split over {self.R} ranks")
         F = F // self.R
         self.cfg, self.B, self.F, self.H, self.W, self.L = cfg, B, F, H, W, L_ctx
+        self.B_ctx = B               # number of context (text) branches; self.B drops to 1 while a shared prefix is recorded
         self.device = device
         self.breaks = []            # (op index, callable): collectives issued before that recorded op
         self.pool = Pool(device)
         self.S = ops.Stream(record=True)
+        self.Sctx = ops.Stream(record=True)      # step-invariant launches: K / V of the text context (run by context_updated())
         self._keepalive = []
         self._ws = None
         self._gnws = torch.empty(4 << 20, dtype=torch.float32, device=device)
@@ -364,12 +371,12 @@ class UNetEngine:
         if self.taps is None:
             self.pool.put(a.buf)
 
-    def _gemm(self, label, M, N, segs, wkey, out: Act, bias=None, geom=None, **kw):
+    def _gemm(self, label, M, N, segs, wkey, out: Act, bias=None, geom=None, stream=None, **kw):
         """N is informational: the launch always covers every (4-padded) row of the packed weight."""
         W = self.w[wkey]
         ks, ws = (0, None) if kw.get("rowstat") else self._ksplit(M, W.shape[0], segs)      # (folded-LN GEMMs: no split-K)
         p = ops.gemm_params(M, W.shape[0], segs, W, out.ptr, out.C, bias=bias, geom=geom, ksplit=ks, workspace=ws, **kw)
-        self.S.gemm(p, label)
+        (stream or self.S).gemm(p, label)
 
     def _ksplit(self, M, N, segs):
         """Split K when the tile grid cannot fill 256 CUs and the reduction is long (small-spatial levels)."""
@@ -470,6 +477,13 @@ class UNetEngine:
                                        x.rows, x.C, 1e-5), label)
         return y
 
+    def _replicate(self, x: Act, label) -> Act:
+        """[T, C] (one branch) -> [2 T, C]: both CFG branches start from the shared prefix's tensor."""
+        y = self.act(2 * x.rows, x.C)
+        n16 = x.rows * x.C // 8
+        self.S.copy(ops.copy_params(x.ptr, y.ptr, 2, 1, 1, n16, 0, 0), label)
+        return y
+
     # ------------------------------------------------------------------ blocks
     def _res_block(self, p, m, srcs: List[Act], h, w) -> Act:
         B, F = self.B, self.F
@@ -515,7 +529,9 @@ class UNetEngine:
             cur = self._switch(cur, h * w, to_pixel=False)
         return cur
 
-    def _tblock(self, p, a: Act, heads, temporal: bool, h, w, cross_ctx: bool) -> Act:
+    def _tblock(self, p, a: Act, heads, temporal: bool, h, w, cross_ctx: bool, phase: str = "all") -> Act:
+        """phase "pre": stop after the first (self-)attention and return a1; "post": `a` IS a1, continue from the second
+        attention (the shared-prefix cut, see __init__); "all": the whole block."""
         B, F = self.B, self.F
         T = a.rows
         inner = a.C
@@ -552,24 +568,35 @@ class UNetEngine:
             q = self.act(T, inner)
             self._ln_linear(f"{p}.{tag}.q", x, f"{p}.{normkey}", inner, f"{p}.{tag}.q", q)
             Lc = self.L
-            kv = self.act(B * Lc, 2 * inner)
+            # K / V of the text tokens do not depend on x_t or t: computed once per sample (context_updated()), on B*L rows
+            # — the reference recomputes them on 24 copies of the tokens in every forward (unet_t2v.py:346, util.py:224-225)
+            Bc = self.B_ctx
+            kvt = torch.empty(Bc * Lc, 2 * inner, dtype=L.elem(), device=self.device)
+            self._keepalive.append(kvt)
+            kv = Act(kvt.view(torch.uint8).view(-1), Bc * Lc, 2 * inner)
             cd = self.ctx_rows.shape[1]
-            self._gemm(f"{p}.{tag}.kv", B * Lc, 2 * inner, ops.linear_segs([(self.ctx_rows.data_ptr(), cd, cd)]),
-                       f"{p}.{tag}.kv", kv)
+            self._gemm(f"{p}.{tag}.kv", Bc * Lc, 2 * inner, ops.linear_segs([(self.ctx_rows.data_ptr(), cd, cd)]),
+                       f"{p}.{tag}.kv", kv, stream=self.Sctx)
             ao = self.act(T, inner)
             kvm = ops.seq_map(Lc * 2 * inner, 0, 2 * inner, inner=1)
             self.S.attention(ops.attn_params(q.ptr, kv.ptr, kv.ptr + 2 * inner, ao.ptr, maps(inner), kvm, kvm, maps(inner),
                                              n_outer, heads, Nq, Lc, scale, kv_div=F), f"{p}.{tag}.attn")
-            self.release(q); self.release(kv)
+            self.release(q)
             y = self.act(T, inner)
             self._gemm(f"{p}.{tag}.out", T, inner, ops.linear_segs([(ao.ptr, ao.C, ao.C)]), f"{p}.{tag}.to_out.0.weight", y,
                        bias=self.w[f"{p}.{tag}.to_out.0.bias"], residual=x.ptr, ldr=x.C)
             self.release(ao)
             return y
 
-        a1 = self_attn("attn1", a, "norm1")
+        if phase == "post":
+            a1 = a
+        else:
+            a1 = self_attn("attn1", a, "norm1")
+            if phase == "pre":
+                return a1
         a2 = cross_attn("attn2", a1, "norm2") if cross_ctx else self_attn("attn2", a1, "norm2")
-        self.release(a1)
+        if phase != "post":
+            self.release(a1)
         ff = self.act(T, 4 * inner)
         self._ln_linear(f"{p}.ff.geglu", a2, f"{p}.norm3", 8 * inner, f"{p}.ff.net.0.proj.weight", ff,
                         bias=self.w[f"{p}.ff.net.0.proj.bias"], epilogue=L.EPI_GEGLU)
@@ -579,7 +606,9 @@ class UNetEngine:
         self.release(ff); self.release(a2)
         return a3
 
-    def _transformer(self, kind, p, m, x: Act, h, w) -> Act:
+    def _transformer(self, kind, p, m, x: Act, h, w, cut: bool = False) -> Act:
+        """cut (shared prefix, spatial transformer only): x and everything up to the first self-attention live on ONE
+        branch's rows; x and a1 are then replicated and the rest of the block runs on both branches."""
         B, F = self.B, self.F
         T = x.rows
         C = x.C
@@ -596,12 +625,25 @@ class UNetEngine:
         self._gemm(p + ".proj_in", T, inner, ops.linear_segs([(n0.ptr, n0.C, n0.C)]), f"{p}.proj_in.weight", a,
                    bias=self.w[f"{p}.proj_in.bias"])
         self.release(n0)
-        a3 = self._tblock(f"{p}.transformer_blocks.0", a, m["heads"], temporal, h, w, cross_ctx=not temporal)
-        self.release(a)
+        if cut:
+            assert not temporal and self.B == 1
+            a1 = self._tblock(f"{p}.transformer_blocks.0", a, m["heads"], temporal, h, w, cross_ctx=True, phase="pre")
+            self.release(a)
+            self.B = self.B_ctx                        # ---- the branches diverge here (cross-attention on their own text)
+            x_full, a1_full = self._replicate(x, p + ".share.x"), self._replicate(a1, p + ".share.a1")
+            self.release(a1)
+            x, T = x_full, x_full.rows                 # (the caller releases the one-branch x; x_full is released below)
+            a3 = self._tblock(f"{p}.transformer_blocks.0", a1_full, m["heads"], temporal, h, w, cross_ctx=True, phase="post")
+            self.release(a1_full)
+        else:
+            a3 = self._tblock(f"{p}.transformer_blocks.0", a, m["heads"], temporal, h, w, cross_ctx=not temporal)
+            self.release(a)
         y = self.act(T, C)
         self._gemm(p + ".proj_out", T, C, ops.linear_segs([(a3.ptr, a3.C, a3.C)]), f"{p}.proj_out.weight", y,
                    bias=self.w[f"{p}.proj_out.bias"], residual=x.ptr, ldr=x.C)
         self.release(a3)
+        if cut:
+            self.release(x)
         if sharded:
             self.release(x)
             y = self._switch(y, h * w, to_pixel=False)
@@ -614,13 +656,14 @@ class UNetEngine:
         for kind, p, m in blk:
             ins = srcs if x is None else [x]
             if kind == "conv_in":
-                y = self.act(self.T0, m["cout"])
-                self._gemm(p, self.T0, m["cout"], ops.conv3x3_segs([(self.x_rows.data_ptr(), self.cin_pad, self.cin_pad)]),
+                T_in = self.B * self.F * h * w          # (one branch's rows while the shared prefix is recorded)
+                y = self.act(T_in, m["cout"])
+                self._gemm(p, T_in, m["cout"], ops.conv3x3_segs([(self.x_rows.data_ptr(), self.cin_pad, self.cin_pad)]),
                            p + ".weight", y, bias=self.w[p + ".bias"], geom=ops.Geom(OH=h, OW=w, IH=h, IW=w))
             elif kind == "res":
                 y = self._res_block(p, m, ins, h, w)
             elif kind in ("st", "tt"):
-                y = self._transformer(kind, p, m, ins[0], h, w)
+                y = self._transformer(kind, p, m, ins[0], h, w, cut=(kind == "st" and self.B != self.B_ctx))
             elif kind == "down":
                 xin = ins[0]
                 oh, ow = (h + 1) // 2, (w + 1) // 2
@@ -657,11 +700,24 @@ class UNetEngine:
         h, w = self.H, self.W
         xs = []
         x = None
-        for blk in self.inp:
+        share = self.share_prefix and len(self.inp) > 1 and any(k == "st" for k, _, _ in self.inp[1])
+        if share:
+            self.B = 1           # record the shared prefix on one branch's rows; _transformer(cut) switches back
+        for bi, blk in enumerate(self.inp):
             x, h, w = self._run_block(blk, [x] if x is not None else [], h, w)
+            if share and bi == 0:            # block 0's output is also a decoder skip: both branches need their copy
+                x1 = x
+                x_skip = self._replicate(x1, "share.skip0")
+                xs.append((x_skip, h, w))
+                if self.taps is not None:
+                    self.taps[blk[0][1]] = (x_skip, h, w)
+                continue
+            if share and bi == 1:
+                self.release(x1)             # (block 1 has consumed the one-branch tensor)
             xs.append((x, h, w))
             if self.taps is not None:
                 self.taps[blk[0][1]] = (x, h, w)
+        assert self.B == self.B_ctx
         # encoder outputs double as skips: _run_block never releases its inputs
         x_last = x
         x, h, w = self._run_block(self.mid, [x], h, w)
@@ -689,6 +745,12 @@ class UNetEngine:
     def set_context(self, y: torch.Tensor):
         """y [B, L, ctx] -> bf16 context rows (dtype cast only)."""
         self.ctx_rows.copy_(y.reshape(self.B * self.L, -1).to(L.elem()))
+        self.context_updated()
+
+    def context_updated(self):
+        """ctx_rows changed (new prompt): recompute the step-invariant K / V of every cross-attention layer."""
+        if self.Sctx.nops:
+            self.Sctx.run()
 
     def set_camera(self, camera_data: Optional[torch.Tensor]):
         """camera_data [b, F, 16] with b = 1 (shared by all branches) or b = B: the camera-embedding MLP
@@ -702,6 +764,8 @@ class UNetEngine:
         n = cam.shape[0]
         if n not in (self.F, self.B * self.F):
             raise ValueError(f"camera_data has {n} rows, expected {self.F} or {self.B * self.F}")
+        if self.share_prefix and n != self.F:
+            raise ValueError("per-branch camera_data needs an engine built with share_prefix=False")
         self.n_cam_rows = n
         self.cam_rows.zero_()
         self.cam_rows[:n, : cam.shape[1]].copy_(cam.to(L.elem()))

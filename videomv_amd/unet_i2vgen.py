@@ -14,6 +14,8 @@ The LGM branch raises ``NotImplementedError`` as in ``unet_t2v.py``.
 import math
 from typing import Dict
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -138,6 +140,7 @@ class I2VFrontEnd:
         ops.sinusoidal(t_f, sin, t_f.numel(), self.dim)
         fe = self._mlp(S, sin, "fps_embedding", out_fp32=True)
         eng.extra_emb = fe if fe.shape[0] == eng.n_t else fe[:1].expand(eng.n_t, -1).contiguous()
+        eng.context_updated()           # K / V of the (text + local-image + image) context tokens: once per sample
         if dev.type == "cuda":
             torch.cuda.synchronize()          # temporaries above are released when this returns
         self._keep = []
@@ -194,11 +197,12 @@ class UNetSD_I2VGen(nn.Module, LgmMixin):
         self._engines.clear()
         self._front.clear()
 
-    def _get(self, B, F, H, W, L, device, n_t):
-        key = (B, F, H, W, L, str(device), n_t)
+    def _get(self, B, F, H, W, L, device, n_t, share_prefix=False):
+        share_prefix = bool(share_prefix) and os.environ.get("VMV_SHARE_PREFIX", "1") != "0"
+        key = (B, F, H, W, L, str(device), n_t, share_prefix)
         if key not in self._engines:
             sd = {k: v.detach() for k, v in self.state_dict().items()}
-            self._engines[key] = UNetEngine(self.arch, sd, B, F, H, W, L, device, n_t=n_t)
+            self._engines[key] = UNetEngine(self.arch, sd, B, F, H, W, L, device, n_t=n_t, share_prefix=share_prefix)
             if str(device) not in self._front:
                 self._front[str(device)] = I2VFrontEnd(sd, self.dim, self.num_tokens, device)
         return self._engines[key], self._front[str(device)]
@@ -246,7 +250,8 @@ class UNetSD_I2VGen(nn.Module, LgmMixin):
         if ku.get("image") is None:
             raise NotImplementedError("uncond branch without image tokens (use_zero_infer=False) has a shorter context")
         L_ctx = kc["y"].shape[1] + 64 + self.num_tokens
-        eng, front = self._get(2, f, h, w, L_ctx, dev, n_t=1)
+        # (local_image / fps / camera are checked to be the same for both branches below: the CFG pair shares its prefix)
+        eng, front = self._get(2, f, h, w, L_ctx, dev, n_t=1, share_prefix=True)
         same_for_both_branches("local_image", kc.get("local_image"), ku.get("local_image"))
         same_for_both_branches("fps", kc.get("fps"), ku.get("fps"))
         same_for_both_branches("camera_data", kc.get("camera_data"), ku.get("camera_data"))

@@ -17,6 +17,8 @@ The LGM refinement branch (``autoencoder is not None``, unet_t2v.py:404-433; ``u
 import math
 from typing import Dict, Optional
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -195,13 +197,16 @@ class UNetSD_T2VBase(nn.Module, LgmMixin):
         self.frame_comm = comm
         self._engines.clear()
 
-    def engine_for(self, B, F, H, W, L, device, n_t=1, taps=None) -> UNetEngine:
-        """F = frames of the whole sample."""
-        key = (B, F, H, W, L, str(device), n_t, taps is not None)
+    def engine_for(self, B, F, H, W, L, device, n_t=1, taps=None, share_prefix=False) -> UNetEngine:
+        """F = frames of the whole sample.  share_prefix: the B = 2 branches are a CFG pair with identical x_t / t / camera /
+        fps (UNetEngine.__init__)."""
+        share_prefix = bool(share_prefix) and os.environ.get("VMV_SHARE_PREFIX", "1") != "0"
+        key = (B, F, H, W, L, str(device), n_t, taps is not None, share_prefix)
         eng = self._engines.get(key)
         if eng is None:
             sd = {k: v.detach() for k, v in self.state_dict().items()}
-            eng = UNetEngine(self.arch, sd, B, F, H, W, L, device, n_t=n_t, taps=taps, comm=self.frame_comm)
+            eng = UNetEngine(self.arch, sd, B, F, H, W, L, device, n_t=n_t, taps=taps, comm=self.frame_comm,
+                             share_prefix=share_prefix)
             if taps is None:
                 self._engines[key] = eng
         return eng
@@ -261,7 +266,10 @@ class UNetSD_T2VBase(nn.Module, LgmMixin):
         dev = xt.device
         if self.frame_comm is not None:
             f = f * self.frame_comm.world
-        eng = self.engine_for(2, f, h, w, y_cond.shape[1], dev, n_t=1)
+        cam_shared = (not self.use_camera_condition) or cam_u is camera_data or (
+            cam_u is not None and camera_data is not None and cam_u.shape == camera_data.shape
+            and torch.equal(cam_u.to(camera_data.device), camera_data))
+        eng = self.engine_for(2, f, h, w, y_cond.shape[1], dev, n_t=1, share_prefix=cam_shared)
         cache = eng.__dict__.setdefault("_cond", CondCache())
         if not cache.hit(y_cond, y_uncond, camera_data, cam_u, cond_kwargs.get("fps")):      # context / camera are step-invariant: once per sample
             cam = None
