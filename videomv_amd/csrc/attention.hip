@@ -304,6 +304,138 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
     }
 }
 
+// ---- short problems (Nq, Nk <= 32: the 24-frame temporal attention of every pixel x head) — HBM-bound.
+// One wave per problem, as attn_kernel<1, .>, but built for memory-level parallelism instead of generality:
+//   * every global load of the problem (Q: 2, K: 4, V: 4 wave-instructions of 16 B per lane) is issued before the first
+//     use, so a wave pays ONE memory round trip instead of three dependent ones;
+//   * only the 32-key half that can hold valid keys exists: 2 S^T tiles instead of 4, one P.V k-step instead of 2 (half
+//     the MFMAs, the exponentials and the registers: 4-5 waves per SIMD instead of 2-3), and the V^T stage is
+//     [64 d][32 keys] = 4 KB per wave, filled from the 4 valid row groups only (32 instead of 64 16-bit LDS writes);
+//   * the stage is private to the wave: no block barrier anywhere.
+// Same transposed formulation and key permutation as attn_kernel (header of this file).
+__global__ __launch_bounds__(256, 4) void attn_short_kernel(const VmvAttnParams p, const int nproblems) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem_s[4 * 4096];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int u = lane & 15, g = lane >> 4;
+    const int pidx = blockIdx.x * 4 + wave;
+    if (pidx >= nproblems) return;                      // (no block-level synchronisation below)
+    const int h = pidx % p.heads, o = pidx / p.heads;
+    const uint16_t* qp = reinterpret_cast<const uint16_t*>(p.q) + seq_base(p.qm, o) + h * 64;
+    const uint16_t* kp = reinterpret_cast<const uint16_t*>(p.k) + seq_base(p.km, o / p.kv_div) + h * 64;
+    const uint16_t* vp = reinterpret_cast<const uint16_t*>(p.v) + seq_base(p.vm, o / p.kv_div) + h * 64;
+    uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + seq_base(p.om, o) + h * 64;
+    uint16_t* Vtd = reinterpret_cast<uint16_t*>(smem_s + wave * 4096);
+
+    // ---- all loads of the problem, back to back
+    u32x4_t qv[2][2], kv[2][2], vv[4];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = qt * 16 + u;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            qv[qt][kk] = u32x4_t{0u, 0u, 0u, 0u};
+            if (q < p.Nq) qv[qt][kk] = *reinterpret_cast<const u32x4_t*>(qp + (long)q * p.qm.s_row + kk * 32 + g * 8);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int key = 8 * (u >> 2) + 4 * t + (u & 3);          // permuted key order (file header), keys 0..31
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            kv[t][kk] = u32x4_t{0u, 0u, 0u, 0u};
+            if (key < p.Nk) kv[t][kk] = *reinterpret_cast<const u32x4_t*>(kp + (long)key * p.km.s_row + kk * 32 + g * 8);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int key = (lane >> 3) + 8 * i;
+        vv[i] = u32x4_t{0u, 0u, 0u, 0u};
+        if (key < p.Nk) vv[i] = *reinterpret_cast<const u32x4_t*>(vp + (long)key * p.vm.s_row + (lane & 7) * 8);
+    }
+    // ---- V^T stage: element (d, key) at Vtd[d * 32 + (key ^ 8 * (((d >> 3) ^ (d >> 1)) & 3))]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int key = (lane >> 3) + 8 * i, slot = lane & 7;
+        const uint32_t w[4] = {vv[i].x, vv[i].y, vv[i].z, vv[i].w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = slot * 8 + j;
+            const int fk = ((slot ^ (j >> 1)) & 3) << 3;
+            Vtd[d * 32 + (key ^ fk)] = (j & 1) ? (uint16_t)(w[j >> 1] >> 16) : (uint16_t)(w[j >> 1] & 0xffffu);
+        }
+    }
+    // ---- S^T = K Q^T (2 key tiles x 2 query tiles) and the softmax of each query over its <= 32 keys
+    const float sc = p.scale * 1.44269504088896341f;
+    elem8_t pf[2];
+    float linv[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        f32x4_t s[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                s[t] = VMV_MFMA16(__builtin_bit_cast(elem8_t, kv[t][kk]), __builtin_bit_cast(elem8_t, qv[qt][kk]), s[t], 0, 0, 0);
+        }
+        // lane (u, g) holds the scores of query 16 qt + u against keys 8 g + 4 t + r
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (8 * g + 4 * t + r >= p.Nk) s[t][r] = NEG_BIG;
+        float mx = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float nm = -mx * sc;
+        float e[2][4], psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                e[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], sc, nm));
+                psum += e[t][r];
+            }
+        psum += __shfl_xor(psum, 16, 64);
+        psum += __shfl_xor(psum, 32, 64);
+        linv[qt] = 1.0f / psum;
+        u32x4_t w;
+        w.x = pack_elem2(e[0][0], e[0][1]); w.y = pack_elem2(e[0][2], e[0][3]);
+        w.z = pack_elem2(e[1][0], e[1][1]); w.w = pack_elem2(e[1][2], e[1][3]);
+        pf[qt] = __builtin_bit_cast(elem8_t, w);               // = P^T B-operand for keys 8 g + 0..7
+    }
+    // ---- O^T = V^T P^T (the wave's own LDS writes above are complete: same-wave LDS ops execute in order)
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    asm volatile("" ::: "memory");
+    const u32x4_t* Vt16 = reinterpret_cast<const u32x4_t*>(Vtd);
+    f32x4_t oacc[2][4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const int d = dt * 16 + u;
+        const int fsl = ((d >> 3) ^ (d >> 1)) & 3;
+        const elem8_t vf = __builtin_bit_cast(elem8_t, Vt16[d * 4 + (g ^ fsl)]);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+            oacc[qt][dt] = VMV_MFMA16(vf, pf[qt], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = qt * 16 + u;
+        if (q < p.Nq) {
+            uint16_t* orow = op + (long)q * p.om.s_row + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const f32x4_t a = oacc[qt][dt] * linv[qt];
+                u32x2_t w;
+                w.x = pack_elem2(a.x, a.y); w.y = pack_elem2(a.z, a.w);
+                *reinterpret_cast<u32x2_t*>(orow + dt * 16) = w;
+            }
+        }
+    }
+}
+
 int map_ok(const VmvSeqMap& m) {
     return m.inner > 0 && !(m.s_outer & 7) && !(m.s_inner & 7) && !(m.s_row & 3);
 }
@@ -319,7 +451,12 @@ extern "C" int vmv_attention(const VmvAttnParams* pp, void* stream) {
     if ((p.qm.s_row & 7) || (p.km.s_row & 7) || (p.vm.s_row & 7)) return VMV_EALIGN;
     if (!vmv_aligned16(p.q) || !vmv_aligned16(p.k) || !vmv_aligned16(p.v) || (((uintptr_t)p.o) & 7)) return VMV_EALIGN;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (p.Nq <= 32) {
+    static int short_env = -1;
+    if (short_env < 0) { const char* e = getenv("VMV_ATTN_SHORT"); short_env = e ? atoi(e) : 1; }
+    if (p.Nq <= 32 && p.Nk <= 32 && short_env) {
+        const int nproblems = p.n_outer * p.heads;
+        hipLaunchKernelGGL(attn_short_kernel, dim3((nproblems + 3) / 4), dim3(256), 0, st, p, nproblems);
+    } else if (p.Nq <= 32) {
         const int nproblems = p.n_outer * p.heads;
         static bool attr1 = false;
         if (!attr1) {
