@@ -29,7 +29,7 @@ extern "C" {
 #define VMV_ENULL        -3   /* required pointer is NULL */
 #define VMV_ERANGE       -4   /* size outside what the kernel supports */
 
-#define VMV_ABI_VERSION   2
+#define VMV_ABI_VERSION   3
 int vmv_abi_version(void);
 /* The 16-bit storage / MFMA operand type ("elem") this build of the library computes in.  The same sources are
  * compiled once per type: libvmv_hip_f16.so (VMV_ELEM_F16: IEEE fp16 — the default; the reference's own half mode,
@@ -163,6 +163,14 @@ typedef struct {
 
 int vmv_groupnorm_stats(const VmvGroupNormParams* p, void* stream);
 int vmv_groupnorm_apply(const VmvGroupNormParams* p, void* stream);
+/* One-launch GroupNorm for stat groups that fit on chip: a block stages all rows_per_stat rows of `cols` channels (a
+ * whole number of groups, cols % 8 == 0, rows_per_stat * cols * 2 <= VMV_GN_FUSED_BYTES) in LDS, computes the statistics
+ * TWO-PASS (mean, then sum of squared deviations: no E[x^2] - mean^2 cancellation), applies them and writes y — one
+ * launch and one read of x instead of stats (+ fold) + apply.  partial / totals / chunk_rows / fold_ranks are unused.
+ * Returns VMV_ERANGE when the group does not fit (use the two-kernel form).  The small levels of the UNet, where the
+ * two- / three-launch form is pure launch latency. */
+#define VMV_GN_FUSED_BYTES 131072
+int vmv_groupnorm_fused(const VmvGroupNormParams* p, int32_t cols, void* stream);
 
 /* LayerNorm over the channel axis of [rows][C] elem (nn.LayerNorm, eps 1e-5: util.py:528-530) */
 typedef struct {
@@ -349,6 +357,7 @@ typedef struct VmvPlan VmvPlan;
 #define VMV_OP_ATTENTION   5
 #define VMV_OP_SOFTMAX     6
 #define VMV_OP_COPY        7
+#define VMV_OP_GN_FUSED    8   /* args: VmvGroupNormParams with chunk_rows = cols of vmv_groupnorm_fused */
 VmvPlan* vmv_plan_create(void);
 void     vmv_plan_destroy(VmvPlan* plan);
 int      vmv_plan_add(VmvPlan* plan, int op, const void* params, size_t nbytes);

@@ -123,6 +123,20 @@ def groupnorm(p: L.GroupNormParams):
     _rows(p.y, p.rows, p.ldy)[:, :Cc] = y.to(L.elem())
 
 
+def groupnorm_fused(p: L.GroupNormParams):
+    """vmv_groupnorm_fused: statistics (two-pass) + apply in one op."""
+    x, Cc = _gn_input(p)
+    nstat = p.rows // p.rows_per_stat
+    xg = x.view(nstat, p.rows_per_stat, 32, Cc // 32).double()
+    mean = xg.mean(dim=(1, 3), keepdim=True)
+    var = ((xg - mean) ** 2).mean(dim=(1, 3), keepdim=True)
+    y = ((xg - mean) * torch.rsqrt(var + p.eps)).float().view(p.rows, Cc)
+    y = y * _view(p.gamma, Cc, "f32") + _view(p.beta, Cc, "f32")
+    if p.silu:
+        y = torch.nn.functional.silu(y)
+    _rows(p.y, p.rows, p.ldy)[:, :Cc] = y.to(L.elem())
+
+
 def permute_copy(p: L.CopyParams):
     """dst[i0][i1][i2][:] = src[i0*ss0 + i1*ss1 + i2*ss2 + :], 16-byte units (8 bf16)."""
     span = (p.n0 - 1) * p.ss0 + (p.n1 - 1) * p.ss1 + (p.n2 - 1) * p.ss2 + p.inner16
@@ -184,6 +198,8 @@ def run_recorded(recorded):
             softmax_rows(params)
         elif op == L.OP_COPY:
             permute_copy(params)
+        elif op == L.OP_GN_FUSED:
+            groupnorm_fused(params)
         else:
             raise ValueError(op)
 

@@ -294,9 +294,15 @@ def test_groupnorm(rows, rps, C0, C1, silu, eps):
     I.groupnorm_stats(build(cpu))
     I.groupnorm(build(cpu))
     dev = c.on("cuda")
-    ops.Stream(record=False).groupnorm(build(dev))
+    S = ops.Stream(record=False)
+    S.groupnorm_stats(build(dev))                   # the general two-launch form, explicitly
+    S.groupnorm_apply(build(dev))
     torch.cuda.synchronize()
     check(dev["y"], cpu["y"], tol_l2=5e-3, tol_max=1.5e-2)
+    dev2 = c.on("cuda")
+    S.groupnorm(build(dev2))                        # auto: one fused launch where the stat group fits on chip
+    torch.cuda.synchronize()
+    check(dev2["y"], cpu["y"], tol_l2=5e-3, tol_max=1.5e-2)
 
 
 @pytest.mark.parametrize("rows,rps,Cc,silu", [(2 * 61440, 61440, 320, True), (2 * 960, 960, 1280, False), (3 * 500, 500, 64, True)])
@@ -379,6 +385,39 @@ def test_permute_copy_matches_torch():
     bad = ops.copy_params(x, out, 0, 1, 1, 1, 0, 0)
     import ctypes
     assert L.load().vmv_permute_copy(ctypes.byref(bad), None) == -1          # VMV_EINVAL
+
+@pytest.mark.parametrize("rows,rps,C0,C1,silu", [(2 * 3 * 160, 160, 1280, 0, True), (2 * 40, 40, 1280, 1280, True),
+                                                  (2 * 960, 960, 1280, 0, False), (4 * 640, 640, 640, 0, True),
+                                                  (3 * 160, 160, 1280, 640, True)])
+def test_groupnorm_fused(rows, rps, C0, C1, silu):
+    """vmv_groupnorm_fused (one launch: LDS-resident stat group, two-pass statistics) vs the interpreter, incl. the
+    decoder's two-source concat, the all-frame groups of L3 and a large DC offset (|mean| = 30 std: the single-pass
+    E[x^2] - mean^2 of the general path would lose ~3 digits there; the two-pass form must not)."""
+    C = C0 + C1
+    cols = ops.gn_fused_cols(rps, C)
+    assert cols > 0 and cols % (C // 32) == 0
+    for offset in (0.0, 30.0):
+        def build(t):
+            return ops.gn_params(t["x"], C0, C0, rows, rps, t["x"], t["gamma"], t["beta"], 1e-5, silu, t["y"], C,
+                                 x1=t["x1"] if C1 else None, ld1=C1, C1=C1)
+        case = Case(x=(rnd((rows, C0), 1, dtype=torch.float32) + offset).to(BF),
+                    x1=(rnd((rows, max(C1, 8)), 2, dtype=torch.float32) * 2.0 - offset).to(BF),
+                    gamma=rnd((C,), 3, dtype=torch.float32) + 1.0, beta=rnd((C,), 4, dtype=torch.float32),
+                    y=torch.zeros(rows, C, dtype=BF))
+        cpu = case.on("cpu")
+        I.groupnorm_fused(build(cpu))
+        dev = case.on("cuda")
+        S = ops.Stream(record=False)
+        S.groupnorm_fused(build(dev), cols, "t")
+        torch.cuda.synchronize()
+        check(dev["y"], cpu["y"], tol_l2=5e-3, tol_max=2e-2)
+        # the auto-selecting entry takes the same path
+        dev2 = case.on("cuda")
+        S.groupnorm(build(dev2), "t")
+        torch.cuda.synchronize()
+        assert torch.equal(dev2["y"], dev["y"])
+    assert ops.gn_fused_cols(2560, 320) == 0 and ops.gn_fused_cols(3840, 1280) == 0      # too large: two-kernel form
+
 
 
 @pytest.mark.parametrize("rows,Cc", [(37, 320), (1000, 1280), (5, 512), (64, 64), (3, 2048)])

@@ -47,7 +47,8 @@ TILE_AUTO, TILE_128x128, TILE_128x160, TILE_128x64, TILE_64x64, TILE_256x128, TI
 TILE_G128x128, TILE_G128x160, TILE_P256x128, TILE_P256x160, TILE_PP256x128, TILE_PP256x160 = 7, 8, 9, 10, 11, 12
 TILE_Q128x128, TILE_Q96x160 = 13, 14
 TILE_S256x128, TILE_S192x160, TILE_S256x160 = 15, 16, 17
-OP_GEMM, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTENTION, OP_SOFTMAX, OP_COPY = 1, 2, 3, 4, 5, 6, 7
+OP_GEMM, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTENTION, OP_SOFTMAX, OP_COPY, OP_GN_FUSED = 1, 2, 3, 4, 5, 6, 7, 8
+GN_FUSED_BYTES = 131072
 
 
 class GemmSeg(C.Structure):
@@ -133,6 +134,7 @@ SYMBOLS = {
     "vmv_gemm": (C.c_int, [C.POINTER(GemmParams), _P]),
     "vmv_groupnorm_stats": (C.c_int, [C.POINTER(GroupNormParams), _P]),
     "vmv_groupnorm_apply": (C.c_int, [C.POINTER(GroupNormParams), _P]),
+    "vmv_groupnorm_fused": (C.c_int, [C.POINTER(GroupNormParams), C.c_int32, _P]),
     "vmv_layernorm": (C.c_int, [C.POINTER(LayerNormParams), _P]),
     "vmv_attention": (C.c_int, [C.POINTER(AttnParams), _P]),
     "vmv_softmax_rows": (C.c_int, [C.POINTER(SoftmaxParams), _P]),
@@ -180,7 +182,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the ABI drifted
         fn.restype = res
         fn.argtypes = args
-    if lib.vmv_abi_version() != 2:
+    if lib.vmv_abi_version() != 3:
         raise RuntimeError(f"{LIB_PATH}: ABI version mismatch")
     if lib.vmv_elem_type() != (ELEM_F16 if _elem == "f16" else ELEM_BF16):
         raise RuntimeError(f"{LIB_PATH} was built for another element type")

@@ -193,6 +193,135 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const VmvGroupNormParams 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ GN fused (small groups)
+// grid = (C / CW, nstat).  A block owns ALL rows of one stat group for CW channels (whole groups), stages them in LDS as
+// they stream in, and normalises from the stage: one launch and one read of x where the general path needs stats (+ fold)
+// + apply — at the small levels those are ~5-9 us of launch latency each for < 10 us of work.  Statistics are two-pass
+// (the data is on chip): mean first, then the squared deviations.  Fixed reduction order: bitwise reproducible.
+__global__ __launch_bounds__(256) void gn_fused_kernel(const VmvGroupNormParams p, const int CW) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];
+    const int C = p.C0 + p.C1;
+    const int cpg = C >> 5;
+    const int G = CW / cpg;                       // groups of this block
+    const int SW = CW >> 3;                       // 16-byte slots per staged row
+    const int TPR = SW < 256 ? SW : 256;
+    const int RPP = 256 / TPR;
+    const int tid = threadIdx.x;
+    const int rl = tid / TPR, cl = tid - rl * TPR;
+    const bool active = rl < RPP;
+    const int stat = blockIdx.y, c0 = blockIdx.x * CW;
+    const int rows = p.rows_per_stat;
+    const long row0 = (long)stat * rows;
+    u32x4_t* stage = reinterpret_cast<u32x4_t*>(sh);                  // [rows][SW]
+    float* red = sh + (size_t)rows * SW * 4;                          // [RPP][CW]
+    float* scale = red + RPP * CW;                                    // [CW]
+    float* shift = scale + CW;                                        // [CW]
+    float* s_mean = shift + CW;                                       // [32]
+    float* s_rstd = s_mean + 32;                                      // [32]
+    const uint16_t* x0 = reinterpret_cast<const uint16_t*>(p.x);
+    const uint16_t* x1 = reinterpret_cast<const uint16_t*>(p.x1);
+    // ---- pass 1: stream in, stage, column sums
+    for (int cs = cl; cs < SW; cs += TPR) {
+        float s[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] = 0.f;
+        if (active) {
+            const int c = c0 + cs * 8;
+            const bool first = c < p.C0;
+            const uint16_t* base = first ? (x0 + c) : (x1 + (c - p.C0));
+            const long ld = first ? p.ld : p.ld1;
+            int r = rl;
+            for (; r + 3 * RPP < rows; r += 4 * RPP) {
+                u32x4_t v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const u32x4_t*>(base + (row0 + r + k * RPP) * ld);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    stage[(size_t)(r + k * RPP) * SW + cs] = v[k];
+                    float f[8];
+                    unpack8(v[k], f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s[e] += f[e];
+                }
+            }
+            for (; r < rows; r += RPP) {
+                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(base + (row0 + r) * ld);
+                stage[(size_t)r * SW + cs] = v;
+                float f[8];
+                unpack8(v, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] += f[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[rl * CW + cs * 8 + e] = s[e];
+        }
+    }
+    __syncthreads();
+    const float n = (float)rows * (float)cpg;
+    if (tid < G) {
+        float s = 0.f;
+        for (int r = 0; r < RPP; ++r)
+            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) s += red[r * CW + c];
+        s_mean[tid] = s / n;
+    }
+    __syncthreads();
+    // ---- pass 2 (from the stage): squared deviations from the group mean
+    for (int cs = cl; cs < SW; cs += TPR) {
+        if (active) {
+            float mu[8], q[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { mu[e] = s_mean[(cs * 8 + e) / cpg]; q[e] = 0.f; }
+            for (int r = rl; r < rows; r += RPP) {
+                float f[8];
+                unpack8(stage[(size_t)r * SW + cs], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = f[e] - mu[e]; q[e] += d * d; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[rl * CW + cs * 8 + e] = q[e];
+        }
+    }
+    __syncthreads();
+    if (tid < G) {
+        float q = 0.f;
+        for (int r = 0; r < RPP; ++r)
+            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) q += red[r * CW + c];
+        s_rstd[tid] = rsqrtf(q / n + p.eps);
+    }
+    __syncthreads();
+    for (int c = tid; c < CW; c += 256) {
+        const int g = c / cpg;
+        const float sc = s_rstd[g] * p.gamma[c0 + c];
+        scale[c] = sc;
+        shift[c] = p.beta[c0 + c] - s_mean[g] * sc;
+    }
+    __syncthreads();
+    // ---- apply from the stage
+    uint16_t* y = reinterpret_cast<uint16_t*>(p.y);
+    if (active) {
+        for (int cs = cl; cs < SW; cs += TPR) {
+            float a[8], b[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a[e] = scale[cs * 8 + e]; b[e] = shift[cs * 8 + e]; }
+            uint16_t* dst = y + c0 + cs * 8;
+            auto run = [&](auto silu_tag) {
+                constexpr bool SILU = decltype(silu_tag)::value;
+                for (int r = rl; r < rows; r += RPP) {
+                    float f[8];
+                    unpack8(stage[(size_t)r * SW + cs], f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        f[e] = f[e] * a[e] + b[e];
+                        if constexpr (SILU) f[e] = silu_f(f[e]);
+                    }
+                    *reinterpret_cast<u32x4_t*>(dst + (row0 + r) * p.ldy) = pack8(f);
+                }
+            };
+            if (p.silu) run(std::true_type{}); else run(std::false_type{});
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ LayerNorm
 // LPR lanes per row (64 / LPR rows per wave, 4 waves per block): a 320-channel row is only 40 16-byte slots, so with a
 // whole wave per row 24 lanes idle and too few bytes are in flight; LPR = 8 / 16 / 32 / 64 for C = 320 / 640 / 1280 /
@@ -340,6 +469,34 @@ extern "C" int vmv_groupnorm_apply(const VmvGroupNormParams* pp, void* stream) {
     const int nblk = (p.rows_per_stat + apply_rows - 1) / apply_rows;
     hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, nstat), dim3(256), (size_t)(2 * C + 64) * sizeof(float),
                        reinterpret_cast<hipStream_t>(stream), p, nchunk, apply_rows, nstat);
+    return vmv_launch_status();
+}
+
+extern "C" int vmv_groupnorm_fused(const VmvGroupNormParams* pp, int32_t cols, void* stream) {
+    if (!pp) return VMV_ENULL;
+    VmvGroupNormParams p = *pp;
+    if (!p.partial) p.partial = reinterpret_cast<float*>(const_cast<void*>(p.x));      // (unused here; gn_check wants it non-NULL)
+    if (p.chunk_rows <= 0) p.chunk_rows = 1;
+    int rc = gn_check(p);
+    if (rc != VMV_OK) return rc;
+    if (!p.y || !p.gamma || !p.beta) return VMV_ENULL;
+    if (!vmv_aligned16(p.y) || (p.ldy & 7) || !vmv_aligned16(p.gamma) || !vmv_aligned16(p.beta)) return VMV_EALIGN;
+    const int C = p.C0 + p.C1, cpg = C >> 5;
+    if (cols <= 0 || (cols & 7) || (cols % cpg) || (C % cols)) return VMV_EINVAL;
+    if (p.fold_ranks > 1) return VMV_EINVAL;
+    if ((long)p.rows_per_stat * cols * 2 > VMV_GN_FUSED_BYTES) return VMV_ERANGE;
+    const int SW = cols >> 3;
+    const int TPR = SW < 256 ? SW : 256, RPP = 256 / TPR;
+    const size_t shbytes = (size_t)p.rows_per_stat * cols * 2 + (size_t)(RPP * cols + 2 * cols + 64) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    if (shbytes > 160 * 1024) return VMV_ERANGE;
+    hipLaunchKernelGGL(gn_fused_kernel, dim3(C / cols, p.rows / p.rows_per_stat), dim3(256), shbytes,
+                       reinterpret_cast<hipStream_t>(stream), p, cols);
     return vmv_launch_status();
 }
 

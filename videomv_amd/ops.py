@@ -5,6 +5,7 @@
 handles (``data_ptr()``); all arithmetic happens in the HIP kernels.  Nothing here falls back to PyTorch math.
 """
 import ctypes as C
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -96,6 +97,24 @@ def gn_chunk_rows(rows_per_stat: int, C: int) -> int:
     return min(r, rows_per_stat)
 
 
+def gn_fused_cols(rows_per_stat: int, C: int) -> int:
+    """Channels per block of the one-launch GroupNorm (vmv_groupnorm_fused), or 0 when a stat group does not fit on chip:
+    the narrowest slab of whole groups whose rows are still >= 128 B (else >= 64 B) contiguous — most blocks, least LDS."""
+    if os.environ.get("VMV_GN_FUSED", "1") == "0":
+        return 0
+    cpg = C // 32
+    for min_bytes in (128, 64):
+        G = 1
+        while G <= 32:
+            cols = G * cpg
+            if cols % 8 == 0 and cols * 2 >= min_bytes and C % cols == 0:
+                if rows_per_stat * cols * 2 <= L.GN_FUSED_BYTES:
+                    return cols
+                break                       # wider slabs only need more LDS
+            G *= 2
+    return 0
+
+
 def gn_partial_floats(rows, rows_per_stat, C, chunk_rows=None) -> int:
     cr = chunk_rows or gn_chunk_rows(rows_per_stat, C)
     nchunk = (rows_per_stat + cr - 1) // cr
@@ -177,8 +196,18 @@ class Stream:
         self._go(L.OP_GEMM, params, self.lib.vmv_gemm, label)
 
     def groupnorm(self, params, label="gn"):
+        """statistics + apply; one fused launch when the stat group fits on chip (gn_fused_cols), else two."""
+        cols = 0 if (params.totals or params.fold_ranks > 1) else gn_fused_cols(params.rows_per_stat, params.C0 + params.C1)
+        if cols:
+            return self.groupnorm_fused(params, cols, label)
         self._go(L.OP_GN_STATS, params, self.lib.vmv_groupnorm_stats, label + ".stats")
         self._go(L.OP_GN_APPLY, params, self.lib.vmv_groupnorm_apply, label + ".apply")
+
+    def groupnorm_fused(self, params, cols, label="gn"):
+        """One launch: statistics + apply from an LDS-resident stage (cols from gn_fused_cols)."""
+        params.chunk_rows = int(cols)
+        fn = lambda pp, st: self.lib.vmv_groupnorm_fused(pp, int(cols), st)
+        self._go(L.OP_GN_FUSED, params, fn, label + ".fused")
 
     def groupnorm_stats(self, params, label="gn"):
         self._go(L.OP_GN_STATS, params, self.lib.vmv_groupnorm_stats, label + ".stats")

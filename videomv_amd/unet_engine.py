@@ -409,8 +409,12 @@ class UNetEngine:
         base = dict(x1=srcs[1].ptr if C1 else None, ld1=srcs[1].C if C1 else 0, C1=C1)
         args = (srcs[0].ptr, srcs[0].C, C0, rows, rows_per_stat, self._gnws, self.w[wkey + ".weight"], self.w[wkey + ".bias"],
                 eps, silu, y.ptr, C)
-        if not all_frames:
+        if not all_frames:      # (one fused launch when the stat group fits on chip — the small levels — else stats + apply)
             self.S.groupnorm(ops.gn_params(*args, **base), label)
+            return y
+        fused = 0 if self.comm is not None else ops.gn_fused_cols(rows_per_stat, C)
+        if fused:               # all-frame norm whose stat group still fits on chip (L3 / middle block)
+            self.S.groupnorm_fused(ops.gn_params(*args, **base), fused, label)
             return y
         # all-frame norm: up to 256 chunks per stat group -> a one-block fold after the stats folds them once (pre-folded totals)
         assert nstat <= 64
