@@ -128,6 +128,8 @@ typedef struct {
 #define VMV_TILE_S256x128 15   /* persistent, wave-specialised: 8 MFMA waves + 4 LDS-DMA loader waves (gemm_sglds.hip) */
 #define VMV_TILE_S192x160 16
 #define VMV_TILE_S256x160 17
+#define VMV_TILE_A128x160 18   /* A-stationary persistent kernel, deferred epilogue: K <= 320, wide N (gemm_astat.hip) */
+#define VMV_TILE_A128x128 19
 
 int vmv_gemm(const VmvGemmParams* p, void* stream);
 

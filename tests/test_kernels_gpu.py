@@ -315,7 +315,8 @@ def test_groupnorm_prefolded_totals(rows, rps, Cc, silu):
     tot = torch.zeros(64 * 64, device="cuda")
     y0, y1 = torch.zeros(rows, Cc, dtype=BF, device="cuda"), torch.zeros(rows, Cc, dtype=BF, device="cuda")
     S = ops.Stream(record=False)
-    S.groupnorm(ops.gn_params(x, Cc, Cc, rows, rps, part, gamma, beta, 1e-5, silu, y0, Cc))
+    p0 = ops.gn_params(x, Cc, Cc, rows, rps, part, gamma, beta, 1e-5, silu, y0, Cc)
+    S.groupnorm_stats(p0); S.groupnorm_apply(p0)                          # (the plain two-launch form, explicitly)
     S.groupnorm(ops.gn_params(x, Cc, Cc, rows, rps, part, gamma, beta, 1e-5, silu, y1, Cc, totals=tot))
     torch.cuda.synchronize()
     check(y1, y0.float().cpu(), tol_l2=1e-4, tol_max=2e-2)                  # (<= 1 bf16 ulp where the rounding flips)
@@ -450,7 +451,13 @@ def test_layernorm_stats_out(rows, Cc):
 @pytest.mark.parametrize("M,N,K,geglu,tile", [(300, 960, 320, False, 0), (1000, 640, 640, False, L.TILE_P256x160),
                                                (70000, 320, 320, False, 0), (513, 1280, 320, True, 0),
                                                (70000, 1280, 320, True, L.TILE_P256x128), (257, 128, 192, False, L.TILE_128x128),
-                                               (300, 512, 64, True, L.TILE_128x128), (2000, 3840, 1280, False, 0)])
+                                               (300, 512, 64, True, L.TILE_128x128), (2000, 3840, 1280, False, 0),
+                                               # the A-stationary deferred-epilogue kernel: M tail, several panels per
+                                               # block (M > 128 x 256 CUs), N tail (N = 1000: not a multiple of 160 / 128)
+                                               (70001, 960, 320, False, L.TILE_A128x160), (70001, 2560, 320, True, L.TILE_A128x128),
+                                               (1000, 1000, 320, False, L.TILE_A128x160), (300, 640, 256, True, L.TILE_A128x128),
+                                               (129, 320, 320, False, L.TILE_A128x128), (50000, 960, 320, False, 0),
+                                               (50000, 2560, 320, True, 0)])
 def test_gemm_layernorm_folded(M, N, K, geglu, tile):
     """y = Linear(LayerNorm(x)) as ONE GEMM on the raw rows (packing.fold_layernorm + rowstat / colsum epilogue) against
     the unfused definition, x with a large per-row offset (mean / sigma ~ 3) to exercise the cancellation."""
@@ -476,6 +483,30 @@ def test_gemm_layernorm_folded(M, N, K, geglu, tile):
         a, gate = h.chunk(2, dim=-1)
         h = a * torch.nn.functional.gelu(gate)
     check(out, h, tol_l2=6e-3, tol_max=2e-2)
+
+@pytest.mark.parametrize("M,N,K,geglu,bias,tile", [(40000, 640, 320, False, True, L.TILE_A128x160), (513, 1280, 320, True, True, L.TILE_A128x128),
+                                                   (900, 960, 256, False, False, L.TILE_A128x160), (33000, 1280, 320, True, False, L.TILE_A128x128)])
+def test_gemm_astat_plain(M, N, K, geglu, bias, tile):
+    """gemm_astat.hip without the LayerNorm fold (bias on / off, GEGLU on / off) against the interpreter; two runs bitwise
+    identical (fixed accumulation order, no atomics)."""
+    c = Case(a=rnd((M, K), 1), w=rnd((N, K), 2, K ** -0.5), b=torch.randn(N, generator=g(3)),
+             out=torch.zeros(M, N // 2 if geglu else N, dtype=BF))
+
+    def build(t):
+        return ops.gemm_params(M, N, ops.linear_segs([(t["a"], K, K)]), t["w"], t["out"], t["out"].shape[1],
+                               bias=t["b"] if bias else None, epilogue=L.EPI_GEGLU if geglu else L.EPI_NONE, tile=tile)
+    cpu = c.on("cpu")
+    I.gemm(build(cpu))
+    dev = c.on("cuda")
+    S = ops.Stream(record=False)
+    S.gemm(build(dev), "t")
+    torch.cuda.synchronize()
+    check(dev["out"], cpu["out"])
+    dev2 = c.on("cuda")
+    S.gemm(build(dev2), "t")
+    torch.cuda.synchronize()
+    assert torch.equal(dev2["out"], dev["out"])
+
 
 
 def test_gemm_layernorm_folded_rejects_split_k_and_gathers():

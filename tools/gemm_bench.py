@@ -7,7 +7,7 @@ import torch
 from videomv_amd import _lib as L, ops
 
 BF = L.elem()
-N160 = (L.TILE_128x160, L.TILE_256x160, L.TILE_G128x160, L.TILE_P256x160, L.TILE_PP256x160, L.TILE_Q96x160, L.TILE_S192x160, L.TILE_S256x160)
+N160 = (L.TILE_128x160, L.TILE_256x160, L.TILE_G128x160, L.TILE_P256x160, L.TILE_PP256x160, L.TILE_Q96x160, L.TILE_S192x160, L.TILE_S256x160, L.TILE_A128x160)
 
 
 def bench(fn, reps=20):
@@ -90,7 +90,7 @@ def main():
                     base = int(t[0, 0])
                     rows = [" ".join(f"{int(v) - base:7d}" for v in r) for r in t[:6]]
                     line += "\n      stamps(block0; tile start / loop done / epi start / epi end):\n      " + "\n      ".join(rows)
-            if stamps is not None and tile in (L.TILE_S256x128, L.TILE_S192x160, L.TILE_S256x160):
+            if stamps is not None and tile in (L.TILE_S256x128, L.TILE_S192x160, L.TILE_S256x160, L.TILE_A128x160):
                 t = stamps.cpu().view(-1, 8)[:int(os.environ.get("VMV_STAMP_ROWS", "40"))]
                 base = int(t[0, 0])
                 line += "\n   chunk: loader[before wait, after wait, after B, after issue]  mfma[before B, after B]\n   " + \

@@ -22,6 +22,8 @@ using namespace vmvg;
 int vmv_gemm_glds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st);   // gemm_glds.hip
 int vmv_gemm_pglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st);  // gemm_pglds.hip
 int vmv_gemm_sglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st);  // gemm_sglds.hip
+int vmv_gemm_astat_launch(const VmvGemmParams& p, int tile, hipStream_t st);                   // gemm_astat.hip
+bool vmv_gemm_astat_eligible(const VmvGemmParams& p);
 
 namespace {
 
@@ -265,9 +267,25 @@ int gemm_policy() {
     return pol;
 }
 
+int astat_policy() {
+    // VMV_GEMM_ASTAT (A/B experiments): 1 = the A-stationary deferred-epilogue kernel (gemm_astat.hip) takes the K <= 320,
+    // wide-N linears of the largest level (LayerNorm-folded qkv / q, GEGLU); 0 (default) = off.  Measured (round 2, same
+    // box): +12-25 % on the L0 qkv shapes in isolation, GEGLU +-2 %, but the full step gets 0.6 ms SLOWER — with every MFMA
+    // removed (VMV_GEMM_ABLATE=1) the kernel is no faster, without its stores +15-33 %: like the tile-per-item kernels it is
+    // bound by the CU's vector-memory path (DMA issue + in-order vmcnt behind store round trips), not by the matrix pipes.
+    static int pol = -1;
+    if (pol < 0) {
+        const char* e = getenv("VMV_GEMM_ASTAT");
+        pol = e ? atoi(e) : 0;
+    }
+    return pol;
+}
+
 int pick_tile(const VmvGemmParams& p, int total_steps) {
     if (p.tile != VMV_TILE_AUTO) return p.tile;
     const int geglu = p.epilogue == VMV_EPI_GEGLU;
+    if (gemm_policy() >= 2 && astat_policy() && p.N >= 640 && p.M >= 128 * 256 && vmv_gemm_astat_eligible(p))
+        return (!geglu && p.N % 160 == 0) ? VMV_TILE_A128x160 : VMV_TILE_A128x128;
     auto padded = [&](int bn) { return ((p.N + bn - 1) / bn) * bn; };
     int best = VMV_TILE_128x128, best_pad = padded(128);
     if (!geglu && padded(160) <= best_pad) { best = VMV_TILE_128x160; best_pad = padded(160); }
@@ -348,7 +366,7 @@ extern "C" int vmv_gemm(const VmvGemmParams* pp, void* stream) {
         for (int s = 0; s < p.nseg; ++s) if (p.seg[s].mode != VMV_SEG_LINEAR) return VMV_EINVAL;
     }
     int picked = pick_tile(p, total_steps);
-    if (p.rowstat && picked != VMV_TILE_P256x128 && picked != VMV_TILE_P256x160 && picked != VMV_TILE_Q128x128 &&
+    if (p.rowstat && picked != VMV_TILE_A128x160 && picked != VMV_TILE_A128x128 && picked != VMV_TILE_P256x128 && picked != VMV_TILE_P256x160 && picked != VMV_TILE_Q128x128 &&
         picked != VMV_TILE_Q96x160 && picked != VMV_TILE_128x128 && picked != VMV_TILE_128x160 && picked != VMV_TILE_128x64 &&
         picked != VMV_TILE_64x64)
         picked = (p.epilogue != VMV_EPI_GEGLU && p.N % 160 == 0) ? VMV_TILE_P256x160 : VMV_TILE_P256x128;
@@ -377,6 +395,11 @@ extern "C" int vmv_gemm(const VmvGemmParams* pp, void* stream) {
             rc = vmv_gemm_sglds_launch(p, total_steps, picked, st);
             if (rc == VMV_GLDS_UNSUPPORTED) rc = vmv_gemm_glds_launch(p, total_steps, VMV_TILE_256x160, st);
             if (rc == VMV_GLDS_UNSUPPORTED) rc = launch_cfg<4, 5>(p, total_steps, st);
+            break;
+        case VMV_TILE_A128x160:
+        case VMV_TILE_A128x128:
+            rc = vmv_gemm_astat_launch(p, picked, st);
+            if (rc == VMV_GLDS_UNSUPPORTED) return VMV_EINVAL;      // (only reachable with a forced tile id)
             break;
         case VMV_TILE_Q128x128:
             rc = vmv_gemm_pglds_launch(p, total_steps, VMV_TILE_Q128x128, st);

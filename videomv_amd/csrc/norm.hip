@@ -258,13 +258,25 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const VmvGroupNormParams 
     }
     __syncthreads();
     const float n = (float)rows * (float)cpg;
-    if (tid < G) {
-        float s = 0.f;
-        for (int r = 0; r < RPP; ++r)
-            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) s += red[r * CW + c];
-        s_mean[tid] = s / n;
-    }
-    __syncthreads();
+    // group totals in two parallel stages (fixed order): thread c < CW folds the RPP row lanes of column c, then one wave
+    // per group sums the group's cpg columns with a shuffle tree
+    auto group_totals = [&](float* dst, auto finish) {
+        float cs = 0.f;
+        if (tid < CW)
+            for (int r = 0; r < RPP; ++r) cs += red[r * CW + tid];
+        __syncthreads();
+        if (tid < CW) red[tid] = cs;
+        __syncthreads();
+        const int wv = tid >> 6, ln = tid & 63;
+        for (int g = wv; g < G; g += 4) {
+            float s = 0.f;
+            for (int c = ln; c < cpg; c += 64) s += red[g * cpg + c];
+            s = wave_sum(s);
+            if (ln == 0) dst[g] = finish(s);
+        }
+        __syncthreads();
+    };
+    group_totals(s_mean, [&](float s) { return s / n; });
     // ---- pass 2 (from the stage): squared deviations from the group mean
     for (int cs = cl; cs < SW; cs += TPR) {
         if (active) {
@@ -282,13 +294,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const VmvGroupNormParams 
         }
     }
     __syncthreads();
-    if (tid < G) {
-        float q = 0.f;
-        for (int r = 0; r < RPP; ++r)
-            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) q += red[r * CW + c];
-        s_rstd[tid] = rsqrtf(q / n + p.eps);
-    }
-    __syncthreads();
+    group_totals(s_rstd, [&](float q) { return rsqrtf(q / n + p.eps); });
     for (int c = tid; c < CW; c += 256) {
         const int g = c / cpg;
         const float sc = s_rstd[g] * p.gamma[c0 + c];
