@@ -96,6 +96,13 @@ def _worker(rank, world, port, q):
         xt = x[:, :, sl].clone().contiguous()
         diff.ddim_step_hip(xt, 501, m, kc, ku, 9.0, 500)
         x_next = gather_frames(comm, xt)
+        # the fused pass ran branch-pipelined: two B = 1 plans, one permute copy per layout switch, shared packed weights
+        pe = m._pipe["engs"]
+        out["pipe"] = dict(n=len(pe), shared_w=pe[0].w is pe[1].w,
+                           copies=[sum(1 for l in e.S.labels if l.startswith("shard.")) for e in pe],
+                           switches=[sum(1 for i, _ in e.breaks if True) for e in pe],
+                           copies_b2=sum(1 for l in eng.S.labels if l.startswith("shard.")),
+                           a2a_b2=sum(1 for l in eng.S.labels if l.endswith(".unpack")))
         m.set_frame_parallel(None)
         xt1 = x.clone()
         diff.ddim_step_hip(xt1, 501, m, kc, ku, 9.0, 500)
@@ -128,6 +135,9 @@ def test_two_rank_frame_parallel_plan_matches_single_rank_and_oracle():
         assert r["e_single"] < 3e-2, r
         assert r["e_module"] < 3e-2, r
         assert r["e_ddim"] < 6e-2, r
+        pp = r["pipe"]
+        assert pp["n"] == 2 and pp["shared_w"]
+        assert pp["copies"][0] == pp["copies"][1] == pp["a2a_b2"] and pp["copies_b2"] == 2 * pp["a2a_b2"], pp
 
 
 def _entrance_worker(rank, world, port, tmp, q):

@@ -28,6 +28,17 @@ class FrameComm:
         self.local_only = self.world == 1 and os.environ.get("VMV_COMM_FORCE") != "1"
         self.n_all_to_all = 0
         self.n_all_gather = 0
+        self._twin = None
+
+    def twin(self) -> "FrameComm":
+        """A second communicator over the same ranks (its own process group, so that its collectives can be in flight on
+        another stream at the same time): the pipelined frame-parallel mode runs the two CFG branches on two streams, one
+        communicator each.  Collective: every rank must call it at the same point."""
+        if self._twin is None:
+            ranks = dist.get_process_group_ranks(self.group) if self.group is not None else list(range(dist.get_world_size()))
+            self._twin = FrameComm(dist.new_group(ranks=ranks, backend=self.backend))
+            self._twin._twin = self
+        return self._twin
 
     def _staged(self, t):
         return self.backend == "gloo" and t.is_cuda

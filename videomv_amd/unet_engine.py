@@ -191,7 +191,8 @@ class Act:
 # --------------------------------------------------------------------------------------------- the engine
 class UNetEngine:
     def __init__(self, cfg: dict, weights: Dict[str, torch.Tensor], B: int, F: int, H: int, W: int, L_ctx: int,
-                 device, n_t: int = 1, taps: Optional[dict] = None, comm=None, share_prefix: bool = False):
+                 device, n_t: int = 1, taps: Optional[dict] = None, comm=None, share_prefix: bool = False,
+                 packed: Optional[dict] = None, eps_out: Optional[torch.Tensor] = None):
         """weights: reference-named fp32 state dict (any device).  B = number of batched branches
         (2 = cond + uncond CFG pair sharing x_t), n_t = number of distinct timesteps rows (B // n_t branches
         share each).  F = number of frames of the whole sample.
@@ -231,7 +232,17 @@ class UNetEngine:
         # LayerNorm -> Linear pairs of the transformer blocks run as ONE GEMM on the raw rows + a statistics pass (vmv.h,
         # VmvGemmParams.rowstat): saves writing and re-reading LN(x) (VMV_FOLD_LN=0 keeps the two-kernel form)
         self.fold_ln = os.environ.get("VMV_FOLD_LN", "1") != "0"
-        self._pack(weights)
+        # packed weights are immutable and shape-independent: engines of one model (other B / resolution / frame count, the
+        # two branch engines of the pipelined frame-parallel mode) share ONE copy (`packed` = another engine's .packed)
+        if packed is not None and packed.get("fold_ln") == self.fold_ln and packed.get("device") == str(device):
+            for k, v in packed.items():
+                if k not in ("fold_ln", "device"):
+                    setattr(self, k, v)
+        else:
+            self._pack(weights)
+        self.packed = dict(fold_ln=self.fold_ln, device=str(device), w=self.w, has_cam=self.has_cam, has_fps=self.has_fps,
+                           emb_off=self.emb_off, emb_total=self.emb_total, out_pad=self.out_pad)
+        self._eps_out = eps_out
         self._static_inputs()
         self._build()
 
@@ -349,7 +360,11 @@ class UNetEngine:
         self.ctx_rows = torch.zeros(B * self.L, self.cfg["context_dim"], dtype=L.elem(), device=dev)
         self.t_dev = torch.zeros(self.n_t, dtype=torch.float32, device=dev)
         self.cam_rows = torch.zeros(B * F, (self.cfg.get("camera_dim", 16) + 7) // 8 * 8, dtype=L.elem(), device=dev)
-        self.eps_rows = torch.zeros(self.T0, self.out_pad, dtype=torch.float32, device=dev)
+        # eps rows: own buffer, or a caller-provided [T0, out_pad] fp32 view (the two branch engines of the pipelined
+        # frame-parallel mode write the two halves of one buffer, which the fused CFG + DDIM kernel reads)
+        self.eps_rows = (self._eps_out if self._eps_out is not None
+                         else torch.zeros(self.T0, self.out_pad, dtype=torch.float32, device=dev))
+        assert self.eps_rows.shape == (self.T0, self.out_pad) and self.eps_rows.is_contiguous()
         # embedding scratch
         self.sin_emb = torch.zeros(self.n_t, self.dim, dtype=L.elem(), device=dev)
         self.te_hidden = torch.zeros(self.n_t, self.E, dtype=L.elem(), device=dev)
@@ -433,7 +448,10 @@ class UNetEngine:
 
     def _switch(self, x: Act, hw: int, to_pixel: bool, release_in: bool = True) -> Act:
         """frame-major shard [B][F/R][HW][C]  <->  pixel-major shard [B][F][HW/R][C]: pack -> all-to-all -> unpack.
-        Chunk j of the packed buffer goes to rank j; chunk i of the received buffer came from rank i."""
+        Chunk j of the packed buffer goes to rank j; chunk i of the received buffer came from rank i.
+        With B = 1 (the branch engines of the pipelined mode) one of the two copies is the identity: frame-major -> pixel-
+        major receives [rank i's frames][my pixels] = the pixel-major shard itself (no unpack), pixel-major -> frame-major
+        sends [rank j's frames][my pixels] = contiguous slices of the shard (no pack)."""
         R, B, Fl = self.R, self.B, self.F
         if hw % R:
             raise ValueError(f"{hw} pixels per frame do not split over {R} ranks")
@@ -441,24 +459,44 @@ class UNetEngine:
         T, Cc = x.rows, x.C
         assert T == B * Fl * hw and Cc % 8 == 0
         cv = Cc // 8                                 # 16-byte vectors per row
-        send, recv, y = self.act(T, Cc), self.act(T, Cc), self.act(T, Cc)
         tag = "F2P" if to_pixel else "P2F"
-        if to_pixel:   # send[s][b f][p c] <- x[b f][s][p c]
-            self.S.copy(ops.copy_params(x.ptr, send.ptr, R, B * Fl, 1, Pl * cv, Pl * cv, hw * cv), f"shard.{tag}.pack")
-        else:          # send[r][b][f p c] <- x[b][r][f p c]
-            blk = Fl * Pl * cv
-            self.S.copy(ops.copy_params(x.ptr, send.ptr, R, B, 1, blk, blk, R * blk), f"shard.{tag}.pack")
-        if release_in:
-            self.release(x)
+        skip_pack = B == 1 and not to_pixel
+        skip_unpack = B == 1 and to_pixel
+        if skip_pack:
+            send = x
+        else:
+            send = self.act(T, Cc)
+            if to_pixel:   # send[s][b f][p c] <- x[b f][s][p c]
+                self.S.copy(ops.copy_params(x.ptr, send.ptr, R, B * Fl, 1, Pl * cv, Pl * cv, hw * cv), f"shard.{tag}.pack")
+            else:          # send[r][b][f p c] <- x[b][r][f p c]
+                blk = Fl * Pl * cv
+                self.S.copy(ops.copy_params(x.ptr, send.ptr, R, B, 1, blk, blk, R * blk), f"shard.{tag}.pack")
+            if release_in:
+                self.release(x)
+        recv = self.act(T, Cc)
         st, rt = send.tensor().view(R, -1), recv.tensor().view(R, -1)
         self._break(lambda: self.comm.all_to_all(rt, st))
+        if skip_pack and release_in:
+            self._release_after_break(x)
+        if skip_unpack:
+            if not skip_pack:
+                self.release(send)
+            return recv
+        y = self.act(T, Cc)
         if to_pixel:   # y[b][r][f p c] <- recv[r][b][f p c]
             blk = Fl * Pl * cv
             self.S.copy(ops.copy_params(recv.ptr, y.ptr, B, R, 1, blk, blk, B * blk), f"shard.{tag}.unpack")
         else:          # y[b f][s][p c] <- recv[s][b f][p c]
             self.S.copy(ops.copy_params(recv.ptr, y.ptr, B * Fl, R, 1, Pl * cv, Pl * cv, B * Fl * Pl * cv), f"shard.{tag}.unpack")
-        self.release(send); self.release(recv)
+        if not skip_pack:
+            self.release(send)
+        self.release(recv)
         return y
+
+    def _release_after_break(self, a: Act):
+        """A buffer read by a collective is recycled only once a later launch has been recorded behind it (stream order =
+        program order: the collective and the launches share the stream)."""
+        self.release(a)
 
     def _ln_linear(self, label, x: Act, nkey, N, wkey, out: Act, bias=None, **kw):
         """out = Linear(LayerNorm(x)).  Folded: row statistics (mean, rstd) + one GEMM on the raw rows whose epilogue
@@ -823,28 +861,43 @@ class UNetEngine:
         """x [b, C, F, H, W] fp32 on device (b divides B; replicated to the B branches; frame-parallel: this rank's
         F/R frames), t [n_t].
         Leaves eps in ``self.eps_rows`` (fp32 [B*F*H*W, out_pad])."""
+        self.prepare_rows(x, t)
+        self.run_plan()
+        return self.eps_rows
+
+    def prepare_rows(self, x: torch.Tensor, t: torch.Tensor):
+        """Everything of forward_rows before the plan: latent -> rows, timestep, embeddings."""
         nb = x.shape[0]
         # only the latent's own channels are written: channels >= x.shape[1] hold zeros (T2V) or the step-invariant
         # image `concat` of the I2VGen front-end (unet_i2vgen.py:383)
         ops.latent_to_rows_keep(x.contiguous(), self.x_rows, self.cin_pad, self.B // nb)
         self.t_dev.copy_(t.to(torch.float32).reshape(-1)[: self.n_t])
         self._embeddings()
-        self.run_plan()
-        return self.eps_rows
+
+    def segments(self):
+        """The recorded plan cut at its collectives: [(first, last, collective or None)] — launches [first, last) then the
+        collective that precedes launch `last`."""
+        segs, first = [], 0
+        for idx, fn in self.breaks:
+            segs.append((first, idx, fn))
+            first = idx
+        segs.append((first, self.S.nops, None))
+        return segs
+
+    def run_segment(self, seg):
+        first, last, fn = seg
+        if last > first:
+            self.S.run(first, last)
+        if fn is not None:
+            fn()
 
     def run_plan(self):
         """Replay the recorded launches; frame-parallel plans are cut at their collectives."""
         if not self.breaks:
             self.S.run()
             return
-        first = 0
-        for idx, fn in self.breaks:
-            if idx > first:
-                self.S.run(first, idx)
-            fn()
-            first = idx
-        if first < self.S.nops:
-            self.S.run(first, self.S.nops)
+        for seg in self.segments():
+            self.run_segment(seg)
 
     def eps_ncfhw(self) -> torch.Tensor:
         """eps rows -> [B, out_dim, F, H, W] fp32 (reference output layout)."""

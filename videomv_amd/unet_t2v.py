@@ -102,6 +102,13 @@ def gather_frames(comm, x_local: torch.Tensor) -> torch.Tensor:
     return torch.cat(list(out.unbind(0)), dim=2)
 
 
+class _PipeHandle:
+    """What the fused sampler needs from "the engine" of a forward_cfg_rows call (the eps row pitch)."""
+
+    def __init__(self, out_pad):
+        self.out_pad = out_pad
+
+
 class CondCache:
     """Step-invariant conditioning of the fused CFG pass (context rows, camera MLP, I2V image front-end) is evaluated once
     per sample.  The cache key is the IDENTITY and in-place VERSION of the conditioning tensors, and the cache holds
@@ -172,6 +179,7 @@ class UNetSD_T2VBase(nn.Module, LgmMixin):
             self._add_param(key, nn.Parameter(v, requires_grad=False))
         self._init_lgm(use_lgm_refine, lgm_opt)
         self._engines: Dict[tuple, UNetEngine] = {}
+        self._pipe = None             # the two branch engines of the pipelined frame-parallel mode
         self.frame_comm = None        # comm.FrameComm: frame-parallel execution over the ranks of one sample
         self._weights_version = 0
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
@@ -187,6 +195,7 @@ class UNetSD_T2VBase(nn.Module, LgmMixin):
     def _invalidate(self):
         self._lgm = None
         self._engines.clear()
+        self._pipe = None
         self._weights_version += 1
 
     # ------------------------------------------------------------------ engine management
@@ -196,6 +205,7 @@ class UNetSD_T2VBase(nn.Module, LgmMixin):
         (``forward_cfg_rows``) works on this rank's frames.  No reference counterpart (its multi-GPU mode is replicas)."""
         self.frame_comm = comm
         self._engines.clear()
+        self._pipe = None
 
     def engine_for(self, B, F, H, W, L, device, n_t=1, taps=None, share_prefix=False) -> UNetEngine:
         """F = frames of the whole sample.  share_prefix: the B = 2 branches are a CFG pair with identical x_t / t / camera /
@@ -205,8 +215,9 @@ class UNetSD_T2VBase(nn.Module, LgmMixin):
         eng = self._engines.get(key)
         if eng is None:
             sd = {k: v.detach() for k, v in self.state_dict().items()}
+            donor = next(iter(self._engines.values()), None)       # packed weights are shared by all engines of the model
             eng = UNetEngine(self.arch, sd, B, F, H, W, L, device, n_t=n_t, taps=taps, comm=self.frame_comm,
-                             share_prefix=share_prefix)
+                             share_prefix=share_prefix, packed=donor.packed if donor is not None else None)
             if taps is None:
                 self._engines[key] = eng
         return eng
@@ -265,6 +276,8 @@ class UNetSD_T2VBase(nn.Module, LgmMixin):
             raise ValueError("forward_cfg_rows handles one sample (the reference's noise is [1,4,F,h,w])")
         dev = xt.device
         if self.frame_comm is not None:
+            if os.environ.get("VMV_FP_PIPELINE", "1") != "0":
+                return self._forward_cfg_rows_pipelined(xt, t, cond_kwargs, uncond_kwargs)
             f = f * self.frame_comm.world
         cam_shared = (not self.use_camera_condition) or cam_u is camera_data or (
             cam_u is not None and camera_data is not None and cam_u.shape == camera_data.shape
@@ -292,3 +305,72 @@ class UNetSD_T2VBase(nn.Module, LgmMixin):
         for eng in self._engines.values():
             if "_cond" in eng.__dict__:
                 eng._cond.clear()
+        if getattr(self, "_pipe", None) is not None:
+            self._pipe["cond"].clear()
+
+    # ------------------------------------------------------------------ frame-parallel, branch-pipelined
+    @torch.no_grad()
+    def _forward_cfg_rows_pipelined(self, xt, t, cond_kwargs, uncond_kwargs):
+        """Frame-parallel CFG pass as TWO one-branch plans on two streams, one communicator each: while one
+        branch waits for a layout-switch all-to-all or a gathered GroupNorm sum, the other branch's kernels own the GPU, so
+        the 183 latency-bound collectives of a step hide behind compute instead of serialising with it; with B = 1 every
+        layout switch also needs only ONE of its two permute copies (UNetEngine._switch).  The two plans write the two
+        halves of one eps buffer, which the fused CFG + DDIM kernel reads as before.  Weights are packed once and shared."""
+        comm = self.frame_comm
+        b, c, fl, h, w = xt.shape
+        dev = xt.device
+        F_all = fl * comm.world
+        ys = (cond_kwargs["y"], uncond_kwargs["y"])
+        cams = (cond_kwargs.get("camera_data"), uncond_kwargs.get("camera_data"))
+        Lc = ys[0].shape[1]
+        key = (F_all, h, w, Lc, str(dev))
+        pipe = getattr(self, "_pipe", None)
+        if pipe is None or pipe["key"] != key or pipe["comm"] is not comm:
+            sd = {k: v.detach() for k, v in self.state_dict().items()}
+            T1 = fl * h * w
+            out_pad = (self.out_dim + 3) // 4 * 4            # rows of the packed head conv (packing._pad_rows)
+            eps = torch.zeros(2 * T1, out_pad, dtype=torch.float32, device=dev)
+            engs, comms = [], (comm, comm.twin())
+            for br in range(2):
+                engs.append(UNetEngine(self.arch, sd, 1, F_all, h, w, Lc, dev, n_t=1, comm=comms[br],
+                                       packed=engs[0].packed if engs else None, eps_out=eps[br * T1:(br + 1) * T1]))
+            streams = [torch.cuda.Stream(device=dev) for _ in range(2)] if dev.type == "cuda" else [None, None]
+            pipe = dict(key=key, comm=comm, engs=engs, eps=eps, streams=streams, cond=CondCache(), out_pad=engs[0].out_pad)
+            self._pipe = pipe
+        engs, streams = pipe["engs"], pipe["streams"]
+        if not pipe["cond"].hit(ys[0], ys[1], cams[0], cams[1], cond_kwargs.get("fps")):
+            for br in range(2):
+                engs[br].set_context(ys[br].to(dev).float())
+                cam = cams[br]
+                engs[br].set_camera(cam.to(dev) if (cam is not None and self.use_camera_condition) else None)
+                engs[br].set_fps((cond_kwargs, uncond_kwargs)[br].get("fps") if self.use_fps_condition else None)
+        x32, t_dev = xt.float(), t.to(dev)
+        if streams[0] is None:                       # CPU (gloo tests): same schedule, no streams
+            for br in range(2):
+                engs[br].prepare_rows(x32, t_dev)
+            segs = [e.segments() for e in engs]
+            for k in range(max(len(segs[0]), len(segs[1]))):
+                for br in range(2):
+                    if k < len(segs[br]):
+                        engs[br].run_segment(segs[br][k])
+        else:
+            cur = torch.cuda.current_stream(dev)
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            segs = [e.segments() for e in engs]
+            for br in range(2):
+                streams[br].wait_event(ready)
+                with torch.cuda.stream(streams[br]):
+                    engs[br].prepare_rows(x32, t_dev)
+            # interleave the enqueueing segment by segment so that neither stream's host-side launches starve the other
+            for k in range(max(len(segs[0]), len(segs[1]))):
+                for br in range(2):
+                    if k < len(segs[br]):
+                        with torch.cuda.stream(streams[br]):
+                            engs[br].run_segment(segs[br][k])
+            for br in range(2):
+                done = torch.cuda.Event()
+                done.record(streams[br])
+                cur.wait_event(done)
+            x32.record_stream(streams[0]); x32.record_stream(streams[1])
+        return _PipeHandle(pipe["out_pad"]), pipe["eps"]
