@@ -3,11 +3,12 @@
 # separate PMC passes; summaries land in gpurun_out/ and are copied to profiles/ by hand.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
+RN=${RN:-r2}      # round tag of the output files; VMV_COMMIT (git hash of the submitted tree) is recorded in the traffic JSON
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py"
-$B > $O/r1_bench_40x64.json 2> $O/bench_full.err
-$B --latent 32x32 --no-cpu-baseline > $O/r1_bench_32x32.json 2>> $O/bench_full.err
-$B --no-cpu-baseline --no-sample --dump-ops $O/r1_ops_40x64.tsv > /dev/null 2>> $O/bench_full.err
+$B > $O/${RN}_bench_40x64.json 2> $O/bench_full.err
+$B --latent 32x32 --no-cpu-baseline > $O/${RN}_bench_32x32.json 2>> $O/bench_full.err
+$B --no-cpu-baseline --no-sample --dump-ops $O/${RN}_ops_40x64.tsv > /dev/null 2>> $O/bench_full.err
 P="--no-cpu-baseline --no-sample --no-op-profile"
 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_kt -- $B $P --steps 5 --warmup 1 > $O/prof_kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -f csv -d $O/prof_fetch -- $B $P --steps 2 --warmup 1 > $O/prof_fetch.log 2>&1
@@ -15,11 +16,11 @@ rocprofv3 --pmc WRITE_SIZE -f csv -d $O/prof_write -- $B $P --steps 2 --warmup 1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT -f csv -d $O/prof_mfma -- $B $P --steps 2 --warmup 1 > $O/prof_mfma.log 2>&1
 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -f csv -d $O/prof_lds -- $B $P --steps 2 --warmup 1 > $O/prof_lds.log 2>&1
 cd $R
-python tools/prof_summary.py $O/prof_kt $O/r1_kernel_stats.txt
-python tools/prof_summary.py $O/prof_fetch $O/r1_pmc_fetch.txt
-python tools/prof_summary.py $O/prof_write $O/r1_pmc_write.txt
-python tools/prof_summary.py $O/prof_mfma $O/r1_pmc_mfma.txt
-python tools/prof_summary.py $O/prof_lds $O/r1_pmc_lds.txt
-python tools/gemm_traffic.py $O/prof_fetch $O/prof_write $O/r1_gemm_traffic.json
+python tools/prof_summary.py $O/prof_kt $O/${RN}_kernel_stats.txt
+python tools/prof_summary.py $O/prof_fetch $O/${RN}_pmc_fetch.txt
+python tools/prof_summary.py $O/prof_write $O/${RN}_pmc_write.txt
+python tools/prof_summary.py $O/prof_mfma $O/${RN}_pmc_mfma.txt
+python tools/prof_summary.py $O/prof_lds $O/${RN}_pmc_lds.txt
+python tools/gemm_traffic.py $O/prof_fetch $O/prof_write $O/${RN}_gemm_traffic.json
 rm -rf $O/prof_kt $O/prof_fetch $O/prof_write $O/prof_mfma $O/prof_lds
-tail -c 600 $O/r1_bench_40x64.json
+tail -c 600 $O/${RN}_bench_40x64.json
