@@ -205,7 +205,7 @@ int vmv_softmax_rows(const VmvSoftmaxParams* p, void* stream);
  *   spatial cross : same queries, Nk = 77 text tokens shared by all frames of a batch item (kv_div = F)
  *   temporal      : problems (b, pixel, head), Nq = Nk = F, rows strided by H*W   
  * Row address of sequence position i of problem `o`, head h:
- *     base + (o / inner) * s_outer + (o % inner) * s_inner + i * s_row + h * 64      (elements)
+ *     base + (o / inner) * s_outer + (o % inner) * s_inner + i * s_row + h * head_dim      (elements)
  * ---------------------------------------------------------------------------------------------------- */
 typedef struct {
     int64_t s_outer, s_inner, s_row;
@@ -220,6 +220,8 @@ typedef struct {
     int32_t heads;
     int32_t Nq, Nk;
     float scale;
+    int32_t head_dim;      /* 64 (0 = 64) or 32; 32 only for long sequences (LGM MVAttention, core/attention.py:67-84) */
+    int32_t _pad;
 } VmvAttnParams;
 int vmv_attention(const VmvAttnParams* p, void* stream);
 

@@ -157,23 +157,24 @@ def layernorm(p: L.LayerNormParams):
     _rows(p.y, p.rows, p.ldy)[:, : p.C] = y.to(L.elem())
 
 
-def _seq_rows(ptr, mp, o, h, n):
-    base = (o // mp.inner) * mp.s_outer + (o % mp.inner) * mp.s_inner + h * 64
-    flat = _view(ptr, int(base + (n - 1) * mp.s_row + 64), "elem")
-    idx = base + torch.arange(n)[:, None] * mp.s_row + torch.arange(64)[None, :]
+def _seq_rows(ptr, mp, o, h, n, hd=64):
+    base = (o // mp.inner) * mp.s_outer + (o % mp.inner) * mp.s_inner + h * hd
+    flat = _view(ptr, int(base + (n - 1) * mp.s_row + hd), "elem")
+    idx = base + torch.arange(n)[:, None] * mp.s_row + torch.arange(hd)[None, :]
     return flat, idx
 
 
 def attention(p: L.AttnParams):
+    hd = p.head_dim or 64
     for o in range(p.n_outer):
         for h in range(p.heads):
-            qf, qi = _seq_rows(p.q, p.qm, o, h, p.Nq)
-            kf, ki = _seq_rows(p.k, p.km, o // p.kv_div, h, p.Nk)
-            vf, vi = _seq_rows(p.v, p.vm, o // p.kv_div, h, p.Nk)
+            qf, qi = _seq_rows(p.q, p.qm, o, h, p.Nq, hd)
+            kf, ki = _seq_rows(p.k, p.km, o // p.kv_div, h, p.Nk, hd)
+            vf, vi = _seq_rows(p.v, p.vm, o // p.kv_div, h, p.Nk, hd)
             q, k, v = qf[qi].float(), kf[ki].float(), vf[vi].float()
             s = torch.softmax(q @ k.t() * p.scale, dim=-1)
             out = (s @ v).to(L.elem())
-            of, oi = _seq_rows(p.o, p.om, o, h, p.Nq)
+            of, oi = _seq_rows(p.o, p.om, o, h, p.Nq, hd)
             of[oi.reshape(-1)] = out.reshape(-1)
 
 

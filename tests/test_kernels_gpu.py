@@ -578,6 +578,26 @@ def test_attention_sharp_softmax():
     check(dev["o"], cpu["o"], tol_l2=6e-3, tol_max=2e-2)
 
 
+@pytest.mark.parametrize("T,heads", [(1000, 4), (4096, 2), (130, 3)])
+def test_attention_head_dim_32(T, heads):
+    """head_dim 32 (LGM MVAttention at 512 channels / 16 heads, core/attention.py:67-84): the flash kernel instantiated with
+    one k-step per S^T tile and two output tiles, against the interpreter; token counts with query / key tails."""
+    Cc = heads * 32
+    c = Case(qkv=rnd((T, 3 * Cc), 5), o=torch.zeros(T, Cc, dtype=BF))
+
+    def build(t):
+        m = lambda: ops.seq_map(0, 0, 3 * Cc, inner=1)
+        base = t["qkv"].data_ptr()
+        return ops.attn_params(base, base + 2 * Cc, base + 4 * Cc, t["o"], m(), m(), m(), ops.seq_map(0, 0, Cc, inner=1),
+                               1, heads, T, T, 32 ** -0.5, head_dim=32)
+    cpu = c.on("cpu")
+    I.attention(build(cpu))
+    dev = c.on("cuda")
+    ops.Stream(record=False).attention(build(dev), "t")
+    torch.cuda.synchronize()
+    check(dev["o"], cpu["o"], tol_l2=6e-3, tol_max=2e-2)
+
+
 # ------------------------------------------------------------------------------------------------- sampler glue
 def test_layout_and_ddim_kernels():
     nb, Cc, F_, H, W = 1, 4, 5, 6, 7

@@ -36,3 +36,34 @@ out = ref.renderer.render(ga.unsqueeze(0), gs["cam_view"].to(dev), gs["cam_view_
 small = torch.rand(24, 3, 256, 256, generator=g, device=dev) * 2 - 1
 z = vae.encode_firsr_stage(small, 0.18215); t4 = sync()
 print(f"decode4 {1000*(t1-t0):.1f} ms | lgm unet {1000*(t2-t1):.1f} ms | 24 renders {1000*(t3-t2):.1f} ms ({sum(ref.renderer.last_num_rendered)/24/1e6:.2f} M inst/view) | encode24 {1000*(t4-t3):.1f} ms")
+
+
+# ---- per-op tables of the three recorded plans (events on the launch stream, min of 3 replays)
+from videomv_amd import _lib as L
+from videomv_amd.flops import gemm_flops, attn_flops
+
+
+def op_table(S, name):
+    n = S.nops
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(n + 1)] for _ in range(3)]
+    for r in range(3):
+        torch.cuda.synchronize()
+        ev[r][0].record()
+        for i in range(n):
+            S.run(i, i + 1)
+            ev[r][i + 1].record()
+    torch.cuda.synchronize()
+    ms = [min(ev[r][i].elapsed_time(ev[r][i + 1]) for r in range(3)) for i in range(n)]
+    path = os.path.join(os.environ.get("VMV_OUT", "gpurun_out"), f"r2_ops_{name}.tsv")
+    with open(path, "w") as f:
+        f.write("idx\tlabel\tms\tGFLOP\tTFLOP/s\tM\tN\tK\n")
+        for i, (op, p) in enumerate(S.recorded):
+            fl = gemm_flops(p) if op == L.OP_GEMM else (attn_flops(p) if op == L.OP_ATTENTION else 0.0)
+            mnk = (p.M, p.N, p.ktot) if op == L.OP_GEMM else ("", "", "")
+            f.write(f"{i}\t{S.labels[i]}\t{ms[i]:.4f}\t{fl / 1e9:.2f}\t{(fl / (ms[i] * 1e-3) / 1e12) if fl else 0:.1f}\t{mnk[0]}\t{mnk[1]}\t{mnk[2]}\n")
+    print(name, "ops", n, "sum ms", round(sum(ms), 2))
+
+
+op_table(ref.engine.S, "lgm_unet")
+for key, e in vae._engines.items():
+    op_table(e.S, f"vae_{type(e).__name__}_{key[0]}x{key[1]}x{key[2]}")

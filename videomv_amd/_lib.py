@@ -110,7 +110,7 @@ class AttnParams(C.Structure):
     _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p),
                 ("qm", SeqMap), ("km", SeqMap), ("vm", SeqMap), ("om", SeqMap),
                 ("n_outer", C.c_int32), ("kv_div", C.c_int32), ("heads", C.c_int32),
-                ("Nq", C.c_int32), ("Nk", C.c_int32), ("scale", C.c_float)]
+                ("Nq", C.c_int32), ("Nk", C.c_int32), ("scale", C.c_float), ("head_dim", C.c_int32), ("_pad", C.c_int32)]
 
 
 class SoftmaxParams(C.Structure):

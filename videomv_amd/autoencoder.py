@@ -142,6 +142,10 @@ class _VaeEngine:
         W = self.wt[wkey] if isinstance(wkey, str) else wkey
         if N is None:
             N = W.shape[0]
+        if "ksplit" not in kw and not kw.get("rowstat"):
+            if getattr(self, "_splitk", None) is None:
+                self._splitk = ops.SplitK(self.device if hasattr(self, "device") else self.dev, cap=32)
+            kw["ksplit"], kw["workspace"] = self._splitk.pick(M, N, segs)
         self.S.gemm(ops.gemm_params(M, N, segs, W, out.ptr if isinstance(out, Act) else out,
                                     ldo if ldo is not None else out.C, bias=bias, **kw), label)
 

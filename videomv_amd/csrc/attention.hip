@@ -31,8 +31,12 @@ constexpr float NEG_BIG = -1.0e30f;
 // QT = 16-query tiles per wave (QT = 4: 64 queries per wave, 256 per block — every K / V fragment read from LDS and
 // every staged K / V tile then serves twice the MFMAs; the LDS port, shared by all the blocks of a CU, is what bounds the
 // 128-query version at long sequences)
-template <int WPP, int QT>
+// D = head dimension: 64 (the video UNet) or 32 (the LGM U-Net's 512-channel / 16-head MVAttention; WPP = 4 only): the
+// same kernel with D / 32 k-steps in S^T = K Q^T, D / 16 output tiles in O^T = V^T P^T and D / 8 16-byte slots per staged K row.
+template <int WPP, int QT, int D = 64>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, const int nproblems) {
+    static_assert(D == 64 || (D == 32 && WPP == 4), "head_dim 64, or 32 on the 4-waves-per-problem variant");
+    constexpr int KK = D / 32, DT = D / 16, SLOTS = D / 8, SLOG = (D == 64) ? 3 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -50,10 +54,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
         const int pi = wvalid ? pidx : 0;
         h = pi % p.heads; o = pi / p.heads; q0 = 0;
     }
-    const uint16_t* qp = reinterpret_cast<const uint16_t*>(p.q) + seq_base(p.qm, o) + h * 64;
-    const uint16_t* kp = reinterpret_cast<const uint16_t*>(p.k) + seq_base(p.km, o / p.kv_div) + h * 64;
-    const uint16_t* vp = reinterpret_cast<const uint16_t*>(p.v) + seq_base(p.vm, o / p.kv_div) + h * 64;
-    uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + seq_base(p.om, o) + h * 64;
+    const uint16_t* qp = reinterpret_cast<const uint16_t*>(p.q) + seq_base(p.qm, o) + h * D;
+    const uint16_t* kp = reinterpret_cast<const uint16_t*>(p.k) + seq_base(p.km, o / p.kv_div) + h * D;
+    const uint16_t* vp = reinterpret_cast<const uint16_t*>(p.v) + seq_base(p.vm, o / p.kv_div) + h * D;
+    uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + seq_base(p.om, o) + h * D;
 
     // ---- staging group
     constexpr int NT = (WPP == 4) ? 256 : 64;
@@ -62,25 +66,25 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
     // per stage: K tile [64 keys][8 slots] in 16-B units (8 KB) then V^T tile [64 d][64 keys] bf16 (8 KB)
 
     // ---- Q fragments (B operand): row q0 + 16*qt + u, k-slot kk*32 + 8*g
-    elem8_t qf[QT][2];
+    elem8_t qf[QT][KK];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         const int q = q0 + qt * 16 + u;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < KK; ++kk) {
             u32x4_t v = {0u, 0u, 0u, 0u};
             if (wvalid && q < p.Nq) v = *reinterpret_cast<const u32x4_t*>(qp + (long)q * p.qm.s_row + kk * 32 + g * 8);
             qf[qt][kk] = __builtin_bit_cast(elem8_t, v);
         }
     }
 
-    f32x4_t oacc[QT][4];
+    f32x4_t oacc[QT][DT];
     float m_run[QT], l_run[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         m_run[qt] = NEG_BIG; l_run[qt] = 0.f;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) oacc[qt][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < DT; ++dt) oacc[qt][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
     const float sc = p.scale * 1.44269504088896341f;   // exp2 domain (> 0)
 
@@ -88,14 +92,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
     // K/V staging.  WPP = 4: two LDS stages; the next tile's global loads are issued BEFORE the current tile's MFMAs
     // and written to the other stage after them (one barrier per tile, HBM/L2 latency hidden under the math).
     // WPP = 1 (one short problem per wave, a single tile in practice): plain load -> write -> barrier.
-    constexpr int NPIECE = 512 / NT;               // 16-byte pieces of K (and of V) per lane per tile
+    constexpr int NPIECE = (64 * SLOTS) / NT;      // 16-byte pieces of K (and of V) per lane per tile
     u32x4_t kreg[(WPP == 4) ? NPIECE : 1], vreg[(WPP == 4) ? NPIECE : 1];
     auto load_tile = [&](int kt2) {
         if constexpr (WPP == 4) {
 #pragma unroll
             for (int i = 0; i < NPIECE; ++i) {
                 const int idx = stid + i * NT;
-                const int row = idx >> 3, slot = idx & 7;
+                const int row = idx >> SLOG, slot = idx & (SLOTS - 1);
                 const int key = kt2 * 64 + row;
                 u32x4_t kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
                 if (key < p.Nk) {
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
         }
     };
     auto write_vt = [&](uint16_t* Vtd, int idx, const u32x4_t& vv) {
-        const int row = idx >> 3, slot = idx & 7;
+        const int row = idx >> SLOG, slot = idx & (SLOTS - 1);
         const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -118,8 +122,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
         }
     };
     auto write_piece = [&](u32x4_t* Ksd, uint16_t* Vtd, int idx, const u32x4_t& kv, const u32x4_t& vv) {
-        const int row = idx >> 3, slot = idx & 7;
-        Ksd[row * 8 + (slot ^ k_swz(row))] = kv;
+        const int row = idx >> SLOG, slot = idx & (SLOTS - 1);
+        Ksd[row * SLOTS + (slot ^ (k_swz(row) & (SLOTS - 1)))] = kv;
         const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -174,15 +178,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
         }
 
         // ---- S^T tiles (two query tiles at a time: the K fragments stay in registers for all QT of them) + online softmax
-        elem8_t kf[4][2];
+        elem8_t kf[4][KK];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int krow = 32 * (t >> 1) + 8 * (u >> 2) + 4 * (t & 1) + (u & 3);
             const int ksw = k_swz(krow);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
+            for (int kk = 0; kk < KK; ++kk) {
                 if constexpr (WPP == 4) {
-                    kf[t][kk] = __builtin_bit_cast(elem8_t, Ks[krow * 8 + ((kk * 4 + g) ^ ksw)]);
+                    kf[t][kk] = __builtin_bit_cast(elem8_t, Ks[krow * SLOTS + ((kk * 4 + g) ^ (ksw & (SLOTS - 1)))]);
                 } else {
                     u32x4_t kv = {0u, 0u, 0u, 0u};
                     const int key = key0 + krow;
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
+                for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
                     for (int q2 = 0; q2 < 2; ++q2)
                         s[q2][t] = VMV_MFMA16(kf[t][kk], qf[2 * qp + q2][kk], s[q2][t], 0, 0, 0);
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
                     m_run[qt] = m_new;
                     l_run[qt] *= alpha;
     #pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) oacc[qt][dt] *= alpha;
+                    for (int dt = 0; dt < DT; ++dt) oacc[qt][dt] *= alpha;
                 }
                 l_run[qt] += psum;
     #pragma unroll
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
         // ---- O^T += V^T P^T
         const u32x4_t* Vt16 = reinterpret_cast<const u32x4_t*>(Vt);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
+        for (int dt = 0; dt < DT; ++dt) {
             const int d = dt * 16 + u;
             const int fsl = ((d >> 3) ^ (d >> 1)) & 7;   // 8-key block swizzle of row d
 #pragma unroll
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
         if (wvalid && q < p.Nq) {
             uint16_t* orow = op + (long)q * p.om.s_row + 4 * g;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < DT; ++dt) {
                 const f32x4_t a = oacc[qt][dt] * inv;
                 u32x2_t w;
                 w.x = pack_elem2(a.x, a.y); w.y = pack_elem2(a.z, a.w);
@@ -451,6 +455,13 @@ extern "C" int vmv_attention(const VmvAttnParams* pp, void* stream) {
     if ((p.qm.s_row & 7) || (p.km.s_row & 7) || (p.vm.s_row & 7)) return VMV_EALIGN;
     if (!vmv_aligned16(p.q) || !vmv_aligned16(p.k) || !vmv_aligned16(p.v) || (((uintptr_t)p.o) & 7)) return VMV_EALIGN;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int hd = p.head_dim ? p.head_dim : 64;
+    if (hd == 32) {                  // LGM MVAttention (core/attention.py:67-84): long sequences only
+        if (p.n_outer > 65535 || p.heads > 65535) return VMV_ERANGE;
+        hipLaunchKernelGGL((attn_kernel<4, 2, 32>), dim3((p.Nq + 127) / 128, p.heads, p.n_outer), dim3(256), 32768, st, p, 0);
+        return vmv_launch_status();
+    }
+    if (hd != 64) return VMV_EINVAL;
     static int short_env = -1;
     if (short_env < 0) { const char* e = getenv("VMV_ATTN_SHORT"); short_env = e ? atoi(e) : 1; }
     if (p.Nq <= 32 && p.Nk <= 32 && short_env) {

@@ -12,6 +12,7 @@ channels, 4096 tokens) as QK^T GEMM -> row softmax -> PV GEMM per head (K heads 
 The Gaussian activations run in ``vmv_gaussian_activation``; nothing here computes in PyTorch.
 """
 import dataclasses
+import os
 import math
 from typing import Dict, Tuple
 
@@ -178,6 +179,10 @@ class LgmEngine:
         Wt = self.wt[W] if isinstance(W, str) else W
         if N is None:
             N = Wt.shape[0]
+        if "ksplit" not in kw and not kw.get("rowstat"):
+            if getattr(self, "_splitk", None) is None:
+                self._splitk = ops.SplitK(self.device if hasattr(self, "device") else self.dev, cap=32)
+            kw["ksplit"], kw["workspace"] = self._splitk.pick(M, N, segs)
         self.S.gemm(ops.gemm_params(M, N, segs, Wt, out.ptr if isinstance(out, Act) else out,
                                     ldo if ldo is not None else out.C, bias=bias, **kw), label)
 
@@ -225,11 +230,11 @@ class LgmEngine:
         qkv = self.act(T, 3 * C)
         self._gemm(p + ".qkv", T, ops.linear_segs([(hn.ptr, C, C)]), p + ".qkv", qkv)
         ao = self.act(T, C)
-        if hd == 64:
-            self.rel(hn)
+        if hd == 64 or (hd == 32 and os.environ.get("VMV_ATTN_D32", "1") != "0"):
+            self.rel(hn)                            # flash kernel (head_dim 64, and 32: the 'big' model's 512 / 16 heads)
             m = lambda: ops.seq_map(0, 0, 3 * C, inner=1)
             self.S.attention(ops.attn_params(qkv.ptr, qkv.ptr + 2 * C, qkv.ptr + 4 * C, ao.ptr, m(), m(), m(),
-                                             ops.seq_map(0, 0, C, inner=1), 1, heads, T, T, hd ** -0.5), p + ".attn")
+                                             ops.seq_map(0, 0, C, inner=1), 1, heads, T, T, hd ** -0.5, head_dim=hd), p + ".attn")
         else:
             if hd % 8 or T % 8:
                 raise NotImplementedError("LGM attention: head_dim and token count must be multiples of 8")

@@ -97,6 +97,31 @@ def gn_chunk_rows(rows_per_stat: int, C: int) -> int:
     return min(r, rows_per_stat)
 
 
+class SplitK:
+    """Split-K policy + workspace for the small-M implicit GEMMs (a tile grid that cannot fill the 256 CUs with a long
+    reduction): K is cut into `ks` slices (fp32 slabs in the workspace, deterministic reduce + epilogue pass, vmv.h).
+    One instance per engine: the slab is shared by all of its launches (single stream: launches are ordered)."""
+
+    def __init__(self, device, cap=8):
+        self.device, self.cap, self.ws, self.keep = device, cap, None, []
+
+    def pick(self, M, N, segs):
+        steps = sum((s.k + 63) // 64 for s in segs)
+        bn = 160 if N % 160 == 0 else 128
+        tiles = ((M + 127) // 128) * ((N + bn - 1) // bn)
+        if tiles >= 192 or steps < 16:
+            return 0, None
+        # the split-K shapes run on the 4-wave LDS-DMA kernel, two blocks per CU: aim at ~2 x 256 blocks
+        ks = min(self.cap, max(1, (480 + tiles // 2) // tiles), steps // 8)
+        if ks < 2:
+            return 0, None
+        need = ks * M * N * 4
+        if self.ws is None or self.ws.numel() < need:
+            self.ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=self.device)
+            self.keep.append(self.ws)      # earlier recorded launches keep pointing at the old slab
+        return ks, self.ws
+
+
 def gn_fused_cols(rows_per_stat: int, C: int) -> int:
     """Channels per block of the one-launch GroupNorm (vmv_groupnorm_fused), or 0 when a stat group does not fit on chip:
     the narrowest slab of whole groups whose rows are still >= 128 B (else >= 64 B) contiguous — most blocks, least LDS."""
@@ -136,11 +161,12 @@ def seq_map(s_outer, s_inner, s_row, inner=1) -> L.SeqMap:
     return m
 
 
-def attn_params(q, k, v, o, qm, km, vm, om, n_outer, heads, Nq, Nk, scale, kv_div=1) -> L.AttnParams:
+def attn_params(q, k, v, o, qm, km, vm, om, n_outer, heads, Nq, Nk, scale, kv_div=1, head_dim=64) -> L.AttnParams:
     p = L.AttnParams()
     p.q, p.k, p.v, p.o = _ptr(q), _ptr(k), _ptr(v), _ptr(o)
     p.qm, p.km, p.vm, p.om = qm, km, vm, om
     p.n_outer, p.kv_div, p.heads, p.Nq, p.Nk, p.scale = int(n_outer), int(kv_div), int(heads), int(Nq), int(Nk), float(scale)
+    p.head_dim = int(head_dim)
     return p
 
 

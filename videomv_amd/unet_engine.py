@@ -219,7 +219,7 @@ class UNetEngine:
         self.S = ops.Stream(record=True)
         self.Sctx = ops.Stream(record=True)      # step-invariant launches: K / V of the text context (run by context_updated())
         self._keepalive = []
-        self._ws = None
+        self._splitk = None
         self._gnws = torch.empty(4 << 20, dtype=torch.float32, device=device)
         # pre-folded statistics of the all-frame norms: [nstat][32][2] per rank (+ the gathered [R][nstat][32][2]), tickets
         self._gn_tot = torch.zeros(64 * 64, dtype=torch.float32, device=device)
@@ -395,20 +395,9 @@ class UNetEngine:
 
     def _ksplit(self, M, N, segs):
         """Split K when the tile grid cannot fill 256 CUs and the reduction is long (small-spatial levels)."""
-        steps = sum((s.k + 63) // 64 for s in segs)
-        bn = 160 if N % 160 == 0 else 128
-        tiles = ((M + 127) // 128) * ((N + bn - 1) // bn)
-        if tiles >= 192 or steps < 16:
-            return 0, None
-        # the split-K shapes run on the 4-wave LDS-DMA kernel, two blocks per CU: aim at ~2 x 256 blocks
-        ks = min(8, max(1, (480 + tiles // 2) // tiles), steps // 8)
-        if ks < 2:
-            return 0, None
-        need = ks * M * N * 4
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=self.device)
-            self._keepalive.append(self._ws)   # earlier recorded launches keep pointing at the old slab
-        return ks, self._ws
+        if self._splitk is None:
+            self._splitk = ops.SplitK(self.device, cap=8)
+        return self._splitk.pick(M, N, segs)
 
     def _gn(self, label, srcs, rows, rows_per_stat, wkey, eps, silu, all_frames=False) -> Act:
         """all_frames: a 5-D norm whose statistics span every frame.  Frame-parallel: the input is the
