@@ -282,14 +282,15 @@ int vmv_adaptive_avgpool_rows(const void* in, int ld, void* out, int ldo, int n,
  *   eps_rows fp32 [2*F*HW][ld] (branch-major), xt [1][C][F][HW], out [4][C][HW].
  * vmv_lgm_pack_input: decoded VAE images [4][3][HW] in [-1,1] -> clamp(0.5*d+0.5, 0, 1) -> (x - mean)/std (ImageNet) into
  *   out[:, 0:3], rays [4][6][HW] copied into out[:, 3:9]; out [4][9][HW].
- * vmv_lgm_render_to_vae: rendered images [V][3][2S][2S] in [0,1] -> nearest down-sampling by 2 (F.interpolate) and
+ * vmv_lgm_render_to_vae: rendered images [V][3][S_in][S_in] in [0,1] -> nearest resampling to [S][S] (F.interpolate(...,
+ *   (S, S), mode='nearest'): source index floor(dst * S_in / S), unet_t2v.py:425-427) and
  *   (x - 0.5) / 0.5; out [V][3][S][S].
  * vmv_ddim_x0_step: x0 = u + guide * (c - u) (CFG on the two branches' latent_z), eps = (c_recip*xt - x0)/c_recipm1,
  *   xt <- sqrt(a_prev) * x0 + sqrt(1 - a_prev) * eps, in place; all [n] floats. */
 int vmv_lgm_x0_views(const float* eps_rows, int ld, int branch, const float* xt, int C, int F, int HW, const int32_t* idx4,
                      float c_recip, float c_recipm1, float inv_scale, float* out, void* stream);
 int vmv_lgm_pack_input(const float* decoded, const float* rays, float* out, int nviews, int HW, void* stream);
-int vmv_lgm_render_to_vae(const float* images, float* out, int nviews, int S, void* stream);
+int vmv_lgm_render_to_vae(const float* images, float* out, int nviews, int S_in, int S, void* stream);
 int vmv_ddim_x0_step(const float* x0_cond, const float* x0_uncond, float* xt, long n, float guide, float c_recip,
                      float c_recipm1, float a_prev, void* stream);
 

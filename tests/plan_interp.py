@@ -268,7 +268,7 @@ def lgm_pack_input(decoded, rays, out):
 
 
 def lgm_render_to_vae(images, out):
-    out.copy_((images[:, :, ::2, ::2] - 0.5) / 0.5)
+    out.copy_((torch.nn.functional.interpolate(images, size=out.shape[-2:], mode="nearest") - 0.5) / 0.5)
 
 
 def ddim_x0_step(x0_cond, x0_uncond, xt, guide, c_recip, c_recipm1, a_prev):

@@ -679,3 +679,15 @@ def test_gaussian_activation_matches_reference_semantics():
     x = raw[:, :14]
     exp_rot = torch.nn.functional.normalize(x[None, :, 7:11])[0]          # the reference call: default dim=1 on [B, N, 4]
     assert torch.allclose(out.cpu()[:, 7:11], exp_rot, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("S_in,S", [(128, 64), (96, 64), (64, 64), (80, 32)])
+def test_lgm_render_to_vae_matches_interpolate(S_in, S):
+    """rendered views -> VAE input: F.interpolate(images, (S, S), mode='nearest') then [0,1] -> [-1,1] (unet_t2v.py:425-427),
+    for any render / target size ratio."""
+    img = torch.rand(3, 3, S_in, S_in, generator=g(2))
+    out = torch.empty(3, 3, S, S, device="cuda")
+    ops.lgm_render_to_vae(img.cuda(), out)
+    torch.cuda.synchronize()
+    ref = (torch.nn.functional.interpolate(img, size=(S, S), mode="nearest") - 0.5) / 0.5
+    assert torch.allclose(out.cpu(), ref, atol=1e-6)

@@ -143,7 +143,7 @@ SYMBOLS = {
     "vmv_gaussian_activation": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P]),
     "vmv_lgm_x0_views": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, C.c_float, C.c_float, C.c_float, _P, _P]),
     "vmv_lgm_pack_input": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
-    "vmv_lgm_render_to_vae": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "vmv_lgm_render_to_vae": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "vmv_ddim_x0_step": (C.c_int, [_P, _P, _P, C.c_long, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "vmv_gs_workspace_bytes": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "vmv_gs_preprocess": (C.c_int, [C.POINTER(GsParams), _P]),

@@ -71,12 +71,14 @@ __global__ void lgm_pack_input_kernel(const float* __restrict__ dec, const float
     }
 }
 
-__global__ void lgm_render_to_vae_kernel(const float* __restrict__ img, float* __restrict__ out, int nviews, int S) {
+// nearest resampling as F.interpolate(mode='nearest') does it: source index = floor(dst * in / out)
+__global__ void lgm_render_to_vae_kernel(const float* __restrict__ img, float* __restrict__ out, int nviews, int S_in, int S) {
     const long total = (long)nviews * 3 * S * S;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int x = (int)(i % S), y = (int)((i / S) % S);
         const long vc = i / ((long)S * S);
-        out[i] = (img[(vc * 2 * S + 2 * y) * 2 * S + 2 * x] - 0.5f) / 0.5f;
+        const int sx = (int)(((long)x * S_in) / S), sy = (int)(((long)y * S_in) / S);
+        out[i] = (img[(vc * S_in + sy) * S_in + sx] - 0.5f) / 0.5f;
     }
 }
 
@@ -369,11 +371,11 @@ extern "C" int vmv_lgm_pack_input(const float* decoded, const float* rays, float
     return vmv_launch_status();
 }
 
-extern "C" int vmv_lgm_render_to_vae(const float* images, float* out, int nviews, int S, void* stream) {
+extern "C" int vmv_lgm_render_to_vae(const float* images, float* out, int nviews, int S_in, int S, void* stream) {
     if (!images || !out) return VMV_ENULL;
-    if (nviews <= 0 || S <= 0) return VMV_EINVAL;
+    if (nviews <= 0 || S <= 0 || S_in <= 0) return VMV_EINVAL;
     hipLaunchKernelGGL(lgm_render_to_vae_kernel, dim3(grid_for((long)nviews * 3 * S * S)), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), images, out, nviews, S);
+                       reinterpret_cast<hipStream_t>(stream), images, out, nviews, S_in, S);
     return vmv_launch_status();
 }
 

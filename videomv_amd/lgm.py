@@ -427,7 +427,11 @@ class LgmRefiner:
                                    None, bg_color=bg)
         images = out["image"][0]                                                        # [T, 3, 2S, 2S]
         T = images.shape[0]
-        small = torch.empty(T, 3, images.shape[-1] // 2, images.shape[-1] // 2, dtype=torch.float32, device=self.device)
+        # F.interpolate(images, (256, 256), mode='nearest') in the reference (unet_t2v.py:425-427) = 8 x the latent size here,
+        # whatever the render size (output_size need not be twice it)
+        small = torch.empty(T, 3, 8 * h, 8 * w, dtype=torch.float32, device=self.device)
+        if h != w:
+            raise ValueError("the LGM branch renders square views")
         ops.lgm_render_to_vae(images.contiguous(), small)
         z = autoencoder.encode_firsr_stage(small, scale_factor)                         # [T, C, h, w]
         return z.reshape(1, T, z.shape[1], z.shape[2], z.shape[3]).permute(0, 2, 1, 3, 4).contiguous()

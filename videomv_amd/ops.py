@@ -326,8 +326,10 @@ def lgm_pack_input(decoded, rays, out):
 
 
 def lgm_render_to_vae(images, out):
+    """rendered [n,3,S_in,S_in] in [0,1] -> nearest-resampled [n,3,S,S] in [-1,1] (any size ratio, as F.interpolate)."""
     n, _, S, _ = out.shape
-    L.check(L.load().vmv_lgm_render_to_vae(images.data_ptr(), out.data_ptr(), n, S, _stream_ptr()), "lgm_render_to_vae")
+    L.check(L.load().vmv_lgm_render_to_vae(images.data_ptr(), out.data_ptr(), n, images.shape[-1], S, _stream_ptr()),
+            "lgm_render_to_vae")
 
 
 def ddim_x0_step(x0_cond, x0_uncond, xt, guide, c_recip, c_recipm1, a_prev):
