@@ -205,6 +205,9 @@ def worker_i2v(gpu, cfg, cfg_update):
         cfg = AttrDict(assign_signle_cfg(cfg, cfg_update, 'vldm_cfg'))
         merge_into(cfg, _plain(dict(cfg_update)))
     cfg.gpu, cfg.seed, cfg.rank = gpu, int(cfg.seed), cfg.pmi_rank
+    if cfg.get('hip_dtype'):                        # (not a reference key) 16-bit storage type of the kernels: fp16 | bf16
+        from . import _lib
+        _lib.set_elem(cfg.hip_dtype)
     torch.manual_seed(rank_seed(cfg.seed, cfg.rank))
     on_gpu = str(cfg.device).startswith("cuda")
     device = torch.device("cuda", gpu) if on_gpu else torch.device(cfg.device)
