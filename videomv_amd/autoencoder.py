@@ -403,6 +403,8 @@ class AutoencoderKL(nn.Module):
         if pretrained is not None:
             self.init_from_ckpt(pretrained, ignore_keys=ignore_keys)
 
+    frame_independent = True      # decode / encode treat every frame on its own: callers may batch any number of frames
+
     def init_from_ckpt(self, path, ignore_keys=list()):
         sd = torch.load(path, map_location="cpu")["state_dict"]
         new = collections.OrderedDict()
