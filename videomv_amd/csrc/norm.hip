@@ -40,7 +40,19 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const VmvGroupNormParams 
             const uint16_t* base = first ? (x0 + c) : (x1 + (c - p.C0));
             const long ld = first ? p.ld : p.ld1;
             long r = row0 + rl;
-            for (; r + 3L * RPP < row_end; r += 4L * RPP) {      // 4 independent 16-B loads in flight per lane
+            for (; r + 7L * RPP < row_end; r += 8L * RPP) {      // 8 independent 16-B loads in flight per lane
+                u32x4_t v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const u32x4_t*>(base + (r + (long)k * RPP) * ld);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float f[8];
+                    unpack8(v[k], f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+                }
+            }
+            for (; r + 3L * RPP < row_end; r += 4L * RPP) {
                 u32x4_t v[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const u32x4_t*>(base + (r + (long)k * RPP) * ld);
