@@ -278,7 +278,8 @@ def main():
             if not done.wait(args.frame_parallel_budget):
                 if rank == 0:
                     out = headline()
-                    out["frame_parallel"] = {"error": f"leg exceeded {args.frame_parallel_budget}s at stage {state['stage']}"}
+                    out["frame_parallel"] = dict(state.get("partial") or {}, error=f"leg exceeded {args.frame_parallel_budget}s at "
+                                                                               f"stage {state['stage']}")
                     print(json.dumps(out), flush=True)
                 os._exit(0)
 
@@ -292,32 +293,46 @@ def main():
             ys, y0s = torch.randn(1, 77, 1024, generator=gs, device=dev), torch.randn(1, 77, 1024, generator=gs, device=dev)
             cams = cam
             fl = args.frames // world
-            xs = noise_s[:, :, rank * fl:(rank + 1) * fl].clone().contiguous()
             kc, ku = dict(y=ys, camera_data=cams), dict(y=y0s, camera_data=cams)
-            state["stage"] = "warmup"
-            for i in range(max(1, args.warmup)):
-                dif.ddim_step_hip(xs, steps[i % len(steps)], model, kc, ku, 9.0, stride)
-            fence()
-            state["stage"] = "timed"
-            t0 = time.perf_counter()
-            for i in range(args.steps):
-                dif.ddim_step_hip(xs, steps[(args.warmup + i) % len(steps)], model, kc, ku, 9.0, stride)
-            fence()
-            dtf = time.perf_counter() - t0
-            tt = torch.tensor([dtf], device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dtf = float(tt[0])
+
+            def timed_leg(tag):
+                xs = noise_s[:, :, rank * fl:(rank + 1) * fl].clone().contiguous()
+                state["stage"] = tag + ":warmup"
+                for i in range(max(1, args.warmup)):
+                    dif.ddim_step_hip(xs, steps[i % len(steps)], model, kc, ku, 9.0, stride)
+                fence()
+                state["stage"] = tag + ":timed"
+                t0 = time.perf_counter()
+                for i in range(args.steps):
+                    dif.ddim_step_hip(xs, steps[(args.warmup + i) % len(steps)], model, kc, ku, 9.0, stride)
+                fence()
+                dtf = time.perf_counter() - t0
+                tt = torch.tensor([dtf], device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dtf = float(tt[0])
+                r = dict(steps_per_s=round(args.steps / dtf, 4), ms_per_step=round(1000.0 * dtf / args.steps, 3),
+                         finite=bool(torch.isfinite(xs).all()))
+                if step_tflop:
+                    r["whole_step_frac_of_peak"] = round(step_tflop * r["steps_per_s"] / world / PEAK_BF16_TFLOPS, 4)
+                return r
+
+            # the single-plan mode first (one B = 2 plan, one communicator), then the branch-pipelined default (two B = 1
+            # plans on two streams, a communicator each): a problem in the second can never cost the first its number
+            os.environ["VMV_FP_PIPELINE"] = "0"
+            single = timed_leg("single-plan")
             eng = model.engine_for(2, args.frames, H, W, 77, dev, n_t=1)
-            fpar = dict(steps_per_s=round(args.steps / dtf, 4), ms_per_step=round(1000.0 * dtf / args.steps, 3),
-                        scaling="strong", views_per_gpu=fl, collectives_per_step=len(eng.breaks),
-                        all_to_all_per_step=sum(1 for i, _ in eng.breaks if eng.S.labels[i].endswith(".unpack")),
-                        finite=bool(torch.isfinite(xs).all()),
-                        parallelism=f"frames x{world} (frame-major <-> pixel-major all-to-all, DESIGN.md §8)")
-            if step_tflop:
-                fpar["whole_step_frac_of_peak"] = round(step_tflop * fpar["steps_per_s"] / world / PEAK_BF16_TFLOPS, 4)
+            common = dict(scaling="strong", views_per_gpu=fl, collectives_per_branch_plan=len(eng.breaks),
+                          all_to_all_per_step=sum(1 for i, _ in eng.breaks if eng.S.labels[i].endswith(".unpack")),
+                          parallelism=f"frames x{world} (frame-major <-> pixel-major all-to-all, DESIGN.md §8)")
+            state["partial"] = dict(common, mode="single-plan", **single)
+            os.environ["VMV_FP_PIPELINE"] = "1"
+            piped = timed_leg("branch-pipelined")
+            best, mode = (piped, "branch-pipelined") if piped["steps_per_s"] >= single["steps_per_s"] else (single, "single-plan")
+            fpar = dict(common, mode=mode, **best, single_plan=single, branch_pipelined=piped)
         except Exception as e:      # the headline (replicas) line must survive any problem in this leg
-            fpar = {"error": f"{type(e).__name__}: {e}"}
+            fpar = dict(state.get("partial") or {}, error=f"{type(e).__name__}: {e}")
         finally:
+            os.environ.pop("VMV_FP_PIPELINE", None)
             model.set_frame_parallel(None)
             done.set()
 
