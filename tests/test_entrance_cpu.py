@@ -176,3 +176,24 @@ def test_checkpoint_round_trip(monkeypatch, tmp_path, golden_dir):
     assert all(torch.equal(v, vsd[k]) for k, v in v1.state_dict().items())
     v2 = AUTO_ENCODER.build(dict(type="AutoencoderKL", ddconfig=dd, embed_dim=4, pretrained=str(vpath)))   # init_from_ckpt, strict
     assert all(torch.equal(v, vsd[k]) for k, v in v2.state_dict().items())
+
+
+def test_video_writer_matches_reference_frames(tmp_path):
+    """save_video_frames (utils/video_op.py:166-211): frame k of sample 0 = uint8(clamp(v * std + mean, 0, 1) * 255) (truncation),
+    written as <name>/{k:05d}.png next to <name>.mp4 (the mp4 itself only where an encoder exists); one frame -> <path>.png."""
+    import numpy as np
+    from PIL import Image
+    from videomv_amd.entrance import save_video_frames
+    g = torch.Generator().manual_seed(0)
+    vid = torch.randn(1, 3, 5, 16, 24, generator=g)
+    mean, std = [0.5, 0.5, 0.5], [0.5, 0.5, 0.5]
+    path = str(tmp_path / "rank_01_00_0000_a_chair_15_2.00.mp4")
+    files = save_video_frames(path, vid.clone(), mean, std)
+    frame_dir = path.replace(".mp4", "")
+    assert sorted(os.listdir(frame_dir)) == [f"{k:05d}.png" for k in range(5)]
+    ref = ((vid * 0.5 + 0.5).clamp(0, 1) * 255.0)[0].permute(1, 2, 3, 0).numpy().astype("uint8")
+    for k in range(5):
+        assert np.array_equal(np.asarray(Image.open(os.path.join(frame_dir, f"{k:05d}.png"))), ref[k])
+    assert (path in files) == os.path.exists(path)
+    one = save_video_frames(str(tmp_path / "single.mp4"), vid[:, :, :1].clone(), mean, std)
+    assert one == [str(tmp_path / "single.mp4") + ".png"] and os.path.exists(one[0])

@@ -6,8 +6,9 @@ Kept: config layering (python defaults <- YAML/CLI dict-merge <- ``vldm_cfg`` ov
 (``state_dict``/``step`` wrapper, ``strict=False``), orbit ``camera_data``, latent noise shape
 ``[1, 4, max_frames, res_y/scale, res_x/scale]``, CFG kwargs pair, 50-step DDIM (``cfg.ddim_timesteps``, new key — the
 reference hard-codes 50 at :264), VAE decode in ``decoder_bs`` chunks, output naming.
-Different by design: launches go to ``libvmv_hip_{f16,bf16}.so`` (``hip_dtype`` config key / ``VMV_DTYPE``); frames are
-written as a ``.pt`` tensor + PNG contact sheet (the mp4 writer is out of scope); the second, LGM-refined loop (:271-278)
+Different by design: launches go to ``libvmv_hip_{f16,bf16}.so`` (``hip_dtype`` config key / ``VMV_DTYPE``); per sample the entrance
+writes the reference's frame PNGs (``<name>/{fid:05d}.png``) and ``<name>.mp4`` when an H.264 encoder exists (none ships here),
+plus a ``.pt`` tensor and a PNG contact sheet; the second, LGM-refined loop (:271-278)
 runs when ``UNet.use_lgm_refine`` is set (not combined with ``frame_parallel``).
 """
 import logging
@@ -152,9 +153,11 @@ def worker(gpu, cfg, cfg_update):
         path = osp.join(cfg.log_dir, stem + '.pt')
         torch.save({'latent': x0.cpu(), 'video': video.cpu(), 'caption': caption}, path)
         _save_contact_sheet(video.cpu(), osp.join(cfg.log_dir, stem + '.png'), cfg.mean, cfg.std)
+        _save_frames_safe(osp.join(cfg.log_dir, stem + '.mp4'), video, cfg)          # the reference's <name>.mp4 + frame PNGs
         if video_gs is not None:                     # the reference's second file: <name>_gs
             torch.save({'latent': x0_gs.cpu(), 'video': video_gs.cpu(), 'caption': caption}, osp.join(cfg.log_dir, stem + '_gs.pt'))
             _save_contact_sheet(video_gs.cpu(), osp.join(cfg.log_dir, stem + '_gs.png'), cfg.mean, cfg.std)
+            _save_frames_safe(osp.join(cfg.log_dir, stem + '_gs.mp4'), video_gs, cfg)
         logging.info('Save views to %s' % path)
         outputs.append(path)
     logging.info('Congratulations! The inference is completed!')
@@ -277,6 +280,7 @@ def worker_i2v(gpu, cfg, cfg_update):
         path = osp.join(cfg.log_dir, stem + '.pt')
         torch.save({'latent': x0.cpu(), 'video': video.cpu(), 'image': line}, path)
         _save_contact_sheet(video.cpu(), osp.join(cfg.log_dir, stem + '.png'), cfg.mean, cfg.std)
+        _save_frames_safe(osp.join(cfg.log_dir, stem + '.mp4'), video, cfg)
         if use_lgm:       # second, LGM-refined loop from the same noise (inference_i2vgen_entrance.py:281-292)
             from .lgm import prepare_gs_data
             gs_data = prepare_gs_data(camera_data, model.lgm_opt)
@@ -286,6 +290,7 @@ def worker_i2v(gpu, cfg, cfg_update):
             video_gs = decode_views(autoencoder, x0_gs, int(cfg.decoder_bs), cfg.scale_factor)
             torch.save({'latent': x0_gs.cpu(), 'video': video_gs.cpu(), 'image': line}, osp.join(cfg.log_dir, stem + '_gs.pt'))
             _save_contact_sheet(video_gs.cpu(), osp.join(cfg.log_dir, stem + '_gs.png'), cfg.mean, cfg.std)
+            _save_frames_safe(osp.join(cfg.log_dir, stem + '_gs.mp4'), video_gs, cfg)
         logging.info('Save views to %s' % path)
         outputs.append(path)
     logging.info('Congratulations! The inference is completed!')
@@ -296,6 +301,58 @@ def worker_i2v(gpu, cfg, cfg_update):
         dist.destroy_process_group()
     cfg.outputs = outputs
     return cfg
+
+
+def _save_frames_safe(local_path, video, cfg):
+    try:                                            # (inference_text2video_entrance.py:296-300: errors are logged, not raised)
+        save_video_frames(local_path, video, cfg.mean, cfg.std)
+        logging.info('Save video to dir %s:' % local_path)
+    except Exception as e:
+        logging.info(f'Step: save text or video error with {e}')
+
+
+def save_video_frames(local_path, gen_video, mean, std, save_fps=8):
+    """The reference writer's outputs (utils/video_op.py:166-211, ``save_i2vgen_video_safe``) as far as this image allows:
+    the de-normalised frames ``clamp(v * std + mean, 0, 1) * 255`` truncated to uint8, one PNG per view named
+    ``<local_path minus .mp4>/{fid:05d}.png`` (written by cv2 in the reference, PIL here: same pixels), and
+    ``<local_path>`` itself — an H.264 mp4 at ``save_fps`` — when an encoder exists (``imageio`` with ffmpeg, or an ``ffmpeg``
+    binary on PATH; neither ships in this image, in which case only the PNGs are written and the fact is logged).
+    A single-frame video becomes ``<local_path>.png`` as in the reference.  Returns the list of files written."""
+    import shutil
+    import subprocess
+    import numpy as np
+    from PIL import Image
+    v = gen_video.detach().float().cpu()
+    v = v * torch.tensor(std).view(1, -1, 1, 1, 1) + torch.tensor(mean).view(1, -1, 1, 1, 1)
+    v = (v.clamp(0, 1) * 255.0)[0].permute(1, 2, 3, 0)                   # f h w c  (the reference saves sample 0)
+    frames = [f.numpy().astype('uint8') for f in v]                      # astype truncates, as the reference does
+    written = []
+    if len(frames) == 1:
+        Image.fromarray(frames[0]).save(local_path + '.png')
+        return [local_path + '.png']
+    frame_dir = local_path.replace('.mp4', '')
+    os.makedirs(frame_dir, exist_ok=True)
+    for fid, frame in enumerate(frames):
+        fp = os.path.join(frame_dir, '{:05d}.png'.format(fid))
+        Image.fromarray(frame).save(fp)
+        written.append(fp)
+    try:
+        import imageio                                                    # the reference's encoder
+        writer = imageio.get_writer(local_path, fps=save_fps, codec='libx264', quality=8)
+        for frame in frames:
+            writer.append_data(frame)
+        writer.close()
+        written.append(local_path)
+    except Exception:
+        exe = shutil.which('ffmpeg')
+        if exe is not None:
+            cmd = [exe, '-y', '-loglevel', 'quiet', '-framerate', str(save_fps), '-start_number', '0', '-i',
+                   os.path.join(frame_dir, '%05d.png'), '-vcodec', 'libx264', '-crf', '17', '-pix_fmt', 'yuv420p', local_path]
+            if subprocess.run(cmd).returncode == 0:
+                written.append(local_path)
+        else:
+            logging.info(f'no H.264 encoder in this environment (imageio / ffmpeg): wrote {len(frames)} PNG frames to {frame_dir}')
+    return written
 
 
 def _save_contact_sheet(video, path, mean, std):
