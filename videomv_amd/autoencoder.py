@@ -7,7 +7,7 @@ State-dict names/shapes are the reference's (248 keys at full size, encoder incl
 ``encode`` / ``encode_firsr_stage`` (used by the I2VGen entrance for ``local_image`` and by the LGM refinement loop) run on
 the same kernels (``VaeEncoderEngine``); the posterior noise is drawn on the host RNG like the reference.
 
-Decoder plan (channels-last bf16 rows, one chunk of n frames):
+Decoder plan (channels-last 16-bit rows, one chunk of n frames):
   post_quant 1x1 -> conv_in 3x3 -> Res -> Attn(1 head, d = C: GEMM QK^T -> row softmax -> GEMM PV per frame)
   -> Res -> 4 levels x 3 Res (1x1 nin_shortcut folded into conv2's K loop) with nearest-x2 folded into the
   up-sampling conv's gather -> GN + swish -> conv_out (fp32 rows) -> NCHW.
@@ -138,7 +138,7 @@ class _VaeEngine:
         self.pool.put(a.buf)
 
     def _gemm(self, label, M, segs, wkey, out, ldo=None, bias=None, N=None, **kw):
-        """wkey: name of a packed weight, or a raw device pointer to bf16 [N][K] rows (then N must be given)."""
+        """wkey: name of a packed weight, or a raw device pointer to 16-bit [N][K] rows (then N must be given)."""
         W = self.wt[wkey] if isinstance(wkey, str) else wkey
         if N is None:
             N = W.shape[0]
@@ -188,7 +188,7 @@ class _VaeEngine:
         hwp = (hw + 7) // 8 * 8
         vT = self.act(C, hwp)                       # V^T of one frame: [C][hw]
         sc = self.act(hw, hwp, torch.float32)       # scores of one frame
-        pr = self.act(hw, hwp)                      # probabilities (bf16)
+        pr = self.act(hw, hwp)                      # probabilities (16-bit)
         if hwp != hw:
             raise NotImplementedError("VAE attention needs h*w % 8 == 0")
         ao = self.act(T, C)

@@ -2,7 +2,7 @@
 pixel-aligned 3-D Gaussians (reference ``core/unet.py``, ``core/models.py:87-113``, registered inside the video UNet as
 ``self.lgm_big``, ``tools/modules/unet/unet_t2v.py:125-129``).
 
-``LgmEngine`` records the forward as a plan of C-ABI launches over channels-last bf16 rows ``[V*H*W, C]`` like the
+``LgmEngine`` records the forward as a plan of C-ABI launches over channels-last 16-bit rows ``[V*H*W, C]`` like the
 other engines: ResnetBlock = GN+SiLU -> conv3x3 -> GN+SiLU -> conv3x3 (+1x1 shortcut folded into the K loop), with the
 block's ``(x + res) * skip_scale`` folded into pre-scaled weights and ``res_scale``; the decoder's ``torch.cat`` is a
 segment list; down = stride-2 conv, up = nearest-x2 folded into the conv's gather.  MVAttention attends over the

@@ -2,7 +2,7 @@
 
 ``UNetEngine`` turns one ``UNetSD_T2VBase`` forward at a fixed shape (B branches x F frames x H x W latent,
 L context tokens) into a static sequence of C-ABI launches over pooled device buffers and replays it.
-Activations are channels-last bf16 "rows" ``[B*F*H*W, C]`` end-to-end: the reference's
+Activations are channels-last 16-bit (fp16 | bf16: _lib.elem()) "rows" ``[B*F*H*W, C]`` end-to-end: the reference's
 ``(b f) c h w`` / ``b (hw) c`` / ``(b hw) f c`` views (unet_t2v.py:348, util.py:362, :1054-1062) are index
 maps over that one buffer, so none of its ~150 ``rearrange(...).contiguous()`` copies exist here.
 
@@ -466,7 +466,7 @@ class UNetEngine:
         st, rt = send.tensor().view(R, -1), recv.tensor().view(R, -1)
         self._break(lambda: self.comm.all_to_all(rt, st))
         if skip_pack and release_in:
-            self._release_after_break(x)
+            self.release(x)      # (recycled by LATER launches only: the collective and the launches share one stream)
         if skip_unpack:
             if not skip_pack:
                 self.release(send)
@@ -481,11 +481,6 @@ class UNetEngine:
             self.release(send)
         self.release(recv)
         return y
-
-    def _release_after_break(self, a: Act):
-        """A buffer read by a collective is recycled only once a later launch has been recorded behind it (stream order =
-        program order: the collective and the launches share the stream)."""
-        self.release(a)
 
     def _ln_linear(self, label, x: Act, nkey, N, wkey, out: Act, bias=None, **kw):
         """out = Linear(LayerNorm(x)).  Folded: row statistics (mean, rstd) + one GEMM on the raw rows whose epilogue
@@ -774,7 +769,7 @@ class UNetEngine:
 
     # ------------------------------------------------------------------ execution
     def set_context(self, y: torch.Tensor):
-        """y [B, L, ctx] -> bf16 context rows (dtype cast only)."""
+        """y [B, L, ctx] -> 16-bit context rows (dtype cast only)."""
         self.ctx_rows.copy_(y.reshape(self.B * self.L, -1).to(L.elem()))
         self.context_updated()
 

@@ -6,7 +6,7 @@ What stays identical to the reference:
   * the ``state_dict`` key names/shapes (1484 keys at full size, typos included — SURVEY F13), so reference
     checkpoints load with ``load_state_dict(sd, strict=False)``;
   * the ``forward`` signature and the output layout/dtype (``[b, out_dim, f, h, w]``, fp32).
-What differs by design: there is no PyTorch math in ``forward``.  Parameters are repacked to bf16 GEMM
+What differs by design: there is no PyTorch math in ``forward``.  Parameters are repacked to 16-bit GEMM
 operands on first use and the whole forward is a recorded plan of HIP launches (``unet_engine.UNetEngine``).
 If the HIP library is missing, construction of the engine raises — there is no CPU fallback.
 
@@ -15,9 +15,8 @@ The LGM refinement branch (``autoencoder is not None``, unet_t2v.py:404-433; ``u
 :370-400, which needs ground-truth renders and the LGM losses) raises ``NotImplementedError``.
 """
 import math
-from typing import Dict, Optional
-
 import os
+from typing import Dict, Optional
 
 import torch
 import torch.nn as nn
