@@ -29,7 +29,7 @@ extern "C" {
 #define VMV_ENULL        -3   /* required pointer is NULL */
 #define VMV_ERANGE       -4   /* size outside what the kernel supports */
 
-#define VMV_ABI_VERSION   3
+#define VMV_ABI_VERSION   4
 int vmv_abi_version(void);
 /* The 16-bit storage / MFMA operand type ("elem") this build of the library computes in.  The same sources are
  * compiled once per type: libvmv_hip_f16.so (VMV_ELEM_F16: IEEE fp16 — the default; the reference's own half mode,
@@ -156,11 +156,17 @@ typedef struct {
     int32_t fold_ranks;    /* 0/1: `partial` holds this launch's sums.  R > 1 (frame-sharded 5-D norms): apply
                               folds `partial` = [R][nstat][nchunk][32][2] — the all-gathered sums of R equally sized shards of
                               each stat group — and normalises by R * rows_per_stat rows.  Ignored by _stats.            */
-    /* Optional pre-folded statistics (long stat groups: the all-frame norms have up to 256 chunks, which every apply block
-     * would otherwise re-fold).  With `totals` set, _stats follows up with a one-block-per-stat fold of that group's chunks,
-     * in fixed order, into totals[stat][32][2]; _apply then reads totals instead of partial: [nstat][32][2], or
-     * [R][nstat][32][2] gathered when fold_ranks = R > 1.                                                                  */
-    float* totals;
+    /* Optional stat-group totals (long stat groups: the all-frame norms have up to 256 chunks, which every apply block would
+     * otherwise re-fold).  With `totals` set, every _stats block ADDS its 32 (sum, sumsq) pairs to totals[stat][32][2] with
+     * 64-bit integer atomics in fixed point (value * 2^12): integer addition commutes, so the result is bitwise
+     * reproducible whatever the arrival order, and no fold launch and no release fence is needed.  The accumulators must be
+     * ZERO when _stats starts.  _apply reads totals instead of partial ([nstat][32][2], or [R][nstat][32][2] gathered when
+     * fold_ranks = R > 1) and, when `totals_clear` is set, zeroes `clear_count` entries there — the accumulators of the
+     * NEXT norm (two buffers used alternately: the buffer being cleared was last read one norm ago).                     */
+    int64_t* totals;
+    int64_t* totals_clear;
+    int32_t clear_count;
+    int32_t _pad;
 } VmvGroupNormParams;
 
 int vmv_groupnorm_stats(const VmvGroupNormParams* p, void* stream);

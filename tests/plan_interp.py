@@ -18,6 +18,8 @@ def _view(ptr, n, kind):
     if kind == "elem":
         arr = np.ctypeslib.as_array((C.c_uint16 * n).from_address(ptr))
         return torch.from_numpy(arr.view(np.int16)).view(L.elem())
+    if kind == "i64":
+        return torch.from_numpy(np.ctypeslib.as_array((C.c_int64 * n).from_address(ptr)))
     arr = np.ctypeslib.as_array((C.c_float * n).from_address(ptr))
     return torch.from_numpy(arr)
 
@@ -98,8 +100,9 @@ def groupnorm_stats(p: L.GroupNormParams):
         blk = xg[:, c * p.chunk_rows:(c + 1) * p.chunk_rows]
         part[:, c, :, 0] = blk.sum(dim=(1, 3))
         part[:, c, :, 1] = (blk * blk).sum(dim=(1, 3))
-    if p.totals:
-        _view(p.totals, nstat * 64, "f32").view(nstat, 32, 2).copy_(part.sum(dim=1))
+    if p.totals:       # fixed-point integer accumulation (order-independent), as the kernel does
+        tot = _view(p.totals, nstat * 64, "i64").view(nstat, 32, 2)
+        tot += torch.round(part.double() * 4096.0).to(torch.int64).sum(dim=1)
 
 
 def groupnorm(p: L.GroupNormParams):
@@ -109,7 +112,9 @@ def groupnorm(p: L.GroupNormParams):
     nchunk = (p.rows_per_stat + p.chunk_rows - 1) // p.chunk_rows
     R = max(1, p.fold_ranks)
     if p.totals:
-        part = _view(p.totals, R * nstat * 64, "f32").view(R, nstat, 32, 2).double().sum(dim=0)
+        part = _view(p.totals, R * nstat * 64, "i64").view(R, nstat, 32, 2).sum(dim=0).double() / 4096.0
+        if p.totals_clear:
+            _view(p.totals_clear, p.clear_count, "i64").zero_()
     else:
         part = _view(p.partial, R * nstat * nchunk * 64, "f32").view(R, nstat, nchunk, 32, 2).double().sum(dim=(0, 2))
     n = float(p.rows_per_stat) * (Cc // 32) * R

@@ -307,23 +307,28 @@ def test_groupnorm(rows, rps, C0, C1, silu, eps):
 
 @pytest.mark.parametrize("rows,rps,Cc,silu", [(2 * 61440, 61440, 320, True), (2 * 960, 960, 1280, False), (3 * 500, 500, 64, True)])
 def test_groupnorm_prefolded_totals(rows, rps, Cc, silu):
-    """Long stat groups (the all-frame norms): a one-block fold after the stats writes totals[stat][32][2]; apply reads
-    the totals.  Same statistics as the plain two-launch path up to fp32 summation order (a different fixed order)."""
+    """Long stat groups (the all-frame norms): the stats blocks add their sums to 64-bit fixed-point integer accumulators
+    totals[stat][32][2] (order-independent => deterministic, no fold launch); apply reads them and clears the next norm's.
+    Same statistics as the plain two-launch path up to summation order / the 2^-12 fixed-point rounding."""
     x = rnd((rows, Cc), 21, 1.3).cuda() + 0.1
     gamma, beta = (1 + 0.1 * torch.randn(Cc, generator=g(3))).cuda(), (0.1 * torch.randn(Cc, generator=g(4))).cuda()
     part = torch.zeros(ops.gn_partial_floats(rows, rps, Cc) + 64, device="cuda")
-    tot = torch.zeros(64 * 64, device="cuda")
+    tot = torch.zeros(2, 64 * 64, dtype=torch.int64, device="cuda")
     y0, y1 = torch.zeros(rows, Cc, dtype=BF, device="cuda"), torch.zeros(rows, Cc, dtype=BF, device="cuda")
     S = ops.Stream(record=False)
     p0 = ops.gn_params(x, Cc, Cc, rows, rps, part, gamma, beta, 1e-5, silu, y0, Cc)
     S.groupnorm_stats(p0); S.groupnorm_apply(p0)                          # (the plain two-launch form, explicitly)
-    S.groupnorm(ops.gn_params(x, Cc, Cc, rows, rps, part, gamma, beta, 1e-5, silu, y1, Cc, totals=tot))
+    S.groupnorm(ops.gn_params(x, Cc, Cc, rows, rps, part, gamma, beta, 1e-5, silu, y1, Cc, totals=tot[0],
+                              totals_clear=tot[1], clear_count=tot[1].numel()))
     torch.cuda.synchronize()
-    check(y1, y0.float().cpu(), tol_l2=1e-4, tol_max=2e-2)                  # (<= 1 bf16 ulp where the rounding flips)
-    y2 = torch.zeros_like(y1)
-    S.groupnorm(ops.gn_params(x, Cc, Cc, rows, rps, part, gamma, beta, 1e-5, silu, y2, Cc, totals=tot))
+    check(y1, y0.float().cpu(), tol_l2=1e-4 / TS, tol_max=2e-2)             # (<= 1 ulp where the rounding flips)
+    assert int(tot[0].abs().sum()) > 0 and int(tot[1].abs().sum()) == 0
+    y2 = torch.zeros_like(y1)                                               # next norm: the other buffer, which apply cleared
+    S.groupnorm(ops.gn_params(x, Cc, Cc, rows, rps, part, gamma, beta, 1e-5, silu, y2, Cc, totals=tot[1],
+                              totals_clear=tot[0], clear_count=tot[0].numel()))
     torch.cuda.synchronize()
-    assert torch.equal(y1, y2)                                           # deterministic
+    assert torch.equal(y1, y2)                                           # deterministic (integer accumulation)
+    assert int(tot[0].abs().sum()) == 0
 
 
 @pytest.mark.parametrize("R,B,rps_loc,Cc", [(2, 2, 96, 320), (8, 2, 15, 1280), (4, 1, 640, 64)])
@@ -350,7 +355,7 @@ def test_groupnorm_sharded_statistics(R, B, rps_loc, Cc):
     got = torch.cat([y.view(B, rps_loc, Cc) for y in ys], dim=1)
     check(got, ref.to(BF), tol_l2=5e-3, tol_max=3e-2)
     # the same through pre-folded totals: every "rank" folds its own chunks, the [R][B][32][2] totals are "gathered"
-    tot_all = torch.zeros(R * B * 64, device="cuda")
+    tot_all = torch.zeros(R * B * 64, dtype=torch.int64, device="cuda")
     ys2 = [torch.zeros(B * rps_loc, Cc, dtype=BF, device="cuda") for _ in range(R)]
     for r in range(R):
         S.groupnorm_stats(ops.gn_params(xd[r], Cc, Cc, B * rps_loc, rps_loc, part_all, gd, bd, 1e-5, True, ys2[r], Cc,

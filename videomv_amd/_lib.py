@@ -77,7 +77,7 @@ class GroupNormParams(C.Structure):
                 ("C0", C.c_int32), ("C1", C.c_int32), ("rows", C.c_int32), ("rows_per_stat", C.c_int32),
                 ("chunk_rows", C.c_int32), ("partial", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
                 ("eps", C.c_float), ("silu", C.c_int32), ("y", C.c_void_p), ("ldy", C.c_int32), ("fold_ranks", C.c_int32),
-                ("totals", C.c_void_p)]
+                ("totals", C.c_void_p), ("totals_clear", C.c_void_p), ("clear_count", C.c_int32), ("_pad", C.c_int32)]
 
 
 class GsParams(C.Structure):
@@ -183,7 +183,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the ABI drifted
         fn.restype = res
         fn.argtypes = args
-    if lib.vmv_abi_version() != 3:
+    if lib.vmv_abi_version() != 4:
         raise RuntimeError(f"{LIB_PATH}: ABI version mismatch")
     if lib.vmv_elem_type() != (ELEM_F16 if _elem == "f16" else ELEM_BF16):
         raise RuntimeError(f"{LIB_PATH} was built for another element type")

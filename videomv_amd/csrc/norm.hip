@@ -1,7 +1,7 @@
 // norm.hip — GroupNorm(32) statistics / apply(+SiLU) and LayerNorm over channels-last bf16 rows (gfx950).
 // All three are HBM-bound streaming kernels: 16-byte vector loads/stores (8 bf16 per lane), fp32 math,
-// wave-shuffle + LDS reductions, and NO atomics (partial sums are written per chunk and reduced in a fixed
-// order, so results are bitwise reproducible run to run).
+// wave-shuffle + LDS reductions; partial sums are written per chunk and reduced in a fixed order, or (long stat groups)
+// added to 64-bit fixed-point integer accumulators — either way results are bitwise reproducible run to run.
 #include "common.h"
 #include <type_traits>
 
@@ -11,6 +11,8 @@ namespace {
 // grid = (nchunk, nstat).  Block (256 threads) owns `chunk_rows` rows of one stat group and ALL channels.
 // Thread -> fixed column slot (8 channels) so sums stay in registers; lanes that share a column are combined
 // through an LDS [lane_rows][C] array in fixed order; then 32 threads produce the per-group (sum, sumsq).
+constexpr float GN_FX = 4096.0f;          // fixed-point scale of the integer stat-group accumulators (VmvGroupNormParams.totals)
+
 __global__ __launch_bounds__(256) void gn_stats_kernel(const VmvGroupNormParams p, const int nchunk) {
     extern __shared__ __attribute__((aligned(16))) float sh[];
     const int C = p.C0 + p.C1;
@@ -81,26 +83,15 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const VmvGroupNormParams 
         float s = 0.f, q = 0.f;
         for (int r = 0; r < RPP; ++r)
             for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { s += lsum[r * C + c]; q += lsq[r * C + c]; }
-        float* out = p.partial + (((long)stat * nchunk + chunk) * 32 + tid) * 2;
-        out[0] = s; out[1] = q;
+        if (p.totals) {        // fixed-point 64-bit atomics: order-independent, hence deterministic (vmv.h)
+            unsigned long long* t = reinterpret_cast<unsigned long long*>(p.totals) + ((long)stat * 32 + tid) * 2;
+            atomicAdd(t, (unsigned long long)__float2ll_rn(s * GN_FX));
+            atomicAdd(t + 1, (unsigned long long)__float2ll_rn(q * GN_FX));
+        } else {
+            float* out = p.partial + (((long)stat * nchunk + chunk) * 32 + tid) * 2;
+            out[0] = s; out[1] = q;
+        }
     }
-}
-
-// Pre-fold for long stat groups (the all-frame norms, up to 256 chunks): one block per stat group folds the chunks in
-// fixed order into totals[stat][32][2] — a ~3 us launch instead of every apply block re-reading nchunk * 64 floats.
-// (A last-block ticket inside gn_stats was measured 2.3x slower: the release fence per block costs more than this launch.)
-__global__ __launch_bounds__(1024) void gn_fold_kernel(const VmvGroupNormParams p, const int nchunk) {
-    // 32 lanes per group; every lane sums its chunks (independent loads, all in flight at once), then a fixed-order
-    // shuffle tree: deterministic, ~2 memory round trips in total
-    const int tid = threadIdx.x, stat = blockIdx.x;
-    const int g = tid >> 5, sub = tid & 31;
-    float s = 0.f, q = 0.f;
-    const float2* pp = reinterpret_cast<const float2*>(p.partial) + (long)stat * nchunk * 32 + g;
-#pragma unroll 8
-    for (int c = sub; c < nchunk; c += 32) { const float2 v = pp[(long)c * 32]; s += v.x; q += v.y; }
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-    if (sub == 0) { p.totals[((long)stat * 32 + g) * 2] = s; p.totals[((long)stat * 32 + g) * 2 + 1] = q; }
 }
 
 // ------------------------------------------------------------------------------------------------ GN apply
@@ -124,12 +115,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const VmvGroupNormParams 
         float s = 0.f, q = 0.f;
         // fold_ranks R > 1: partial = [R][nstat][nchunk][64] (all-gathered shards); every rank folds in the same order
         const int R = p.fold_ranks > 1 ? p.fold_ranks : 1;
-        if (p.totals) {      // pre-folded: one (sum, sumsq) pair per (rank, stat, group)
-            if (sub == 0)
+        if (p.totals) {      // integer totals: one (sum, sumsq) pair per (rank, stat, group), exact integer sum over the ranks
+            if (sub == 0) {
+                long long si = 0, qi = 0;
                 for (int r = 0; r < R; ++r) {
-                    const float* pp = p.totals + (((long)r * nstat + stat) * 32 + g) * 2;
-                    s += pp[0]; q += pp[1];
+                    const long long* pp = reinterpret_cast<const long long*>(p.totals) + (((long)r * nstat + stat) * 32 + g) * 2;
+                    si += pp[0]; qi += pp[1];
                 }
+                s = (float)((double)si * (1.0 / GN_FX)); q = (float)((double)qi * (1.0 / GN_FX));
+            }
         } else {
             for (int r = 0; r < R; ++r) {
                 const float* pp = p.partial + (((long)r * nstat + stat) * nchunk * 32 + g) * 2;
@@ -148,6 +142,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const VmvGroupNormParams 
         }
     }
     __syncthreads();
+    if (p.totals_clear && blockIdx.x == 0 && blockIdx.y == 0)     // the NEXT norm's accumulators (never the ones read above)
+        for (int i = tid; i < p.clear_count; i += 256) p.totals_clear[i] = 0;
     for (int c = tid; c < C; c += 256) {
         const int g = c / cpg;
         const float sc = s_rstd[g] * p.gamma[c];
@@ -441,7 +437,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const VmvSoftmaxParam
 }
 
 int gn_check(const VmvGroupNormParams& p) {
-    if (!p.x || !p.partial) return VMV_ENULL;
+    if (!p.x || (!p.partial && !p.totals)) return VMV_ENULL;
     const int C = p.C0 + p.C1;
     if (C <= 0 || (C & 31) || (p.C0 & 7) || (p.C1 & 7)) return VMV_EINVAL;
     if (p.C1 > 0 && !p.x1) return VMV_ENULL;
@@ -465,9 +461,8 @@ extern "C" int vmv_groupnorm_stats(const VmvGroupNormParams* pp, void* stream) {
     const int nstat = p.rows / p.rows_per_stat;
     const int nchunk = (p.rows_per_stat + p.chunk_rows - 1) / p.chunk_rows;
     const size_t shbytes = (size_t)2 * RPP * C * sizeof(float);
+    if (p.totals && (((uintptr_t)p.totals) & 7)) return VMV_EALIGN;
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, nstat), dim3(256), shbytes, reinterpret_cast<hipStream_t>(stream), p, nchunk);
-    if (p.totals)
-        hipLaunchKernelGGL(gn_fold_kernel, dim3(nstat), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), p, nchunk);
     return vmv_launch_status();
 }
 

@@ -79,14 +79,16 @@ def gemm_params(M, N, segs: Sequence[Seg], W, out, ldo, bias=None, rowvec=None, 
 
 
 def gn_params(x, ld, C0, rows, rows_per_stat, partial, gamma, beta, eps, silu, y, ldy, x1=None, ld1=0, C1=0,
-              chunk_rows=None, fold_ranks=0, totals=None) -> L.GroupNormParams:
+              chunk_rows=None, fold_ranks=0, totals=None, totals_clear=None, clear_count=0) -> L.GroupNormParams:
+    """totals / totals_clear: int64 fixed-point stat-group accumulators (include/vmv.h): `totals` must be zero when the
+    statistics pass starts; the apply pass zeroes `clear_count` entries of `totals_clear` (the next norm's accumulators)."""
     p = L.GroupNormParams()
     p.x, p.x1, p.ld, p.ld1, p.C0, p.C1 = _ptr(x), _ptr(x1), int(ld), int(ld1), int(C0), int(C1)
     p.rows, p.rows_per_stat = int(rows), int(rows_per_stat)
     p.chunk_rows = int(chunk_rows or gn_chunk_rows(rows_per_stat, C0 + C1))
     p.partial, p.gamma, p.beta = _ptr(partial), _ptr(gamma), _ptr(beta)
     p.eps, p.silu, p.y, p.ldy, p.fold_ranks = float(eps), 1 if silu else 0, _ptr(y), int(ldy), int(fold_ranks)
-    p.totals = _ptr(totals)
+    p.totals, p.totals_clear, p.clear_count = _ptr(totals), _ptr(totals_clear), int(clear_count)
     return p
 
 

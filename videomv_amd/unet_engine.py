@@ -222,8 +222,10 @@ class UNetEngine:
         self._splitk = None
         self._gnws = torch.empty(4 << 20, dtype=torch.float32, device=device)
         # pre-folded statistics of the all-frame norms: [nstat][32][2] per rank (+ the gathered [R][nstat][32][2]), tickets
-        self._gn_tot = torch.zeros(64 * 64, dtype=torch.float32, device=device)
-        self._gn_tot_all = torch.zeros(64 * 64 * self.R, dtype=torch.float32, device=device) if comm is not None else None
+        # two buffers used alternately by consecutive all-frame norms (the apply pass of one clears the other's)
+        self._gn_tot2 = torch.zeros(2, 64 * 64, dtype=torch.int64, device=device)
+        self._gn_tot_k = 0
+        self._gn_tot_all = torch.zeros(64 * 64 * self.R, dtype=torch.int64, device=device) if comm is not None else None
         self.taps = taps            # optional dict: prefix -> Act (buffers are then never recycled)
         self.n_t = n_t
         self.dim = cfg["dim"]
@@ -422,13 +424,16 @@ class UNetEngine:
             return y
         # all-frame norm: up to 256 chunks per stat group -> a one-block fold after the stats folds them once (pre-folded totals)
         assert nstat <= 64
+        tot, nxt = self._gn_tot2[self._gn_tot_k & 1], self._gn_tot2[(self._gn_tot_k + 1) & 1]
+        self._gn_tot_k += 1
+        clr = dict(totals_clear=nxt, clear_count=nxt.numel())
         if self.comm is None:
-            self.S.groupnorm(ops.gn_params(*args, totals=self._gn_tot, **base), label)
+            self.S.groupnorm(ops.gn_params(*args, totals=tot, **clr, **base), label)
             return y
-        self.S.groupnorm_stats(ops.gn_params(*args, totals=self._gn_tot, **base), label)
-        loc, allr = self._gn_tot[: nstat * 64], self._gn_tot_all[: nstat * 64 * self.R]
+        self.S.groupnorm_stats(ops.gn_params(*args, totals=tot, **base), label)
+        loc, allr = tot[: nstat * 64], self._gn_tot_all[: nstat * 64 * self.R]
         self._break(lambda: self.comm.all_gather(allr, loc))
-        self.S.groupnorm_apply(ops.gn_params(*args, totals=self._gn_tot_all, fold_ranks=self.R, **base), label)
+        self.S.groupnorm_apply(ops.gn_params(*args, totals=self._gn_tot_all, fold_ranks=self.R, **clr, **base), label)
         return y
 
     # ------------------------------------------------------------------ frame-parallel layout switches
@@ -852,6 +857,7 @@ class UNetEngine:
     def prepare_rows(self, x: torch.Tensor, t: torch.Tensor):
         """Everything of forward_rows before the plan: latent -> rows, timestep, embeddings."""
         nb = x.shape[0]
+        self._gn_tot2.zero_()         # stat-group accumulators start clean whatever the previous replay left (odd count, abort)
         # only the latent's own channels are written: channels >= x.shape[1] hold zeros (T2V) or the step-invariant
         # image `concat` of the I2VGen front-end (unet_i2vgen.py:383)
         ops.latent_to_rows_keep(x.contiguous(), self.x_rows, self.cin_pad, self.B // nb)
