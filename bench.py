@@ -296,8 +296,10 @@ def main():
             fl = args.frames // world
             kc, ku = dict(y=ys, camera_data=cams), dict(y=y0s, camera_data=cams)
 
-            def timed_leg(tag):
-                xs = noise_s[:, :, rank * fl:(rank + 1) * fl].clone().contiguous()
+            def timed_leg(tag, srank=None, sworld=None):
+                srank = rank if srank is None else srank
+                fls = args.frames // (world if sworld is None else sworld)
+                xs = noise_s[:, :, srank * fls:(srank + 1) * fls].clone().contiguous()
                 state["stage"] = tag + ":warmup"
                 for i in range(max(1, args.warmup)):
                     dif.ddim_step_hip(xs, steps[i % len(steps)], model, kc, ku, 9.0, stride)
@@ -330,6 +332,17 @@ def main():
             piped = timed_leg("branch-pipelined")
             best, mode = (piped, "branch-pipelined") if piped["steps_per_s"] >= single["steps_per_s"] else (single, "single-plan")
             fpar = dict(common, mode=mode, **best, single_plan=single, branch_pipelined=piped)
+            state["partial"] = dict(fpar)
+            if world % 2 == 0 and args.frames % (world // 2) == 0:
+                # CFG-parallel x frame-parallel: one branch per half of the ranks, frames sharded world/2 ways inside each half
+                from videomv_amd.comm import CfgFrameComm
+                state["stage"] = "cfg-parallel:groups"
+                comm2 = CfgFrameComm()
+                model.set_frame_parallel(comm2)
+                cfgp = timed_leg("cfg-parallel", comm2.rank, comm2.world)
+                fpar["cfg_x_frame"] = dict(cfgp, parallelism=f"2 branch groups x {comm2.world} frame shards")
+                if cfgp["steps_per_s"] > fpar["steps_per_s"]:
+                    fpar.update(cfgp, mode="cfg-parallel x frame-parallel")
         except Exception as e:      # the headline (replicas) line must survive any problem in this leg
             fpar = dict(state.get("partial") or {}, error=f"{type(e).__name__}: {e}")
         finally:

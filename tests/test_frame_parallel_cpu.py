@@ -194,3 +194,77 @@ def test_entrance_frame_parallel_two_ranks_matches_one_rank(tmp_path):
     assert torch.isfinite(b["video"]).all()
     assert rel_l2(b["latent"], a["latent"]) < 8e-2, rel_l2(b["latent"], a["latent"])
     assert rel_l2(b["video"], a["video"]) < 8e-2, rel_l2(b["video"], a["video"])
+
+
+def _cfgpar_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        torch.set_num_threads(2)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from tests import plan_interp
+        plan_interp.install(_Patch)
+        from oracle.unet_ref import UNetCfg
+        from oracle.weights import random_state_dict, unet_param_shapes
+        from videomv_amd.comm import CfgFrameComm
+        from videomv_amd.registry import MODEL, DIFFUSION
+        from videomv_amd.unet_t2v import gather_frames
+        import videomv_amd  # noqa: F401
+        ocfg = UNetCfg(**{k: v for k, v in CFG.items() if k in {f.name for f in dataclasses.fields(UNetCfg)}})
+        sd = random_state_dict(unet_param_shapes(ocfg), 99)
+        F_, H, W, L = 4, 8, 8, 5
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(1, 4, F_, H, W, generator=g)
+        y = torch.randn(2, L, 1024, generator=g)
+        cam = torch.randn(1, F_, 16, generator=g)
+        m = MODEL.build(dict(type="UNetSD_T2VBase", **{k: v for k, v in CFG.items()}))
+        m.load_state_dict(sd, strict=False)
+        diff = DIFFUSION.build(dict(type="DiffusionDDIM", schedule="linear_sd",
+                                    schedule_param=dict(num_timesteps=1000, init_beta=0.00085, last_beta=0.0120),
+                                    mean_type="eps", var_type="fixed_small"))
+        kc, ku = dict(y=y[:1], camera_data=cam), dict(y=y[1:], camera_data=cam)
+        ref = x.clone()
+        diff.ddim_step_hip(ref, 501, m, kc, ku, 9.0, 500)                       # single-rank batched plan
+        comm = CfgFrameComm()
+        m.set_frame_parallel(comm)
+        fl = F_ // comm.world
+        xt = x[:, :, comm.rank * fl:(comm.rank + 1) * fl].clone().contiguous()
+        diff.ddim_step_hip(xt, 501, m, kc, ku, 9.0, 500)
+        full = gather_frames(comm, xt)
+        eng = m._pipe["engs"][0]
+        # whole loop through the sampler API as well (2 steps)
+        xl = diff.ddim_sample_loop(noise=x, model=m, model_kwargs=[kc, ku], guide_scale=9.0, ddim_timesteps=2, eta=0.0)
+        m.set_frame_parallel(None)
+        xr = diff.ddim_sample_loop(noise=x, model=m, model_kwargs=[kc, ku], guide_scale=9.0, ddim_timesteps=2, eta=0.0)
+        q.put(dict(rank=rank, branch=comm.branch, fp_world=comm.world, e_step=rel_l2(full, ref), e_loop=rel_l2(xl, xr),
+                   B=eng.B, breaks=len(eng.breaks), finite=bool(torch.isfinite(xl).all())))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put(dict(rank=rank, error=traceback.format_exc()))
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_cfg_parallel_times_frame_parallel(world):
+    """comm.CfgFrameComm on gloo: world 2 = one CFG branch per rank (no frame sharding), world 4 = 2 branch groups x 2
+    frame shards.  Every rank must end a fused CFG + DDIM step / a 2-step loop with the single-rank result (same tolerance
+    as the frame-parallel tests: decorrelated storage rounding, amplified by CFG 9)."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cfgpar_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert "error" not in r, r["error"]
+    for r in res:
+        assert r["B"] == 1 and r["fp_world"] == world // 2 and r["branch"] == r["rank"] // (world // 2)
+        assert r["finite"] and r["e_step"] < 6e-2 and r["e_loop"] < 8e-2, r
+    assert {r["branch"] for r in res} == {0, 1}

@@ -65,3 +65,40 @@ class FrameComm:
             out.copy_(o)
         else:
             dist.all_gather_into_tensor(out, inp, group=self.group)
+
+
+class CfgFrameComm:
+    """CFG-parallel x frame-parallel (SURVEY §8e "other cheap axis"): W ranks = 2 branch groups of W/2.  Group b runs ONLY the
+    b-th classifier-free-guidance branch (0 = cond, 1 = uncond), its frames sharded W/2 ways with the same layout-switch
+    schedule as ``FrameComm`` — half the launches per rank, half as many peers per collective, no second copy of anything —
+    and the partner ranks (r, r + W/2), which hold the same frames of the two branches, exchange their eps rows once per
+    step (one small all-gather in a 2-rank group) before the fused CFG + DDIM update, which both then compute identically.
+    Frame-sharding view for callers (sampler, ``gather_frames``): ``world`` = W/2, ``rank`` = index inside the branch group.
+    Collective: every rank constructs it at the same point (it creates W/2 + 2 process groups)."""
+
+    def __init__(self):
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("CFG-parallel sampling needs an initialised torch.distributed process group")
+        W, r = dist.get_world_size(), dist.get_rank()
+        if W % 2:
+            raise ValueError(f"CFG-parallel needs an even number of ranks, got {W}")
+        half = W // 2
+        backend = dist.get_backend()
+        self.branch, self.rank, self.world = r // half, r % half, half
+        fp_groups = [dist.new_group(ranks=[b * half + i for i in range(half)], backend=backend) for b in range(2)]
+        pair_groups = [dist.new_group(ranks=[i, i + half], backend=backend) for i in range(half)]
+        self.fp = FrameComm(fp_groups[self.branch])          # frame-parallel communicator of my branch group
+        self.pair = FrameComm(pair_groups[self.rank])        # me and the rank holding the other branch of my frames
+        assert self.fp.rank == self.rank and self.fp.world == half and self.pair.rank == self.branch
+        self.local_only = False
+
+    # frame-sharding collectives (gather_frames, whole-sample forward) go to the branch group
+    def all_gather(self, out, inp):
+        self.fp.all_gather(out, inp)
+
+    def all_to_all(self, out, inp):
+        self.fp.all_to_all(out, inp)
+
+    def exchange_branches(self, out, mine):
+        """out [2, n] <- (cond rows, uncond rows) of this rank's frames: slot b comes from the rank of branch b."""
+        self.pair.all_gather(out, mine)

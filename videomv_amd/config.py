@@ -60,6 +60,7 @@ def default_cfg() -> AttrDict:
     # keys added by this implementation (defaults preserve the reference behaviour)
     c.device = 'cuda'                 # the hot path has no CPU implementation; tests route launches to an interpreter
     c.allow_random_init = False       # run with random weights when a checkpoint file is missing (benchmarks / CI)
+    c.cfg_parallel = False            # with frame_parallel: 2 x N/2 — one CFG branch per half of the ranks (comm.CfgFrameComm)
     c.hip_dtype = ''                  # 16-bit storage / MFMA operand type of the HIP kernels: '' (VMV_DTYPE or fp16) | fp16 | bf16
     c.num_views = None                # None -> max_frames
     return c

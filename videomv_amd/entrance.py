@@ -113,8 +113,9 @@ def worker(gpu, cfg, cfg_update):
     _load_weights(model, cfg.get('test_model'), cfg.allow_random_init, "UNet")
     model.eval()
     if fpar:
-        from .comm import FrameComm
-        model.set_frame_parallel(FrameComm())
+        from .comm import FrameComm, CfgFrameComm
+        # cfg_parallel (not a reference key): 2 x N/2 — one CFG branch per half of the ranks, frames sharded inside each half
+        model.set_frame_parallel(CfgFrameComm() if bool(cfg.get('cfg_parallel', False)) else FrameComm())
         logging.info(f"frame-parallel sampling: {cfg.world_size} ranks x {int(cfg.num_views or cfg.max_frames) // cfg.world_size} views")
 
     with open(cfg.test_list_path, 'r') as f:

@@ -275,6 +275,8 @@ class UNetSD_T2VBase(nn.Module, LgmMixin):
             raise ValueError("forward_cfg_rows handles one sample (the reference's noise is [1,4,F,h,w])")
         dev = xt.device
         if self.frame_comm is not None:
+            if hasattr(self.frame_comm, "exchange_branches"):          # comm.CfgFrameComm: one branch per rank group
+                return self._forward_cfg_rows_cfgpar(xt, t, cond_kwargs, uncond_kwargs)
             if os.environ.get("VMV_FP_PIPELINE", "1") != "0":
                 return self._forward_cfg_rows_pipelined(xt, t, cond_kwargs, uncond_kwargs)
             f = f * self.frame_comm.world
@@ -306,6 +308,37 @@ class UNetSD_T2VBase(nn.Module, LgmMixin):
                 eng._cond.clear()
         if getattr(self, "_pipe", None) is not None:
             self._pipe["cond"].clear()
+
+    # ------------------------------------------------------------------ CFG-parallel x frame-parallel
+    @torch.no_grad()
+    def _forward_cfg_rows_cfgpar(self, xt, t, cond_kwargs, uncond_kwargs):
+        """comm.CfgFrameComm: this rank runs ONE branch (cond for the first half of the ranks, uncond for the second) on its
+        frames of that branch group, then swaps eps rows with the rank that ran the other branch on the same frames."""
+        comm = self.frame_comm
+        b, c, fl, h, w = xt.shape
+        dev = xt.device
+        F_all = fl * comm.world
+        kw = (cond_kwargs, uncond_kwargs)[comm.branch]
+        y, cam = kw["y"], kw.get("camera_data")
+        key = ("cfgpar", F_all, h, w, y.shape[1], str(dev))
+        pipe = getattr(self, "_pipe", None)
+        if pipe is None or pipe["key"] != key or pipe["comm"] is not comm:
+            sd = {k: v.detach() for k, v in self.state_dict().items()}
+            T1 = fl * h * w
+            out_pad = (self.out_dim + 3) // 4 * 4
+            eps = torch.zeros(2 * T1, out_pad, dtype=torch.float32, device=dev)
+            mine = torch.zeros(T1, out_pad, dtype=torch.float32, device=dev)
+            eng = UNetEngine(self.arch, sd, 1, F_all, h, w, y.shape[1], dev, n_t=1, comm=comm.fp, eps_out=mine)
+            pipe = dict(key=key, comm=comm, engs=[eng], eps=eps, mine=mine, cond=CondCache(), out_pad=out_pad)
+            self._pipe = pipe
+        eng = pipe["engs"][0]
+        if not pipe["cond"].hit(y, cam, kw.get("fps")):
+            eng.set_context(y.to(dev).float())
+            eng.set_camera(cam.to(dev) if (cam is not None and self.use_camera_condition) else None)
+            eng.set_fps(kw.get("fps") if self.use_fps_condition else None)
+        eng.forward_rows(xt.float(), t.to(dev))
+        comm.exchange_branches(pipe["eps"].view(2, -1), pipe["mine"].view(-1))
+        return _PipeHandle(pipe["out_pad"]), pipe["eps"]
 
     # ------------------------------------------------------------------ frame-parallel, branch-pipelined
     @torch.no_grad()
