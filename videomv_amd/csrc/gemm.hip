@@ -281,9 +281,26 @@ int astat_policy() {
     return pol;
 }
 
+// Step-level A/B hooks (experiments): VMV_GEMM_TILE_GEGLU / _LIN160 / _LIN128 force a tile id for the short-K (<= 24 chunks)
+// LINEAR GEMMs with GEGLU / N % 160 == 0 / other N, M >= 16384 (the L0 / L1 transformer linears); 0 = policy below.
+int tile_override(int which) {
+    static int ov[3] = {-1, -1, -1};
+    static const char* names[3] = {"VMV_GEMM_TILE_GEGLU", "VMV_GEMM_TILE_LIN160", "VMV_GEMM_TILE_LIN128"};
+    if (ov[which] < 0) { const char* e = getenv(names[which]); ov[which] = e ? atoi(e) : 0; }
+    return ov[which];
+}
+
 int pick_tile(const VmvGemmParams& p, int total_steps) {
     if (p.tile != VMV_TILE_AUTO) return p.tile;
     const int geglu = p.epilogue == VMV_EPI_GEGLU;
+    {
+        bool lin = p.ksplit <= 1 && total_steps <= 24 && p.M >= 16384;
+        for (int i = 0; i < p.nseg; ++i) lin = lin && p.seg[i].mode == VMV_SEG_LINEAR;
+        if (lin) {
+            const int o = tile_override(geglu ? 0 : (p.N % 160 == 0 ? 1 : 2));
+            if (o > 0) return o;
+        }
+    }
     if (gemm_policy() >= 2 && astat_policy() && p.N >= 640 && p.M >= 128 * 256 && vmv_gemm_astat_eligible(p))
         return (!geglu && p.N % 160 == 0) ? VMV_TILE_A128x160 : VMV_TILE_A128x128;
     auto padded = [&](int bn) { return ((p.N + bn - 1) / bn) * bn; };
