@@ -37,7 +37,8 @@ def elem():
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "lib", f"libvmv_hip_{_elem}.so")
+    # VMV_LIB_DIR: an alternative build of the same ABI (A/B experiments: tools/experiments/*_ab.sh)
+    return os.path.join(os.environ.get("VMV_LIB_DIR") or os.path.join(_HERE, "lib"), f"libvmv_hip_{_elem}.so")
 
 VMV_MAX_SEGS = 24
 SEG_LINEAR, SEG_SPATIAL, SEG_TEMPORAL = 0, 1, 2
