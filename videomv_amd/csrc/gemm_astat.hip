@@ -47,13 +47,6 @@ struct AsCfg {
     static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
 };
 
-// 4-byte LDS-DMA (bias / column-sum / row-statistic strips): lane l lands at lptr + 4 l, OOB lanes write zeros
-VMV_DEV void blds4(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lptr, uint32_t voff, uint32_t soff) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lptr), 4, voff, soff, 0, 0);
-#endif
-}
-
 VMV_DEV void wait_vmcnt_n(int n) {
     switch (n) {
         case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;

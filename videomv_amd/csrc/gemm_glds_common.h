@@ -30,6 +30,12 @@ VMV_DEV void blds16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lptr, uint32_t v
 #endif
 }
 #define VMV_BLDS16(rsrc, lptr, voff, soff) blds16(rsrc, lptr, voff, soff)
+// 4-byte LDS-DMA (bias / column-sum / row-statistic strips): lane l lands at lptr + 4 l, OOB lanes write zeros
+VMV_DEV void blds4(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lptr, uint32_t voff, uint32_t soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lptr), 4, voff, soff, 0, 0);
+#endif
+}
 constexpr uint32_t OOB = 0x80000000u;          // > num_records of every descriptor below
 constexpr uint32_t SRD_RECORDS = 0x7ffffff0u;
 constexpr uint32_t SRD_FLAGS = 0x00020000u;

@@ -258,8 +258,8 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
     u32x4_t sd_prev[NR_MAX];                  // store data of the last 16-row group written (see the epilogue)
 #pragma unroll
     for (int r = 0; r < NR_MAX; ++r) sd_prev[r] = u32x4_t{0u, 0u, 0u, 0u};
-    f32x4_t bias_hold = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    f32x4_t csum_hold = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t bias_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.bias ? p.N * 4 : 0, SRD_FLAGS);
+    const __amdgpu_buffer_rsrc_t csum_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.colsum), 0, p.colsum ? p.N * 4 : 0, SRD_FLAGS);
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, SRD_RECORDS, SRD_FLAGS);
     const __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual), 0, SRD_RECORDS, SRD_FLAGS);
     const bool has_res = staged && p.residual != nullptr;
@@ -288,14 +288,20 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
         constexpr int OWC = GEGLU ? 8 * WN : 16 * WN;
         constexpr int NR = (16 * (OWC / 8) + 63) / 64;
         const int nbase = n0 + wave_n * 16 * WN + 4 * fgrp;
-        {   // this wave's 16*WN bias values: loaded now (lane l < 4*WN holds 4 of them), written to the wave's LDS strip at the
-            // start of the epilogue — writing it here would put a vmcnt(0) drain of the ring into the main loop
-            const int n = n0 + wave_n * 16 * WN + 4 * lane;
-            bias_hold = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            if (p.bias && lane < 4 * WN && n < p.N) bias_hold = *reinterpret_cast<const f32x4_t*>(p.bias + n);
-            if (p.rowstat) {
-                csum_hold = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                if (lane < 4 * WN && n < p.N) csum_hold = *reinterpret_cast<const f32x4_t*>(p.colsum + n);
+        {   // this wave's 16*WN bias values (and, with a folded LayerNorm, column sums) go straight into the wave's LDS strip by
+            // 4-byte LDS-DMA: no registers held across the tile's last MFMAs (8 of them made <4,3,5> spill into the epilogue,
+            // where every scratch reload waits out the in-order vmcnt queue), no ds_write, and columns >= N read as zero
+            // through the descriptor's range check.  They land with the wait_vmcnt<0> that precedes the epilogue.
+            constexpr int NB = 16 * WN;
+            const int n = n0 + wave_n * NB;
+#pragma unroll
+            for (int q = 0; q < (NB + 63) / 64; ++q) {
+                const int cnt = NB - 64 * q < 64 ? NB - 64 * q : 64;
+                if (lane < cnt) {
+                    const uint32_t vo = (uint32_t)(n + 64 * q + lane) * 4u;
+                    blds4(bias_rsrc, reinterpret_cast<unsigned char*>(bias_lds) + 256 * q, vo, 0);
+                    if (p.rowstat) blds4(csum_rsrc, reinterpret_cast<unsigned char*>(csum_lds) + 256 * q, vo, 0);
+                }
             }
         }
         if (has_res) {
@@ -334,8 +340,6 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
         constexpr int RB = OWC * 2 + 16;                      // slab row pitch (+16 B: spreads the 8-byte writes over banks)
         constexpr int NU = 16 * UW;                           // units per 16-row group
         constexpr int NR = (NU + 63) / 64;
-        if (lane < 4 * WN) *reinterpret_cast<f32x4_t*>(bias_lds + 4 * lane) = bias_hold;
-        if (p.rowstat && lane < 4 * WN) *reinterpret_cast<f32x4_t*>(csum_lds + 4 * lane) = csum_hold;
         float2 ms_next = make_float2(0.f, 0.f);
         if (p.rowstat) ms_next = *reinterpret_cast<const float2*>(p.rowstat + (size_t)(mbase < p.M ? mbase : 0) * 2);
         asm volatile("" ::: "memory");
