@@ -29,7 +29,7 @@ extern "C" {
 #define VMV_ENULL        -3   /* required pointer is NULL */
 #define VMV_ERANGE       -4   /* size outside what the kernel supports */
 
-#define VMV_ABI_VERSION   4
+#define VMV_ABI_VERSION   5
 int vmv_abi_version(void);
 /* The 16-bit storage / MFMA operand type ("elem") this build of the library computes in.  The same sources are
  * compiled once per type: libvmv_hip_f16.so (VMV_ELEM_F16: IEEE fp16 — the default; the reference's own half mode,
@@ -108,6 +108,12 @@ typedef struct {
      * with rowstat = fp32 [M][2] (mean, rstd) from vmv_layernorm(stats_out).  Linear segments only, no split-K.       */
     const float* rowstat;
     const float* colsum;     /* fp32 [N] (pre-GEGLU numbering), required with rowstat */
+    /* rowstat == NULL, colsum != NULL, ln_eps > 0: the same folded LayerNorm with (mean, rstd) of every row accumulated in
+     * the GEMM's own main loop from the A fragments it multiplies (no statistics pass, no rowstat traffic); the K range
+     * must be the normalised row: ONE linear segment, k == ktot == LayerNorm width, no split-K, no residual / rowvec, 16-bit output.  Served by the
+     * persistent kernel only: ask vmv_gemm_ln_inline_ok() first, vmv_gemm returns VMV_EINVAL otherwise.               */
+    float ln_eps;
+    int32_t _pad2;
 } VmvGemmParams;
 
 #define VMV_TILE_AUTO     0
@@ -132,6 +138,8 @@ typedef struct {
 #define VMV_TILE_A128x128 19
 
 int vmv_gemm(const VmvGemmParams* p, void* stream);
+/* 1 if vmv_gemm accepts *p (rowstat ignored) with in-loop LayerNorm statistics (VmvGemmParams.ln_eps), else 0 */
+int vmv_gemm_ln_inline_ok(const VmvGemmParams* p);
 
 /* ------------------------------------------------------------------------------------------------------
  * GroupNorm(32 groups) over row blocks + optional SiLU (torch group_norm + silu: util.py:329,649,673,1014,

@@ -62,6 +62,10 @@ def gemm(p: L.GemmParams):
     if p.rowstat:          # LayerNorm folded into the GEMM: rstd[m] * (acc - mean[m] * colsum[n])
         st = _view(p.rowstat, 2 * M, "f32").view(M, 2)
         acc = (acc - st[:, :1] * _view(p.colsum, N, "f32")[None, :]) * st[:, 1:2]
+    elif p.colsum and p.ln_eps > 0:      # the same, statistics taken from the rows the GEMM multiplies (VmvGemmParams.ln_eps)
+        mean = A.mean(dim=1, keepdim=True)
+        rstd = torch.rsqrt(((A * A).mean(dim=1, keepdim=True) - mean * mean).clamp_min(0) + p.ln_eps)
+        acc = (acc - mean * _view(p.colsum, N, "f32")[None, :]) * rstd
     if p.bias:
         acc = acc + _view(p.bias, N, "f32")
     if p.epilogue == L.EPI_GEGLU:

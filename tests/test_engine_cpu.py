@@ -59,12 +59,14 @@ def test_recorded_plan_matches_oracle(monkeypatch):
     assert rel_l2(eps, eps_ref) < 2e-2, rel_l2(eps, eps_ref)
 
 
-@pytest.mark.parametrize("fold", ["0", "1"])
-def test_layernorm_folding_is_equivalent(monkeypatch, fold):
-    """VMV_FOLD_LN: LayerNorm -> Linear as one GEMM on the raw rows (statistics pass + rowstat / colsum epilogue,
-    packing.fold_layernorm) or as two launches — both within the oracle bound, and the folded plan has no LN(x) buffer."""
+@pytest.mark.parametrize("fold,inline", [("0", "1"), ("1", "0"), ("1", "1")])
+def test_layernorm_folding_is_equivalent(monkeypatch, fold, inline):
+    """VMV_FOLD_LN: LayerNorm -> Linear as one GEMM on the raw rows (packing.fold_layernorm; row statistics from a separate
+    pass — rowstat — or, VMV_LN_INLINE, taken inside the GEMM's own main loop — ln_eps) or as two launches: all within the
+    oracle bound, and the folded plans have no LN(x) buffer."""
     plan_interp.install(monkeypatch)
     monkeypatch.setenv("VMV_FOLD_LN", fold)
+    monkeypatch.setenv("VMV_LN_INLINE", inline)
     from videomv_amd import _lib as L
     from videomv_amd.unet_engine import UNetEngine
     ocfg = UNetCfg(**{k: v for k, v in CFG.items() if k in {f.name for f in dataclasses.fields(UNetCfg)}})
@@ -82,8 +84,11 @@ def test_layernorm_folding_is_equivalent(monkeypatch, fold):
     assert rel_l2(eng.eps_ncfhw(), eps_ref) < 2e-2
     lns = [p for op, p in eng.S.recorded if op == L.OP_LAYERNORM]
     folded = [p for op, p in eng.S.recorded if op == L.OP_GEMM and p.rowstat]
-    if fold == "1":
-        assert lns and all(p.stats_out and not p.y for p in lns) and len(folded) == len(lns)
+    inl = [p for op, p in eng.S.recorded if op == L.OP_GEMM and p.colsum and not p.rowstat]
+    if fold == "1" and inline == "1":
+        assert not lns and not folded and inl and all(p.ln_eps > 0 and p.nseg == 1 and not p.residual for p in inl)
+    elif fold == "1":
+        assert not inl and lns and all(p.stats_out and not p.y for p in lns) and len(folded) == len(lns)
     else:
         assert lns and all(p.y and not p.stats_out for p in lns) and not folded
 

@@ -489,6 +489,63 @@ def test_gemm_layernorm_folded(M, N, K, geglu, tile):
         h = a * torch.nn.functional.gelu(gate)
     check(out, h, tol_l2=6e-3, tol_max=2e-2)
 
+@pytest.mark.parametrize("M,N,K,geglu,tile", [(300, 960, 320, False, 0), (1000, 640, 640, False, L.TILE_P256x160),
+                                               (70000, 960, 320, False, 0), (513, 1280, 320, True, 0),
+                                               (70000, 2560, 320, True, L.TILE_P256x128), (257, 128, 192, False, 0),
+                                               (300, 512, 72, True, 0), (2000, 3840, 1280, False, 0), (61, 1920, 640, False, 0)])
+def test_gemm_layernorm_inline(M, N, K, geglu, tile):
+    """The same folded LayerNorm with the row statistics accumulated inside the GEMM's main loop (VmvGemmParams.ln_eps: no
+    statistics pass) against the unfused definition — rows with a large offset (mean / sigma ~ 3), K tails (72, 192: chunks
+    of 64 with zero-filled lanes), M tails, several tiles per block; and bitwise equal over two runs."""
+    import ctypes as C
+    x = (rnd((M, K), 1, 1.5).float() + 4.0 * torch.randn(M, 1, generator=g(9))).to(BF)
+    w = torch.randn(N, K, generator=g(2)) * K ** -0.5
+    b = torch.randn(N, generator=g(3))
+    gamma, beta = 1 + 0.2 * torch.randn(K, generator=g(4)), 0.2 * torch.randn(K, generator=g(5))
+    wf, bf, cs = P.fold_layernorm(w, b, gamma, beta)
+    if geglu:
+        wf, bf, cs = P.geglu_interleave(wf), P.geglu_interleave(bf), P.geglu_interleave(cs)
+    No = N // 2 if geglu else N
+    xd, wd, bd, cd = x.cuda(), wf.cuda(), bf.cuda(), cs.cuda()
+    S = ops.Stream(record=False)
+    outs = []
+    for _ in range(2):
+        out = torch.zeros(M, No, dtype=BF, device="cuda")
+        p = ops.gemm_params(M, N, ops.linear_segs([(xd, K, K)]), wd, out, No, bias=bd, colsum=cd, ln_eps=1e-5,
+                            epilogue=L.EPI_GEGLU if geglu else L.EPI_NONE, tile=tile)
+        assert S.lib.vmv_gemm_ln_inline_ok(C.byref(p)) == 1
+        S.gemm(p)
+        torch.cuda.synchronize()
+        outs.append(out)
+    ln = torch.nn.functional.layer_norm(x.float(), (K,), gamma, beta, 1e-5)
+    h = ln @ w.t() + b
+    if geglu:
+        a, gate = h.chunk(2, dim=-1)
+        h = a * torch.nn.functional.gelu(gate)
+    check(outs[0], h, tol_l2=6e-3, tol_max=2e-2)
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_gemm_layernorm_inline_eligibility():
+    """vmv_gemm_ln_inline_ok / vmv_gemm agree on what the in-loop statistics cannot serve: residual, split-K, fp32 output,
+    several segments, a forced non-persistent tile."""
+    import ctypes as C
+    lib = L.load()
+    x = rnd((256, 128), 1).cuda(); w = rnd((128, 128), 2).cuda(); o = torch.zeros(256, 128, dtype=BF, device="cuda")
+    cs = torch.zeros(128, device="cuda"); ws = torch.zeros(2 * 256 * 128, device="cuda")
+    segs = ops.linear_segs([(x, 128, 128)])
+    ok = ops.gemm_params(256, 128, segs, w, o, 128, colsum=cs, ln_eps=1e-5)
+    assert lib.vmv_gemm_ln_inline_ok(C.byref(ok)) == 1
+    bad = [ops.gemm_params(256, 128, segs, w, o, 128, colsum=cs, ln_eps=1e-5, residual=o, ldr=128),
+           ops.gemm_params(256, 128, segs, w, o, 128, colsum=cs, ln_eps=1e-5, ksplit=2, workspace=ws),
+           ops.gemm_params(256, 128, segs, w, ws, 128, colsum=cs, ln_eps=1e-5, out_fp32=True),
+           ops.gemm_params(256, 128, ops.linear_segs([(x, 128, 64), (x, 128, 64)]), w, o, 128, colsum=cs, ln_eps=1e-5),
+           ops.gemm_params(256, 128, segs, w, o, 128, colsum=cs, ln_eps=1e-5, tile=L.TILE_128x128)]
+    for p in bad:
+        assert lib.vmv_gemm_ln_inline_ok(C.byref(p)) == 0
+        assert lib.vmv_gemm(C.byref(p), None) == -1          # VMV_EINVAL
+
+
 @pytest.mark.parametrize("M,N,K,geglu,bias,tile", [(40000, 640, 320, False, True, L.TILE_A128x160), (513, 1280, 320, True, True, L.TILE_A128x128),
                                                    (900, 960, 256, False, False, L.TILE_A128x160), (33000, 1280, 320, True, False, L.TILE_A128x128)])
 def test_gemm_astat_plain(M, N, K, geglu, bias, tile):

@@ -6,9 +6,6 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
 RN=${RN:-r2}      # round tag of the output files; VMV_COMMIT (git hash of the submitted tree) is recorded in the traffic JSON
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py"
-$B > $O/${RN}_bench_40x64.json 2> $O/bench_full.err
-$B --latent 32x32 --no-cpu-baseline > $O/${RN}_bench_32x32.json 2>> $O/bench_full.err
-$B --no-cpu-baseline --no-sample --dump-ops $O/${RN}_ops_40x64.tsv > /dev/null 2>> $O/bench_full.err
 P="--no-cpu-baseline --no-sample --no-op-profile"
 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_kt -- $B $P --steps 5 --warmup 1 > $O/prof_kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -f csv -d $O/prof_fetch -- $B $P --steps 2 --warmup 1 > $O/prof_fetch.log 2>&1
@@ -22,5 +19,12 @@ python tools/prof_summary.py $O/prof_write $O/${RN}_pmc_write.txt
 python tools/prof_summary.py $O/prof_mfma $O/${RN}_pmc_mfma.txt
 python tools/prof_summary.py $O/prof_lds $O/${RN}_pmc_lds.txt
 python tools/gemm_traffic.py $O/prof_fetch $O/prof_write $O/${RN}_gemm_traffic.json
+# the bench lines come last: roofline.traffic is read from profiles/${RN}_gemm_traffic.json, i.e. from THIS run's PMC passes
+cp $O/${RN}_gemm_traffic.json $R/profiles/${RN}_gemm_traffic.json
+cd /tmp
+$B > $O/${RN}_bench_40x64.json 2> $O/bench_full.err
+$B --latent 32x32 --no-cpu-baseline > $O/${RN}_bench_32x32.json 2>> $O/bench_full.err
+$B --no-cpu-baseline --no-sample --dump-ops $O/${RN}_ops_40x64.tsv > /dev/null 2>> $O/bench_full.err
+cd $R
 rm -rf $O/prof_kt $O/prof_fetch $O/prof_write $O/prof_mfma $O/prof_lds
 tail -c 600 $O/${RN}_bench_40x64.json

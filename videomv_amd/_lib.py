@@ -70,7 +70,8 @@ class GemmParams(C.Structure):
                 ("stride", C.c_int32), ("ups", C.c_int32),
                 ("F", C.c_int32), ("P", C.c_int32),
                 ("ksplit", C.c_int32), ("workspace", C.c_void_p),
-                ("tile", C.c_int32), ("res_scale", C.c_float), ("rowstat", C.c_void_p), ("colsum", C.c_void_p)]
+                ("tile", C.c_int32), ("res_scale", C.c_float), ("rowstat", C.c_void_p), ("colsum", C.c_void_p),
+                ("ln_eps", C.c_float), ("_pad2", C.c_int32)]
 
 
 class GroupNormParams(C.Structure):
@@ -134,6 +135,7 @@ SYMBOLS = {
     "vmv_sizeof": (C.c_int, [C.c_int]),
     "vmv_error_string": (C.c_char_p, [C.c_int]),
     "vmv_gemm": (C.c_int, [C.POINTER(GemmParams), _P]),
+    "vmv_gemm_ln_inline_ok": (C.c_int, [C.POINTER(GemmParams)]),
     "vmv_groupnorm_stats": (C.c_int, [C.POINTER(GroupNormParams), _P]),
     "vmv_groupnorm_apply": (C.c_int, [C.POINTER(GroupNormParams), _P]),
     "vmv_groupnorm_fused": (C.c_int, [C.POINTER(GroupNormParams), C.c_int32, _P]),
@@ -184,7 +186,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the ABI drifted
         fn.restype = res
         fn.argtypes = args
-    if lib.vmv_abi_version() != 4:
+    if lib.vmv_abi_version() != 5:
         raise RuntimeError(f"{LIB_PATH}: ABI version mismatch")
     if lib.vmv_elem_type() != (ELEM_F16 if _elem == "f16" else ELEM_BF16):
         raise RuntimeError(f"{LIB_PATH} was built for another element type")

@@ -36,6 +36,15 @@ VMV_DEV uint32_t pack_elem2(float lo, float hi) {
     const f32x2_t f = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, elem2_t));
 }
+// acc += a.lo * b.lo + a.hi * b.hi on packed element pairs (v_dot2c_f32_{f16,bf16}); volatile so that the caller's placement
+// between MFMAs survives (the compiler otherwise sinks a fragment's sums into one block behind the MFMA batch)
+#if defined(VMV_BUILD_BF16)
+#define VMV_ELEM_ONE2 0x3f803f80u
+VMV_DEV void elem_dot2c(float& acc, uint32_t a, uint32_t b) { asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b)); }
+#else
+#define VMV_ELEM_ONE2 0x3c003c00u
+VMV_DEV void elem_dot2c(float& acc, uint32_t a, uint32_t b) { asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b)); }
+#endif
 VMV_DEV uint32_t f32_to_elem_bits(float f) { return pack_elem2(f, 0.f) & 0xffffu; }
 
 VMV_DEV void unpack8(const u32x4_t& v, float* f) {

@@ -21,6 +21,7 @@ using namespace vmvg;
 
 int vmv_gemm_glds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st);   // gemm_glds.hip
 int vmv_gemm_pglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st);  // gemm_pglds.hip
+bool vmv_gemm_pglds_supported(const VmvGemmParams& p);
 int vmv_gemm_sglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st);  // gemm_sglds.hip
 int vmv_gemm_astat_launch(const VmvGemmParams& p, int tile, hipStream_t st);                   // gemm_astat.hip
 bool vmv_gemm_astat_eligible(const VmvGemmParams& p);
@@ -346,7 +347,18 @@ int pick_tile(const VmvGemmParams& p, int total_steps) {
     return best;
 }
 
+bool ln_inline_ok(const VmvGemmParams& p) {
+    if (!p.W || !p.out || !p.colsum || p.nseg != 1 || p.seg[0].mode != VMV_SEG_LINEAR || p.seg[0].k != p.ktot) return false;
+    if (p.ksplit > 1 || p.out_fp32 || p.rowvec || p.residual) return false;
+    if (p.tile != VMV_TILE_AUTO && p.tile != VMV_TILE_P256x128 && p.tile != VMV_TILE_P256x160) return false;
+    const int n_out = p.epilogue == VMV_EPI_GEGLU ? p.N / 2 : p.N;
+    if ((p.ldo & 7) || (n_out & 7) || !vmv_aligned16(p.out)) return false;                  // the staged epilogue
+    return vmv_gemm_pglds_supported(p);
+}
+
 }  // namespace
+
+extern "C" int vmv_gemm_ln_inline_ok(const VmvGemmParams* pp) { return pp && ln_inline_ok(*pp) ? 1 : 0; }
 
 extern "C" int vmv_gemm(const VmvGemmParams* pp, void* stream) {
     if (!pp) return VMV_ENULL;
@@ -382,7 +394,13 @@ extern "C" int vmv_gemm(const VmvGemmParams* pp, void* stream) {
         if (p.ksplit > 1) return VMV_EINVAL;
         for (int s = 0; s < p.nseg; ++s) if (p.seg[s].mode != VMV_SEG_LINEAR) return VMV_EINVAL;
     }
+    const bool ln_inline = vmv_gemm_ln_inline(p);
+    if (ln_inline) {       // statistics in the main loop: the persistent one-block-per-CU kernel, staged 16-bit output
+        if (!ln_inline_ok(p)) return VMV_EINVAL;
+        if (!vmv_aligned16(p.colsum)) return VMV_EALIGN;
+    }
     int picked = pick_tile(p, total_steps);
+    if (ln_inline && p.tile == VMV_TILE_AUTO) picked = (p.epilogue != VMV_EPI_GEGLU && p.N % 160 == 0) ? VMV_TILE_P256x160 : VMV_TILE_P256x128;
     if (p.rowstat && picked != VMV_TILE_A128x160 && picked != VMV_TILE_A128x128 && picked != VMV_TILE_P256x128 && picked != VMV_TILE_P256x160 && picked != VMV_TILE_Q128x128 &&
         picked != VMV_TILE_Q96x160 && picked != VMV_TILE_128x128 && picked != VMV_TILE_128x160 && picked != VMV_TILE_128x64 &&
         picked != VMV_TILE_64x64)
@@ -430,11 +448,13 @@ extern "C" int vmv_gemm(const VmvGemmParams* pp, void* stream) {
             break;
         case VMV_TILE_P256x128:
             rc = vmv_gemm_pglds_launch(p, total_steps, VMV_TILE_P256x128, st);
+            if (rc == VMV_GLDS_UNSUPPORTED && ln_inline) return VMV_EINVAL;
             if (rc == VMV_GLDS_UNSUPPORTED && !p.rowstat) rc = vmv_gemm_glds_launch(p, total_steps, VMV_TILE_256x128, st);
             if (rc == VMV_GLDS_UNSUPPORTED) rc = launch_cfg<4, 4>(p, total_steps, st);
             break;
         case VMV_TILE_P256x160:
             rc = vmv_gemm_pglds_launch(p, total_steps, VMV_TILE_P256x160, st);
+            if (rc == VMV_GLDS_UNSUPPORTED && ln_inline) return VMV_EINVAL;
             if (rc == VMV_GLDS_UNSUPPORTED && !p.rowstat) rc = vmv_gemm_glds_launch(p, total_steps, VMV_TILE_256x160, st);
             if (rc == VMV_GLDS_UNSUPPORTED) rc = launch_cfg<4, 5>(p, total_steps, st);
             break;

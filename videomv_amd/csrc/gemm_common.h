@@ -6,6 +6,8 @@
 namespace vmvg {
 
 constexpr int BK = 64;
+// LayerNorm folded into the GEMM with the row statistics taken in its own main loop (vmv.h: VmvGemmParams.ln_eps)
+inline bool vmv_gemm_ln_inline(const VmvGemmParams& p) { return !p.rowstat && p.colsum && p.ln_eps > 0.f; }
 constexpr int VMV_GLDS_UNSUPPORTED = -100;   // internal: the LDS-DMA kernel cannot address these operands
 
 struct RowInfo {

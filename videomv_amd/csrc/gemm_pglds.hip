@@ -47,7 +47,10 @@ struct PgCfg {
     static_assert(BM % (8 * NW) == 0, "A rows split evenly over the waves");
 };
 
-template <int NWM, int WM, int WN, int ablate, bool IL>
+// LNS: the (mean, rstd) of a LayerNorm folded into this GEMM (vmv.h, VmvGemmParams.ln_eps) are accumulated from the A
+// fragments the MFMAs consume — the K loop of such a GEMM walks each row completely, a wave's lanes hold output row
+// m = frow for both the fragments and the accumulators — instead of being read from a statistics pass.
+template <int NWM, int WM, int WN, int ablate, bool IL, bool LNS = false>
 __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel(const VmvGemmParams p, const int tiles_n, const int total_steps,
                                                          const int nitems, const int panel_order) {
     using Cfg = PgCfg<NWM, WM, WN>;
@@ -177,11 +180,16 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
 
     // ------------------------------------------------------------------ MFMA side
     f32x4_t acc[WN][WM];
+    float rs1[WM], rs2[WM];                   // LNS: this lane's share of sum x, sum x^2 of output rows frow + 16 i
     auto zero_acc = [&]() {
 #pragma unroll
         for (int j = 0; j < WN; ++j)
 #pragma unroll
             for (int i = 0; i < WM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if constexpr (LNS) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i) { rs1[i] = 0.f; rs2[i] = 0.f; }
+        }
     };
     zero_acc();
     const int frow = lane & 15;
@@ -198,11 +206,34 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
         for (int j = 0; j < WN; ++j) wf[j] = __builtin_bit_cast(elem8_t, w[j * 16 * 8 + slot]);
     };
     auto mma = [&](const elem8_t (&af)[WM], const elem8_t (&wf)[WN]) {
+        if constexpr (LNS) {
+            // + the row sums of the A fragments: 8 dot2c per fragment (sum x against packed ones, sum x^2 against itself), two
+            // of them pinned behind each MFMA so that they issue in its shadow (left to the compiler they end up as one
+            // block of 48 behind the chunk's MFMAs, with the matrix pipe idle: measured 7-9 % on the L0 / L1 shapes)
+            const uint32_t one2 = VMV_ELEM_ONE2;
 #pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
+            for (int m = 0; m < WM * WN; ++m) {
+                const int j = m / WM, i = m % WM;
                 acc[j][i] = VMV_MFMA16(wf[j], af[i], acc[j][i], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int idx = 2 * m + r;
+                    if (idx < 8 * WM) {
+                        const int fi = idx / 8, e = idx % 8;
+                        const u32x4_t u = __builtin_bit_cast(u32x4_t, af[fi]);
+                        const uint32_t x = (e >> 1) == 0 ? u.x : (e >> 1) == 1 ? u.y : (e >> 1) == 2 ? u.z : u.w;
+                        if (e & 1) elem_dot2c(rs2[fi], x, x); else elem_dot2c(rs1[fi], x, one2);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+                    acc[j][i] = VMV_MFMA16(wf[j], af[i], acc[j][i], 0, 0, 0);
+        }
     };
 
     // One MFMA phase of the interleaved loop: the WM*WN MFMAs on (af, wf), with the WM+WN fragment reads of the NEXT phase
@@ -262,7 +293,7 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
     const __amdgpu_buffer_rsrc_t csum_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.colsum), 0, p.colsum ? p.N * 4 : 0, SRD_FLAGS);
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, SRD_RECORDS, SRD_FLAGS);
     const __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual), 0, SRD_RECORDS, SRD_FLAGS);
-    const bool has_res = staged && p.residual != nullptr;
+    const bool has_res = !LNS && staged && p.residual != nullptr;      // (LNS: no residual — 24 registers the sums need)
     const float res_scale = p.res_scale != 0.f ? p.res_scale : 1.f;
     auto unit_offsets = [&](int m0, int n0, int i, int r, int ld, auto geglu_tag) -> uint32_t {
         // byte offset (relative to the group's scalar base) of 16-byte unit `lane + 64 r` of row group i, or OOB
@@ -300,7 +331,7 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
                 if (lane < cnt) {
                     const uint32_t vo = (uint32_t)(n + 64 * q + lane) * 4u;
                     blds4(bias_rsrc, reinterpret_cast<unsigned char*>(bias_lds) + 256 * q, vo, 0);
-                    if (p.rowstat) blds4(csum_rsrc, reinterpret_cast<unsigned char*>(csum_lds) + 256 * q, vo, 0);
+                    if (LNS || p.rowstat) blds4(csum_rsrc, reinterpret_cast<unsigned char*>(csum_lds) + 256 * q, vo, 0);
                 }
             }
         }
@@ -341,7 +372,18 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
         constexpr int NU = 16 * UW;                           // units per 16-row group
         constexpr int NR = (NU + 63) / 64;
         float2 ms_next = make_float2(0.f, 0.f);
-        if (p.rowstat) ms_next = *reinterpret_cast<const float2*>(p.rowstat + (size_t)(mbase < p.M ? mbase : 0) * 2);
+        if constexpr (LNS) {       // lanes frow, frow + 16, + 32, + 48 hold the four k-quarters of row frow's sums
+            const float inv_k = 1.0f / (float)p.ktot;
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                float a = rs1[i], b = rs2[i];
+                a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
+                a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
+                const float mean = a * inv_k;
+                const float var = fmaxf(b * inv_k - mean * mean, 0.f);
+                rs1[i] = mean; rs2[i] = __builtin_amdgcn_rsqf(var + p.ln_eps);
+            }
+        } else if (p.rowstat) ms_next = *reinterpret_cast<const float2*>(p.rowstat + (size_t)(mbase < p.M ? mbase : 0) * 2);
         asm volatile("" ::: "memory");
         unsigned char* slab = Cfg::DEDICATED ? smem + Cfg::LDS_BYTES + Cfg::STRIPS + wave * 2816
                                              : slot_base + wave * 4096;                       // 16 rows x RB <= 2816 B
@@ -363,7 +405,11 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
             // Two phases, separated for the scheduler: (A) bias reads + math for every column tile, (B) the slab writes.
             // LayerNorm folded into this GEMM (vmv.h): acc <- rstd[m] * (acc - mean[m] * colsum[n]); the row's two statistics
             // and the columns' sums are L2-resident fp32 (read per 16-row group, only on this path)
-            if (p.rowstat) {       // (column sums from the wave's LDS strip, like the bias; this group's row statistics were
+            if constexpr (LNS) {
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[j][i] = (acc[j][i] - *reinterpret_cast<const f32x4_t*>(csum_lds + 16 * j + 4 * fgrp) * rs1[i]) * rs2[i];
+            } else if (p.rowstat) {       // (column sums from the wave's LDS strip, like the bias; this group's row statistics were
                                    //  requested one group ahead)
                 const float2 ms = ms_next;
                 if (i + 1 < WM) ms_next = *reinterpret_cast<const float2*>(p.rowstat + (size_t)(m + 16 < p.M ? m + 16 : 0) * 2);
@@ -640,6 +686,22 @@ int launch_pglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
         return go_il(tag, std::false_type{});
     };
     int rc;
+    if (vmv_gemm_ln_inline(p)) {               // row statistics in the main loop: the one-block-per-CU configurations only
+        if constexpr (NWM == 4) {
+            static bool attr_set_lns = false;
+            if (!attr_set_lns) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pglds_kernel<NWM, WM, WN, 0, false, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_TOTAL);
+                if (e != hipSuccess) return (int)e;
+                attr_set_lns = true;
+            }
+            hipLaunchKernelGGL((gemm_pglds_kernel<NWM, WM, WN, 0, false, true>), grid, dim3(Cfg::NT), Cfg::LDS_TOTAL, st, p, tiles_n,
+                               total_steps, nitems, order);
+            return vmv_launch_status();
+        } else {
+            return VMV_EINVAL;
+        }
+    }
     switch (ablate) {
         case 1: rc = go(std::integral_constant<int, 1>{}); break;
         case 2: rc = go(std::integral_constant<int, 2>{}); break;
@@ -656,18 +718,23 @@ int launch_pglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
 }  // namespace
 
 // Called by vmv_gemm (gemm.hip) after argument validation; split-K shapes stay on the non-persistent kernels.
-int vmv_gemm_pglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st) {
-    if (p.ksplit > 1) return VMV_GLDS_UNSUPPORTED;
+bool vmv_gemm_pglds_supported(const VmvGemmParams& p) {
+    if (p.ksplit > 1) return false;
     for (int i = 0; i < p.nseg; ++i)
-        if (p.seg[i].mode != VMV_SEG_LINEAR) return VMV_GLDS_UNSUPPORTED;
+        if (p.seg[i].mode != VMV_SEG_LINEAR) return false;
     long maxrows = p.M;
     if (p.OH > 0) { const long src_rows = (long)(p.M / (p.OH * p.OW) + 1) * p.IH * p.IW; if (src_rows > maxrows) maxrows = src_rows; }
     for (int i = 0; i < p.nseg; ++i)
-        if (maxrows * (long)p.seg[i].ld * 2 >= (1L << 31) - 65536) return VMV_GLDS_UNSUPPORTED;
-    if ((long)p.N * p.ktot * 2 >= (1L << 31) - 65536) return VMV_GLDS_UNSUPPORTED;
+        if (maxrows * (long)p.seg[i].ld * 2 >= (1L << 31) - 65536) return false;
+    if ((long)p.N * p.ktot * 2 >= (1L << 31) - 65536) return false;
     // the epilogue addresses out / residual through buffer descriptors too (32-bit byte offsets)
-    if ((long)(p.M + 256) * p.ldo * (p.out_fp32 ? 4 : 2) >= (1L << 31) - 65536) return VMV_GLDS_UNSUPPORTED;
-    if (p.residual && (long)(p.M + 256) * p.ldr * 2 >= (1L << 31) - 65536) return VMV_GLDS_UNSUPPORTED;
+    if ((long)(p.M + 256) * p.ldo * (p.out_fp32 ? 4 : 2) >= (1L << 31) - 65536) return false;
+    if (p.residual && (long)(p.M + 256) * p.ldr * 2 >= (1L << 31) - 65536) return false;
+    return true;
+}
+
+int vmv_gemm_pglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st) {
+    if (!vmv_gemm_pglds_supported(p)) return VMV_GLDS_UNSUPPORTED;
     if (tile == VMV_TILE_P256x128) return launch_pglds<4, 4, 4>(p, total_steps, st);
     if (tile == VMV_TILE_Q128x128) return launch_pglds<2, 4, 4>(p, total_steps, st);
     if (tile == VMV_TILE_Q96x160) {

@@ -11,6 +11,7 @@ per block follows ``ResBlock._forward`` (util.py:703-730), ``TemporalConvBlock_v
 ``SpatialTransformer.forward`` (:354-373), ``TemporalTransformer.forward`` (:1043-1089),
 ``BasicTransformerBlock.forward`` (:536-540) and ``MemoryEfficientCrossAttention.forward`` (:230-268).
 """
+import ctypes as C
 import math
 import os
 from typing import Dict, List, Optional
@@ -234,6 +235,10 @@ class UNetEngine:
         # LayerNorm -> Linear pairs of the transformer blocks run as ONE GEMM on the raw rows + a statistics pass (vmv.h,
         # VmvGemmParams.rowstat): saves writing and re-reading LN(x) (VMV_FOLD_LN=0 keeps the two-kernel form)
         self.fold_ln = os.environ.get("VMV_FOLD_LN", "1") != "0"
+        # VMV_LN_INLINE=1: the statistics inside the consumer GEMM's main loop instead of a pass of their own.  Measured
+        # (round 2, same box): 99 launches / 1.2 ms of statistics passes go away, but the 48-64 dot2c per chunk
+        # cost the short-K GEMMs 7-15 % and the step gets 0.5 ms SLOWER — off by default.
+        self.ln_inline = os.environ.get("VMV_LN_INLINE", "0") == "1"
         # packed weights are immutable and shape-independent: engines of one model (other B / resolution / frame count, the
         # two branch engines of the pipelined frame-parallel mode) share ONE copy (`packed` = another engine's .packed)
         if packed is not None and packed.get("fold_ln") == self.fold_ln and packed.get("device") == str(device):
@@ -496,9 +501,19 @@ class UNetEngine:
             self.release(ln)
             return
         base = wkey[:-len(".weight")] if wkey.endswith(".weight") else wkey
+        W = self.w[base + ".ln.weight"]
+        segs = ops.linear_segs([(x.ptr, x.C, x.C)])
+        if self.ln_inline:
+            # statistics taken inside the GEMM's main loop from the rows it multiplies (vmv.h: VmvGemmParams.ln_eps): no
+            # statistics launch, no rowstat traffic — when the persistent kernel can address this shape
+            p = ops.gemm_params(x.rows, W.shape[0], segs, W, out.ptr, out.C, bias=self.w[base + ".ln.bias"],
+                                colsum=self.w[base + ".ln.colsum"], ln_eps=1e-5, **kw)
+            if self.S.lib.vmv_gemm_ln_inline_ok(C.byref(p)):
+                self.S.gemm(p, label)
+                return
         st = self.act(x.rows, 2, dtype=torch.float32)
         self.S.layernorm(ops.ln_params(x.ptr, x.C, None, 0, None, None, x.rows, x.C, 1e-5, stats_out=st.ptr), label + ".lnstat")
-        self._gemm(label, x.rows, N, ops.linear_segs([(x.ptr, x.C, x.C)]), base + ".ln.weight", out,
+        self._gemm(label, x.rows, N, segs, base + ".ln.weight", out,
                    bias=self.w[base + ".ln.bias"], rowstat=st.ptr, colsum=self.w[base + ".ln.colsum"], **kw)
         self.release(st)
 
