@@ -228,26 +228,34 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
                             if (kb + r >= p.Nk) s[q2][t][r] = NEG_BIG;
                     }
                 }
-                float mx = fmaxf(fmaxf(s[q2][0][0], s[q2][0][1]), fmaxf(s[q2][0][2], s[q2][0][3]));
-    #pragma unroll
-                for (int t = 1; t < 4; ++t)
-                    mx = fmaxf(mx, fmaxf(fmaxf(s[q2][t][0], s[q2][t][1]), fmaxf(s[q2][t][2], s[q2][t][3])));
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                // (v_max3 through asm: fmaxf() is llvm.maxnum, which in IEEE mode first quiets every MFMA result with a
+                //  v_max x, x — 12 extra instructions per query tile; the cross-lane steps are gfx950's VALU lane swaps
+                //  instead of two ds_bpermute round trips)
+                float mx = vmax3(s[q2][0][0], s[q2][0][1], s[q2][0][2]);
+                mx = vmax3(mx, s[q2][0][3], s[q2][1][0]);
+                mx = vmax3(mx, s[q2][1][1], s[q2][1][2]);
+                mx = vmax3(mx, s[q2][1][3], s[q2][2][0]);
+                mx = vmax3(mx, s[q2][2][1], s[q2][2][2]);
+                mx = vmax3(mx, s[q2][2][3], s[q2][3][0]);
+                mx = vmax3(mx, s[q2][3][1], s[q2][3][2]);
+                mx = vmax2(mx, s[q2][3][3]);
+                mx = xor16_max(mx);
                 const float m_old = m_run[qt];
-                const float m_new = fmaxf(m_old, mx);
+                const float m_new = xor32_max3(mx, m_old);
                 const float nm = -m_new * sc;
-                float psum = 0.f;
+                const f32x2_t sc2 = {sc, sc}, nm2 = {nm, nm};
+                f32x2_t ps2 = {0.f, 0.f};
                 float pv[4][4];
     #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-    #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[q2][t][r], sc, nm));
-                        pv[t][r] = e;
-                        psum += e;
-                    }
+                for (int t = 0; t < 4; ++t) {           // packed fp32: one v_pk_fma / v_pk_add per two scores
+                    f32x2_t a = {s[q2][t][0], s[q2][t][1]}, b = {s[q2][t][2], s[q2][t][3]};
+                    a = a * sc2 + nm2; b = b * sc2 + nm2;
+                    const f32x2_t ea = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+                    const f32x2_t eb = {__builtin_amdgcn_exp2f(b.x), __builtin_amdgcn_exp2f(b.y)};
+                    pv[t][0] = ea.x; pv[t][1] = ea.y; pv[t][2] = eb.x; pv[t][3] = eb.y;
+                    ps2 += ea; ps2 += eb;
                 }
+                const float psum = ps2.x + ps2.y;
                 if (__builtin_amdgcn_ballot_w64(m_new != m_old) != 0ull) {          // some query of this wave has a new maximum
                     const float alpha = __builtin_amdgcn_exp2f((m_old - m_new) * sc);
                     m_run[qt] = m_new;
@@ -290,9 +298,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
     // ---- normalise and store: lane owns O[q = q0 + 16 qt + u][d = 16 dt + 4 g + 0..3]
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        float l = l_run[qt];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        const float l = xor16_32_sum(l_run[qt]);
         const float inv = 1.0f / l;
         const int q = q0 + qt * 16 + u;
         if (wvalid && q < p.Nq) {
@@ -390,9 +396,11 @@ __global__ __launch_bounds__(256, 4) void attn_short_kernel(const VmvAttnParams 
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (8 * g + 4 * t + r >= p.Nk) s[t][r] = NEG_BIG;
-        float mx = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float mx = vmax3(s[0][0], s[0][1], s[0][2]);
+        mx = vmax3(mx, s[0][3], s[1][0]);
+        mx = vmax3(mx, s[1][1], s[1][2]);
+        mx = vmax2(mx, s[1][3]);
+        mx = xor32_max3(xor16_max(mx), NEG_BIG);
         const float nm = -mx * sc;
         float e[2][4], psum = 0.f;
 #pragma unroll
@@ -402,9 +410,7 @@ __global__ __launch_bounds__(256, 4) void attn_short_kernel(const VmvAttnParams 
                 e[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], sc, nm));
                 psum += e[t][r];
             }
-        psum += __shfl_xor(psum, 16, 64);
-        psum += __shfl_xor(psum, 32, 64);
-        linv[qt] = 1.0f / psum;
+        linv[qt] = 1.0f / xor16_32_sum(psum);
         u32x4_t w;
         w.x = pack_elem2(e[0][0], e[0][1]); w.y = pack_elem2(e[0][2], e[0][3]);
         w.z = pack_elem2(e[1][0], e[1][1]); w.w = pack_elem2(e[1][2], e[1][3]);

@@ -60,6 +60,42 @@ VMV_DEV u32x4_t pack8(const float* f) {
     return v;
 }
 
+// ---- max / cross-lane helpers of the softmax kernels.  Plain instructions through asm (not volatile: free to schedule):
+// fmaxf() lowers to llvm.maxnum, which in the kernels' IEEE mode first canonicalises each operand with a v_max x, x.
+VMV_DEV float vmax2(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+VMV_DEV float vmax3(float a, float b, float c) { float d; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+// all-reduce steps over the lane pairs l ^ 16 and l ^ 32 with gfx950's VALU lane swaps (v_permlane16_swap exchanges lanes
+// 16-31 / 48-63 of its first operand with lanes 0-15 / 32-47 of its second; v_permlane32_swap the upper half of the first
+// with the lower half of the second): called with the same value twice, the two results hold, in every lane, the lane's and
+// its partner's value — no LDS round trip as with ds_bpermute
+typedef __attribute__((ext_vector_type(2))) unsigned int vmv_u2_t;
+VMV_DEV float xor16_max(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const vmv_u2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return vmax2(__uint_as_float(r.x), __uint_as_float(r.y));
+#else
+    return x;
+#endif
+}
+VMV_DEV float xor32_max3(float x, float c) {          // max(x, partner's x, c)
+#if defined(__HIP_DEVICE_COMPILE__)
+    const vmv_u2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return vmax3(__uint_as_float(r.x), __uint_as_float(r.y), c);
+#else
+    return x > c ? x : c;
+#endif
+}
+VMV_DEV float xor16_32_sum(float x) {                 // sum over lanes l, l ^ 16, l ^ 32, l ^ 48
+#if defined(__HIP_DEVICE_COMPILE__)
+    vmv_u2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(r.x) + __uint_as_float(r.y);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+#else
+    return x;
+#endif
+}
+
 VMV_DEV float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16 output ulp): 1 rcp + 1 exp + 6 FMA,
 // ~4x cheaper than libdevice erff in the GEGLU epilogue.  gelu(x) = x * Phi(x), exact-erf form (F.gelu default).
