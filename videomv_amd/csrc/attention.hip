@@ -27,6 +27,9 @@ VMV_DEV long seq_base(const VmvSeqMap& m, int o) {
 VMV_DEV int k_swz(int key) { return (((key >> 3) & 3) << 1) | ((key >> 1) & 1); }
 
 constexpr float NEG_BIG = -1.0e30f;
+#ifndef VMV_ATTN_ABLATE
+#define VMV_ATTN_ABLATE 0   // experiments (tools/experiments/run_attn_ablate.sh): 1 no exp, 2 no softmax VALU, 3 no PV MFMAs, 4 no K/V restaging, 5 = 4 + no barrier
+#endif
 
 // QT = 16-query tiles per wave (QT = 4: 64 queries per wave, 256 per block — every K / V fragment read from LDS and
 // every staged K / V tile then serves twice the MFMAs; the LDS port, shared by all the blocks of a CU, is what bounds the
@@ -121,17 +124,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
             Vtd[d * 64 + (row ^ fk)] = val;
         }
     };
+    // V (WPP = 4) stays ROW-major in LDS — one 16-byte write per piece instead of eight scattered 2-byte writes of a
+    // transposed image — and the PV fragments come from gfx950's transpose read: ds_read_b64_tr_b16 hands lane j of a
+    // 16-lane group column j of the [4 rows][16 columns] block whose row j / 4, columns 4 (j % 4)..+3 the lanes address
+    // (tools/experiments/tr_probe.hip).  Image: per 16-d subtile (2 KB) sixteen 128-byte blocks of [4 keys][16 d]; the
+    // block of keys 32 kk + 8 g + 4 h + 0..3 sits at position (8 kk + 4 h + g) ^ (dt & 1), so that the two lane groups
+    // of a half-wave (g, g + 1) read different 128-byte bank halves.
     auto write_piece = [&](u32x4_t* Ksd, uint16_t* Vtd, int idx, const u32x4_t& kv, const u32x4_t& vv) {
         const int row = idx >> SLOG, slot = idx & (SLOTS - 1);
         Ksd[row * SLOTS + (slot ^ (k_swz(row) & (SLOTS - 1)))] = kv;
-        const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int d = slot * 8 + j;
-            const int fk = ((slot ^ (((slot & 1) << 2) | (j >> 1))) & 7) << 3;   // = 8*(((d>>3)^(d>>1))&7)
-            const uint16_t val = (j & 1) ? (uint16_t)(w[j >> 1] >> 16) : (uint16_t)(w[j >> 1] & 0xffffu);
-            Vtd[d * 64 + (row ^ fk)] = val;
-        }
+        const int dt = slot >> 1;
+        const int pos = (((row >> 5) << 3) + (((row >> 2) & 1) << 2) + ((row >> 3) & 3)) ^ (dt & 1);
+        *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned char*>(Vtd) + dt * 2048 + (pos << 7) + ((row & 3) << 5) + ((slot & 1) << 4)) = vv;
     };
     auto store_tile = [&](int buf) {
         if constexpr (WPP == 4) {
@@ -151,9 +155,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
         const u32x4_t* Ks;
         const uint16_t* Vt;
         if constexpr (WPP == 4) {
+#if VMV_ATTN_ABLATE == 4 || VMV_ATTN_ABLATE == 5
+            Ks = reinterpret_cast<const u32x4_t*>(region);
+            Vt = reinterpret_cast<const uint16_t*>(region + 8192);
+#else
             if (kt + 1 < ntile) load_tile(kt + 1);
             Ks = reinterpret_cast<const u32x4_t*>(region + (kt & 1) * 16384);
             Vt = reinterpret_cast<const uint16_t*>(region + (kt & 1) * 16384 + 8192);
+#endif
         } else {
             // One short problem per wave (the 24-frame temporal attention: HBM-bound).  Only V^T goes through LDS — the K
             // fragments are 16 contiguous bytes of a key row and are loaded straight into registers below — so a wave
@@ -231,6 +240,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
                 // (v_max3 through asm: fmaxf() is llvm.maxnum, which in IEEE mode first quiets every MFMA result with a
                 //  v_max x, x — 12 extra instructions per query tile; the cross-lane steps are gfx950's VALU lane swaps
                 //  instead of two ds_bpermute round trips)
+#if VMV_ATTN_ABLATE == 2
+                const float m_old = m_run[qt];
+                const float m_new = m_old;
+#else
                 float mx = vmax3(s[q2][0][0], s[q2][0][1], s[q2][0][2]);
                 mx = vmax3(mx, s[q2][0][3], s[q2][1][0]);
                 mx = vmax3(mx, s[q2][1][1], s[q2][1][2]);
@@ -242,6 +255,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
                 mx = xor16_max(mx);
                 const float m_old = m_run[qt];
                 const float m_new = xor32_max3(mx, m_old);
+#endif
                 const float nm = -m_new * sc;
                 const f32x2_t sc2 = {sc, sc}, nm2 = {nm, nm};
                 f32x2_t ps2 = {0.f, 0.f};
@@ -250,8 +264,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
                 for (int t = 0; t < 4; ++t) {           // packed fp32: one v_pk_fma / v_pk_add per two scores
                     f32x2_t a = {s[q2][t][0], s[q2][t][1]}, b = {s[q2][t][2], s[q2][t][3]};
                     a = a * sc2 + nm2; b = b * sc2 + nm2;
+#if VMV_ATTN_ABLATE == 1 || VMV_ATTN_ABLATE == 2
+                    const f32x2_t ea = a, eb = b;
+#else
                     const f32x2_t ea = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
                     const f32x2_t eb = {__builtin_amdgcn_exp2f(b.x), __builtin_amdgcn_exp2f(b.y)};
+#endif
                     pv[t][0] = ea.x; pv[t][1] = ea.y; pv[t][2] = eb.x; pv[t][3] = eb.y;
                     ps2 += ea; ps2 += eb;
                 }
@@ -276,22 +294,57 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
             }
         }
         // ---- O^T += V^T P^T
-        const u32x4_t* Vt16 = reinterpret_cast<const u32x4_t*>(Vt);
+        if constexpr (WPP == 4) {
+            typedef short s16x4_t __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_p;
+            const unsigned char* vlane = reinterpret_cast<const unsigned char*>(Vt) + ((u >> 2) << 5) + ((u & 3) << 3);
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const int d = dt * 16 + u;
-            const int fsl = ((d >> 3) ^ (d >> 1)) & 7;   // 8-key block swizzle of row d
+            for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const elem8_t vf = __builtin_bit_cast(elem8_t, Vt16[d * 8 + ((kk * 4 + g) ^ fsl)]);
+                for (int kk = 0; kk < 2; ++kk) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                    const unsigned char* b0 = vlane + dt * 2048 + (((kk * 8 + g) ^ (dt & 1)) << 7);
+                    const unsigned char* b1 = vlane + dt * 2048 + (((kk * 8 + 4 + g) ^ (dt & 1)) << 7);
+                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(b0));
+                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(b1));
+                    const u32x2_t lo2 = __builtin_bit_cast(u32x2_t, lo), hi2 = __builtin_bit_cast(u32x2_t, hi);
+                    const elem8_t vf = __builtin_bit_cast(elem8_t, u32x4_t{lo2.x, lo2.y, hi2.x, hi2.y});
+#else
+                    const elem8_t vf = {};
+#endif
 #pragma unroll
-                for (int qt = 0; qt < QT; ++qt)
-                    oacc[qt][dt] = VMV_MFMA16(vf, pf[qt][kk], oacc[qt][dt], 0, 0, 0);
+                    for (int qt = 0; qt < QT; ++qt) {
+#if VMV_ATTN_ABLATE == 3
+                        if (kk == 0 && dt == 0) { oacc[qt][0][0] += (float)vf[0] + (float)pf[qt][0][0] + (float)pf[qt][1][0]; }
+#else
+                        oacc[qt][dt] = VMV_MFMA16(vf, pf[qt][kk], oacc[qt][dt], 0, 0, 0);
+#endif
+                    }
+                }
+            }
+        } else {
+            const u32x4_t* Vt16 = reinterpret_cast<const u32x4_t*>(Vt);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = dt * 16 + u;
+                const int fsl = ((d >> 3) ^ (d >> 1)) & 7;   // 8-key block swizzle of row d
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const elem8_t vf = __builtin_bit_cast(elem8_t, Vt16[d * 8 + ((kk * 4 + g) ^ fsl)]);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+                        oacc[qt][dt] = VMV_MFMA16(vf, pf[qt][kk], oacc[qt][dt], 0, 0, 0);
+                }
             }
         }
         if constexpr (WPP == 4) {
+#if VMV_ATTN_ABLATE == 4
+            __syncthreads();
+#elif VMV_ATTN_ABLATE == 5
+#else
             if (kt + 1 < ntile) store_tile((kt + 1) & 1);     // the other stage: last read two tiles ago
             __syncthreads();
+#endif
         }
     }
 
