@@ -136,6 +136,10 @@ typedef struct {
 #define VMV_TILE_S256x160 17
 #define VMV_TILE_A128x160 18   /* A-stationary persistent kernel, deferred epilogue: K <= 320, wide N (gemm_astat.hip) */
 #define VMV_TILE_A128x128 19
+#define VMV_TILE_X256x320 20   /* 8 waves x 64 x {160,128,64} wave tiles, four-stage ring of 32-deep chunks (gemm_xglds.hip): the
+                                  long-K convolutions / temporal convolutions of the large levels */
+#define VMV_TILE_X256x256 21
+#define VMV_TILE_X256x128 22
 
 int vmv_gemm(const VmvGemmParams* p, void* stream);
 /* 1 if vmv_gemm accepts *p (rowstat ignored) with in-loop LayerNorm statistics (VmvGemmParams.ln_eps), else 0 */

@@ -92,7 +92,13 @@ def run_gemm(build, case, out_keys=("out",), cpu_ref=True):
                                         (70000, 320, 320, L.TILE_S192x160), (70000, 384, 128, L.TILE_S256x128),
                                         (66000, 160, 64, L.TILE_S192x160), (1000, 960, 320, L.TILE_S256x160),
                                         (70000, 320, 320, L.TILE_S256x160), (2000, 1280, 1280, L.TILE_S256x160),
-                                        (66000, 100, 72, L.TILE_S256x160)])
+                                        (66000, 100, 72, L.TILE_S256x160),
+                                        # wide-tile kernel (gemm_xglds.hip): M / N tails, several tiles per block column, K = 128 .. 1280
+                                        (640, 640, 640, L.TILE_X256x320), (1000, 960, 320, L.TILE_X256x320), (300, 320, 128, L.TILE_X256x320),
+                                        (2000, 1280, 1280, L.TILE_X256x320), (70000, 320, 320, L.TILE_X256x320), (513, 200, 192, L.TILE_X256x320),
+                                        (640, 640, 640, L.TILE_X256x256), (257, 256, 192, L.TILE_X256x256), (2000, 1280, 1280, L.TILE_X256x256),
+                                        (66000, 512, 128, L.TILE_X256x256), (640, 640, 640, L.TILE_X256x128), (257, 128, 192, L.TILE_X256x128),
+                                        (70000, 384, 128, L.TILE_X256x128)])
 def test_gemm_linear_bias(M, N, K, tile):
     c = Case(a=rnd((M, K), 1), w=rnd((N, K), 2, K ** -0.5), b=torch.randn(N, generator=g(3)), out=torch.zeros(M, N, dtype=BF))
 
@@ -134,7 +140,8 @@ def test_gemm_geglu(tile):
     check(dev["out"], x * torch.nn.functional.gelu(gate))
 
 
-@pytest.mark.parametrize("tile", [0, L.TILE_256x128, L.TILE_G128x128, L.TILE_P256x128, L.TILE_PP256x128, L.TILE_Q128x128, L.TILE_S256x128, L.TILE_S192x160, L.TILE_S256x160])
+@pytest.mark.parametrize("tile", [0, L.TILE_256x128, L.TILE_G128x128, L.TILE_P256x128, L.TILE_PP256x128, L.TILE_Q128x128, L.TILE_S256x128, L.TILE_S192x160, L.TILE_S256x160,
+                                  L.TILE_X256x320, L.TILE_X256x256, L.TILE_X256x128])
 @pytest.mark.parametrize("stride,ups,two_src,skip", [(1, 0, False, False), (2, 0, False, False), (1, 1, False, False),
                                                      (1, 0, True, True)])
 def test_gemm_conv3x3(stride, ups, two_src, skip, tile):
@@ -206,7 +213,7 @@ def test_gemm_splitk(ks, tile):
     check(dev["out"], cpu["out"])
 
 
-@pytest.mark.parametrize("tile", [L.TILE_S256x128, L.TILE_S192x160, L.TILE_S256x160, L.TILE_256x160])
+@pytest.mark.parametrize("tile", [L.TILE_S256x128, L.TILE_S192x160, L.TILE_S256x160, L.TILE_256x160, L.TILE_X256x320, L.TILE_X256x256, L.TILE_X256x128])
 def test_gemm_conv3x3_many_tiles(tile):
     """>= 2 tiles per persistent block (M = 2*24*40*64/2 rows), residual + per-image row vector, two sources + 1x1 skip."""
     n, IH, IW, C0, C1, N = 24, 40, 64, 64, 32, 320
@@ -231,7 +238,7 @@ def test_gemm_conv3x3_many_tiles(tile):
     check(dev["out"], ref.permute(0, 2, 3, 1).reshape(M, N))
 
 
-@pytest.mark.parametrize("tile", [L.TILE_S256x128, L.TILE_S192x160, L.TILE_S256x160])
+@pytest.mark.parametrize("tile", [L.TILE_S256x128, L.TILE_S192x160, L.TILE_S256x160, L.TILE_X256x320, L.TILE_X256x256])
 def test_gemm_temporal_conv_many_tiles(tile):
     Bn, F_, Pp, Cc = 2, 24, 1280, 320
     M = Bn * F_ * Pp
@@ -247,6 +254,21 @@ def test_gemm_temporal_conv_many_tiles(tile):
     ref = torch.nn.functional.conv3d(x5, wt.to(BF).float(), cpu["b"], padding=(1, 0, 0))
     ref = ref[..., 0].permute(0, 2, 3, 1).reshape(M, Cc) + cpu["res"].float()
     check(dev["out"], ref)
+
+
+@pytest.mark.parametrize("tile", [L.TILE_X256x320, L.TILE_X256x128])
+def test_gemm_wide_tile_rowvec_act_residual(tile):
+    """The wide-tile kernel's staged epilogue: bias + per-group row vector + SiLU + scaled residual, 16-bit output, M tail."""
+    M, N, K = 1000, 320, 256
+    c = Case(a=rnd((M, K), 1), w=rnd((N, K), 2, K ** -0.5), b=torch.randn(N, generator=g(3)),
+             rv=torch.randn((M + 63) // 64, 512, generator=g(4)), res=rnd((M, N), 5), out=torch.zeros(M, N, dtype=BF))
+
+    def build(t):
+        return ops.gemm_params(M, N, ops.linear_segs([(t["a"], K, K)]), t["w"], t["out"], N, bias=t["b"],
+                               rowvec=t["rv"].data_ptr() + 4 * 64, rowvec_div=64, rowvec_ld=512, act=L.ACT_SILU,
+                               residual=t["res"], ldr=N, res_scale=0.5, tile=tile)
+    cpu, dev = run_gemm(build, c)
+    check(dev["out"], cpu["out"])
 
 
 def test_gemm_geglu_many_tiles():

@@ -73,6 +73,8 @@ def main():
         for tile in tiles:
             if tile in N160 and (N % 160 or kind in ("geglu", "lngeglu")):
                 line += "      -    "; continue
+            if tile in (L.TILE_X256x320, L.TILE_X256x256, L.TILE_X256x128) and (kind in ("geglu", "lngeglu", "lnlin") or (tile == L.TILE_X256x320 and N % 320)):
+                line += "      -    "; continue
             stamps = torch.zeros(8 * 64, dtype=torch.int64, device=dev) if os.environ.get("VMV_GEMM_ABLATE") in ("4", "7", "8") else None
             ks = int(os.environ.get("VMV_BENCH_KSPLIT", "0"))
             if ks > 1:

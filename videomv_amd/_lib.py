@@ -49,6 +49,7 @@ TILE_G128x128, TILE_G128x160, TILE_P256x128, TILE_P256x160, TILE_PP256x128, TILE
 TILE_Q128x128, TILE_Q96x160 = 13, 14
 TILE_S256x128, TILE_S192x160, TILE_S256x160 = 15, 16, 17
 TILE_A128x160, TILE_A128x128 = 18, 19
+TILE_X256x320, TILE_X256x256, TILE_X256x128 = 20, 21, 22
 OP_GEMM, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTENTION, OP_SOFTMAX, OP_COPY, OP_GN_FUSED = 1, 2, 3, 4, 5, 6, 7, 8
 GN_FUSED_BYTES = 131072
 

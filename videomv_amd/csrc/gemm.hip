@@ -22,6 +22,7 @@ using namespace vmvg;
 int vmv_gemm_glds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st);   // gemm_glds.hip
 int vmv_gemm_pglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st);  // gemm_pglds.hip
 bool vmv_gemm_pglds_supported(const VmvGemmParams& p);
+int vmv_gemm_xglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st);  // gemm_xglds.hip
 int vmv_gemm_sglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st);  // gemm_sglds.hip
 int vmv_gemm_astat_launch(const VmvGemmParams& p, int tile, hipStream_t st);                   // gemm_astat.hip
 bool vmv_gemm_astat_eligible(const VmvGemmParams& p);
@@ -291,9 +292,33 @@ int tile_override(int which) {
     return ov[which];
 }
 
+int xglds_policy() {
+    // VMV_GEMM_XGLDS (A/B experiments): 1 (default) = the wide-tile kernel (gemm_xglds.hip: 256 x 320 tiles, 64 x 160 wave tiles,
+    // four-stage ring of 32-deep chunks) takes the long-K GATHERED GEMMs — 3x3 convolutions, temporal convolutions — whose
+    // tiles fill the chip (the two large levels); 0 = off.  Measured (round 2, one box): L0 conv 785 -> 929, L0 temporal conv
+    // 687 -> 759, L1 conv 996 -> 1072, L1 temporal conv 882 -> 921 TFLOP/s; the plain-row linears (FF down, K = 1280 / 2560) are
+    // 1-5 % faster on the persistent kernel and stay there; full step -0.8 ms.
+    static int pol = -1;
+    if (pol < 0) {
+        const char* e = getenv("VMV_GEMM_XGLDS");
+        pol = e ? atoi(e) : 1;
+    }
+    return pol;
+}
+
 int pick_tile(const VmvGemmParams& p, int total_steps) {
     if (p.tile != VMV_TILE_AUTO) return p.tile;
     const int geglu = p.epilogue == VMV_EPI_GEGLU;
+    if (gemm_policy() >= 2 && xglds_policy() && !geglu && p.ksplit <= 1 && !p.rowstat && !vmv_gemm_ln_inline(p) && total_steps >= 12 &&
+        p.N % 320 == 0) {
+        bool any_gather = false;
+        for (int i = 0; i < p.nseg; ++i) any_gather = any_gather || p.seg[i].mode != VMV_SEG_LINEAR;
+        // one 256 x 320 tile costs about 2 / 1.1 tiles of the 256 x 160 kernel: take it when its rounds over the 256 CUs are
+        // no more than that many of the other's (the two large levels; at the third, 120 tiles would leave half the chip idle)
+        const long tm = (p.M + 255) / 256;
+        const long rounds_x = (tm * (p.N / 320) + 255) / 256, rounds_g = (tm * (p.N / 160) + 255) / 256;
+        if (any_gather && 20 * rounds_x <= 11 * rounds_g) return VMV_TILE_X256x320;
+    }
     {
         bool lin = p.ksplit <= 1 && total_steps <= 24 && p.M >= 16384;
         for (int i = 0; i < p.nseg; ++i) lin = lin && p.seg[i].mode == VMV_SEG_LINEAR;
@@ -430,6 +455,16 @@ extern "C" int vmv_gemm(const VmvGemmParams* pp, void* stream) {
             rc = vmv_gemm_sglds_launch(p, total_steps, picked, st);
             if (rc == VMV_GLDS_UNSUPPORTED) rc = vmv_gemm_glds_launch(p, total_steps, VMV_TILE_256x160, st);
             if (rc == VMV_GLDS_UNSUPPORTED) rc = launch_cfg<4, 5>(p, total_steps, st);
+            break;
+        case VMV_TILE_X256x320:
+        case VMV_TILE_X256x256:
+        case VMV_TILE_X256x128:
+            rc = vmv_gemm_xglds_launch(p, total_steps, picked, st);
+            if (rc == VMV_GLDS_UNSUPPORTED) {
+                if (p.tile != VMV_TILE_AUTO) return VMV_EINVAL;
+                rc = vmv_gemm_glds_launch(p, total_steps, p.N % 160 == 0 ? VMV_TILE_256x160 : VMV_TILE_256x128, st);
+                if (rc == VMV_GLDS_UNSUPPORTED) rc = p.N % 160 == 0 ? launch_cfg<4, 5>(p, total_steps, st) : launch_cfg<4, 4>(p, total_steps, st);
+            }
             break;
         case VMV_TILE_A128x160:
         case VMV_TILE_A128x128:

@@ -1,0 +1,332 @@
+// gemm_xglds.hip — 8-wave LDS-DMA implicit GEMM with WIDE wave tiles and a four-stage ring of 32-deep chunks (same contract
+// as gemm.hip / vmv.h).
+//
+// Why: per 64-deep chunk of its 256 x 160 tile gemm_glds.hip's eight 64 x 80 wave tiles pull 147 KB of fragments out of LDS
+// and the LDS-DMA writes 52 KB into it (~1570 cycles of the 128 B/clk port) and the CU's DMA path needs ~1350 cycles for the
+// 52 1-KB wave-instructions — against 1280 cycles of MFMAs per SIMD.  The long-K convolutions therefore sit at ~43 % of peak
+// with three units equally busy.  Here the block tile is 256 x 320 (N = 320 / 640 / 1280 are all multiples) and a wave owns
+// 64 x 160: per MAC 22 % fewer fragment bytes and 31 % fewer DMA bytes; per barrier interval (one 32-deep chunk: 1280 MFMA
+// cycles per SIMD) the LDS port is busy ~1180 cycles and the DMA path ~940.
+// 160 accumulators per lane leave room for ONE double-buffered half-chunk of fragments: a chunk is two phases of 20 MFMAs
+// (column half h), the fragment reads of the next phase (5 W fragments, plus the 4 A fragments when the chunk changes) are
+// issued before the MFMAs of the current one; the second wave of the SIMD covers what latency remains.  A 72-KB stage per
+// 64-deep chunk would allow two stages only, hence 32-deep chunks (36 KB) and FOUR stages: chunk t + 4 goes out behind the
+// block barrier of step t.  LDS rows are 64 B: logical 16-byte k-slot s of row r sits at s ^ ((r >> 2) & 3).  Zero fill by
+// descriptor and the K-segment walk are those of gemm_glds.hip; no split-K, no GEGLU, no folded LayerNorm.
+// (tools/experiments/gemm_wglds.hip is the 4-wave / 512-register sibling that lost to LDS-DMA issue stalls.)
+#include "gemm_glds_common.h"
+#include <cstdlib>
+#include <type_traits>
+
+using namespace vmvg;
+
+namespace {
+
+constexpr int WBK = 32;                 // this kernel's K chunk: ONE k-step of v_mfma_f32_16x16x32 (see above)
+
+template <int NH, int WH>
+struct WgCfg {
+    static constexpr int WM = 4, WN = NH * WH;              // 16-row / 16-column MFMA tiles per wave
+    static constexpr int NW = 8, NT = 512;                  // 4 waves along M x 2 along N
+    static constexpr int BM = 64 * WM, BN = 32 * WN;
+    static constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64;         // rows of 32 elements = 64 B
+    static constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
+    static constexpr int STAGES = 4;
+    static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
+    static constexpr int NAI = BM / (16 * NW);              // A wave-instructions per wave per chunk (16 rows x 64 B each) = 2
+    static constexpr int WGROUPS = BN / 16;                 // 16-row groups of W per chunk (20 at BN = 320)
+    static constexpr int NWI = WGROUPS / NW;                // W wave-instructions of EVERY wave per chunk ...
+    static constexpr int NWX = WGROUPS % NW;                // ... and one more for the waves < NWX
+    static constexpr int LPT = NAI + NWI;                   // loads per lane per chunk (waves < NWX: LPT + 1)
+    static constexpr int HALF_ROWS = 128;                   // epilogue staging: half a tile at a time
+    static_assert(HALF_ROWS * (BN * 2 + 16) <= LDS_BYTES && LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+struct WRow {        // gather state of one A row of the lane beyond its index m (recomputed: it lives beside 160 accumulators)
+    int nb;          // spatial: image base row (n * IH * IW); temporal: frame index
+    int yx;          // spatial: (oy << 16) | ox
+};
+
+template <int NH, int WH>
+__global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams p, const int tiles_m, const int tiles_n, const int nsteps) {
+    using Cfg = WgCfg<NH, WH>;
+    constexpr int WM = Cfg::WM, WN = Cfg::WN, NW = Cfg::NW, BM = Cfg::BM, BN = Cfg::BN, S = Cfg::STAGES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+
+    // ---- XCD-aware tile mapping (bijective, as gemm_glds.hip)
+    const int nblk = tiles_m * tiles_n;
+    int logical;
+    {
+        const int bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (logical / tiles_n) * BM, n0 = (logical % tiles_n) * BN;
+
+    // ---- loader.  A wave instruction covers 16 rows x 64 B; lane -> (row in group = lane >> 2, physical 16-B slot = lane & 3).
+    //      Row r keeps logical k-slot s at s ^ ((r >> 2) & 3) — the 16 lanes of a fragment read (rows r .. r + 15, one logical
+    //      slot) then touch all 64 banks once — applied to the SOURCE address (the LDS image of a DMA is lane-linear); for the
+    //      rows of this lane (16 g + (lane >> 2)) the term is (lane >> 4) & 3.
+    const int lrow = lane >> 2;
+    const int lsw = (lane & 3) ^ ((lane >> 4) & 3);
+    WRow rows[Cfg::NAI];
+#pragma unroll
+    for (int i = 0; i < Cfg::NAI; ++i) {
+        const int m = m0 + (i * NW + wave) * 16 + lrow;
+        WRow r;
+        r.nb = 0; r.yx = 0;
+        if (p.OH > 0) {
+            const int hw = p.OH * p.OW;
+            const int n = m / hw, rem = m - n * hw;
+            const int oy = rem / p.OW;
+            r.nb = n * p.IH * p.IW;
+            r.yx = (oy << 16) | (rem - oy * p.OW);
+        } else if (p.P > 0) {
+            r.nb = (m / p.P) % p.F;
+        }
+        rows[i] = r;
+    }
+    auto row_offset = [&](const VmvGemmSeg& sg, const WRow& r, const int m) -> int {       // element offset of the source row, or -1 (zero row)
+        if (m >= p.M) return -1;
+        if (sg.mode == VMV_SEG_LINEAR) return m * sg.ld;
+        if (sg.mode == VMV_SEG_SPATIAL) {
+            const int iy = (r.yx >> 16) * p.stride + sg.d0;
+            const int ix = (r.yx & 0xffff) * p.stride + sg.d1;
+            const int VH = p.IH << p.ups, VW = p.IW << p.ups;
+            if (iy < 0 || iy >= VH || ix < 0 || ix >= VW) return -1;
+            return (r.nb + (iy >> p.ups) * p.IW + (ix >> p.ups)) * sg.ld;
+        }
+        const int f = r.nb + sg.d0;
+        if (f < 0 || f >= p.F) return -1;
+        return (m + sg.d0 * p.P) * sg.ld;
+    };
+    // weights: this lane's row of W group j is n0 + (j NW + wave) 16 + lrow — linear in j, so ONE offset register; rows >= N
+    // fall outside the descriptor and read as zero
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, (uint32_t)p.N * (uint32_t)p.ktot * 2u, SRD_FLAGS);
+    const uint32_t wvo0 = (uint32_t)((n0 + wave * 16 + lrow) * p.ktot + lsw * 8) * 2u;
+    const uint32_t wstride = (uint32_t)(NW * 16 * p.ktot) * 2u;
+
+    int s = 0, kc = 0, koff = 0;
+    uint32_t avo[Cfg::NAI];
+    auto enter_segment = [&]() {
+#pragma unroll
+        for (int i = 0; i < Cfg::NAI; ++i) {
+            const int off = row_offset(p.seg[s], rows[i], m0 + (i * NW + wave) * 16 + lrow);
+            avo[i] = off >= 0 ? (uint32_t)(off + lsw * 8) * 2u : OOB;
+        }
+    };
+    enter_segment();
+    auto issue = [&](int stage) {           // LDS-DMA one chunk into ring slot `stage`, then advance the K walk
+        const VmvGemmSeg& sg = p.seg[s];
+        const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(sg.src), 0, SRD_RECORDS, SRD_FLAGS);
+        const bool kvalid = (kc + WBK) <= sg.k || (kc + lsw * 8) < sg.k;      // k tail of a segment: zero fill
+        unsigned char* abase = smem + stage * Cfg::STAGE_BYTES + wave * 1024;
+        unsigned char* wbase = smem + stage * Cfg::STAGE_BYTES + Cfg::A_BYTES + wave * 1024;
+        const uint32_t a_so = (uint32_t)kc * 2u, w_so = (uint32_t)(koff + kc) * 2u;
+#pragma unroll
+        for (int i = 0; i < Cfg::NAI; ++i) VMV_BLDS16(a_rsrc, abase + i * (NW * 1024), kvalid ? avo[i] : OOB, a_so);
+#pragma unroll
+        for (int j = 0; j < Cfg::NWI; ++j) VMV_BLDS16(w_rsrc, wbase + j * (NW * 1024), kvalid ? wvo0 + (uint32_t)j * wstride : OOB, w_so);
+        if (Cfg::NWX > 0 && wave < Cfg::NWX)
+            VMV_BLDS16(w_rsrc, wbase + Cfg::NWI * (NW * 1024), kvalid ? wvo0 + (uint32_t)Cfg::NWI * wstride : OOB, w_so);
+        kc += WBK;
+        if (kc >= sg.k) {
+            koff += sg.k; ++s; kc = 0;
+            if (s < p.nseg) enter_segment();
+        }
+    };
+
+    // ---- MFMA side
+    f32x4_t acc[WN][WM];
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int i = 0; i < WM; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fgrp = lane >> 4;
+    const int fslot = fgrp ^ ((frow >> 2) & 3);             // physical 16-B slot of this lane's k-slice in every fragment row
+    elem8_t af[2][WM], wf[2][WH];
+    auto read_a = [&](int slot_idx, elem8_t (&a)[WM]) {
+        const u32x4_t* ap = reinterpret_cast<const u32x4_t*>(smem + slot_idx * Cfg::STAGE_BYTES) + (wave_m * 16 * WM + frow) * 4 + fslot;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a[i] = __builtin_bit_cast(elem8_t, ap[i * 16 * 4]);
+    };
+    auto read_w = [&](int slot_idx, int h, elem8_t (&w)[WH]) {
+        const u32x4_t* wp = reinterpret_cast<const u32x4_t*>(smem + slot_idx * Cfg::STAGE_BYTES + Cfg::A_BYTES) +
+                            (wave_n * 16 * WN + h * 16 * WH + frow) * 4 + fslot;
+#pragma unroll
+        for (int j = 0; j < WH; ++j) w[j] = __builtin_bit_cast(elem8_t, wp[j * 16 * 4]);
+    };
+    // A chunk is NH phases of WM * WH MFMAs (column half h).  Phase (t, h) multiplies af[t & 1] with wf[(t NH + h) & 1]; the
+    // fragments of the NEXT phase are read before its MFMAs are issued.  The chunk parity is a compile-time value: the loop
+    // body covers two chunks.
+    auto mma_phase = [&](auto par_tag, auto h_tag) {
+        constexpr int par = decltype(par_tag)::value, h = decltype(h_tag)::value;
+        constexpr int ws = (par * NH + h) & 1;
+#pragma unroll
+        for (int j = 0; j < WH; ++j)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+                acc[h * WH + j][i] = VMV_MFMA16(wf[ws][j], af[par][i], acc[h * WH + j][i], 0, 0, 0);
+    };
+    auto prefetch_phase = [&](int slot_idx, auto par_tag, auto h_tag) {     // the fragment reads phase (par, h) needs
+        constexpr int par = decltype(par_tag)::value, h = decltype(h_tag)::value;
+        if constexpr (h == 0) read_a(slot_idx, af[par]);
+        read_w(slot_idx, h, wf[(par * NH + h) & 1]);
+    };
+
+    // (the launcher guarantees an even nsteps >= S: the loop body is two chunks, the fragment-set parity a compile-time value)
+    int issued = 0;
+#pragma unroll
+    for (int i = 0; i < S; ++i) { issue(i); ++issued; }
+    const bool xw = Cfg::NWX > 0 && wave < Cfg::NWX;          // this wave issues LPT + 1 loads per chunk (uniform)
+    if (xw) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 1) * (Cfg::LPT + 1)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 1) * Cfg::LPT) : "memory");      // chunk 0 landed (mine)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    prefetch_phase(0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    int st = 0;
+    auto chunk = [&](int t, auto par_tag) {
+        constexpr int par = decltype(par_tag)::value;
+        using P0 = std::integral_constant<int, par>;
+        using P1 = std::integral_constant<int, par ^ 1>;
+        using H0 = std::integral_constant<int, 0>;
+        using H1 = std::integral_constant<int, 1>;
+        const int stn = st + 1 == S ? 0 : st + 1;
+        if constexpr (NH == 2) {
+            prefetch_phase(st, P0{}, H1{});
+            __builtin_amdgcn_sched_barrier(0);
+            mma_phase(P0{}, H0{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // last phase of the chunk: chunk t + 1 must have landed (for every wave) and every wave must be done with slot st
+        if (t + 1 < nsteps) {
+            // steady state: chunks t + 2, t + 3 stay in flight; in the tail (nothing left to issue) simply drain
+            if (t + S > nsteps) wait_vmcnt<0>();
+            else if (xw) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * (Cfg::LPT + 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * Cfg::LPT) : "memory");
+            __builtin_amdgcn_s_waitcnt(0xc07f);               // my fragment reads of slot st are done
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            prefetch_phase(stn, P1{}, H0{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mma_phase(P0{}, std::integral_constant<int, NH - 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (issued < nsteps) { issue(st); ++issued; }         // chunk t + S into the slot the barrier freed
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        st = stn;
+    };
+    for (int t = 0; t < nsteps; t += 2) {
+        chunk(t, std::integral_constant<int, 0>{});
+        chunk(t + 1, std::integral_constant<int, 1>{});
+    }
+
+    // ---- epilogue
+    const int mbase = m0 + wave_m * 16 * WM + frow;
+    const int nbase = n0 + wave_n * 16 * WN + 4 * fgrp;
+    // (the launcher only sends GEMMs whose outputs can be staged: 16-bit, 16-byte aligned rows)
+    // 16-bit outputs go through LDS (whole rows, 16-byte lanes, residual read the same way), half a tile (the two waves of
+    // one wave row) at a time: the ring holds 128 rows of BN outputs
+    constexpr int row_bytes = BN * 2 + 16;          // +16 B: spreads the 8-byte writes over the banks
+    constexpr int U = BN >> 3;                      // 16-byte units per tile row
+    uint16_t* outp = reinterpret_cast<uint16_t*>(p.out);
+    const uint16_t* resp = reinterpret_cast<const uint16_t*>(p.residual);
+    const float rs = p.res_scale != 0.f ? p.res_scale : 1.f;
+#pragma unroll 1
+    for (int hh = 0; hh < 2; ++hh) {
+        __syncthreads();                            // ring (or the previous half's slab) no longer read by anyone
+        if ((wave_m >> 1) == hh) {
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int n = nbase + 16 * j;
+                f32x4_t bias = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                if (p.bias && n < p.N) bias = *reinterpret_cast<const f32x4_t*>(p.bias + n);
+#pragma unroll
+                for (int i = 0; i < WM; ++i) {
+                    const int m = mbase + 16 * i;
+                    f32x4_t v = acc[j][i] + bias;
+                    if (n < p.N) {
+                        if (p.rowvec && m < p.M)
+                            v += *reinterpret_cast<const f32x4_t*>(p.rowvec + (size_t)(m / p.rowvec_div) * p.rowvec_ld + n);
+                        if (p.act == VMV_ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+                    }
+                    u32x2_t o;
+                    o.x = pack_elem2(v.x, v.y); o.y = pack_elem2(v.z, v.w);
+                    *reinterpret_cast<u32x2_t*>(smem + ((wave_m & 1) * 16 * WM + 16 * i + frow) * row_bytes + (wave_n * 16 * WN + 16 * j + 4 * fgrp) * 2) = o;
+                }
+            }
+        }
+        __syncthreads();
+        // Store-data discipline (see gemm_pglds.hip): the stored registers are a VALU-written copy, never the destination of an
+        // LDS read, and the previous iteration's copy stays alive until this iteration's LDS read has returned.
+        u32x4_t sd_prev = u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll 1
+        for (int idx = tid; idx < Cfg::HALF_ROWS * U; idx += Cfg::NT) {
+            const int r = idx / U, u = idx - r * U;
+            const int m = m0 + hh * Cfg::HALF_ROWS + r, n = n0 + u * 8;
+            if (m >= p.M || n >= p.N) continue;
+            u32x4_t v = *reinterpret_cast<const u32x4_t*>(smem + r * row_bytes + u * 16);
+            if (resp) {
+                const u32x4_t rr = *reinterpret_cast<const u32x4_t*>(resp + (size_t)m * p.ldr + n);
+                float a[8], b[8];
+                unpack8(v, a); unpack8(rr, b);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] += rs * b[e];
+                v = pack8(a);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            asm volatile("" ::"v"(sd_prev));
+            u32x4_t sd;
+            asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                         : "=&v"(sd.x), "=&v"(sd.y), "=&v"(sd.z), "=&v"(sd.w)
+                         : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+            *reinterpret_cast<u32x4_t*>(outp + (size_t)m * p.ldo + n) = sd;
+            sd_prev = sd;
+        }
+    }
+}
+
+template <int NH, int WH>
+int launch_xglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
+    using Cfg = WgCfg<NH, WH>;
+    const int tiles_m = (p.M + Cfg::BM - 1) / Cfg::BM;
+    const int tiles_n = (p.N + Cfg::BN - 1) / Cfg::BN;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_xglds_kernel<NH, WH>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    int nsteps = 0;                                          // chunks of WBK = 32 (total_steps counts the other kernels' 64)
+    for (int i = 0; i < p.nseg; ++i) nsteps += (p.seg[i].k + WBK - 1) / WBK;
+    (void)total_steps;
+    if (nsteps < Cfg::STAGES || (nsteps & 1)) return VMV_GLDS_UNSUPPORTED;
+    hipLaunchKernelGGL((gemm_xglds_kernel<NH, WH>), dim3(tiles_m * tiles_n), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n, nsteps);
+    return vmv_launch_status();
+}
+
+}  // namespace
+
+// Called by vmv_gemm (gemm.hip) after argument validation.
+int vmv_gemm_xglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st) {
+    if (p.ksplit > 1 || p.epilogue == VMV_EPI_GEGLU || p.rowstat || vmv_gemm_ln_inline(p)) return VMV_GLDS_UNSUPPORTED;
+    long maxrows = p.M;
+    if (p.OH > 0) { const long src_rows = (long)(p.M / (p.OH * p.OW) + 1) * p.IH * p.IW; if (src_rows > maxrows) maxrows = src_rows; }
+    for (int i = 0; i < p.nseg; ++i)
+        if (maxrows * (long)p.seg[i].ld * 2 >= (1L << 31) - 65536) return VMV_GLDS_UNSUPPORTED;
+    if ((long)(p.N + 320) * p.ktot * 2 >= (1L << 31) - 65536) return VMV_GLDS_UNSUPPORTED;
+    if (p.OH > 0 && (p.OH >= 32768 || p.OW >= 32768)) return VMV_GLDS_UNSUPPORTED;      // (oy, ox) packed in one register
+    if (p.out_fp32 || (p.ldo & 7) || (p.N & 7) || !vmv_aligned16(p.out) ||
+        (p.residual && ((p.ldr & 7) || !vmv_aligned16(p.residual)))) return VMV_GLDS_UNSUPPORTED;   // staged epilogue only
+    if (tile == VMV_TILE_X256x320) return launch_xglds<2, 5>(p, total_steps, st);
+    if (tile == VMV_TILE_X256x256) return launch_xglds<2, 4>(p, total_steps, st);
+    if (tile == VMV_TILE_X256x128) return launch_xglds<1, 4>(p, total_steps, st);
+    return VMV_EINVAL;
+}
