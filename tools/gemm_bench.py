@@ -39,6 +39,9 @@ def main():
         ("conv L3 1280", 1920, 1280, 1280, "conv"), ("conv L3 2560->1280", 1920, 1280, 2560, "conv"),
         ("tcnv L3 1280", 1920, 1280, 1280, "tconv"), ("down L3 N1280 K5120", 1920, 1280, 5120, "linres"),
         ("lin+res L3 N1280 K1280", 1920, 1280, 1280, "linres"),
+        # VAE decoder levels at 24 frames of 320 x 512 (decode_views takes all frames in one plan)
+        ("vae conv 512 @80x128", 24 * 80 * 128, 512, 512, "conv"), ("vae conv 256 @160x256", 24 * 160 * 256, 256, 256, "conv"),
+        ("vae conv 128 @320x512", 24 * 320 * 512, 128, 128, "conv"),
     ]
     flt = os.environ.get("VMV_BENCH_SHAPES", "")
     for name, M, N, C, kind in shapes:
@@ -59,7 +62,8 @@ def main():
                 kw["epilogue"] = L.EPI_GEGLU; No = N // 2
         elif kind == "conv":
             K = 9 * C; segs = ops.conv3x3_segs([(x, C, C)])
-            hw = {M0: (40, 64), M1: (20, 32), M2: (10, 16), 1920: (5, 8)}[M]
+            hw = {M0: (40, 64), M1: (20, 32), M2: (10, 16), 1920: (5, 8), 24 * 80 * 128: (80, 128), 24 * 160 * 256: (160, 256),
+                  24 * 320 * 512: (320, 512)}[M]
             geom = ops.Geom(OH=hw[0], OW=hw[1], IH=hw[0], IW=hw[1])
         else:
             K = 3 * C; segs = ops.temporal_segs(x, C, C); geom = ops.Geom(F=24, P=M // 48)

@@ -295,9 +295,10 @@ int tile_override(int which) {
 int xglds_policy() {
     // VMV_GEMM_XGLDS (A/B experiments): 1 (default) = the wide-tile kernel (gemm_xglds.hip: 256 x 320 tiles, 64 x 160 wave tiles,
     // four-stage ring of 32-deep chunks) takes the long-K GATHERED GEMMs — 3x3 convolutions, temporal convolutions — whose
-    // tiles fill the chip (the two large levels); 0 = off.  Measured (round 2, one box): L0 conv 785 -> 929, L0 temporal conv
-    // 687 -> 759, L1 conv 996 -> 1072, L1 temporal conv 882 -> 921 TFLOP/s; the plain-row linears (FF down, K = 1280 / 2560) are
-    // 1-5 % faster on the persistent kernel and stay there; full step -0.8 ms.
+    // tiles fill the chip (the two large levels); 0 = off.  Measured (round 2, one box): L0 conv 806 -> 953, L0 temporal conv
+    // 683 -> 787, L1 conv 1040 -> 1140, L1 temporal conv 901 -> 980, VAE 512- / 256-channel convs +12 / +9 % (256 x 256 tiles) TFLOP/s;
+    // the plain-row linears (FF down, K = 1280 / 2560) are 1-5 % faster on the persistent kernel and the 128-channel VAE level on
+    // gemm_glds, and stay there; full step -0.9 ms.
     static int pol = -1;
     if (pol < 0) {
         const char* e = getenv("VMV_GEMM_XGLDS");
@@ -310,14 +311,16 @@ int pick_tile(const VmvGemmParams& p, int total_steps) {
     if (p.tile != VMV_TILE_AUTO) return p.tile;
     const int geglu = p.epilogue == VMV_EPI_GEGLU;
     if (gemm_policy() >= 2 && xglds_policy() && !geglu && p.ksplit <= 1 && !p.rowstat && !vmv_gemm_ln_inline(p) && total_steps >= 12 &&
-        p.N % 320 == 0) {
+        (p.N % 320 == 0 || p.N % 256 == 0)) {
         bool any_gather = false;
         for (int i = 0; i < p.nseg; ++i) any_gather = any_gather || p.seg[i].mode != VMV_SEG_LINEAR;
-        // one 256 x 320 tile costs about 2 / 1.1 tiles of the 256 x 160 kernel: take it when its rounds over the 256 CUs are
-        // no more than that many of the other's (the two large levels; at the third, 120 tiles would leave half the chip idle)
+        // one 256 x 320 (256 x 256) tile costs about 2 / 1.1 tiles of the 256 x 160 (256 x 128) kernel: take it when its rounds over
+        // the 256 CUs are no more than that many of the other's (the UNet's two large levels, the VAE's 256- / 512-channel
+        // levels at 24 frames; at the UNet's third level 120 tiles would leave half the chip idle)
+        const int bx = p.N % 320 == 0 ? 320 : 256;
         const long tm = (p.M + 255) / 256;
-        const long rounds_x = (tm * (p.N / 320) + 255) / 256, rounds_g = (tm * (p.N / 160) + 255) / 256;
-        if (any_gather && 20 * rounds_x <= 11 * rounds_g) return VMV_TILE_X256x320;
+        const long rounds_x = (tm * (p.N / bx) + 255) / 256, rounds_g = (tm * (p.N / (bx / 2)) + 255) / 256;
+        if (any_gather && 20 * rounds_x <= 11 * rounds_g) return bx == 320 ? VMV_TILE_X256x320 : VMV_TILE_X256x256;
     }
     {
         bool lin = p.ksplit <= 1 && total_steps <= 24 && p.M >= 16384;
