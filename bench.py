@@ -236,7 +236,7 @@ def main():
             traffic = round(tj["bytes_per_launch"])
             traffic_src = (f"profiles/r2_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
                            f"separate runs, commit {tj.get('commit', '?')}, dtype {tj.get('dtype', '?')})")
-        roof = dict(bound="mfma", kernel="16-bit MFMA implicit-GEMM family (gemm_glds_kernel / gemm_pglds_kernel / gemm_kernel: "
+        roof = dict(bound="mfma", kernel="16-bit MFMA implicit-GEMM family (gemm_xglds_kernel / gemm_glds_kernel / gemm_pglds_kernel / gemm_kernel: "
                     "conv3x3, temporal conv, linear)",
                     achieved=round(ach, 1), peak=PEAK_MFMA16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_MFMA16_TFLOPS, 4),
                     traffic=traffic, traffic_source=traffic_src,
@@ -259,7 +259,7 @@ def main():
                     f.write(f"{i}\t{labels[i]}\t{ms[i]:.4f}\t{fl / 1e9:.2f}\t{(fl / (ms[i] * 1e-3) / 1e12) if fl else 0:.1f}\n")
 
     def headline():
-        return {"metric": "denoise-steps/sec, t2v 320x512x24 (latent 24x%dx%d), CFG 9.0, 50-step DDIM schedule" % (H, W),
+        return {"metric": "denoise-steps/sec, t2v %dx%dx%d (latent %dx%dx%d), CFG 9.0, 50-step DDIM schedule" % (8 * H, 8 * W, args.frames, args.frames, H, W),
                "value": round(steps_per_s, 4), "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": L.elem_name(), "data": "synthetic (seeded randn latents/text, real orbit cameras; random-init "
