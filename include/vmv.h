@@ -144,6 +144,9 @@ typedef struct {
 int vmv_gemm(const VmvGemmParams* p, void* stream);
 /* 1 if vmv_gemm accepts *p (rowstat ignored) with in-loop LayerNorm statistics (VmvGemmParams.ln_eps), else 0 */
 int vmv_gemm_ln_inline_ok(const VmvGemmParams* p);
+/* the VMV_TILE_* configuration vmv_gemm's policy picks for *p when p->tile == VMV_TILE_AUTO (p->tile otherwise); host logic only:
+ * no launch, no device access (a launcher may still fall back when it cannot address the operands) */
+int vmv_gemm_pick_tile(const VmvGemmParams* p);
 
 /* ------------------------------------------------------------------------------------------------------
  * GroupNorm(32 groups) over row blocks + optional SiLU (torch group_norm + silu: util.py:329,649,673,1014,

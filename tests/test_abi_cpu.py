@@ -68,3 +68,37 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(L, "lib_path", lambda: "/nonexistent/libvmv_hip_f16.so")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         L.load()
+
+
+def test_gemm_tile_policy(monkeypatch):
+    """vmv_gemm_pick_tile (host logic): which kernel family the default policy gives the UNet's / VAE's characteristic GEMMs at
+    latent 24x40x64 — pins DESIGN 4.1's table (pointers are never dereferenced: fake non-null addresses)."""
+    for k in ("VMV_GEMM_POLICY", "VMV_GEMM_XGLDS", "VMV_GEMM_ASTAT", "VMV_GEMM_TILE_GEGLU", "VMV_GEMM_TILE_LIN160", "VMV_GEMM_TILE_LIN128"):
+        assert k not in os.environ, "policy overrides must be unset for this test"
+    lib = L.load()
+    X = 1 << 20          # any non-null, 16-byte aligned address
+
+    def pick(M, N, segs, geom=None, **kw):
+        p = ops.gemm_params(M, N, segs, X, X, N // 2 if kw.get("epilogue") == L.EPI_GEGLU else N, geom=geom, **kw)
+        return lib.vmv_gemm_pick_tile(C.byref(p))
+    M0, M1, M2, M3 = 122880, 30720, 7680, 1920
+    g0, g1, g2 = ops.Geom(OH=40, OW=64, IH=40, IW=64), ops.Geom(OH=20, OW=32, IH=20, IW=32), ops.Geom(OH=10, OW=16, IH=10, IW=16)
+    # 3x3 / temporal convolutions of the two large levels: the wide-tile kernel; the third level keeps 256 x 160 tiles
+    assert pick(M0, 320, ops.conv3x3_segs([(X, 320, 320)]), g0) == L.TILE_X256x320
+    assert pick(M0 // 2, 320, ops.conv3x3_segs([(X, 320, 320)]), g0) == L.TILE_X256x320          # shared CFG prefix: one branch
+    assert pick(M0, 320, ops.temporal_segs(X, 320, 320), ops.Geom(F=24, P=M0 // 48)) == L.TILE_X256x320
+    assert pick(M1, 640, ops.conv3x3_segs([(X, 640, 640)]), g1) == L.TILE_X256x320
+    assert pick(M2, 1280, ops.conv3x3_segs([(X, 1280, 1280)]), g2) == L.TILE_256x160
+    # transformer linears of the large levels: the persistent kernel (192 x 160 / 256 x 128 tiles)
+    lin = lambda k: ops.linear_segs([(X, k, k)])
+    assert pick(M0, 960, lin(320)) == L.TILE_P256x160
+    assert pick(M0, 320, lin(1280), residual=X, ldr=320) == L.TILE_P256x160
+    assert pick(M0, 2560, lin(320), epilogue=L.EPI_GEGLU) == L.TILE_P256x128
+    assert pick(M1, 5120, lin(640), epilogue=L.EPI_GEGLU) == L.TILE_P256x128
+    # VAE decoder at 24 frames of 320 x 512: 512- / 256-channel levels on 256 x 256 wide tiles, the 128-channel level on 256 x 128
+    assert pick(24 * 80 * 128, 512, ops.conv3x3_segs([(X, 512, 512)]), ops.Geom(OH=80, OW=128, IH=80, IW=128)) == L.TILE_X256x256
+    assert pick(24 * 160 * 256, 256, ops.conv3x3_segs([(X, 256, 256)]), ops.Geom(OH=160, OW=256, IH=160, IW=256)) == L.TILE_X256x256
+    assert pick(24 * 320 * 512, 128, ops.conv3x3_segs([(X, 128, 128)]), ops.Geom(OH=320, OW=512, IH=320, IW=512)) == L.TILE_256x128
+    # split-K shapes of the smallest level stay on the 128-row LDS-DMA kernel; a forced tile is returned as is
+    assert pick(M3, 1280, ops.conv3x3_segs([(X, 1280, 1280)]), ops.Geom(OH=5, OW=8, IH=5, IW=8), ksplit=8, workspace=X) == L.TILE_G128x160
+    assert pick(M0, 320, lin(320), tile=L.TILE_128x64) == L.TILE_128x64

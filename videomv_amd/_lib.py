@@ -137,6 +137,7 @@ SYMBOLS = {
     "vmv_error_string": (C.c_char_p, [C.c_int]),
     "vmv_gemm": (C.c_int, [C.POINTER(GemmParams), _P]),
     "vmv_gemm_ln_inline_ok": (C.c_int, [C.POINTER(GemmParams)]),
+    "vmv_gemm_pick_tile": (C.c_int, [C.POINTER(GemmParams)]),
     "vmv_groupnorm_stats": (C.c_int, [C.POINTER(GroupNormParams), _P]),
     "vmv_groupnorm_apply": (C.c_int, [C.POINTER(GroupNormParams), _P]),
     "vmv_groupnorm_fused": (C.c_int, [C.POINTER(GroupNormParams), C.c_int32, _P]),

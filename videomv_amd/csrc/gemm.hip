@@ -388,6 +388,13 @@ bool ln_inline_ok(const VmvGemmParams& p) {
 
 extern "C" int vmv_gemm_ln_inline_ok(const VmvGemmParams* pp) { return pp && ln_inline_ok(*pp) ? 1 : 0; }
 
+extern "C" int vmv_gemm_pick_tile(const VmvGemmParams* pp) {
+    if (!pp || pp->nseg <= 0 || pp->nseg > VMV_MAX_SEGS) return VMV_EINVAL;
+    int total_steps = 0;
+    for (int s = 0; s < pp->nseg; ++s) total_steps += (pp->seg[s].k + BK - 1) / BK;
+    return pick_tile(*pp, total_steps);
+}
+
 extern "C" int vmv_gemm(const VmvGemmParams* pp, void* stream) {
     if (!pp) return VMV_ENULL;
     const VmvGemmParams& p = *pp;
