@@ -29,7 +29,7 @@ extern "C" {
 #define VMV_ENULL        -3   /* required pointer is NULL */
 #define VMV_ERANGE       -4   /* size outside what the kernel supports */
 
-#define VMV_ABI_VERSION   5
+#define VMV_ABI_VERSION   6
 int vmv_abi_version(void);
 /* The 16-bit storage / MFMA operand type ("elem") this build of the library computes in.  The same sources are
  * compiled once per type: libvmv_hip_f16.so (VMV_ELEM_F16: IEEE fp16 — the default; the reference's own half mode,
@@ -113,7 +113,13 @@ typedef struct {
      * must be the normalised row: ONE linear segment, k == ktot == LayerNorm width, no split-K, no residual / rowvec, 16-bit output.  Served by the
      * persistent kernel only: ask vmv_gemm_ln_inline_ok() first, vmv_gemm returns VMV_EINVAL otherwise.               */
     float ln_eps;
-    int32_t _pad2;
+    /* Grouped weights (batched small GEMMs in ONE launch: the VAE's single-head attention, autoencoder.py:366-390, runs
+     * Q K^T and P V of all frames at once): output rows [g * wgroup_rows, (g + 1) * wgroup_rows) multiply the weight matrix at
+     * W + g * wgroup_stride elements (same [N][ktot] layout for every group).  wgroup_rows = 0: one W for all rows.
+     * wgroup_rows must be a multiple of 256 (a tile never straddles two groups); no split-K; served by the 128-column
+     * LDS-DMA kernels (vmv_gemm returns VMV_EINVAL for other forced tiles).                                          */
+    int32_t wgroup_rows;
+    int64_t wgroup_stride;
 } VmvGemmParams;
 
 #define VMV_TILE_AUTO     0

@@ -57,8 +57,15 @@ def gemm(p: L.GemmParams):
         a[~valid] = 0
         cols.append(a)
     A = torch.cat(cols, dim=1)
-    W = _rows(p.W, N, p.ktot).float()
-    acc = A @ W.t()
+    if p.wgroup_rows > 0:     # grouped weights (vmv.h): rows [g R, (g + 1) R) multiply the matrix at W + g * stride elements
+        R = p.wgroup_rows
+        acc = torch.empty(M, N)
+        for gi in range((M + R - 1) // R):
+            Wg = _rows(p.W + 2 * gi * p.wgroup_stride, N, p.ktot).float()
+            acc[gi * R:(gi + 1) * R] = A[gi * R:(gi + 1) * R] @ Wg.t()
+    else:
+        W = _rows(p.W, N, p.ktot).float()
+        acc = A @ W.t()
     if p.rowstat:          # LayerNorm folded into the GEMM: rstd[m] * (acc - mean[m] * colsum[n])
         st = _view(p.rowstat, 2 * M, "f32").view(M, 2)
         acc = (acc - st[:, :1] * _view(p.colsum, N, "f32")[None, :]) * st[:, 1:2]

@@ -271,6 +271,38 @@ def test_gemm_wide_tile_rowvec_act_residual(tile):
     check(dev["out"], cpu["out"])
 
 
+@pytest.mark.parametrize("tile", [0, L.TILE_P256x128, L.TILE_G128x128, L.TILE_256x128, L.TILE_128x128])
+@pytest.mark.parametrize("G,R,N,K,fp32", [(3, 512, 384, 192, False), (24, 1024, 1024, 512, True), (5, 256, 512, 256, False)])
+def test_gemm_grouped_weights(G, R, N, K, fp32, tile):
+    """VmvGemmParams.wgroup_rows: rows [g R, (g + 1) R) multiply the g-th weight matrix (the VAE attention's batched Q K^T /
+    P V) — against one GEMM per group on the same operands, and against the interpreter."""
+    M = G * R
+    c = Case(a=rnd((M, K), 1), w=rnd((G * N, K), 2, K ** -0.5), b=torch.randn(N, generator=g(3)),
+             out=torch.zeros(M, N) if fp32 else torch.zeros(M, N, dtype=BF))
+
+    def build(t):
+        return ops.gemm_params(M, N, ops.linear_segs([(t["a"], K, K)]), t["w"], t["out"], N, bias=t["b"], out_fp32=fp32,
+                               wgroup_rows=R, wgroup_stride=N * K, tile=tile)
+    cpu, dev = run_gemm(build, c)
+    tol = dict(tol_l2=8e-3, tol_max=1.6e-2) if fp32 else {}       # (x TS = 0.125 for fp16 operands: 1e-3 / 2e-3)
+    check(dev["out"], cpu["out"], **tol)
+    ref = torch.cat([cpu["a"][gi * R:(gi + 1) * R].float() @ cpu["w"][gi * N:(gi + 1) * N].float().t() for gi in range(G)]) + cpu["b"]
+    check(dev["out"], ref, **tol)
+
+
+def test_gemm_grouped_weights_validation():
+    import ctypes as C
+    lib = L.load()
+    a = rnd((512, 64), 1).cuda(); w = rnd((2 * 64, 64), 2).cuda(); o = torch.zeros(512, 64, dtype=BF, device="cuda")
+    ws = torch.zeros(2 * 512 * 64, device="cuda")
+    segs = ops.linear_segs([(a, 64, 64)])
+    for kw in (dict(wgroup_rows=100, wgroup_stride=64 * 64), dict(wgroup_rows=256, wgroup_stride=64 * 64 + 4),
+               dict(wgroup_rows=256, wgroup_stride=64 * 64, ksplit=2, workspace=ws),
+               dict(wgroup_rows=256, wgroup_stride=64 * 64, tile=L.TILE_P256x160)):
+        p = ops.gemm_params(512, 64, segs, w, o, 64, **kw)
+        assert lib.vmv_gemm(C.byref(p), None) == -1, kw          # VMV_EINVAL
+
+
 def test_gemm_geglu_many_tiles():
     M, I2, K = 70000, 1280, 320
     w = rnd((I2, K), 2, K ** -0.5)

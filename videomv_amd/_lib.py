@@ -72,7 +72,7 @@ class GemmParams(C.Structure):
                 ("F", C.c_int32), ("P", C.c_int32),
                 ("ksplit", C.c_int32), ("workspace", C.c_void_p),
                 ("tile", C.c_int32), ("res_scale", C.c_float), ("rowstat", C.c_void_p), ("colsum", C.c_void_p),
-                ("ln_eps", C.c_float), ("_pad2", C.c_int32)]
+                ("ln_eps", C.c_float), ("wgroup_rows", C.c_int32), ("wgroup_stride", C.c_int64)]
 
 
 class GroupNormParams(C.Structure):
@@ -188,7 +188,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the ABI drifted
         fn.restype = res
         fn.argtypes = args
-    if lib.vmv_abi_version() != 5:
+    if lib.vmv_abi_version() != 6:
         raise RuntimeError(f"{LIB_PATH}: ABI version mismatch")
     if lib.vmv_elem_type() != (ELEM_F16 if _elem == "f16" else ELEM_BF16):
         raise RuntimeError(f"{LIB_PATH} was built for another element type")

@@ -14,6 +14,7 @@ Decoder plan (channels-last 16-bit rows, one chunk of n frames):
 """
 import collections
 import math
+import os
 from typing import Dict
 
 import torch
@@ -186,15 +187,38 @@ class _VaeEngine:
         self._gemm(p + ".q", T, lin, p + ".q.weight", q, bias=self.wt[p + ".q.bias"])
         self._gemm(p + ".k", T, lin, p + ".k.weight", k, bias=self.wt[p + ".k.bias"])
         hwp = (hw + 7) // 8 * 8
-        vT = self.act(C, hwp)                       # V^T of one frame: [C][hw]
-        sc = self.act(hw, hwp, torch.float32)       # scores of one frame
-        pr = self.act(hw, hwp)                      # probabilities (16-bit)
         if hwp != hw:
             raise NotImplementedError("VAE attention needs h*w % 8 == 0")
         ao = self.act(T, C)
         wv = self.wt[p + ".v.weight"]
-        for f in range(n):
-            off = f * hw * C * 2
+        # All frames in ONE launch per stage when a 256-row tile never straddles two frames (grouped weights, vmv.h:
+        # VmvGemmParams.wgroup_rows — the "weight" operand of Q K^T / P V / V^T is the frame's own K / V^T / h): 4 launches
+        # instead of 4 n small ones that fill a quarter of the chip each; frames in groups that keep the fp32 scores <= 1 GiB.
+        batched = hw % 256 == 0 and C % 256 == 0 and os.environ.get("VMV_VAE_ATTN_BATCHED", "1") != "0"
+        G = max(1, min(n, (1 << 30) // (hw * hwp * 4))) if batched else 1
+        vT = self.act(G * C, hwp)                   # V^T of G frames: [g][C][hw]
+        sc = self.act(G * hw, hwp, torch.float32)   # scores
+        pr = self.act(G * hw, hwp)                  # probabilities (16-bit)
+        if batched:
+            rep = getattr(self, "_wv_rep", None)
+            if rep is None:
+                rep = self._wv_rep = {}
+            if (p, G) not in rep:
+                rep[(p, G)] = wv.repeat(G, 1).contiguous()      # A operand of the grouped V^T GEMM: Wv once per frame
+        for f0 in range(0, n, G):
+            g = min(G, n - f0)
+            off = f0 * hw * C * 2
+            if batched:
+                # V^T[f][c][j] = sum_k Wv[c][k] hn[f][j][k]   (bias bv is added after P.V: softmax rows sum to 1)
+                self._gemm(f"{p}.vT[{f0}+{g}]", g * C, ops.linear_segs([(rep[(p, G)].data_ptr(), C, C)]), hn.ptr + off, vT, ldo=hwp,
+                           N=hw, ksplit=0, wgroup_rows=C, wgroup_stride=hw * C)
+                self._gemm(f"{p}.qk[{f0}+{g}]", g * hw, ops.linear_segs([(q.ptr + off, C, C)]), k.ptr + off, sc, ldo=hwp,
+                           out_fp32=True, N=hw, ksplit=0, wgroup_rows=hw, wgroup_stride=hw * C)
+                self.S.softmax(ops.softmax_params(sc.ptr, hwp, pr.ptr, hwp, g * hw, hw, float(C) ** -0.5), f"{p}.softmax[{f0}+{g}]")
+                self._gemm(f"{p}.pv[{f0}+{g}]", g * hw, ops.linear_segs([(pr.ptr, hwp, hw)]), vT.ptr, ao.ptr + off, ldo=C,
+                           bias=self.wt[p + ".v.bias"], N=C, ksplit=0, wgroup_rows=hw, wgroup_stride=C * hwp)
+                continue
+            f = f0
             # V^T[c][j] = sum_k Wv[c][k] hn[j][k]   (bias bv is added after P.V: softmax rows sum to 1)
             self._gemm(f"{p}.vT[{f}]", C, ops.linear_segs([(wv.data_ptr(), C, C)]), hn.ptr + off, vT, ldo=hwp, N=hw)
             self._gemm(f"{p}.qk[{f}]", hw, ops.linear_segs([(q.ptr + off, C, C)]), k.ptr + off, sc, ldo=hwp, out_fp32=True,

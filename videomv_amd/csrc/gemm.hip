@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const VmvGemmParams p, const 
     for (int j = 0; j < WN; ++j) {
         const int n = n0 + srow + 32 * j;
         wvalid[j] = n < p.N;
-        wrow[j] = reinterpret_cast<const uint16_t*>(p.W) + (size_t)(wvalid[j] ? n : 0) * p.ktot + sslot * 8;
+        wrow[j] = reinterpret_cast<const uint16_t*>(p.W) + (size_t)(wvalid[j] ? n : 0) * p.ktot + sslot * 8 +
+                  (p.wgroup_rows > 0 ? (long)(m0 / p.wgroup_rows) * p.wgroup_stride : 0L);        // grouped weights (vmv.h)
     }
 
     // ---- K-walk state (segment s, chunk offset kc inside it, cumulative weight offset koff)
@@ -429,6 +430,12 @@ extern "C" int vmv_gemm(const VmvGemmParams* pp, void* stream) {
         if (p.ksplit > 1) return VMV_EINVAL;
         for (int s = 0; s < p.nseg; ++s) if (p.seg[s].mode != VMV_SEG_LINEAR) return VMV_EINVAL;
     }
+    if (p.wgroup_rows != 0) {      // grouped weights: a tile (<= 256 rows) never straddles two groups; the groups' matrices are
+                                   // addressed with 32-bit byte offsets from W
+        if (p.wgroup_rows < 0 || (p.wgroup_rows & 255) || p.wgroup_stride < 0 || (p.wgroup_stride & 7) || p.ksplit > 1) return VMV_EINVAL;
+        const long groups = ((long)p.M + p.wgroup_rows - 1) / p.wgroup_rows;
+        if (((groups - 1) * p.wgroup_stride + (long)p.N * p.ktot) * 2 >= (1L << 31) - 65536) return VMV_ERANGE;
+    }
     const bool ln_inline = vmv_gemm_ln_inline(p);
     if (ln_inline) {       // statistics in the main loop: the persistent one-block-per-CU kernel, staged 16-bit output
         if (!ln_inline_ok(p)) return VMV_EINVAL;
@@ -436,6 +443,16 @@ extern "C" int vmv_gemm(const VmvGemmParams* pp, void* stream) {
     }
     int picked = pick_tile(p, total_steps);
     if (ln_inline && p.tile == VMV_TILE_AUTO) picked = (p.epilogue != VMV_EPI_GEGLU && p.N % 160 == 0) ? VMV_TILE_P256x160 : VMV_TILE_P256x128;
+    if (p.wgroup_rows > 0) {       // served by the generic kernel and the 128-column LDS-DMA kernels (256- / 128-row tiles)
+        if (p.tile != VMV_TILE_AUTO) {
+            if (picked != VMV_TILE_128x128 && picked != VMV_TILE_128x64 && picked != VMV_TILE_64x64 && picked != VMV_TILE_256x128 &&
+                picked != VMV_TILE_G128x128 && picked != VMV_TILE_P256x128) return VMV_EINVAL;
+        } else if (picked == VMV_TILE_P256x160 || picked == VMV_TILE_X256x320 || picked == VMV_TILE_X256x256) picked = VMV_TILE_P256x128;
+        else if (picked == VMV_TILE_256x160) picked = VMV_TILE_256x128;
+        else if (picked == VMV_TILE_G128x160 || picked == VMV_TILE_128x160) picked = VMV_TILE_G128x128;
+        else if (picked != VMV_TILE_128x128 && picked != VMV_TILE_128x64 && picked != VMV_TILE_64x64 && picked != VMV_TILE_256x128 &&
+                 picked != VMV_TILE_G128x128 && picked != VMV_TILE_P256x128) picked = VMV_TILE_G128x128;
+    }
     if (p.rowstat && picked != VMV_TILE_A128x160 && picked != VMV_TILE_A128x128 && picked != VMV_TILE_P256x128 && picked != VMV_TILE_P256x160 && picked != VMV_TILE_Q128x128 &&
         picked != VMV_TILE_Q96x160 && picked != VMV_TILE_128x128 && picked != VMV_TILE_128x160 && picked != VMV_TILE_128x64 &&
         picked != VMV_TILE_64x64)

@@ -86,7 +86,9 @@ __global__ __launch_bounds__(128 * WMW, WMW == 2 ? 2 : 1) void gemm_glds_kernel(
         if (g >= BN / 8) g -= NW;                // duplicate an earlier row group: keeps the per-wave load count uniform
         wgrp[j] = g;
         const int n = n0 + g * 8 + lrow;
-        wvo[j] = (n < p.N) ? (uint32_t)(n * p.ktot + lsw * 8) * 2u : OOB;
+        // (grouped weights, vmv.h: the rows of this tile multiply the weight matrix of group m0 / wgroup_rows)
+        const uint32_t wg = p.wgroup_rows > 0 ? (uint32_t)((long)(m0 / p.wgroup_rows) * p.wgroup_stride) * 2u : 0u;
+        wvo[j] = (n < p.N) ? (uint32_t)(n * p.ktot + lsw * 8) * 2u + wg : OOB;
     }
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, SRD_RECORDS, SRD_FLAGS);
 

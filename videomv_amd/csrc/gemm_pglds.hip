@@ -121,7 +121,9 @@ __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel
 #pragma unroll
         for (int j = 0; j < Cfg::NWI; ++j) {
             const int n = n0 + wgrp[j] * 8 + lrow;
-            wvo[j] = (n < p.N) ? (uint32_t)(n * p.ktot + lsw * 8) * 2u : OOB;
+            // (grouped weights, vmv.h: the rows of this tile multiply the weight matrix of group m0 / wgroup_rows)
+            const uint32_t wg = p.wgroup_rows > 0 ? (uint32_t)((long)(m0 / p.wgroup_rows) * p.wgroup_stride) * 2u : 0u;
+            wvo[j] = (n < p.N) ? (uint32_t)(n * p.ktot + lsw * 8) * 2u + wg : OOB;
         }
         s = 0; kc = 0; koff = 0;
         L_left = total_steps;

@@ -55,7 +55,7 @@ class Geom:
 
 def gemm_params(M, N, segs: Sequence[Seg], W, out, ldo, bias=None, rowvec=None, rowvec_div=1, rowvec_ld=0,
                 residual=None, ldr=0, epilogue=L.EPI_NONE, act=L.ACT_NONE, out_fp32=False, geom: Optional[Geom] = None,
-                ksplit=0, workspace=None, tile=L.TILE_AUTO, res_scale=0.0, rowstat=None, colsum=None, ln_eps=0.0) -> L.GemmParams:
+                ksplit=0, workspace=None, tile=L.TILE_AUTO, res_scale=0.0, rowstat=None, colsum=None, ln_eps=0.0, wgroup_rows=0, wgroup_stride=0) -> L.GemmParams:
     p = L.GemmParams()
     p.M, p.N, p.nseg = int(M), int(N), len(segs)
     if len(segs) > L.VMV_MAX_SEGS:
@@ -75,6 +75,7 @@ def gemm_params(M, N, segs: Sequence[Seg], W, out, ldo, bias=None, rowvec=None, 
     p.OH, p.OW, p.IH, p.IW, p.stride, p.ups, p.F, p.P = g.OH, g.OW, g.IH, g.IW, g.stride, g.ups, g.F, g.P
     p.ksplit, p.workspace, p.tile, p.res_scale = int(ksplit), _ptr(workspace), tile, float(res_scale)
     p.rowstat, p.colsum, p.ln_eps = _ptr(rowstat), _ptr(colsum), float(ln_eps)
+    p.wgroup_rows, p.wgroup_stride = int(wgroup_rows), int(wgroup_stride)
     return p
 
 
