@@ -22,6 +22,9 @@ using namespace vmvg;
 
 namespace {
 
+#ifndef VMV_XGLDS_VARIANT
+#define VMV_XGLDS_VARIANT 0    // experiments: 1 LDS-DMA issue before the chunk's last MFMA phase, 2 s_setprio 1 around MFMA phases, 3 both
+#endif
 #ifndef VMV_XGLDS_ABLATE
 #define VMV_XGLDS_ABLATE 0     // experiments: 1 no MFMAs, 2 no LDS-DMA after the prologue, 3 no fragment reads, 4 no block barriers
 #endif
@@ -174,6 +177,9 @@ __global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams 
     auto mma_phase = [&](auto par_tag, auto h_tag) {
         constexpr int par = decltype(par_tag)::value, h = decltype(h_tag)::value;
         constexpr int ws = (par * NH + h) & 1;
+#if VMV_XGLDS_VARIANT >= 2
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int j = 0; j < WH; ++j)
 #pragma unroll
@@ -182,6 +188,9 @@ __global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams 
                 { if (i == 0 && j == 0) acc[h * WH][0][0] += (float)wf[ws][0][0] + (float)af[par][0][0]; }
 #else
                 acc[h * WH + j][i] = VMV_MFMA16(wf[ws][j], af[par][i], acc[h * WH + j][i], 0, 0, 0);
+#endif
+#if VMV_XGLDS_VARIANT >= 2
+        __builtin_amdgcn_s_setprio(0);
 #endif
     };
     auto prefetch_phase = [&](int slot_idx, auto par_tag, auto h_tag) {     // the fragment reads phase (par, h) needs
@@ -232,10 +241,15 @@ __global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams 
             prefetch_phase(stn, P1{}, H0{});
             __builtin_amdgcn_sched_barrier(0);
         }
+#if VMV_XGLDS_VARIANT == 1 || VMV_XGLDS_VARIANT == 3
+        if (issued < nsteps) { issue(st); ++issued; }
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         mma_phase(P0{}, std::integral_constant<int, NH - 1>{});
         __builtin_amdgcn_sched_barrier(0);
 #if VMV_XGLDS_ABLATE == 2
         ++issued;
+#elif VMV_XGLDS_VARIANT == 1 || VMV_XGLDS_VARIANT == 3
 #else
         if (issued < nsteps) { issue(st); ++issued; }         // chunk t + S into the slot the barrier freed
 #endif
