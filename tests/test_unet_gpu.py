@@ -126,6 +126,47 @@ def test_fused_cfg_ddim_loop_matches_oracle():
     print("fused-vs-oracle", e, "generic-vs-oracle", e_gen_ref, "generic-vs-fused", e_gen)
 
 
+def test_ddim50_psnr_vs_fp32_oracle():
+    """SURVEY 8d's reported number (not a gate there): 50 DDIM steps with CFG 9 — 100 forwards — on the HIP path against the fp32
+    oracle's loop from the same noise, compared on the final latent and on the image the VAE decoder makes of it.  Random
+    weights, so every rounding is amplified by 50 guided steps; the bound asserted is well below what is measured (printed: the
+    PSNR figures DESIGN.md section 6 quotes)."""
+    from videomv_amd.registry import DIFFUSION
+    from oracle.weights import vae_decoder_param_shapes
+    from oracle.vae_ref import vae_decode
+    cfg = dict(in_dim=4, dim=64, context_dim=1024, out_dim=4, dim_mult=[1, 2], num_heads=2, head_dim=64,
+               num_res_blocks=1, attn_scales=[1.0, 0.5])
+    ocfg = UNetCfg(**cfg)
+    sd = random_state_dict(unet_param_shapes(ocfg), 31)
+    m = build_model(cfg, sd).cuda()
+    dif = DIFFUSION.build(dict(type="DiffusionDDIM", schedule="linear_sd",
+                               schedule_param=dict(num_timesteps=1000, init_beta=0.00085, last_beta=0.012,
+                                                   zero_terminal_snr=False),
+                               mean_type="eps", var_type="fixed_small"))
+    gen = torch.Generator().manual_seed(11)
+    noise = torch.randn(1, 4, 4, 8, 8, generator=gen)
+    y, y0 = torch.randn(1, 7, 1024, generator=gen), torch.randn(1, 7, 1024, generator=gen)
+    cam = torch.randn(1, 4, 16, generator=gen)
+    kw = [dict(y=y.cuda(), camera_data=cam), dict(y=y0.cuda(), camera_data=cam)]
+    x_hip = dif.ddim_sample_loop(noise=noise.cuda(), model=m, model_kwargs=kw, guide_scale=9.0, ddim_timesteps=50, eta=0.0).float().cpu()
+    tb = DDIMTables(betas_for("linear_sd"))
+    x_ref = ddim_sample_loop(noise.clone(), lambda xt, t, y, camera_data: unet_forward(sd, ocfg, xt, t, y, camera_data),
+                             tb, [dict(y=y, camera_data=cam), dict(y=y0, camera_data=cam)], 9.0, ddim_timesteps=50)
+    assert torch.isfinite(x_hip).all() and x_hip.shape == x_ref.shape
+
+    def psnr(a, b):
+        peak = float(b.max() - b.min())
+        return 10.0 * torch.log10(torch.tensor(peak * peak) / ((a - b) ** 2).mean().clamp_min(1e-20)).item()
+    p_lat = psnr(x_hip, x_ref)
+    # the images: both latents through the fp32 oracle decoder (the comparison is of the samplers, not of the decoders)
+    vsd = random_state_dict(vae_decoder_param_shapes(ch=32), 77)
+    frames = lambda x: x[0].permute(1, 0, 2, 3) / 0.18215          # [F, 4, h, w]
+    img_hip, img_ref = vae_decode(vsd, frames(x_hip)), vae_decode(vsd, frames(x_ref))
+    p_img = psnr(img_hip, img_ref)
+    print(f"50-step DDIM (CFG 9) vs fp32 oracle: latent PSNR {p_lat:.1f} dB (rel-L2 {rel_l2(x_hip, x_ref):.2e}), decoded-image PSNR {p_img:.1f} dB")
+    assert p_lat > 40.0 and p_img > 40.0, (p_lat, p_img)        # measured: fp16 68 / 70 dB, bf16 52 / 53 dB; SURVEY expects >= 30
+
+
 def test_vae_decode_matches_reference_golden(golden_dir):
     """tests/golden/vae_tiny: image decoded by the imported reference AutoencoderKL (ch 32, 2 frames of 8x8 latents).
     Tolerance: rel-L2 <= 2e-2 (bf16 activations through 15 ResnetBlocks + attention)."""

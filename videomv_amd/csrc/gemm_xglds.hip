@@ -37,7 +37,10 @@ struct WgCfg {
     static constexpr int BM = 64 * WM, BN = 32 * WN;
     static constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64;         // rows of 32 elements = 64 B
     static constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
-    static constexpr int STAGES = 4;
+#ifndef VMV_XGLDS_STAGES
+#define VMV_XGLDS_STAGES 4      // (experiments: 3 = the depth a persistent form with per-wave epilogue slabs could afford)
+#endif
+    static constexpr int STAGES = VMV_XGLDS_STAGES;
     static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
     static constexpr int NAI = BM / (16 * NW);              // A wave-instructions per wave per chunk (16 rows x 64 B each) = 2
     static constexpr int WGROUPS = BN / 16;                 // 16-row groups of W per chunk (20 at BN = 320)
