@@ -371,3 +371,27 @@ def test_shared_cfg_prefix_and_hoisted_context_kv(monkeypatch):
     assert rel_l2(eng.eps_ncfhw(), ref2) < 1e-2
     with pytest.raises(ValueError):
         eng.set_camera(torch.randn(B, F_, 16, generator=g))                    # per-branch cameras cannot share a prefix
+
+
+def test_vae_engines_share_packed_weights(monkeypatch):
+    """decode / encode engines of one AutoencoderKL for other frame counts share ONE packed weight copy, and a
+    load_state_dict drops them all; results are unchanged."""
+    plan_interp.install(monkeypatch)
+    from videomv_amd.registry import AUTO_ENCODER
+    import videomv_amd.autoencoder  # noqa: F401
+    from oracle.weights import random_state_dict, vae_decoder_param_shapes
+    from oracle.vae_ref import vae_decode
+    dd = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 4, 4],
+              num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    sd = random_state_dict(vae_decoder_param_shapes(ch=32), 77)
+    vae = AUTO_ENCODER.build(dict(type="AutoencoderKL", ddconfig=dd, embed_dim=4))
+    vae.load_state_dict(sd, strict=False)
+    z = torch.randn(2, 4, 4, 4, generator=torch.Generator().manual_seed(3))
+    img2 = vae.decode(z)
+    img1 = vae.decode(z[:1])
+    engs = list(vae._engines.values())
+    assert len(engs) == 2 and engs[0].wt is engs[1].wt
+    ref = vae_decode(sd, z)
+    assert rel_l2(img2, ref) < 2e-2 and rel_l2(img1, ref[:1]) < 2e-2
+    vae.load_state_dict(sd, strict=False)
+    assert not vae._engines

@@ -88,14 +88,19 @@ def vae_param_shapes(dd: dict, embed_dim: int) -> Dict[str, tuple]:
 class _VaeEngine:
     """Shared pieces of the decoder / encoder plans: packing, GroupNorm(1e-6)+swish, ResnetBlock, 1-head AttnBlock."""
 
-    def __init__(self, dd: dict, sd: Dict[str, torch.Tensor], n: int, h: int, w: int, device):
+    def __init__(self, dd: dict, sd: Dict[str, torch.Tensor], n: int, h: int, w: int, device, packed=None):
+        """packed: the .wt of another engine of the same kind, model and device — packed weights are immutable and
+        shape-independent, so the engines of one model (other frame counts / resolutions) share ONE copy."""
         self.dd, self.n, self.h, self.w, self.device = dd, n, h, w, device
         self.pool = Pool(device)
         self.S = ops.Stream(record=True)
         self._keep = []
         self._gnws = torch.empty(4 << 20, dtype=torch.float32, device=device)
-        self.wt = {}
-        self._pack(sd)
+        if packed is not None:
+            self.wt = packed
+        else:
+            self.wt = {}
+            self._pack(sd)
         self._build()
 
     def _packers(self, sd):
@@ -261,6 +266,7 @@ class VaeDecoderEngine(_VaeEngine):
         T = n * h * w
         zc = self.dd["z_channels"]
         self.zpad = (zc + 7) // 8 * 8
+        self.out_pad = self.wt["decoder.conv_out.weight"].shape[0]      # (also for an engine that shares another's packed weights)
         self.z_rows = torch.zeros(T, self.zpad, dtype=L.elem(), device=dev)
         self.pq_rows = torch.zeros(T, self.zpad, dtype=L.elem(), device=dev)     # cols >= zc stay zero
         self._gemm("post_quant", T, ops.linear_segs([(self.z_rows.data_ptr(), self.zpad, self.zpad)]),
@@ -437,6 +443,13 @@ class AutoencoderKL(nn.Module):
                 new[k.split('first_stage_model.')[-1]] = v
         self.load_state_dict(new, strict=True)
 
+    def _packed_of(self, kind, device):
+        """The packed weights of an existing engine of this kind on this device (engines are dropped on load_state_dict)."""
+        for eng in self._engines.values():
+            if type(eng) is kind and str(eng.device) == str(device):
+                return eng.wt
+        return None
+
     @torch.no_grad()
     def decode(self, z, **kwargs):
         n, zc, h, w = z.shape
@@ -445,7 +458,7 @@ class AutoencoderKL(nn.Module):
         if eng is None:
             sd = {k: v.detach() for k, v in self.state_dict().items()
                   if k.startswith("decoder.") or k.startswith("post_quant_conv.")}
-            eng = VaeDecoderEngine(self.ddconfig, sd, n, h, w, z.device)
+            eng = VaeDecoderEngine(self.ddconfig, sd, n, h, w, z.device, packed=self._packed_of(VaeDecoderEngine, z.device))
             self._engines[key] = eng
         return eng.decode(z.float())
 
@@ -459,7 +472,7 @@ class AutoencoderKL(nn.Module):
         eng = self._engines.get(key)
         if eng is None:
             sd = {k: v.detach() for k, v in self.state_dict().items() if k.startswith("encoder.") or k.startswith("quant_conv.")}
-            eng = VaeEncoderEngine(self.ddconfig, sd, n, h, w, x.device)
+            eng = VaeEncoderEngine(self.ddconfig, sd, n, h, w, x.device, packed=self._packed_of(VaeEncoderEngine, x.device))
             self._engines[key] = eng
         rows = eng.encode(x.float())
         return DiagonalGaussianDistribution(rows, n, self.ddconfig["z_channels"], eng.LH, eng.LW, x.device)
