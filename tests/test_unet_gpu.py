@@ -402,11 +402,14 @@ def test_lgm_latent_z_matches_oracle_composition():
     assert abs(float(z_hip.mean() - z_ref.mean())) < 3e-2 and abs(float(z_hip.std() - z_ref.std())) < 3e-2
 
 
-def test_lgm_fused_step_equals_reference_structured_step():
-    """The fused LGM step (one batched [cond|uncond] pass, two LgmRefiner calls, vmv_ddim_x0_step) against the
-    reference-structured generic path (model(..., autoencoder=...) twice -> CFG on latent_z -> x0 -> DDIM update),
-    both on the GPU with the same posterior noise: rel-L2 <= 2e-3 (identical kernels, only the fp32 CFG/DDIM arithmetic
-    is organised differently)."""
+@pytest.mark.parametrize("batched", ["0", "1"])
+def test_lgm_fused_step_equals_reference_structured_step(monkeypatch, batched):
+    """The fused LGM step (one batched [cond|uncond] pass, the LGM branch of both CFG branches — per branch, or
+    VMV_LGM_BATCHED: every stage over both at once — and vmv_ddim_x0_step) against the reference-structured generic path
+    (model(..., autoencoder=...) twice -> CFG on latent_z -> x0 -> DDIM update), both on the GPU with the same posterior
+    noise.  Per branch: rel-L2 <= 2e-3 (identical kernels, only the fp32 CFG/DDIM arithmetic is organised differently);
+    batched: the GEMMs see twice the rows and may pick other tiles / split-K factors, held to the per-block bound."""
+    monkeypatch.setenv("VMV_LGM_BATCHED", batched)
     from videomv_amd.registry import MODEL, DIFFUSION, AUTO_ENCODER
     from videomv_amd.lgm import prepare_gs_data
     from videomv_amd.camera import entrance_camera_data
@@ -442,7 +445,8 @@ def test_lgm_fused_step_equals_reference_structured_step():
     xb, _ = dif.ddim_sample(xt0.clone(), t, m, vae, kw, guide_scale=9.0, ddim_timesteps=50)
     torch.cuda.synchronize()
     assert torch.isfinite(xa).all()
-    assert rel_l2(xa, xb.cpu()) < 2e-3, rel_l2(xa, xb.cpu())
+    assert rel_l2(xa, xb.cpu()) < (2e-3 if batched == "0" else TOL_AUX), rel_l2(xa, xb.cpu())
+    print("LGM fused step vs reference-structured, batched =", batched, rel_l2(xa, xb.cpu()))
 
 
 def test_full_size_config1_properties():

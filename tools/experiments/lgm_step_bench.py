@@ -27,6 +27,11 @@ for rep in range(3):
     ref.latent_z(eps, 4, 0, xt, 1.1, 0.5, vae, gs)
     t1 = sync()
 print("latent_z total ms", 1000 * (t1 - t0))
+for rep in range(3):
+    t0 = sync()
+    ref.latent_z_pair(eps, 4, xt, 1.1, 0.5, vae, gs)
+    t1 = sync()
+print("latent_z_pair (both CFG branches batched) total ms", 1000 * (t1 - t0), "= per branch", 500 * (t1 - t0))
 # stages
 z4 = torch.randn(4, 4, 32, 32, generator=g, device=dev)
 t0 = sync(); dec = vae.decode(z4); t1 = sync()

@@ -397,8 +397,13 @@ class DiagonalGaussianDistribution(object):
         ops.rows_to_nchw(self.moment_rows, 2 * self.zc, out)
         return out
 
-    def sample(self, scale=1.0):
-        noise = torch.randn(self.n, self.zc, self.h, self.w).to(device=self.device)
+    def sample(self, scale=1.0, parts=1):
+        """parts > 1: the noise is drawn in that many consecutive host-RNG calls of n / parts images each — what the same number
+        of separate encode calls would have drawn (the batched LGM branch encodes both CFG branches at once)."""
+        if parts > 1 and self.n % parts == 0:
+            noise = torch.cat([torch.randn(self.n // parts, self.zc, self.h, self.w) for _ in range(parts)]).to(device=self.device)
+        else:
+            noise = torch.randn(self.n, self.zc, self.h, self.w).to(device=self.device)
         z = torch.empty(self.n, self.zc, self.h, self.w, dtype=torch.float32, device=self.device)
         ops.posterior_sample(self.moment_rows, 2 * self.zc, noise, z, scale)
         return z
@@ -478,9 +483,9 @@ class AutoencoderKL(nn.Module):
         return DiagonalGaussianDistribution(rows, n, self.ddconfig["z_channels"], eng.LH, eng.LW, x.device)
 
     @torch.no_grad()
-    def encode_firsr_stage(self, x, scale_factor=1.0):
+    def encode_firsr_stage(self, x, scale_factor=1.0, parts=1):
         """scale_factor * posterior.sample()  (autoencoder.py:86-91; the typo is the reference's public name)."""
-        return self.encode(x).sample(scale=scale_factor)
+        return self.encode(x).sample(scale=scale_factor, parts=parts)
 
     def forward(self, input, sample_posterior=True):
         raise NotImplementedError("training-time autoencoding is out of scope (inference hot path only)")

@@ -103,8 +103,13 @@ class DiffusionDDIM(object):
         ref = unet.lgm_refiner(xt.device)
         # predicted x0 of each branch: eps form (unet_t2v.py:405) or v form (unet_i2vgen.py:441-442), following the MODEL
         ca, cb = (k["c_sqrt_ac"], k["c_sqrt_1mac"]) if getattr(unet, "lgm_vpred", False) else (k["c_recip"], k["c_recipm1"])
-        z = [ref.latent_z(eps_rows, eng.out_pad, br, xt, ca, cb, autoencoder, dict(kw["gs_data"]))
-             for br, kw in enumerate((cond_kwargs, uncond_kwargs))]
+        ga, gb = cond_kwargs["gs_data"], uncond_kwargs["gs_data"]
+        same_views = ga is gb or all(ga[k] is gb[k] or torch.equal(ga[k], gb[k]) for k in ("input", "cam_view", "cam_view_proj"))
+        if same_views and ref.pair_supported():           # both branches through every stage together (one camera set)
+            z = ref.latent_z_pair(eps_rows, eng.out_pad, xt, ca, cb, autoencoder, dict(ga))
+        else:
+            z = [ref.latent_z(eps_rows, eng.out_pad, br, xt, ca, cb, autoencoder, dict(kw["gs_data"]))
+                 for br, kw in enumerate((cond_kwargs, uncond_kwargs))]
         ops.ddim_x0_step(z[0], z[1], xt, float(guide_scale), k["c_recip"], k["c_recipm1"], k["a_prev"])
         return xt
 

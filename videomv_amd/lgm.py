@@ -99,17 +99,23 @@ def lgm_param_shapes(o: LgmOptions) -> Dict[str, tuple]:
 
 
 class LgmEngine:
-    """Plan for ``LGM.forward_gaussians`` of ONE sample: images [V, 9, H, W] -> gaussians fp32 [V*S*S, 14]."""
+    """Plan for ``LGM.forward_gaussians`` of ``batch`` samples: images [batch * V, 9, H, W] -> gaussians fp32
+    [batch * V*S*S, 14] (sample-major).  Everything but the multi-view attention is per image; the attention runs over the
+    V*h*w tokens of each sample.  ``packed``: the .wt of another engine of the same model and device (one weight copy)."""
 
-    def __init__(self, opt: LgmOptions, sd: Dict[str, torch.Tensor], H: int, W: int, device, taps=None):
-        self.o, self.V, self.H, self.W, self.device = opt, opt.num_frames, H, W, device
+    def __init__(self, opt: LgmOptions, sd: Dict[str, torch.Tensor], H: int, W: int, device, taps=None, batch: int = 1, packed=None):
+        self.o, self.B, self.H, self.W, self.device = opt, int(batch), H, W, device
+        self.V = opt.num_frames * self.B             # images in the plan (rows are image-major)
         self.pool = Pool(device)
         self.S = ops.Stream(record=True)
         self._gnws = torch.empty(4 << 20, dtype=torch.float32, device=device)
         self._keep = []
         self.taps = taps
-        self.wt: Dict[str, torch.Tensor] = {}
-        self._pack(sd)
+        if packed is not None:
+            self.wt = packed
+        else:
+            self.wt: Dict[str, torch.Tensor] = {}
+            self._pack(sd)
         self._build()
 
     # ------------------------------------------------------------------ weights
@@ -223,19 +229,22 @@ class LgmEngine:
 
     def _attn(self, p, x: Act, h, w) -> Act:
         o = self.o
-        C, T = x.C, x.rows                         # T = V*h*w tokens of the one sample
+        C, T = x.C, x.rows // self.B               # T = V*h*w tokens of one sample
         heads = o.num_heads
         hd = C // heads
         hn = self._gn(p + ".norm", [x], h * w, p + ".norm", False)
-        qkv = self.act(T, 3 * C)
-        self._gemm(p + ".qkv", T, ops.linear_segs([(hn.ptr, C, C)]), p + ".qkv", qkv)
-        ao = self.act(T, C)
+        qkv = self.act(x.rows, 3 * C)
+        self._gemm(p + ".qkv", x.rows, ops.linear_segs([(hn.ptr, C, C)]), p + ".qkv", qkv)
+        ao = self.act(x.rows, C)
         if hd == 64 or (hd == 32 and os.environ.get("VMV_ATTN_D32", "1") != "0"):
             self.rel(hn)                            # flash kernel (head_dim 64, and 32: the 'big' model's 512 / 16 heads)
-            m = lambda: ops.seq_map(0, 0, 3 * C, inner=1)
+            m = lambda: ops.seq_map(T * 3 * C, 0, 3 * C, inner=1)
             self.S.attention(ops.attn_params(qkv.ptr, qkv.ptr + 2 * C, qkv.ptr + 4 * C, ao.ptr, m(), m(), m(),
-                                             ops.seq_map(0, 0, C, inner=1), 1, heads, T, T, hd ** -0.5, head_dim=hd), p + ".attn")
+                                             ops.seq_map(T * C, 0, C, inner=1), self.B, heads, T, T, hd ** -0.5, head_dim=hd),
+                             p + ".attn")
         else:
+            if self.B != 1:
+                raise NotImplementedError("batched LGM plans need head_dim 64 or 32 (the flash kernel)")
             if hd % 8 or T % 8:
                 raise NotImplementedError("LGM attention: head_dim and token count must be multiples of 8")
             # V^T[c][j] = sum_k Wv[c][k] hn[j][k]  -> [C][T]; K gathered head-major [heads][T][hd]
@@ -255,8 +264,8 @@ class LgmEngine:
             for a in (vT, kh, sc, pr):
                 self.rel(a)
         self.rel(qkv)
-        y = self.act(T, C)
-        self._gemm(p + ".proj", T, ops.linear_segs([(ao.ptr, C, C)]), p + ".proj.weight", y, bias=self.wt[p + ".proj.bias"],
+        y = self.act(x.rows, C)
+        self._gemm(p + ".proj", x.rows, ops.linear_segs([(ao.ptr, C, C)]), p + ".proj.weight", y, bias=self.wt[p + ".proj.bias"],
                    residual=x.ptr, ldr=C, res_scale=o.skip_scale)
         self.rel(ao)
         return y
@@ -341,7 +350,7 @@ class LgmEngine:
 
     # ------------------------------------------------------------------ run
     def forward_gaussians(self, images: torch.Tensor) -> torch.Tensor:
-        """images [V, 9, H, W] fp32 on device -> gaussians [V*S*S, 14] fp32 (pos, opacity, scale, rotation, rgb)."""
+        """images [batch * V, 9, H, W] fp32 on device -> gaussians [batch * V*S*S, 14] fp32 (pos, opacity, scale, rotation, rgb)."""
         V, Cc, H, W = images.shape
         assert (V, H, W) == (self.V, self.H, self.W) and Cc == self.o.in_channels
         ops.latent_to_rows(images.reshape(V, Cc, 1, H, W).contiguous(), self.x_rows, self.cin_pad, 1)
@@ -402,10 +411,60 @@ class LgmRefiner:
         from .gs import GaussianRenderer
         self.opt, self.device, self.bg_color = opt, device, float(bg_color)
         self.engine = LgmEngine(opt, lgm_state, opt.input_size, opt.input_size, device)
+        self._engine2 = None                  # two samples per plan (both CFG branches at once), same packed weights
+        self._lgm_state = lgm_state
         self.renderer = GaussianRenderer(opt.output_size, opt.fovy, opt.znear, opt.zfar)
         S = opt.input_size
         self.z4 = None
+        self.z8 = None
         self.inp = torch.zeros(opt.num_frames, 9, S, S, dtype=torch.float32, device=device)
+        self.inp2 = None
+
+    def pair_supported(self) -> bool:
+        hd_ok = all((c // self.opt.num_heads) in (32, 64) for c, a in
+                    list(zip(self.opt.down_channels, self.opt.down_attention)) + list(zip(self.opt.up_channels, self.opt.up_attention))
+                    + [(self.opt.down_channels[-1], self.opt.mid_attention)] if a)
+        return hd_ok and os.environ.get("VMV_LGM_BATCHED", "1") != "0"
+
+    @torch.no_grad()
+    def latent_z_pair(self, eps_rows, ld, xt, c_recip, c_recipm1, autoencoder, gs_data, scale_factor=0.18215):
+        """latent_z of BOTH CFG branches (rows blocks 0 and 1 of ``eps_rows``) with every stage batched over the two: one VAE
+        decode of 8 views, one LGM plan of two samples, 2 x 24 renders, one VAE encode of 48 views.  Same arithmetic per image as
+        two ``latent_z`` calls (the posterior noise is drawn in the same two host-RNG calls); the GEMMs see twice the rows, so
+        fewer, fuller launches."""
+        _, Cc, F_, h, w = xt.shape
+        idxs = [0, 6, 12, 18] if F_ == 24 else [i * F_ // 4 for i in range(4)]
+        V = len(idxs)
+        if self.z8 is None or self.z8.shape[-2:] != (h, w):
+            self.z8 = torch.zeros(2 * V, Cc, h, w, dtype=torch.float32, device=self.device)
+        for br in range(2):
+            ops.lgm_x0_views(eps_rows, ld, br, xt, idxs, c_recip, c_recipm1, 1.0 / scale_factor, self.z8[br * V:(br + 1) * V])
+        decoded = autoencoder.decode(self.z8)                                           # [8, 3, S, S]
+        S = self.opt.input_size
+        if decoded.shape[-1] != S or decoded.shape[-2] != S:
+            raise ValueError(f"LGM expects {S}x{S} decoded views (latent {S // 8}x{S // 8}), got {tuple(decoded.shape[-2:])}")
+        if self._engine2 is None:
+            self._engine2 = LgmEngine(self.opt, self._lgm_state, S, S, self.device, batch=2, packed=self.engine.wt)
+            self.inp2 = torch.zeros(2 * self.opt.num_frames, 9, S, S, dtype=torch.float32, device=self.device)
+        rays = gs_data["input"][0, idxs].to(self.device, torch.float32).contiguous()
+        decoded = decoded.contiguous()
+        for br in range(2):
+            ops.lgm_pack_input(decoded[br * V:(br + 1) * V], rays, self.inp2[br * V:(br + 1) * V])
+        gaussians = self._engine2.forward_gaussians(self.inp2).view(2, -1, 14)
+        bg = torch.full((3,), self.bg_color, dtype=torch.float32, device=self.device)
+        cv, cvp = gs_data["cam_view"].to(self.device), gs_data["cam_view_proj"].to(self.device)
+        if h != w:
+            raise ValueError("the LGM branch renders square views")
+        small = None
+        for br in range(2):
+            images = self.renderer.render(gaussians[br].unsqueeze(0), cv, cvp, None, bg_color=bg)["image"][0].contiguous()
+            T = images.shape[0]
+            if small is None:
+                small = torch.empty(2 * T, 3, 8 * h, 8 * w, dtype=torch.float32, device=self.device)
+            ops.lgm_render_to_vae(images, small[br * T:(br + 1) * T])
+        z = autoencoder.encode_firsr_stage(small, scale_factor, parts=2)                # [2T, C, h, w]
+        z = z.reshape(2, 1, T, z.shape[1], z.shape[2], z.shape[3]).permute(0, 1, 3, 2, 4, 5).contiguous()
+        return z[0], z[1]
 
     @torch.no_grad()
     def latent_z(self, eps_rows, ld, branch, xt, c_recip, c_recipm1, autoencoder, gs_data, scale_factor=0.18215):
