@@ -395,3 +395,69 @@ def test_vae_engines_share_packed_weights(monkeypatch):
     assert rel_l2(img2, ref) < 2e-2 and rel_l2(img1, ref[:1]) < 2e-2
     vae.load_state_dict(sd, strict=False)
     assert not vae._engines
+
+
+def test_lgm_plan_two_samples_equals_two_plans(monkeypatch, golden_dir):
+    """LgmEngine(batch=2) — the plan the batched LGM branch runs for both CFG branches at once — against two single-sample
+    plans on the same weights (shared packed copy): per-image stages see twice the rows, the multi-view attention runs once
+    per sample (n_outer = 2 with a per-sample token stride)."""
+    import json
+    from safetensors import safe_open
+    from safetensors.torch import load_file
+    plan_interp.install(monkeypatch)
+    from videomv_amd.lgm import LgmEngine, LgmOptions
+    from oracle.lgm_ref import LgmCfg, lgm_unet_param_shapes
+    path = os.path.join(golden_dir, "lgm_unet_tiny.safetensors")
+    with safe_open(path, "pt") as f:
+        meta = f.metadata()
+    c = {k: tuple(v) if isinstance(v, list) else v for k, v in json.loads(meta["cfg"]).items()}
+    gg = load_file(os.path.join(golden_dir, "lgm_gaussians_tiny.safetensors"))
+    opt = LgmOptions(**c, input_size=32, splat_size=32, output_size=64)
+    sd = random_state_dict(lgm_unet_param_shapes(LgmCfg(**c)), int(meta["seed"]))
+    lsd = {("unet." + k): v for k, v in sd.items()}
+    lsd["conv.weight"], lsd["conv.bias"] = gg["conv.weight"], gg["conv.bias"]
+    a = gg["images"][0]
+    b = a.flip(0) * 0.7 + 0.1 * torch.randn(a.shape, generator=torch.Generator().manual_seed(5))
+    one = LgmEngine(opt, lsd, 32, 32, torch.device("cpu"))
+    ga = one.forward_gaussians(a).clone()
+    gb = one.forward_gaussians(b).clone()
+    two = LgmEngine(opt, lsd, 32, 32, torch.device("cpu"), batch=2, packed=one.wt)
+    assert two.wt is one.wt
+    g2 = two.forward_gaussians(torch.cat([a, b])).view(2, -1, 14).clone()
+    assert g2.shape[1:] == ga.shape
+    # same arithmetic per image; the doubled row count changes split-K factors / accumulation order, i.e. isolated 16-bit
+    # roundings that a whole U-Net carries along: held to the per-block bound
+    assert rel_l2(g2[0], ga) < 1e-2 and rel_l2(g2[1], gb) < 1e-2, (rel_l2(g2[0], ga), rel_l2(g2[1], gb))
+    assert rel_l2(ga, gb) > 0.05          # (the two samples do differ)
+    # independence: another second sample leaves the first sample's Gaussians unchanged (the attention never mixes samples;
+    # up to the host BLAS's position-dependent blocking, orders of magnitude below the effect of a mixed-in sample)
+    g3 = two.forward_gaussians(torch.cat([a, a])).view(2, -1, 14)
+    assert rel_l2(g3[0], g2[0]) < 1e-3 and rel_l2(g3[1], g3[0]) < 1e-3, (rel_l2(g3[0], g2[0]), rel_l2(g3[1], g3[0]))
+
+
+@pytest.mark.parametrize("batched", ["1", "0"])
+def test_vae_attention_grouped_weights_matches_oracle(monkeypatch, batched):
+    """The VAE's single-head attention with all frames in one launch per stage (grouped weights: VmvGemmParams.wgroup_rows)
+    and per frame (VMV_VAE_ATTN_BATCHED=0): a decoder whose mid block has 256 channels at 16 x 16 (h w = 256: a 256-row tile
+    never straddles two frames) through the interpreter against the fp32 oracle decoder."""
+    plan_interp.install(monkeypatch)
+    monkeypatch.setenv("VMV_VAE_ATTN_BATCHED", batched)
+    from videomv_amd.registry import AUTO_ENCODER
+    from videomv_amd import _lib as L
+    import videomv_amd.autoencoder  # noqa: F401
+    from oracle.weights import random_state_dict, vae_decoder_param_shapes
+    from oracle.vae_ref import vae_decode
+    dd = dict(double_z=True, z_channels=4, resolution=128, in_channels=3, out_ch=3, ch=64, ch_mult=[1, 2, 4, 4],
+              num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    sd = random_state_dict(vae_decoder_param_shapes(ch=64), 78)
+    vae = AUTO_ENCODER.build(dict(type="AutoencoderKL", ddconfig=dd, embed_dim=4))
+    vae.load_state_dict(sd, strict=False)
+    z = torch.randn(3, 4, 16, 16, generator=torch.Generator().manual_seed(4))
+    img = vae.decode(z)
+    eng = next(iter(vae._engines.values()))
+    grouped = [p for op, p in eng.S.recorded if op == L.OP_GEMM and p.wgroup_rows > 0]
+    if batched == "1":
+        assert len(grouped) == 3 and {p.wgroup_rows for p in grouped} == {256}          # V^T, Q K^T, P V of all 3 frames
+    else:
+        assert not grouped
+    assert rel_l2(img, vae_decode(sd, z)) < 2e-2
