@@ -2,11 +2,11 @@
 // as gemm.hip / vmv.h).
 //
 // Why: per 64-deep chunk of its 256 x 160 tile gemm_glds.hip's eight 64 x 80 wave tiles pull 147 KB of fragments out of LDS
-// and the LDS-DMA writes 52 KB into it (~1570 cycles of the 128 B/clk port) and the CU's DMA path needs ~1350 cycles for the
+// (ds_read_b128: 256 B/clk at best) while the LDS-DMA writes 52 KB into it, and the CU's DMA path needs ~1350 cycles for the
 // 52 1-KB wave-instructions — against 1280 cycles of MFMAs per SIMD.  The long-K convolutions therefore sit at ~43 % of peak
-// with three units equally busy.  Here the block tile is 256 x 320 (N = 320 / 640 / 1280 are all multiples) and a wave owns
-// 64 x 160: per MAC 22 % fewer fragment bytes and 31 % fewer DMA bytes; per barrier interval (one 32-deep chunk: 1280 MFMA
-// cycles per SIMD) the LDS port is busy ~1180 cycles and the DMA path ~940.
+// with the matrix pipes, the DMA path and the LDS port all busy.  Here the block tile is 256 x 320 (N = 320 / 640 / 1280 are
+// all multiples) and a wave owns 64 x 160: per MAC 22 % fewer fragment bytes and 31 % fewer DMA bytes; per barrier interval
+// (one 32-deep chunk: 1280 MFMA cycles per SIMD) 115 KB of fragment reads, 36 KB of DMA (~940 cycles of the DMA path).
 // 160 accumulators per lane leave room for ONE double-buffered half-chunk of fragments: a chunk is two phases of 20 MFMAs
 // (column half h), the fragment reads of the next phase (5 W fragments, plus the 4 A fragments when the chunk changes) are
 // issued before the MFMAs of the current one; the second wave of the SIMD covers what latency remains.  A 72-KB stage per
