@@ -8,8 +8,8 @@
 //
 // Why: the 8-wave kernels (gemm_glds.hip) give every wave a 64 x {64,80} tile.  A wave tile of TM x TN reads
 // (TM + TN) * BK * 2 bytes of fragments from LDS per TM * TN * BK MACs, so at 64 x 80 the eight waves pull 147 KB out of
-// LDS per 64-deep chunk of a 256 x 160 block tile, next to the 52 KB the LDS-DMA writes into it: ~1570 cycles of the
-// 128 B/clk LDS port against 1280 cycles of MFMAs.  The long-K convolutions therefore sit at ~43 % of the MFMA peak with the
+// LDS per 64-deep chunk of a 256 x 160 block tile, next to the 52 KB the LDS-DMA writes into it: 800-1600 cycles of the
+// LDS port (256-128 B/clk) against 1280 cycles of MFMAs.  The long-K convolutions therefore sit at ~43 % of the MFMA peak with the
 // LDS port and the vector-memory path both busy, whatever the schedule.  Here a block is FOUR waves — one per SIMD, so a
 // wave may use the whole 512-entry register file (accumulators spill over into the AGPR half) — and a wave owns
 // 128 x {64 .. 160} of a 256 x {128 .. 320} block tile:
