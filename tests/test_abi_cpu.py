@@ -102,3 +102,7 @@ def test_gemm_tile_policy(monkeypatch):
     # split-K shapes of the smallest level stay on the 128-row LDS-DMA kernel; a forced tile is returned as is
     assert pick(M3, 1280, ops.conv3x3_segs([(X, 1280, 1280)]), ops.Geom(OH=5, OW=8, IH=5, IW=8), ksplit=8, workspace=X) == L.TILE_G128x160
     assert pick(M0, 320, lin(320), tile=L.TILE_128x64) == L.TILE_128x64
+    # grouped weights (the VAE attention's batched Q K^T / V^T): the 128-column LDS-DMA kernels; an incompatible forced tile is refused
+    assert pick(24 * 1024, 1024, lin(512), out_fp32=True, wgroup_rows=1024, wgroup_stride=1024 * 512) == L.TILE_P256x128
+    assert pick(24 * 512, 1024, lin(512), wgroup_rows=512, wgroup_stride=1024 * 512) == L.TILE_G128x128
+    assert pick(24 * 1024, 320, lin(512), wgroup_rows=1024, wgroup_stride=320 * 512, tile=L.TILE_P256x160) == -1

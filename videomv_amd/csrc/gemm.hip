@@ -376,6 +376,28 @@ int pick_tile(const VmvGemmParams& p, int total_steps) {
     return best;
 }
 
+// pick_tile + the constraints of the optional features (in-loop LayerNorm statistics, grouped weights, folded LayerNorm): the
+// configuration vmv_gemm launches first, or a negative VMV_E* code for a forced tile that cannot serve the request
+int final_tile(const VmvGemmParams& p, int total_steps) {
+    int picked = pick_tile(p, total_steps);
+    if (vmv_gemm_ln_inline(p) && p.tile == VMV_TILE_AUTO)
+        picked = (p.epilogue != VMV_EPI_GEGLU && p.N % 160 == 0) ? VMV_TILE_P256x160 : VMV_TILE_P256x128;
+    if (p.wgroup_rows > 0) {       // served by the generic kernel and the 128-column LDS-DMA kernels (256- / 128-row tiles)
+        const bool ok = picked == VMV_TILE_128x128 || picked == VMV_TILE_128x64 || picked == VMV_TILE_64x64 || picked == VMV_TILE_256x128 ||
+                        picked == VMV_TILE_G128x128 || picked == VMV_TILE_P256x128;
+        if (p.tile != VMV_TILE_AUTO) {
+            if (!ok) return VMV_EINVAL;
+        } else if (picked == VMV_TILE_P256x160 || picked == VMV_TILE_X256x320 || picked == VMV_TILE_X256x256) picked = VMV_TILE_P256x128;
+        else if (picked == VMV_TILE_256x160) picked = VMV_TILE_256x128;
+        else if (!ok) picked = VMV_TILE_G128x128;
+    }
+    if (p.rowstat && picked != VMV_TILE_A128x160 && picked != VMV_TILE_A128x128 && picked != VMV_TILE_P256x128 && picked != VMV_TILE_P256x160 && picked != VMV_TILE_Q128x128 &&
+        picked != VMV_TILE_Q96x160 && picked != VMV_TILE_128x128 && picked != VMV_TILE_128x160 && picked != VMV_TILE_128x64 &&
+        picked != VMV_TILE_64x64)
+        picked = (p.epilogue != VMV_EPI_GEGLU && p.N % 160 == 0) ? VMV_TILE_P256x160 : VMV_TILE_P256x128;
+    return picked;
+}
+
 bool ln_inline_ok(const VmvGemmParams& p) {
     if (!p.W || !p.out || !p.colsum || p.nseg != 1 || p.seg[0].mode != VMV_SEG_LINEAR || p.seg[0].k != p.ktot) return false;
     if (p.ksplit > 1 || p.out_fp32 || p.rowvec || p.residual) return false;
@@ -393,7 +415,7 @@ extern "C" int vmv_gemm_pick_tile(const VmvGemmParams* pp) {
     if (!pp || pp->nseg <= 0 || pp->nseg > VMV_MAX_SEGS) return VMV_EINVAL;
     int total_steps = 0;
     for (int s = 0; s < pp->nseg; ++s) total_steps += (pp->seg[s].k + BK - 1) / BK;
-    return pick_tile(*pp, total_steps);
+    return final_tile(*pp, total_steps);
 }
 
 extern "C" int vmv_gemm(const VmvGemmParams* pp, void* stream) {
@@ -441,22 +463,8 @@ extern "C" int vmv_gemm(const VmvGemmParams* pp, void* stream) {
         if (!ln_inline_ok(p)) return VMV_EINVAL;
         if (!vmv_aligned16(p.colsum)) return VMV_EALIGN;
     }
-    int picked = pick_tile(p, total_steps);
-    if (ln_inline && p.tile == VMV_TILE_AUTO) picked = (p.epilogue != VMV_EPI_GEGLU && p.N % 160 == 0) ? VMV_TILE_P256x160 : VMV_TILE_P256x128;
-    if (p.wgroup_rows > 0) {       // served by the generic kernel and the 128-column LDS-DMA kernels (256- / 128-row tiles)
-        if (p.tile != VMV_TILE_AUTO) {
-            if (picked != VMV_TILE_128x128 && picked != VMV_TILE_128x64 && picked != VMV_TILE_64x64 && picked != VMV_TILE_256x128 &&
-                picked != VMV_TILE_G128x128 && picked != VMV_TILE_P256x128) return VMV_EINVAL;
-        } else if (picked == VMV_TILE_P256x160 || picked == VMV_TILE_X256x320 || picked == VMV_TILE_X256x256) picked = VMV_TILE_P256x128;
-        else if (picked == VMV_TILE_256x160) picked = VMV_TILE_256x128;
-        else if (picked == VMV_TILE_G128x160 || picked == VMV_TILE_128x160) picked = VMV_TILE_G128x128;
-        else if (picked != VMV_TILE_128x128 && picked != VMV_TILE_128x64 && picked != VMV_TILE_64x64 && picked != VMV_TILE_256x128 &&
-                 picked != VMV_TILE_G128x128 && picked != VMV_TILE_P256x128) picked = VMV_TILE_G128x128;
-    }
-    if (p.rowstat && picked != VMV_TILE_A128x160 && picked != VMV_TILE_A128x128 && picked != VMV_TILE_P256x128 && picked != VMV_TILE_P256x160 && picked != VMV_TILE_Q128x128 &&
-        picked != VMV_TILE_Q96x160 && picked != VMV_TILE_128x128 && picked != VMV_TILE_128x160 && picked != VMV_TILE_128x64 &&
-        picked != VMV_TILE_64x64)
-        picked = (p.epilogue != VMV_EPI_GEGLU && p.N % 160 == 0) ? VMV_TILE_P256x160 : VMV_TILE_P256x128;
+    const int picked = final_tile(p, total_steps);
+    if (picked < 0) return picked;
     switch (picked) {
         case VMV_TILE_128x128: rc = launch_cfg<4, 4>(p, total_steps, st); break;
         case VMV_TILE_128x160:
