@@ -111,7 +111,8 @@ typedef struct {
     /* rowstat == NULL, colsum != NULL, ln_eps > 0: the same folded LayerNorm with (mean, rstd) of every row accumulated in
      * the GEMM's own main loop from the A fragments it multiplies (no statistics pass, no rowstat traffic); the K range
      * must be the normalised row: ONE linear segment, k == ktot == LayerNorm width, no split-K, no residual / rowvec, 16-bit output.  Served by the
-     * persistent kernel only: ask vmv_gemm_ln_inline_ok() first, vmv_gemm returns VMV_EINVAL otherwise.               */
+     * row-stationary kernel (K = 320 / 640: statistics from the resident rows, two-pass) and the persistent kernel: ask
+     * vmv_gemm_ln_inline_ok() first, vmv_gemm returns VMV_EINVAL otherwise.                                           */
     float ln_eps;
     /* Grouped weights (batched small GEMMs in ONE launch: the VAE's single-head attention, autoencoder.py:366-390, runs
      * Q K^T and P V of all frames at once): output rows [g * wgroup_rows, (g + 1) * wgroup_rows) multiply the weight matrix at
@@ -146,10 +147,18 @@ typedef struct {
                                   long-K convolutions / temporal convolutions of the large levels */
 #define VMV_TILE_X256x256 21
 #define VMV_TILE_X256x128 22
+#define VMV_TILE_RS       23   /* row-stationary kernel (gemm_rs.hip): the wave's rows of A live in registers for the whole K = 320 / 640
+                                  range, W streams through an LDS ring, outputs leave per 32-column pair; rows per wave and the column
+                                  split picked by the launcher — the short-K linears of the two large UNet levels */
+#define VMV_TILE_RS512    24   /* the same, forced to 64 rows per wave (512-row blocks; K = 320 only) */
+#define VMV_TILE_RS256    25   /* the same, forced to 32 rows per wave (256-row blocks) */
 
 int vmv_gemm(const VmvGemmParams* p, void* stream);
 /* 1 if vmv_gemm accepts *p (rowstat ignored) with in-loop LayerNorm statistics (VmvGemmParams.ln_eps), else 0 */
 int vmv_gemm_ln_inline_ok(const VmvGemmParams* p);
+/* 1 if vmv_gemm would run *p (tile = VMV_TILE_AUTO) on the row-stationary kernel, which takes the statistics of a folded
+ * LayerNorm from its resident rows: the host then passes colsum + ln_eps and no rowstat (no statistics launch at all) */
+int vmv_gemm_rs_ok(const VmvGemmParams* p);
 /* the VMV_TILE_* configuration vmv_gemm's policy picks for *p when p->tile == VMV_TILE_AUTO (p->tile otherwise); host logic only:
  * no launch, no device access (a launcher may still fall back when it cannot address the operands) */
 int vmv_gemm_pick_tile(const VmvGemmParams* p);

@@ -73,7 +73,7 @@ def test_missing_library_fails_loudly(monkeypatch):
 def test_gemm_tile_policy(monkeypatch):
     """vmv_gemm_pick_tile (host logic): which kernel family the default policy gives the UNet's / VAE's characteristic GEMMs at
     latent 24x40x64 — pins DESIGN 4.1's table (pointers are never dereferenced: fake non-null addresses)."""
-    for k in ("VMV_GEMM_POLICY", "VMV_GEMM_XGLDS", "VMV_GEMM_ASTAT", "VMV_GEMM_TILE_GEGLU", "VMV_GEMM_TILE_LIN160", "VMV_GEMM_TILE_LIN128"):
+    for k in ("VMV_GEMM_POLICY", "VMV_GEMM_XGLDS", "VMV_GEMM_ASTAT", "VMV_GEMM_RS", "VMV_GEMM_TILE_GEGLU", "VMV_GEMM_TILE_LIN160", "VMV_GEMM_TILE_LIN128"):
         assert k not in os.environ, "policy overrides must be unset for this test"
     lib = L.load()
     X = 1 << 20          # any non-null, 16-byte aligned address
@@ -89,12 +89,21 @@ def test_gemm_tile_policy(monkeypatch):
     assert pick(M0, 320, ops.temporal_segs(X, 320, 320), ops.Geom(F=24, P=M0 // 48)) == L.TILE_X256x320
     assert pick(M1, 640, ops.conv3x3_segs([(X, 640, 640)]), g1) == L.TILE_X256x320
     assert pick(M2, 1280, ops.conv3x3_segs([(X, 1280, 1280)]), g2) == L.TILE_256x160
-    # transformer linears of the large levels: the persistent kernel (192 x 160 / 256 x 128 tiles)
+    # transformer linears of the two large levels with K = C (qkv / q, out-projections, proj_in / proj_out, GEGLU): the
+    # row-stationary kernel; the same with a folded LayerNorm (colsum + ln_eps: statistics taken in the kernel); K = 4C (FF down)
+    # and the third level stay on the persistent kernel (192 x 160 / 256 x 128 tiles)
     lin = lambda k: ops.linear_segs([(X, k, k)])
-    assert pick(M0, 960, lin(320)) == L.TILE_P256x160
+    assert pick(M0, 960, lin(320)) == L.TILE_RS
+    assert pick(M0, 960, lin(320), colsum=X, ln_eps=1e-5) == L.TILE_RS
+    assert pick(M0 // 2, 960, lin(320), colsum=X, ln_eps=1e-5) == L.TILE_RS                      # shared CFG prefix: one branch
+    assert pick(M0, 320, lin(320), residual=X, ldr=320) == L.TILE_RS
+    assert pick(M0, 2560, lin(320), epilogue=L.EPI_GEGLU, colsum=X, ln_eps=1e-5) == L.TILE_RS
+    assert pick(M1, 5120, lin(640), epilogue=L.EPI_GEGLU, colsum=X, ln_eps=1e-5) == L.TILE_RS
+    assert pick(M1, 640, lin(640), residual=X, ldr=640) == L.TILE_RS
     assert pick(M0, 320, lin(1280), residual=X, ldr=320) == L.TILE_P256x160
-    assert pick(M0, 2560, lin(320), epilogue=L.EPI_GEGLU) == L.TILE_P256x128
-    assert pick(M1, 5120, lin(640), epilogue=L.EPI_GEGLU) == L.TILE_P256x128
+    assert pick(M2, 10240, lin(1280), epilogue=L.EPI_GEGLU, rowstat=X, colsum=X) == L.TILE_P256x128
+    assert lib.vmv_gemm_rs_ok(C.byref(ops.gemm_params(M0, 960, lin(320), X, X, 960, colsum=X, ln_eps=1e-5))) == 1
+    assert lib.vmv_gemm_rs_ok(C.byref(ops.gemm_params(M2, 3840, lin(1280), X, X, 3840, colsum=X, ln_eps=1e-5))) == 0
     # VAE decoder at 24 frames of 320 x 512: 512- / 256-channel levels on 256 x 256 wide tiles, the 128-channel level on 256 x 128
     assert pick(24 * 80 * 128, 512, ops.conv3x3_segs([(X, 512, 512)]), ops.Geom(OH=80, OW=128, IH=80, IW=128)) == L.TILE_X256x256
     assert pick(24 * 160 * 256, 256, ops.conv3x3_segs([(X, 256, 256)]), ops.Geom(OH=160, OW=256, IH=160, IW=256)) == L.TILE_X256x256

@@ -625,6 +625,122 @@ def test_gemm_astat_plain(M, N, K, geglu, bias, tile):
 
 
 
+# ------------------------------------------------------------------------------------------------- row-stationary GEMM
+RS_LIN = [(1000, 960, 320, L.TILE_RS512), (300, 320, 320, L.TILE_RS256), (70000, 320, 320, L.TILE_RS512), (513, 64, 320, L.TILE_RS256),
+          (1000, 1920, 640, L.TILE_RS256), (513, 640, 640, L.TILE_RS256), (40000, 640, 640, L.TILE_RS), (70001, 960, 320, L.TILE_RS),
+          (2000, 2560, 320, L.TILE_RS512), (35000, 128, 640, L.TILE_RS256)]
+
+
+@pytest.mark.parametrize("M,N,K,tile", RS_LIN)
+@pytest.mark.parametrize("bias,res", [(True, False), (False, False), (True, True)])
+def test_gemm_rs_linear(M, N, K, tile, bias, res):
+    """gemm_rs.hip (rows resident in registers, W streamed through the LDS ring, outputs per 32-column pair): M tails, one to
+    many blocks, every column split the launcher picks for these shapes, bias on / off, residual with res_scale; two runs
+    bitwise identical."""
+    c = Case(a=rnd((M, K), 1), w=rnd((N, K), 2, K ** -0.5), b=torch.randn(N, generator=g(3)), res=rnd((M, N), 5),
+             out=torch.zeros(M, N, dtype=BF))
+
+    def build(t):
+        kw = dict(residual=t["res"], ldr=N, res_scale=0.5) if res else {}
+        return ops.gemm_params(M, N, ops.linear_segs([(t["a"], K, K)]), t["w"], t["out"], N, bias=t["b"] if bias else None, tile=tile, **kw)
+    cpu = c.on("cpu")
+    if M <= 2000:
+        I.gemm(build(cpu))
+        ref = cpu["out"]
+    else:
+        ref = cpu["a"].float() @ cpu["w"].float().t() + (cpu["b"] if bias else 0) + (0.5 * cpu["res"].float() if res else 0)
+    dev = c.on("cuda")
+    S = ops.Stream(record=False)
+    S.gemm(build(dev), "t")
+    torch.cuda.synchronize()
+    check(dev["out"], ref)
+    dev2 = c.on("cuda")
+    S.gemm(build(dev2), "t")
+    torch.cuda.synchronize()
+    assert torch.equal(dev2["out"], dev["out"])
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(1000, 2560, 320, L.TILE_RS512), (300, 128, 320, L.TILE_RS256), (70000, 2560, 320, L.TILE_RS),
+                                         (700, 5120, 640, L.TILE_RS256), (33000, 1280, 640, L.TILE_RS)])
+@pytest.mark.parametrize("ln", [False, True])
+def test_gemm_rs_geglu_layernorm(M, N, K, tile, ln):
+    """GEGLU (x | gate pairs of one body stored as one 32-column unit) with and without the LayerNorm applied to the resident
+    rows (colsum + ln_eps, two-pass statistics in the kernel) against the unfused definition; rows carry a large offset
+    (mean / sigma ~ 3)."""
+    import ctypes as C
+    x = (rnd((M, K), 1, 1.5).float() + 4.0 * torch.randn(M, 1, generator=g(9))).to(BF)
+    w = torch.randn(N, K, generator=g(2)) * K ** -0.5
+    b = torch.randn(N, generator=g(3))
+    gamma, beta = 1 + 0.2 * torch.randn(K, generator=g(4)), 0.2 * torch.randn(K, generator=g(5))
+    if ln:
+        wf, bf, cs = P.fold_layernorm(w, b, gamma, beta)
+    else:
+        wf, bf, cs = w.to(BF).float(), b, None
+    wp, bp = P.geglu_interleave(wf), P.geglu_interleave(bf)
+    xd = x.cuda()
+    out = torch.zeros(M, N // 2, dtype=BF, device="cuda")
+    kw = dict(colsum=P.geglu_interleave(cs).cuda(), ln_eps=1e-5) if ln else {}
+    p = ops.gemm_params(M, N, ops.linear_segs([(xd, K, K)]), wp.to(BF).cuda(), out, N // 2, bias=bp.cuda(), epilogue=L.EPI_GEGLU, tile=tile, **kw)
+    S = ops.Stream(record=False)
+    if ln:
+        assert S.lib.vmv_gemm_ln_inline_ok(C.byref(p)) == 1
+    S.gemm(p)
+    torch.cuda.synchronize()
+    xin = torch.nn.functional.layer_norm(x.float(), (K,), gamma, beta, 1e-5) if ln else x.float()
+    h = xin @ (w if ln else wf).t() + b
+    a, gate = h.chunk(2, dim=-1)
+    check(out, a * torch.nn.functional.gelu(gate), tol_l2=6e-3, tol_max=2e-2)
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(1000, 960, 320, L.TILE_RS512), (70000, 960, 320, L.TILE_RS), (61, 1920, 640, L.TILE_RS256),
+                                         (31000, 1920, 640, L.TILE_RS), (300, 320, 320, L.TILE_RS256)])
+def test_gemm_rs_layernorm(M, N, K, tile):
+    """y = Linear(LayerNorm(x)) on the row-stationary kernel: statistics and normalisation from the resident rows (no rowstat;
+    a rowstat that IS passed is ignored).  Rows with a large offset AND rows that are tiny (1e-3) or huge (3e3): the
+    two-pass variance has no E[x^2] - mean^2 cancellation; zero rows give bias' exactly."""
+    x = rnd((M, K), 1, 1.5).float() + 4.0 * torch.randn(M, 1, generator=g(9))
+    x[1::7] *= 1e-3
+    x[2::7] = x[2::7] * 30 + 3e3
+    x[3] = 0
+    x = x.to(BF)
+    w = torch.randn(N, K, generator=g(2)) * K ** -0.5
+    b = torch.randn(N, generator=g(3))
+    gamma, beta = 1 + 0.2 * torch.randn(K, generator=g(4)), 0.2 * torch.randn(K, generator=g(5))
+    wf, bf, cs = P.fold_layernorm(w, b, gamma, beta)
+    xd = x.cuda()
+    junk = torch.full((M, 2), 7.0, device="cuda")
+    outs = []
+    for rowstat in (None, junk):
+        out = torch.zeros(M, N, dtype=BF, device="cuda")
+        S = ops.Stream(record=False)
+        S.gemm(ops.gemm_params(M, N, ops.linear_segs([(xd, K, K)]), wf.cuda(), out, N, bias=bf.cuda(), colsum=cs.cuda(), ln_eps=1e-5,
+                               rowstat=rowstat, tile=tile))
+        torch.cuda.synchronize()
+        outs.append(out)
+    ref = torch.nn.functional.layer_norm(x.float(), (K,), gamma, beta, 1e-5) @ w.t() + b
+    check(outs[0], ref, tol_l2=6e-3, tol_max=2e-2)
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_gemm_rs_eligibility():
+    """What the row-stationary kernel refuses when forced (VMV_EINVAL), and what the default policy sends to it."""
+    import ctypes as C
+    lib = L.load()
+    x = rnd((512, 320), 1).cuda(); w = rnd((320, 320), 2).cuda(); o = torch.zeros(512, 320, dtype=BF, device="cuda")
+    of = torch.zeros(512, 320, device="cuda"); cs = torch.zeros(320, device="cuda")
+    segs = ops.linear_segs([(x, 320, 320)])
+    bad = [ops.gemm_params(512, 320, segs, w, of, 320, out_fp32=True, tile=L.TILE_RS),
+           ops.gemm_params(512, 320, ops.linear_segs([(x, 320, 256)]), w, o, 320, tile=L.TILE_RS),          # K = 256
+           ops.gemm_params(512, 320, segs, w, o, 320, colsum=cs, ln_eps=1e-5, residual=o, ldr=320, tile=L.TILE_RS),
+           ops.gemm_params(512, 320, segs, w, o, 320, rowvec=of, rowvec_div=64, rowvec_ld=320, tile=L.TILE_RS),
+           ops.gemm_params(512, 160, segs, w, o, 320, tile=L.TILE_RS),                                      # N % 64
+           ops.gemm_params(512, 320, ops.linear_segs([(x.view(256, 640), 640, 640)]), rnd((320, 640), 2).cuda(), o, 320, tile=L.TILE_RS512)]
+    for p in bad:
+        assert lib.vmv_gemm(C.byref(p), None) == -1
+    small = ops.gemm_params(512, 320, segs, w, o, 320)
+    assert lib.vmv_gemm_rs_ok(C.byref(small)) == 0 and lib.vmv_gemm_pick_tile(C.byref(small)) != L.TILE_RS
+
+
 def test_gemm_layernorm_folded_rejects_split_k_and_gathers():
     import ctypes as C
     lib = L.load()

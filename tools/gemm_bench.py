@@ -54,9 +54,8 @@ def main():
             K = C; segs = ops.linear_segs([(x, C, C)]); geom = None
             if kind in ("lnlin", "lngeglu"):
                 kw["colsum"] = torch.randn(N, device=dev)
-                if os.environ.get("VMV_BENCH_LN_INLINE", "0") == "1":     # statistics in the GEMM's own main loop
-                    kw["ln_eps"] = 1e-5
-                else:
+                kw["ln_eps"] = 1e-5      # (in-kernel statistics where the kernel takes them: gemm_rs; ignored next to a rowstat)
+                if os.environ.get("VMV_BENCH_LN_INLINE", "0") != "1":     # 1: statistics in the persistent GEMM's own main loop
                     kw["rowstat"] = torch.randn(M, 2, device=dev).abs() + 0.5
             if kind in ("geglu", "lngeglu"):
                 kw["epilogue"] = L.EPI_GEGLU; No = N // 2
@@ -78,6 +77,8 @@ def main():
             if tile in N160 and (N % 160 or kind in ("geglu", "lngeglu")):
                 line += "      -    "; continue
             if tile in (L.TILE_X256x320, L.TILE_X256x256, L.TILE_X256x128) and (kind in ("geglu", "lngeglu", "lnlin") or (tile == L.TILE_X256x320 and N % 320)):
+                line += "      -    "; continue
+            if tile in (L.TILE_RS, L.TILE_RS512, L.TILE_RS256) and (kind in ("conv", "tconv") or C not in (320, 640) or (tile == L.TILE_RS512 and C != 320)):
                 line += "      -    "; continue
             stamps = torch.zeros(8 * 64, dtype=torch.int64, device=dev) if os.environ.get("VMV_GEMM_ABLATE") in ("4", "7", "8") else None
             ks = int(os.environ.get("VMV_BENCH_KSPLIT", "0"))

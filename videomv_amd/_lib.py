@@ -50,6 +50,7 @@ TILE_Q128x128, TILE_Q96x160 = 13, 14
 TILE_S256x128, TILE_S192x160, TILE_S256x160 = 15, 16, 17
 TILE_A128x160, TILE_A128x128 = 18, 19
 TILE_X256x320, TILE_X256x256, TILE_X256x128 = 20, 21, 22
+TILE_RS, TILE_RS512, TILE_RS256 = 23, 24, 25
 OP_GEMM, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTENTION, OP_SOFTMAX, OP_COPY, OP_GN_FUSED = 1, 2, 3, 4, 5, 6, 7, 8
 GN_FUSED_BYTES = 131072
 
@@ -137,6 +138,7 @@ SYMBOLS = {
     "vmv_error_string": (C.c_char_p, [C.c_int]),
     "vmv_gemm": (C.c_int, [C.POINTER(GemmParams), _P]),
     "vmv_gemm_ln_inline_ok": (C.c_int, [C.POINTER(GemmParams)]),
+    "vmv_gemm_rs_ok": (C.c_int, [C.POINTER(GemmParams)]),
     "vmv_gemm_pick_tile": (C.c_int, [C.POINTER(GemmParams)]),
     "vmv_groupnorm_stats": (C.c_int, [C.POINTER(GroupNormParams), _P]),
     "vmv_groupnorm_apply": (C.c_int, [C.POINTER(GroupNormParams), _P]),

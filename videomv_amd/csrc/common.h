@@ -87,10 +87,14 @@ VMV_DEV float xor32_max3(float x, float c) {          // max(x, partner's x, c)
 }
 VMV_DEV float xor16_32_sum(float x) {                 // sum over lanes l, l ^ 16, l ^ 32, l ^ 48
 #if defined(__HIP_DEVICE_COMPILE__)
-    vmv_u2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    x = __uint_as_float(r.x) + __uint_as_float(r.y);
-    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return __uint_as_float(r.x) + __uint_as_float(r.y);
+    // (not on any inner loop: written with its own wait states — gemm_rs.hip found hipcc's hazard pad in front of a
+    //  v_permlane*_swap one state short when two swaps follow each other, stale data in lanes 28-31 / 60-63)
+    float a = x, b = x;
+    asm("s_nop 3\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    x = a + b;
+    a = x; b = x;
+    asm("s_nop 3\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
 #else
     return x;
 #endif

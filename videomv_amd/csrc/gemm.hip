@@ -25,6 +25,9 @@ bool vmv_gemm_pglds_supported(const VmvGemmParams& p);
 int vmv_gemm_xglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st);  // gemm_xglds.hip
 int vmv_gemm_sglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st);  // gemm_sglds.hip
 int vmv_gemm_astat_launch(const VmvGemmParams& p, int tile, hipStream_t st);                   // gemm_astat.hip
+int vmv_gemm_rs_launch(const VmvGemmParams& p, int tile, hipStream_t st);                      // gemm_rs.hip
+bool vmv_gemm_rs_supported(const VmvGemmParams& p);
+bool vmv_gemm_rs_preferred(const VmvGemmParams& p);
 bool vmv_gemm_astat_eligible(const VmvGemmParams& p);
 
 namespace {
@@ -311,6 +314,8 @@ int xglds_policy() {
 int pick_tile(const VmvGemmParams& p, int total_steps) {
     if (p.tile != VMV_TILE_AUTO) return p.tile;
     const int geglu = p.epilogue == VMV_EPI_GEGLU;
+    // the short-K linears of the two large levels: rows resident in registers, W streamed, outputs per column pair (gemm_rs.hip)
+    if (gemm_policy() >= 2 && vmv_gemm_rs_preferred(p)) return VMV_TILE_RS;
     if (gemm_policy() >= 2 && xglds_policy() && !geglu && p.ksplit <= 1 && !p.rowstat && !vmv_gemm_ln_inline(p) && total_steps >= 12 &&
         (p.N % 320 == 0 || p.N % 256 == 0)) {
         bool any_gather = false;
@@ -380,8 +385,12 @@ int pick_tile(const VmvGemmParams& p, int total_steps) {
 // configuration vmv_gemm launches first, or a negative VMV_E* code for a forced tile that cannot serve the request
 int final_tile(const VmvGemmParams& p, int total_steps) {
     int picked = pick_tile(p, total_steps);
+    const bool rs_tile = picked == VMV_TILE_RS || picked == VMV_TILE_RS512 || picked == VMV_TILE_RS256;
+    if (rs_tile) return vmv_gemm_rs_supported(p) ? picked : VMV_EINVAL;      // (handles rowstat / colsum / grouped weights itself)
     if (vmv_gemm_ln_inline(p) && p.tile == VMV_TILE_AUTO)
-        picked = (p.epilogue != VMV_EPI_GEGLU && p.N % 160 == 0) ? VMV_TILE_P256x160 : VMV_TILE_P256x128;
+        picked = vmv_gemm_rs_supported(p) ? VMV_TILE_RS
+                                          : (p.epilogue != VMV_EPI_GEGLU && p.N % 160 == 0) ? VMV_TILE_P256x160 : VMV_TILE_P256x128;
+    if (picked == VMV_TILE_RS) return picked;
     if (p.wgroup_rows > 0) {       // served by the generic kernel and the 128-column LDS-DMA kernels (256- / 128-row tiles)
         const bool ok = picked == VMV_TILE_128x128 || picked == VMV_TILE_128x64 || picked == VMV_TILE_64x64 || picked == VMV_TILE_256x128 ||
                         picked == VMV_TILE_G128x128 || picked == VMV_TILE_P256x128;
@@ -401,15 +410,22 @@ int final_tile(const VmvGemmParams& p, int total_steps) {
 bool ln_inline_ok(const VmvGemmParams& p) {
     if (!p.W || !p.out || !p.colsum || p.nseg != 1 || p.seg[0].mode != VMV_SEG_LINEAR || p.seg[0].k != p.ktot) return false;
     if (p.ksplit > 1 || p.out_fp32 || p.rowvec || p.residual) return false;
-    if (p.tile != VMV_TILE_AUTO && p.tile != VMV_TILE_P256x128 && p.tile != VMV_TILE_P256x160) return false;
+    const bool rs_forced = p.tile == VMV_TILE_RS || p.tile == VMV_TILE_RS512 || p.tile == VMV_TILE_RS256;
+    if (p.tile != VMV_TILE_AUTO && p.tile != VMV_TILE_P256x128 && p.tile != VMV_TILE_P256x160 && !rs_forced) return false;
     const int n_out = p.epilogue == VMV_EPI_GEGLU ? p.N / 2 : p.N;
     if ((p.ldo & 7) || (n_out & 7) || !vmv_aligned16(p.out)) return false;                  // the staged epilogue
-    return vmv_gemm_pglds_supported(p);
+    if (rs_forced) return vmv_gemm_rs_supported(p);
+    return vmv_gemm_rs_supported(p) || vmv_gemm_pglds_supported(p);
 }
 
 }  // namespace
 
 extern "C" int vmv_gemm_ln_inline_ok(const VmvGemmParams* pp) { return pp && ln_inline_ok(*pp) ? 1 : 0; }
+
+extern "C" int vmv_gemm_rs_ok(const VmvGemmParams* pp) {
+    if (!pp || pp->tile != VMV_TILE_AUTO || pp->nseg <= 0 || pp->nseg > VMV_MAX_SEGS) return 0;
+    return gemm_policy() >= 2 && vmv_gemm_rs_preferred(*pp) ? 1 : 0;
+}
 
 extern "C" int vmv_gemm_pick_tile(const VmvGemmParams* pp) {
     if (!pp || pp->nseg <= 0 || pp->nseg > VMV_MAX_SEGS) return VMV_EINVAL;
@@ -500,6 +516,12 @@ extern "C" int vmv_gemm(const VmvGemmParams* pp, void* stream) {
                 rc = vmv_gemm_glds_launch(p, total_steps, p.N % 160 == 0 ? VMV_TILE_256x160 : VMV_TILE_256x128, st);
                 if (rc == VMV_GLDS_UNSUPPORTED) rc = p.N % 160 == 0 ? launch_cfg<4, 5>(p, total_steps, st) : launch_cfg<4, 4>(p, total_steps, st);
             }
+            break;
+        case VMV_TILE_RS:
+        case VMV_TILE_RS512:
+        case VMV_TILE_RS256:
+            rc = vmv_gemm_rs_launch(p, picked, st);
+            if (rc == VMV_GLDS_UNSUPPORTED) return VMV_EINVAL;      // (final_tile checked eligibility: a forced row tile that does not exist)
             break;
         case VMV_TILE_A128x160:
         case VMV_TILE_A128x128:

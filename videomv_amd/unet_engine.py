@@ -503,14 +503,14 @@ class UNetEngine:
         base = wkey[:-len(".weight")] if wkey.endswith(".weight") else wkey
         W = self.w[base + ".ln.weight"]
         segs = ops.linear_segs([(x.ptr, x.C, x.C)])
-        if self.ln_inline:
-            # statistics taken inside the GEMM's main loop from the rows it multiplies (vmv.h: VmvGemmParams.ln_eps): no
-            # statistics launch, no rowstat traffic — when the persistent kernel can address this shape
-            p = ops.gemm_params(x.rows, W.shape[0], segs, W, out.ptr, out.C, bias=self.w[base + ".ln.bias"],
-                                colsum=self.w[base + ".ln.colsum"], ln_eps=1e-5, **kw)
-            if self.S.lib.vmv_gemm_ln_inline_ok(C.byref(p)):
-                self.S.gemm(p, label)
-                return
+        # The row-stationary kernel (gemm_rs.hip: K = 320 / 640 with enough rows, vmv_gemm_rs_ok) keeps the rows it multiplies in
+        # registers and normalises them there: colsum + ln_eps, no statistics launch, no rowstat traffic.  VMV_LN_INLINE=1 asks
+        # for in-kernel statistics wherever any kernel offers them (the persistent kernel's in-loop sums: slower).
+        p = ops.gemm_params(x.rows, W.shape[0], segs, W, out.ptr, out.C, bias=self.w[base + ".ln.bias"],
+                            colsum=self.w[base + ".ln.colsum"], ln_eps=1e-5, **kw)
+        if self.S.lib.vmv_gemm_rs_ok(C.byref(p)) or (self.ln_inline and self.S.lib.vmv_gemm_ln_inline_ok(C.byref(p))):
+            self.S.gemm(p, label)
+            return
         st = self.act(x.rows, 2, dtype=torch.float32)
         self.S.layernorm(ops.ln_params(x.ptr, x.C, None, 0, None, None, x.rows, x.C, 1e-5, stats_out=st.ptr), label + ".lnstat")
         self._gemm(label, x.rows, N, segs, base + ".ln.weight", out,
