@@ -59,6 +59,37 @@ def test_recorded_plan_matches_oracle(monkeypatch):
     assert rel_l2(eps, eps_ref) < 2e-2, rel_l2(eps, eps_ref)
 
 
+def test_plan_replay_is_self_contained(monkeypatch):
+    """the all-frame GroupNorms add into two alternating int64 accumulator buffers and each apply pass clears only the
+    OTHER one, so after an odd number of such norms (or an aborted replay) the buffer norm 0 uses is dirty.  The plan's first
+    launch clears both: replaying it — whole, by segments, or after garbage was left in the accumulators — needs nothing
+    from prepare_rows() and gives the same eps every time."""
+    monkeypatch.setenv("VMV_GN_FUSED", "0")          # tiny stat groups would otherwise take the one-launch path (no totals)
+    plan_interp.install(monkeypatch)
+    from videomv_amd.unet_engine import UNetEngine
+    ocfg = UNetCfg(**{k: v for k, v in CFG.items() if k in {f.name for f in dataclasses.fields(UNetCfg)}})
+    sd = random_state_dict(unet_param_shapes(ocfg), 99)
+    B, F_, H, W, L = 2, 3, 8, 8, 5
+    x, t, y, cam = _inputs(B, F_, H, W, L)
+    eng = UNetEngine(CFG, sd, B, F_, H, W, L, torch.device("cpu"), n_t=B)
+    assert eng.S.labels[0] == "gn.totals.clear" and eng._gn_tot_k > 0            # the totals path is really on the plan
+    eng.set_context(y)
+    eng.set_camera(cam)
+    eng.forward_rows(x, t)
+    ref = eng.eps_rows.clone()
+    assert rel_l2(eng.eps_ncfhw(), unet_forward(sd, ocfg, x, t, y, cam)) < 2e-2
+    for poison in (False, True):
+        if poison:
+            eng._gn_tot2.fill_(123456789)             # what an aborted replay could leave behind
+        eng.eps_rows.zero_()
+        eng.run_plan()                                # no prepare_rows()
+        assert torch.equal(eng.eps_rows, ref)
+    eng.eps_rows.zero_()
+    for seg in eng.segments():
+        eng.run_segment(seg)
+    assert torch.equal(eng.eps_rows, ref)
+
+
 @pytest.mark.parametrize("fold,inline", [("0", "1"), ("1", "0"), ("1", "1")])
 def test_layernorm_folding_is_equivalent(monkeypatch, fold, inline):
     """VMV_FOLD_LN: LayerNorm -> Linear as one GEMM on the raw rows (packing.fold_layernorm; row statistics from a separate

@@ -268,3 +268,113 @@ def test_cfg_parallel_times_frame_parallel(world):
         assert r["B"] == 1 and r["fp_world"] == world // 2 and r["branch"] == r["rank"] // (world // 2)
         assert r["finite"] and r["e_step"] < 6e-2 and r["e_loop"] < 8e-2, r
     assert {r["branch"] for r in res} == {0, 1}
+
+
+# ------------------------------------------------------------------------------------------------- world 8 (BASELINE configs[2])
+def _w8_reference(path):
+    """Single-rank results at F = 24 (computed once, in the parent): batched eps rows and one fused CFG + DDIM step."""
+    from tests import plan_interp
+    plan_interp.install(_Patch)
+    from oracle.unet_ref import UNetCfg
+    from oracle.weights import random_state_dict, unet_param_shapes
+    from videomv_amd.unet_engine import UNetEngine
+    from videomv_amd.registry import MODEL, DIFFUSION
+    import videomv_amd  # noqa: F401
+    ocfg = UNetCfg(**{k: v for k, v in CFG.items() if k in {f.name for f in dataclasses.fields(UNetCfg)}})
+    sd = random_state_dict(unet_param_shapes(ocfg), 99)
+    B, F_, H, W, L = 2, 24, 8, 8, 5
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 4, F_, H, W, generator=g)
+    t = torch.tensor([501])
+    y = torch.randn(B, L, 1024, generator=g)
+    cam = torch.randn(1, F_, 16, generator=g)
+    eng = UNetEngine(CFG, sd, B, F_, H, W, L, torch.device("cpu"), n_t=1)
+    eng.set_context(y); eng.set_camera(cam)
+    eng.forward_rows(x, t)
+    m = MODEL.build(dict(type="UNetSD_T2VBase", **{k: v for k, v in CFG.items()}))
+    m.load_state_dict(sd, strict=False)
+    diff = DIFFUSION.build(dict(type="DiffusionDDIM", schedule="linear_sd",
+                                schedule_param=dict(num_timesteps=1000, init_beta=0.00085, last_beta=0.0120),
+                                mean_type="eps", var_type="fixed_small"))
+    xt = x.clone()
+    diff.ddim_step_hip(xt, 501, m, dict(y=y[:1], camera_data=cam), dict(y=y[1:], camera_data=cam), 9.0, 500)
+    torch.save(dict(sd=sd, x=x, y=y, cam=cam, eps=eng.eps_ncfhw(), x_next=xt), path)
+
+
+def _w8_worker(rank, world, port, path, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        torch.set_num_threads(1)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from tests import plan_interp
+        plan_interp.install(_Patch)
+        from videomv_amd.comm import FrameComm, CfgFrameComm
+        from videomv_amd.unet_engine import UNetEngine
+        from videomv_amd.registry import MODEL, DIFFUSION
+        from videomv_amd.unet_t2v import gather_frames
+        import videomv_amd  # noqa: F401
+        ref = torch.load(path)
+        sd, x, y, cam = ref["sd"], ref["x"], ref["y"], ref["cam"]
+        B, F_, H, W, L = 2, 24, 8, 8, 5
+        t = torch.tensor([501])
+        out = dict(rank=rank)
+        # (i) the single B = 2 plan, frames sharded 3 per rank, pixels HW / 8 per rank in the temporal ops
+        comm = FrameComm()
+        fl = F_ // world
+        sl = slice(rank * fl, (rank + 1) * fl)
+        eng = UNetEngine(CFG, sd, B, F_, H, W, L, torch.device("cpu"), n_t=1, comm=comm)
+        eng.set_context(y); eng.set_camera(cam)
+        eng.forward_rows(x[:, :, sl].contiguous(), t)
+        out.update(fl=fl, e_plan=rel_l2(eng.eps_ncfhw(), ref["eps"][:, :, sl]), a2a=comm.n_all_to_all, ag=comm.n_all_gather,
+                   collectives_per_plan=len(eng.breaks))
+        # (ii) branch-pipelined fused CFG + DDIM step through the module API
+        m = MODEL.build(dict(type="UNetSD_T2VBase", **{k: v for k, v in CFG.items()}))
+        m.load_state_dict(sd, strict=False)
+        diff = DIFFUSION.build(dict(type="DiffusionDDIM", schedule="linear_sd",
+                                    schedule_param=dict(num_timesteps=1000, init_beta=0.00085, last_beta=0.0120),
+                                    mean_type="eps", var_type="fixed_small"))
+        kc, ku = dict(y=y[:1], camera_data=cam), dict(y=y[1:], camera_data=cam)
+        m.set_frame_parallel(comm)
+        xt = x[:, :, sl].clone().contiguous()
+        diff.ddim_step_hip(xt, 501, m, kc, ku, 9.0, 500)
+        out["e_pipe"] = rel_l2(gather_frames(comm, xt), ref["x_next"])
+        out["pipe_plans"] = len(m._pipe["engs"])
+        # (iii) CFG-parallel x frame-parallel: 2 branch groups x 4 frame shards (6 frames per rank)
+        m.set_frame_parallel(None)
+        cc = CfgFrameComm()
+        m.set_frame_parallel(cc)
+        f2 = F_ // cc.world
+        xt = x[:, :, cc.rank * f2:(cc.rank + 1) * f2].clone().contiguous()
+        diff.ddim_step_hip(xt, 501, m, kc, ku, 9.0, 500)
+        out.update(e_cfgpar=rel_l2(gather_frames(cc, xt), ref["x_next"]), branch=cc.branch, fp_world=cc.world)
+        q.put(out)
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put(dict(rank=rank, error=traceback.format_exc()))
+
+
+def test_world_8_three_frames_per_rank(tmp_path):
+    """BASELINE configs[2]'s partitioning — 24 views, 8 ranks, 3 frames per rank, HW / 8 pixels per rank in the temporal
+    operators — on 8 gloo ranks: the single B = 2 sharded plan, the branch-pipelined fused step and CFG-parallel x
+    frame-parallel (2 x 4, 6 frames per rank) against the single-rank results (tolerances: module docstring)."""
+    path = str(tmp_path / "ref.pt")
+    _w8_reference(path)
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_w8_worker, args=(r, world, port, path, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=1500) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert "error" not in r, r["error"]
+    assert sorted(r["rank"] for r in res) == list(range(8))
+    for r in res:
+        assert r["fl"] == 3 and r["pipe_plans"] == 2 and r["fp_world"] == 4 and r["branch"] == r["rank"] // 4
+        assert r["e_plan"] < 3e-2 and r["e_pipe"] < 6e-2 and r["e_cfgpar"] < 6e-2, r
+        assert r["a2a"] >= 2 * (3 + 4) and r["ag"] >= 4 * 3 + 4, r

@@ -59,6 +59,18 @@ VMV_DEV u32x4_t swap16_xz_yw(u32x4_t v) {
 }
 
 constexpr int RS_GEGLU = 1, RS_LN = 2, RS_RES = 4;
+#ifndef VMV_RS_STAGGER
+#define VMV_RS_STAGGER 0        // experiments: 1 = waves 4-7 take the chunk barrier between the MFMAs and the epilogue of a chunk's last pair
+#endif
+#ifndef VMV_RS_RELAX
+#define VMV_RS_RELAX 1          // experiments: 0 = the chunk-end wait lets only the current chunk's stores stay in flight
+#endif
+#ifndef VMV_RS_PFD
+#define VMV_RS_PFD 1            // W-fragment prefetch distance in k-steps (experiments: 1, 2, 3)
+#endif
+#ifndef VMV_RS_ABLATE
+#define VMV_RS_ABLATE 0         // experiments (results are wrong): 1 no stores, 2 GELU -> identity, 3 no MFMAs, 4 no W DMA after the prologue,
+#endif                          // 5 no LayerNorm arithmetic, 6 no W fragment reads, 7 no chunk barriers; 8 = s_memtime stamps (results right)
 
 template <int RT, int KS, int MODE>
 __global__ __launch_bounds__(512, 1) void gemm_rs_kernel(const VmvGemmParams p, const int tiles_m, const int nsplit, const int cols_per_split) {
@@ -86,6 +98,19 @@ __global__ __launch_bounds__(512, 1) void gemm_rs_kernel(const VmvGemmParams p, 
     const int n_begin = ns * cols_per_split;
     const int ncols = (p.N - n_begin) < cols_per_split ? (p.N - n_begin) : cols_per_split;     // W rows of this block: k * CROWS (launcher)
     const int NC = ncols / Cfg::CROWS;
+#if VMV_RS_ABLATE == 8      // experiments: block 0, waves 0 and 4 stamp s_memtime at the phase boundaries into p.workspace
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(p.workspace);
+    int stamp_i = 0;
+    auto stamp = [&]() {
+        if (stamps && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4) && stamp_i < 256)
+            stamps[(wave == 4 ? 256 : 0) + stamp_i] = __builtin_readcyclecounter();
+        ++stamp_i;
+    };
+#define RS_STAMP() stamp()
+#else
+#define RS_STAMP()
+#endif
+    RS_STAMP();      // 0: kernel start
 
     // ---- the wave's RT x 16 rows of A, whole K range, straight into registers (rows >= M read as zero through the descriptor)
     const VmvGemmSeg& sg = p.seg[0];
@@ -111,25 +136,26 @@ __global__ __launch_bounds__(512, 1) void gemm_rs_kernel(const VmvGemmParams p, 
             VMV_BLDS16(b_rsrc, reinterpret_cast<unsigned char*>(bias_lds) + q * 1024, (uint32_t)(n_begin + q * 256 + 4 * lane) * 4u, 0);
     }
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, (uint32_t)p.N * (uint32_t)p.ktot * 2u, SRD_FLAGS);
-    uint32_t wvo[P];
-#pragma unroll
-    for (int q = 0; q < P; ++q) {
-        const int u = wave * (P * 64) + q * 64 + lane;
-        const int r = u / Cfg::SPR, s = u - r * Cfg::SPR;
-        const int sw = KS == 10 ? ((r >> 1) & 7) : (r & 15);
-        wvo[q] = (uint32_t)(r * p.ktot + (s ^ sw) * 8) * 2u;
-    }
     auto issue_chunk = [&](int c, int slot) {
         unsigned char* base = smem + slot * Cfg::CHUNK_BYTES + wave * (P * 1024);
         const uint32_t so = (uint32_t)((n_begin + c * Cfg::CROWS) * p.ktot) * 2u;
+        // (the five source offsets are recomputed per chunk — ~30 VALU operations per 160+ MFMAs — instead of living in five
+        //  registers next to 160 of resident rows; the empty asm keeps the compiler from hoisting them out of the loop again)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
 #pragma unroll
-        for (int q = 0; q < P; ++q) VMV_BLDS16(w_rsrc, base + q * 1024, wvo[q], so);
+        for (int q = 0; q < P; ++q) {
+            const int u = wave * (P * 64) + q * 64 + ln;
+            const int r = u / Cfg::SPR, s = u - r * Cfg::SPR;
+            const int sw = KS == 10 ? ((r >> 1) & 7) : (r & 15);
+            VMV_BLDS16(w_rsrc, base + q * 1024, (uint32_t)(r * p.ktot + (s ^ sw) * 8) * 2u, so);
+        }
     };
     const int pro = NC < Cfg::STAGES ? NC : Cfg::STAGES;
     for (int c = 0; c < pro; ++c) issue_chunk(c, c);
 
     // ---- LayerNorm of the resident rows (two-pass, fp32): lanes frow, frow + 16, + 32, + 48 hold the four k-quarters of a row
-    if constexpr (LN) {
+    if constexpr (LN && VMV_RS_ABLATE != 5) {
         const float inv_k = 1.0f / (float)Cfg::K;
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
@@ -172,10 +198,14 @@ __global__ __launch_bounds__(512, 1) void gemm_rs_kernel(const VmvGemmParams p, 
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, SRD_RECORDS, SRD_FLAGS);
     const __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual), 0, SRD_RECORDS, SRD_FLAGS);
     const uint32_t ovo = (uint32_t)(frow * p.ldo + lanecol) * 2u;
+    // GEGLU (one 16-column output tile per pair): the swap pairs two ROW tiles instead — lanes with even fgrp end up with 8
+    // channels of row frow of tile i, odd fgrp with those of tile i + 1; columns (fgrp >> 1) * 8 .. + 8
+    const uint32_t ovo_g = (uint32_t)((frow + 16 * (fgrp & 1)) * p.ldo + (fgrp >> 1) * 8) * 2u;
     const uint32_t rvo = (uint32_t)(frow * p.ldr + lanecol) * 2u;
     const float rs = p.res_scale != 0.f ? p.res_scale : 1.f;
     auto row_ok = [&](int i) { return m_wave + 16 * i + frow < p.M; };
 
+    RS_STAMP();      // 1: resident rows loaded (and normalised), DMA issued
     // ---- first chunk (and the bias strip, issued before it) visible to every wave
     if (pro >= 3) wait_vmcnt_rt(2 * P); else if (pro == 2) wait_vmcnt_rt(P); else wait_vmcnt_rt(0);
     __builtin_amdgcn_s_barrier();
@@ -183,6 +213,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rs_kernel(const VmvGemmParams p, 
 
     // fragment addressing: this lane's rows 16 j + frow have swz = fsw (lane constant); k-slot (4 kk + fgrp) ^ fsw =
     // 4 (kk ^ (fsw >> 2)) + (fgrp ^ (fsw & 3)), so with NB = 2 (4) lane offsets, one per kk mod NB, every read is base + 64 kk
+    RS_STAMP();      // 2: first chunk landed, barrier passed
     const int fsw = KS == 10 ? ((frow >> 1) & 7) : frow;      // swz() of this lane's fragment rows
     constexpr int NB = KS == 10 ? 2 : 4;
     int foff[NB];
@@ -194,33 +225,40 @@ __global__ __launch_bounds__(512, 1) void gemm_rs_kernel(const VmvGemmParams p, 
         for (int r = 0; r < NB; ++r) tb[r] = sbase + 32 * q * RB + foff[r];
 #pragma unroll
         for (int i = 0; i < RT; ++i) { c0[i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; c1[i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
-        // W fragments of k-step kk + 1 are requested before the MFMAs of k-step kk (the order is pinned: left alone the compiler
-        // issues each pair of reads right in front of its MFMAs and the matrix pipe waits out the LDS latency 10 times per pair)
-        // (the residual variant at 64 rows per wave has no 8 registers left for the second fragment set: it is HBM-bound anyway)
-        constexpr bool PF = !(RES && RT == 4);
-        u32x4_t w0[2], w1[2];
+        // W fragments of k-step kk + PFD are requested before the MFMAs of k-step kk (the order is pinned: left alone the compiler
+        // issues each pair of reads right in front of its MFMAs and the matrix pipe waits out the LDS latency 10 times per pair;
+        // ablation on the GPU: with the reads removed the kernel runs 36-47 % faster, i.e. one k-step of cover — 8 MFMAs = 128
+        // cycles at 64 rows per wave, 64 cycles at 32 — is less than the loaded LDS latency)
+        // (the residual variant at 64 rows per wave has no registers left for a second fragment set: it is HBM-bound anyway)
+        constexpr int PFD = (RES && RT == 4) ? 0 : (VMV_RS_PFD);
+        constexpr int NBUF = PFD + 1;
+        u32x4_t w0[NBUF], w1[NBUF];
         auto rd = [&](const int kk, u32x4_t& x0, u32x4_t& x1) {
             const unsigned char* t = tb[kk & (NB - 1)] + 64 * kk;
+#if VMV_RS_ABLATE == 6
+            x0 = u32x4_t{(uint32_t)(uintptr_t)t, 1u, 2u, 3u}; x1 = x0;
+#else
             x0 = *reinterpret_cast<const u32x4_t*>(t);
             x1 = *reinterpret_cast<const u32x4_t*>(t + 16 * RB);
+#endif
         };
-        if constexpr (PF) rd(0, w0[0], w1[0]);
+#pragma unroll
+        for (int kk = 0; kk < PFD; ++kk) rd(kk, w0[kk % NBUF], w1[kk % NBUF]);
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
-            constexpr int one = PF ? 1 : 0;
-            const int cur = (kk & 1) * one;
-            if constexpr (PF) {
-                if (kk + 1 < KS) rd(kk + 1, w0[(kk + 1) & 1], w1[(kk + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-            } else {
-                rd(kk, w0[0], w1[0]);
-            }
+            const int cur = kk % NBUF;
+            if (kk + PFD < KS) rd(kk + PFD, w0[(kk + PFD) % NBUF], w1[(kk + PFD) % NBUF]);
+            if constexpr (PFD > 0) __builtin_amdgcn_sched_barrier(0);
+#if VMV_RS_ABLATE == 3
+            c0[0].x += __uint_as_float(w0[cur].x ^ a[kk % RT][kk].x); c1[0].x += __uint_as_float(w1[cur].y ^ a[(kk + 1) % RT][kk].y);
+#else
 #pragma unroll
             for (int i = 0; i < RT; ++i) {
                 c0[i] = VMV_MFMA16(__builtin_bit_cast(elem8_t, w0[cur]), __builtin_bit_cast(elem8_t, a[i][kk]), c0[i], 0, 0, 0);
                 c1[i] = VMV_MFMA16(__builtin_bit_cast(elem8_t, w1[cur]), __builtin_bit_cast(elem8_t, a[i][kk]), c1[i], 0, 0, 0);
             }
-            if constexpr (PF) __builtin_amdgcn_sched_barrier(0);
+#endif
+            if constexpr (PFD > 0) __builtin_amdgcn_sched_barrier(0);
         }
     };
     // residual of one pair in store layout, requested before the pair's MFMAs
@@ -231,6 +269,9 @@ __global__ __launch_bounds__(512, 1) void gemm_rs_kernel(const VmvGemmParams p, 
     };
     auto store_pair = [&](const int ocol, const int i, u32x4_t o) {
         o = swap16_xz_yw(o);
+#if VMV_RS_ABLATE == 1
+        if (o.x == 0x12345u && o.y == 0x54321u)
+#endif
         __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, row_ok(i) ? ovo : OOB, (uint32_t)((m_wave + 16 * i) * p.ldo + ocol) * 2u, 0);
         // Store-data discipline (cf. gemm_pglds.hip): the allocator hands the store's registers to the next row tile's
         // v_pk_add_f32 at once, and with the VALU write directly behind the store the LAST dword of the last four lanes of
@@ -239,45 +280,89 @@ __global__ __launch_bounds__(512, 1) void gemm_rs_kernel(const VmvGemmParams p, 
         asm volatile("s_nop 7" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w) : "memory");
     };
 
-    u32x2_t hprev[RT];            // GEGLU: the packed output tile of the first pair of a body
     // body b: W rows [64 b, 64 b + 64) of the block = two pairs; one chunk (G = 4) or two (G = 2)
     const int nbody = ncols / 64;
     int c = 0, slot = 0;
-    auto chunk_end = [&](const int stores) {       // the wave's stores since the last chunk_end (compile-time per call site)
+    auto chunk_end = [&](const int stores) {       // the wave's stores issued behind chunk c + 2's DMA (or a lower bound)
         if (c + 1 < NC) {
             // chunk c + 1 landed (mine): everything issued after its DMA — chunk c + 2's DMA and this chunk's stores — may stay in flight
+#if VMV_RS_ABLATE == 4 || VMV_RS_ABLATE == 1
+            wait_vmcnt_rt(0);
+#else
             wait_vmcnt_rt((c + 2 < NC ? P : 0) + stores);
+#endif
             __builtin_amdgcn_s_waitcnt(0xc07f);
+#if VMV_RS_ABLATE != 7
             __builtin_amdgcn_s_barrier();          // every wave is done with slot `slot`, chunk c + 1 is visible
+#endif
             asm volatile("" ::: "memory");
+#if VMV_RS_ABLATE != 4
             if (c + Cfg::STAGES < NC) issue_chunk(c + Cfg::STAGES, slot);
+#endif
         }
         ++c;
         slot = slot + 1 == Cfg::STAGES ? 0 : slot + 1;
     };
+    // Staggered halves.  All eight waves meet at the chunk barrier, so left alone the two waves of a SIMD (w and w + 4) run in
+    // lock-step: both multiply, then both run their epilogues with the matrix pipe idle (first GPU run: 8.8 k cycles per body of
+    // 2 x 2.56 k MFMA cycles).  Waves 4-7 therefore take the barrier BETWEEN the MFMAs and the epilogue of a chunk's last pair
+    // (their accumulators simply stay live across it): after every barrier one wave of the SIMD starts multiplying while the
+    // other starts an epilogue, and they keep alternating.  The wait count of the late half names the stores that sit behind
+    // the next chunk's DMA at that point (a smaller count than the true one only waits for more).
+    constexpr bool STAGGER = VMV_RS_STAGGER != 0 && !RES;
+    const bool late = STAGGER && wave >= Cfg::NW / 2;
     for (int b = 0; b < nbody; ++b) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const unsigned char* sbase = smem + slot * Cfg::CHUNK_BYTES;
             const int q = G == 4 ? h : 0;                         // pair index inside the chunk
             const int nrel = 64 * b + 32 * h;                     // first W row of the pair, relative to n_begin
-            const int ocol = GEGLU ? (n_begin + 64 * b) / 2 : n_begin + nrel;      // first output column of the store
+            const int ocol = GEGLU ? (n_begin + nrel) / 2 : n_begin + nrel;        // first output column of the pair
             f32x4_t c0[RT], c1[RT];
             u32x4_t rv[RT];
             if constexpr (RES) load_res(ocol, rv);
+            RS_STAMP();      // 3 + 6 k (+ 3 for h = 1): pair start
             mma_pair(sbase, q, c0, c1);
+            RS_STAMP();      // MFMAs issued
+            const bool cend = G == 2 || h == 1;                   // last pair of its chunk (compile-time after unrolling)
+            constexpr int SP = GEGLU ? RT / 2 : RT;               // store instructions per pair
+            // chunk_end(n): n = this wave's stores issued since chunk c + 1's DMA went out (at the chunk_end two chunks ago); they and
+            // chunk c + 2's DMA may stay in flight.  (The first version waited for all but the last chunk's stores: with the
+            // write path of a store-heavy GEMM backed up that is a write round trip on the critical path of every chunk.)
+            if (cend && late) {
+#if VMV_RS_RELAX
+                if (G == 4) chunk_end(c == 0 ? SP : c == 1 ? 3 * SP : 4 * SP);
+                else chunk_end(c == 0 ? 0 : c == 1 ? SP : 2 * SP);
+#else
+                if (G == 4) chunk_end(c == 0 ? SP : 2 * SP);
+                else chunk_end(c == 0 ? 0 : SP);
+#endif
+            }
             const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(bias_lds + nrel + 4 * fgrp);
             const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(bias_lds + nrel + 16 + 4 * fgrp);
             if constexpr (GEGLU) {
+                u32x2_t hp[RT];
 #pragma unroll
                 for (int i = 0; i < RT; ++i) {
                     f32x4_t v = c0[i] + b0;
                     const f32x4_t gt = c1[i] + b1;
+#if VMV_RS_ABLATE == 2
+                    v *= gt;
+#else
                     v.x *= gelu_erf_f(gt.x); v.y *= gelu_erf_f(gt.y); v.z *= gelu_erf_f(gt.z); v.w *= gelu_erf_f(gt.w);
-                    u32x2_t hp;
-                    hp.x = pack_elem2(v.x, v.y); hp.y = pack_elem2(v.z, v.w);
-                    if (h == 0) hprev[i] = hp;
-                    else store_pair(ocol, i, u32x4_t{hprev[i].x, hprev[i].y, hp.x, hp.y});
+#endif
+                    hp[i].x = pack_elem2(v.x, v.y); hp[i].y = pack_elem2(v.z, v.w);
+                    if (i & 1) {
+                        u32x4_t o = swap16_xz_yw(u32x4_t{hp[i - 1].x, hp[i - 1].y, hp[i].x, hp[i].y});
+                        const bool ok = m_wave + 16 * (i - 1 + (fgrp & 1)) + frow < p.M;
+#if VMV_RS_ABLATE == 1
+                        if (o.x == 0x12345u && o.y == 0x54321u)
+#endif
+                        __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, ok ? ovo_g : OOB, (uint32_t)((m_wave + 16 * (i - 1)) * p.ldo + ocol) * 2u, 0);
+                        asm volatile("s_nop 7" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w) : "memory");       // (store-data discipline: store_pair)
+                    }
+                    // one row tile at a time: left alone the scheduler interleaves all 16 GELUs of the pair for ILP
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
 #pragma unroll
@@ -294,11 +379,12 @@ __global__ __launch_bounds__(512, 1) void gemm_rs_kernel(const VmvGemmParams p, 
                     store_pair(ocol, i, o);
                 }
             }
-            if (G == 2 || h == 1) {
-                constexpr int per_pair = RT;                      // stores of a pair (GEGLU: of a body)
-                if (G == 2) chunk_end(GEGLU ? (h == 1 ? per_pair : 0) : per_pair);
-                else chunk_end(GEGLU ? per_pair : 2 * per_pair);
-            }
+            RS_STAMP();      // epilogue issued
+#if VMV_RS_RELAX
+            if (cend && !late) chunk_end(c == 0 ? SP * (G / 2) : 2 * SP * (G / 2));
+#else
+            if (cend && !late) chunk_end(SP * (G / 2));
+#endif
         }
     }
 }

@@ -225,6 +225,7 @@ class UNetEngine:
         # pre-folded statistics of the all-frame norms: [nstat][32][2] per rank (+ the gathered [R][nstat][32][2]), tickets
         # two buffers used alternately by consecutive all-frame norms (the apply pass of one clears the other's)
         self._gn_tot2 = torch.zeros(2, 64 * 64, dtype=torch.int64, device=device)
+        self._gn_zero = torch.zeros(2, 64 * 64, dtype=torch.int64, device=device)     # source of the plan's own clearing copy
         self._gn_tot_k = 0
         self._gn_tot_all = torch.zeros(64 * 64 * self.R, dtype=torch.int64, device=device) if comm is not None else None
         self.taps = taps            # optional dict: prefix -> Act (buffers are then never recycled)
@@ -737,7 +738,13 @@ class UNetEngine:
     def _build(self):
         B, F = self.B, self.F
         S = self.S
-        # (0) embeddings -> one [B*F, sum Cout] table for all ResBlocks (recorded first)
+        # The plan cleans up after itself: its FIRST launch zeroes both stat-group accumulator buffers of the all-frame norms (each
+        # norm's apply pass only clears the OTHER buffer, so after an odd number of such norms — or an aborted replay — the one
+        # norm 0 adds into would still hold the last statistics).  Replays therefore need nothing from prepare_rows(): run_plan() /
+        # run_segment() / a per-op replay / a hipGraph capture of the plan are all self-contained.  64 KB, ~2 us per forward.
+        S.copy(ops.copy_params(self._gn_zero.data_ptr(), self._gn_tot2.data_ptr(), 1, 1, 1, self._gn_tot2.numel() // 2, 0, 0),
+               "gn.totals.clear")
+        # (0) embeddings -> one [B*F, sum Cout] table for all ResBlocks
         self.n_emb_ops_start = S.nops
         e = Act(self.emb_silu.view(torch.uint8).view(-1), B * F, self.E)
         eo = Act(self.emb_out.view(torch.uint8).view(-1), B * F, self.emb_total, torch.float32)
@@ -872,7 +879,6 @@ class UNetEngine:
     def prepare_rows(self, x: torch.Tensor, t: torch.Tensor):
         """Everything of forward_rows before the plan: latent -> rows, timestep, embeddings."""
         nb = x.shape[0]
-        self._gn_tot2.zero_()         # stat-group accumulators start clean whatever the previous replay left (odd count, abort)
         # only the latent's own channels are written: channels >= x.shape[1] hold zeros (T2V) or the step-invariant
         # image `concat` of the I2VGen front-end (unet_i2vgen.py:383)
         ops.latent_to_rows_keep(x.contiguous(), self.x_rows, self.cin_pad, self.B // nb)
