@@ -130,7 +130,9 @@ def main():
     ap.add_argument("--frame-parallel-budget", type=float, default=300.0, help="seconds before the watchdog abandons that leg")
     ap.add_argument("--no-lgm", action="store_true", help="skip the LGM-refined sample (BASELINE configs[4])")
     ap.add_argument("--no-sample", action="store_true", help="skip the (untimed-region) full 50-step + VAE-decode sample")
-    ap.add_argument("--no-alt-dtype", action="store_true", help="skip the side measurement with the other 16-bit element type")
+    ap.add_argument("--no-alt-dtype", action="store_true", help="(default since round 3; kept for old command lines)")
+    ap.add_argument("--alt-dtype", action="store_true", help="also time the other 16-bit element type's library in a child process "
+                    "(bf16 is the range fallback — DESIGN.md §6 — and not part of the headline line)")
     args = ap.parse_args()
     H, W = (int(v) for v in args.latent.split("x"))
     rank = int(os.environ.get("RANK", "0"))
@@ -392,12 +394,29 @@ def main():
         kw_l = [dict(y=y, camera_data=cam_l, gs_data=gs_data), dict(y=y0, camera_data=cam_l, gs_data=gs_data)]
         xl = noise_l.clone()
         dif.ddim_step_hip(xl, steps[0], model_l, kw_l[0], kw_l[1], 9.0, stride)          # warm-up: plans, VAE engines, LGM
-        dif.ddim_step_lgm(xl, steps[1], model_l, kw_l[0], kw_l[1], 9.0, stride, vae)
+        # the LGM-refined step: 2 warm-up calls, then 6 timed ones (round 2 timed ONE call after one warm-up and the driver's box
+        # recorded it cold: 138 ms against ~80 in the loop); median and min are reported, next to the in-loop figure below
+        for i in range(2):
+            dif.ddim_step_lgm(xl, steps[1 + i], model_l, kw_l[0], kw_l[1], 9.0, stride, vae)
+        t_calls = []
+        for i in range(6):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            dif.ddim_step_lgm(xl, steps[3 + i], model_l, kw_l[0], kw_l[1], 9.0, stride, vae)
+            torch.cuda.synchronize()
+            t_calls.append(time.perf_counter() - t1)
+        t_calls.sort()
+        t_lgm_step, t_lgm_min = 0.5 * (t_calls[2] + t_calls[3]), t_calls[0]
+        # plain steps at this shape (for the in-loop attribution: loop = 47 plain + 3 refined steps)
+        xp = noise_l.clone()
+        for i in range(2):
+            dif.ddim_step_hip(xp, steps[i], model_l, kw_l[0], kw_l[1], 9.0, stride)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        dif.ddim_step_lgm(xl, steps[2], model_l, kw_l[0], kw_l[1], 9.0, stride, vae)
+        for i in range(8):
+            dif.ddim_step_hip(xp, steps[2 + i], model_l, kw_l[0], kw_l[1], 9.0, stride)
         torch.cuda.synchronize()
-        t_lgm_step = time.perf_counter() - t1
+        t_plain = (time.perf_counter() - t1) / 8
         t1 = time.perf_counter()
         x0_l = dif.ddim_sample_loop(noise=noise_l, model=model_l, autoencoder=vae, model_kwargs=kw_l, guide_scale=9.0,
                                     ddim_timesteps=50, eta=0.0)
@@ -407,6 +426,9 @@ def main():
         lgm = dict(workload="t2v + use_lgm_refine=True, latent 24x32x32, 50 DDIM steps, LGM at step indices 20/30/40 "
                             "(2 branches each): LGM 'big' 415 M params, 65 536 Gaussians, 24 renders at 512x512 per branch",
                    ddim50_lgm_seconds=round(t_loop, 4), lgm_refined_step_ms=round(1000 * t_lgm_step, 2),
+                   lgm_refined_step_min_ms=round(1000 * t_lgm_min, 2), lgm_refined_step_calls=6,
+                   plain_step_ms=round(1000 * t_plain, 2),
+                   lgm_refined_step_in_loop_ms=round(1000 * (t_loop - 47 * t_plain) / 3, 2),
                    instances_per_view=int(sum(ref_l.renderer.last_num_rendered) / max(1, len(ref_l.renderer.last_num_rendered))),
                    finite=bool(torch.isfinite(x0_l).all()))
         del model_l
@@ -435,7 +457,7 @@ def main():
     # ---- the same timed region with the OTHER element type's kernels (child process: a process loads one library).  BASELINE
     #      configs[1] says bf16; the default is fp16 because only fp16 meets the stated parity tolerances
     alt = None
-    if rank == 0 and world == 1 and not args.no_alt_dtype and not args.no_sample:
+    if rank == 0 and world == 1 and args.alt_dtype and not args.no_alt_dtype and not args.no_sample:
         import subprocess
         other = "bf16" if L.elem_name() == "fp16" else "fp16"
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--latent",
@@ -454,8 +476,9 @@ def main():
 
     if rank == 0:
         out = headline()
-        out.update({"sample_24view": sample, "lgm_refined_sample": lgm, "frame_parallel": fpar, "cpu_baseline": cpu,
-                    "other_dtype": alt})
+        out.update({"sample_24view": sample, "lgm_refined_sample": lgm, "frame_parallel": fpar, "cpu_baseline": cpu})
+        if alt is not None:
+            out["other_dtype"] = alt
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -29,7 +29,7 @@ extern "C" {
 #define VMV_ENULL        -3   /* required pointer is NULL */
 #define VMV_ERANGE       -4   /* size outside what the kernel supports */
 
-#define VMV_ABI_VERSION   6
+#define VMV_ABI_VERSION   7
 int vmv_abi_version(void);
 /* The 16-bit storage / MFMA operand type ("elem") this build of the library computes in.  The same sources are
  * compiled once per type: libvmv_hip_f16.so (VMV_ELEM_F16: IEEE fp16 — the default; the reference's own half mode,
@@ -38,6 +38,9 @@ int vmv_abi_version(void);
 #define VMV_ELEM_F16      0
 #define VMV_ELEM_BF16     1
 int vmv_elem_type(void);
+/* 1 if this build carries the experiment kernels (make EXPERIMENTS=1: VMV_TILE_S*, VMV_TILE_A*, the ablation hooks), else 0:
+ * vmv_gemm then answers VMV_EINVAL to those forced tile ids */
+int vmv_has_experiments(void);
 /* sizeof() of the argument blocks, so a foreign-language binding can verify its struct layout:
  * which = VMV_OP_* (GN_STATS/GN_APPLY share a block), 100 = VmvDdimParams, 101 = VmvGemmSeg, 102 = VmvSeqMap,
  * 103 = VmvGsParams */
@@ -167,7 +170,7 @@ int vmv_gemm_pick_tile(const VmvGemmParams* p);
  * GroupNorm(32 groups) over row blocks + optional SiLU (torch group_norm + silu: util.py:329,649,673,1014,
  * 1358-1373; unet_t2v.py:262; autoencoder.py Normalize).  A "stat group" is `rows_per_stat` consecutive rows:
  * H*W rows for the per-frame 4-D norms, F*H*W rows for the 5-D norms whose statistics span all frames
- * (SURVEY F9).  Two launches: partial sums (deterministic, no atomics), then normalise(+SiLU).
+ * (SURVEY F9).  Two launches: partial sums (deterministic: fixed order or integer atomics), then normalise(+SiLU).
  * ---------------------------------------------------------------------------------------------------- */
 typedef struct {
     const void* x;         /* elem [rows][ld]   (second source x1 optional: channels [C0, C0+C1) )  */
@@ -186,19 +189,25 @@ typedef struct {
     int32_t fold_ranks;    /* 0/1: `partial` holds this launch's sums.  R > 1 (frame-sharded 5-D norms): apply
                               folds `partial` = [R][nstat][nchunk][32][2] — the all-gathered sums of R equally sized shards of
                               each stat group — and normalises by R * rows_per_stat rows.  Ignored by _stats.            */
-    /* Optional stat-group totals (long stat groups: the all-frame norms have up to 256 chunks, which every apply block would
-     * otherwise re-fold).  With `totals` set, every _stats block ADDS its 32 (sum, sumsq) pairs to totals[stat][32][2] with
-     * 64-bit integer atomics in fixed point (value * 2^12): integer addition commutes, so the result is bitwise
-     * reproducible whatever the arrival order, and no fold launch and no release fence is needed.  The accumulators must be
-     * ZERO when _stats starts.  _apply reads totals instead of partial ([nstat][32][2], or [R][nstat][32][2] gathered when
-     * fold_ranks = R > 1) and, when `totals_clear` is set, zeroes `clear_count` entries there — the accumulators of the
-     * NEXT norm (two buffers used alternately: the buffer being cleared was last read one norm ago).                     */
+    /* Statistics are taken of x - pilot, the pilot of a (stat group, channel group) being its first element (first row of the stat
+     * group, first channel of the group): shift-invariant, no E[x^2] - mean^2 cancellation for |mean| >> sigma.
+     * Optional stat-group totals (long stat groups: the all-frame norms have up to 256 chunks, which every apply block would
+     * otherwise re-fold).  With `totals` set, every _stats block ADDS its 32 (sum, sumsq) pairs to the records
+     * totals[stat][32][VMV_GN_REC] = { sum_hi, sumsq_hi, sum_lo, sumsq_lo, pilot (fp32 bits), 3 x pad } with 64-bit integer atomics:
+     * two-limb fixed point (integer limb + 2^-40 fraction limb: a block's fp32 partial sum is represented exactly for 1e-3-sized
+     * and for 3e3-sized activations alike, |sum| < 2^63).  Integer addition commutes, so the result is bitwise reproducible
+     * whatever the arrival order, and no fold launch and no release fence is needed.  The accumulators must be ZERO when _stats
+     * starts.  _apply reads totals instead of partial ([nstat][32][VMV_GN_REC], or [R][nstat][32][VMV_GN_REC] gathered when
+     * fold_ranks = R > 1: each rank's sums are relative to ITS pilot and are moved to rank 0's in fp64; fold_ranks > 1 requires
+     * totals) and, when `totals_clear` is set, zeroes `clear_count` int64 entries there — the accumulators of the NEXT norm (two
+     * buffers used alternately: the buffer being cleared was last read one norm ago).                                          */
     int64_t* totals;
     int64_t* totals_clear;
     int32_t clear_count;
     int32_t _pad;
 } VmvGroupNormParams;
 
+#define VMV_GN_REC 8
 int vmv_groupnorm_stats(const VmvGroupNormParams* p, void* stream);
 int vmv_groupnorm_apply(const VmvGroupNormParams* p, void* stream);
 /* One-launch GroupNorm for stat groups that fit on chip: a block stages all rows_per_stat rows of `cols` channels (a

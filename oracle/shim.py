@@ -7,10 +7,9 @@ rotary_embedding_torch, easydict, tyro, kiui, pynvml), registers bare package ob
 reference's package ``__init__`` files (which pull in cv2-based datasets) never run, and puts
 ``/root/reference`` on ``sys.path``.
 
-It is used in exactly two places, both in the authoring container only (``/root/reference`` does not
-exist on the GPU box):
-  * ``oracle/make_golden.py`` — generates ``tests/golden/*.safetensors`` from the imported reference;
-  * ``tests/test_oracle_vs_reference.py`` — skipped automatically when ``/root/reference`` is absent.
+It is used in exactly one place, in the authoring container only (``/root/reference`` does not exist on
+the GPU box): ``oracle/make_golden.py``, which generates ``tests/golden/*.safetensors`` from the imported
+reference (``tests/test_oracle_golden.py`` then holds the oracle to those fixtures everywhere).
 
 The xformers stand-in maps ``memory_efficient_attention`` to exact softmax attention
 (``F.scaled_dot_product_attention``): FMHA is exact attention up to rounding, SURVEY §8c.

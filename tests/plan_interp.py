@@ -100,20 +100,34 @@ def _gn_input(p):
     return x, Cc
 
 
+GN_REC = 8          # int64 per (stat, group) record of VmvGroupNormParams.totals (include/vmv.h)
+
+
+def _gn_pilots(x, nstat, rps, Cc):
+    """pilot[stat][group] = first element of the group: first row of the stat group, first channel of the group."""
+    return x.view(nstat, rps, 32, Cc // 32)[:, 0, :, 0].float().contiguous()
+
+
 def groupnorm_stats(p: L.GroupNormParams):
-    """partial[stat][chunk][group] = (sum, sum of squares) over chunk_rows rows x C/32 channels."""
+    """partial[stat][chunk][group] = (sum, sum of squares) of x - pilot over chunk_rows rows x C/32 channels."""
     x, Cc = _gn_input(p)
     nstat = p.rows // p.rows_per_stat
     nchunk = (p.rows_per_stat + p.chunk_rows - 1) // p.chunk_rows
     part = _view(p.partial, nstat * nchunk * 64, "f32").view(nstat, nchunk, 32, 2)
-    xg = x.view(nstat, p.rows_per_stat, 32, Cc // 32)
+    pil = _gn_pilots(x, nstat, p.rows_per_stat, Cc)
+    xg = x.view(nstat, p.rows_per_stat, 32, Cc // 32) - pil[:, None, :, None]
     for c in range(nchunk):
         blk = xg[:, c * p.chunk_rows:(c + 1) * p.chunk_rows]
         part[:, c, :, 0] = blk.sum(dim=(1, 3))
         part[:, c, :, 1] = (blk * blk).sum(dim=(1, 3))
-    if p.totals:       # fixed-point integer accumulation (order-independent), as the kernel does
-        tot = _view(p.totals, nstat * 64, "i64").view(nstat, 32, 2)
-        tot += torch.round(part.double() * 4096.0).to(torch.int64).sum(dim=1)
+    if p.totals:       # two-limb fixed-point integer accumulation (order-independent), as the kernel does
+        tot = _view(p.totals, nstat * 32 * GN_REC, "i64").view(nstat, 32, GN_REC)
+        v = part.float()                                             # [nstat][nchunk][32][2]
+        hi = torch.floor(v)
+        lo = ((v - hi) * float(2 ** 40)).to(torch.int64)
+        tot[:, :, 0:2] += hi.to(torch.int64).sum(dim=1)
+        tot[:, :, 2:4] += lo.sum(dim=1)
+        tot[:, :, 4] = pil.view(torch.int32).to(torch.int64) & 0xffffffff
 
 
 def groupnorm(p: L.GroupNormParams):
@@ -122,15 +136,26 @@ def groupnorm(p: L.GroupNormParams):
     nstat = p.rows // p.rows_per_stat
     nchunk = (p.rows_per_stat + p.chunk_rows - 1) // p.chunk_rows
     R = max(1, p.fold_ranks)
+    nr = float(p.rows_per_stat) * (Cc // 32)
     if p.totals:
-        part = _view(p.totals, R * nstat * 64, "i64").view(R, nstat, 32, 2).sum(dim=0).double() / 4096.0
+        rec = _view(p.totals, R * nstat * 32 * GN_REC, "i64").view(R, nstat, 32, GN_REC)
+        sr = rec[..., 0:2].double() + rec[..., 2:4].double() / float(2 ** 40)            # [R][nstat][32][2]
+        pil = (rec[..., 4] & 0xffffffff).to(torch.int32).view(torch.float32).double()      # [R][nstat][32]
+        d = pil - pil[0:1]
+        S = (sr[..., 0] + nr * d).sum(dim=0)
+        Q = (sr[..., 1] + 2.0 * d * sr[..., 0] + nr * d * d).sum(dim=0)
+        n = nr * R
+        m = S / n
+        mean = pil[0] + m
+        var = (Q / n - m * m).clamp_min(0.0)
         if p.totals_clear:
             _view(p.totals_clear, p.clear_count, "i64").zero_()
     else:
-        part = _view(p.partial, R * nstat * nchunk * 64, "f32").view(R, nstat, nchunk, 32, 2).double().sum(dim=(0, 2))
-    n = float(p.rows_per_stat) * (Cc // 32) * R
-    mean = part[..., 0] / n
-    var = (part[..., 1] / n - mean * mean).clamp_min(0.0)
+        assert R == 1, "shards are folded through the totals records"
+        part = _view(p.partial, nstat * nchunk * 64, "f32").view(nstat, nchunk, 32, 2).double().sum(dim=1)
+        m = part[..., 0] / nr
+        mean = _gn_pilots(x, nstat, p.rows_per_stat, Cc).double() + m
+        var = (part[..., 1] / nr - m * m).clamp_min(0.0)
     xg = x.view(nstat, p.rows_per_stat, 32, Cc // 32)
     y = ((xg - mean.float()[:, None, :, None]) * torch.rsqrt(var.float() + p.eps)[:, None, :, None]).view(p.rows, Cc)
     y = y * _view(p.gamma, Cc, "f32") + _view(p.beta, Cc, "f32")

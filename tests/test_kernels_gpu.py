@@ -311,7 +311,7 @@ def test_gemm_geglu_many_tiles():
 
     def build(t):
         return ops.gemm_params(M, I2, ops.linear_segs([(t["a"], K, K)]), t["w"], t["out"], I2 // 2, bias=t["b"],
-                               epilogue=L.EPI_GEGLU, tile=L.TILE_S256x128)
+                               epilogue=L.EPI_GEGLU, tile=L.TILE_P256x128)
     cpu, dev = run_gemm(build, c, cpu_ref=False)
     h = cpu["a"].float() @ w.float().t() + b
     x, gate = h.chunk(2, dim=-1)
@@ -361,13 +361,13 @@ def test_groupnorm(rows, rps, C0, C1, silu, eps):
 
 @pytest.mark.parametrize("rows,rps,Cc,silu", [(2 * 61440, 61440, 320, True), (2 * 960, 960, 1280, False), (3 * 500, 500, 64, True)])
 def test_groupnorm_prefolded_totals(rows, rps, Cc, silu):
-    """Long stat groups (the all-frame norms): the stats blocks add their sums to 64-bit fixed-point integer accumulators
-    totals[stat][32][2] (order-independent => deterministic, no fold launch); apply reads them and clears the next norm's.
-    Same statistics as the plain two-launch path up to summation order / the 2^-12 fixed-point rounding."""
+    """Long stat groups (the all-frame norms): the stats blocks add their sums to two-limb 64-bit fixed-point integer accumulators
+    totals[stat][32][GN_REC] (order-independent => deterministic, no fold launch); apply reads them and clears the next norm's.
+    Same statistics as the plain two-launch path up to summation order (the two limbs hold each block's fp32 sum exactly)."""
     x = rnd((rows, Cc), 21, 1.3).cuda() + 0.1
     gamma, beta = (1 + 0.1 * torch.randn(Cc, generator=g(3))).cuda(), (0.1 * torch.randn(Cc, generator=g(4))).cuda()
     part = torch.zeros(ops.gn_partial_floats(rows, rps, Cc) + 64, device="cuda")
-    tot = torch.zeros(2, 64 * 64, dtype=torch.int64, device="cuda")
+    tot = torch.zeros(2, 64 * 32 * ops.GN_REC, dtype=torch.int64, device="cuda")
     y0, y1 = torch.zeros(rows, Cc, dtype=BF, device="cuda"), torch.zeros(rows, Cc, dtype=BF, device="cuda")
     S = ops.Stream(record=False)
     p0 = ops.gn_params(x, Cc, Cc, rows, rps, part, gamma, beta, 1e-5, silu, y0, Cc)
@@ -395,31 +395,71 @@ def test_groupnorm_sharded_statistics(R, B, rps_loc, Cc):
     ref = torch.nn.functional.group_norm(full.permute(0, 2, 1), 32, gamma, beta, 1e-5).permute(0, 2, 1)
     ref = torch.nn.functional.silu(ref)
     nfl = ops.gn_partial_floats(B * rps_loc, rps_loc, Cc)
-    part_all = torch.zeros(R * nfl, device="cuda")
+    part = torch.zeros(nfl, device="cuda")
     S = ops.Stream(record=False)
     xd = [x.cuda() for x in xs]
     gd, bd = gamma.cuda(), beta.cuda()
+    # every "rank" folds its own chunks into its records; the [R][B][32][GN_REC] records are "gathered" (each relative to the
+    # rank's own pilot — the shards' first elements differ — and moved to rank 0's by the apply pass)
+    nrec = B * 32 * ops.GN_REC
+    tot_all = torch.zeros(R * nrec, dtype=torch.int64, device="cuda")
     ys = [torch.zeros(B * rps_loc, Cc, dtype=BF, device="cuda") for _ in range(R)]
-    for r in range(R):      # each "rank" writes its partial sums straight into its slot of the gathered buffer
-        S.groupnorm_stats(ops.gn_params(xd[r], Cc, Cc, B * rps_loc, rps_loc, part_all[r * nfl:], gd, bd, 1e-5, True, ys[r], Cc))
     for r in range(R):
-        S.groupnorm_apply(ops.gn_params(xd[r], Cc, Cc, B * rps_loc, rps_loc, part_all, gd, bd, 1e-5, True, ys[r], Cc,
-                                        fold_ranks=R))
+        S.groupnorm_stats(ops.gn_params(xd[r], Cc, Cc, B * rps_loc, rps_loc, part, gd, bd, 1e-5, True, ys[r], Cc,
+                                        totals=tot_all[r * nrec:]))
+    for r in range(R):
+        S.groupnorm_apply(ops.gn_params(xd[r], Cc, Cc, B * rps_loc, rps_loc, part, gd, bd, 1e-5, True, ys[r], Cc,
+                                        fold_ranks=R, totals=tot_all))
     torch.cuda.synchronize()
     got = torch.cat([y.view(B, rps_loc, Cc) for y in ys], dim=1)
     check(got, ref.to(BF), tol_l2=5e-3, tol_max=3e-2)
-    # the same through pre-folded totals: every "rank" folds its own chunks, the [R][B][32][2] totals are "gathered"
-    tot_all = torch.zeros(R * B * 64, dtype=torch.int64, device="cuda")
-    ys2 = [torch.zeros(B * rps_loc, Cc, dtype=BF, device="cuda") for _ in range(R)]
-    for r in range(R):
-        S.groupnorm_stats(ops.gn_params(xd[r], Cc, Cc, B * rps_loc, rps_loc, part_all, gd, bd, 1e-5, True, ys2[r], Cc,
-                                        totals=tot_all[r * B * 64:]))
-    for r in range(R):
-        S.groupnorm_apply(ops.gn_params(xd[r], Cc, Cc, B * rps_loc, rps_loc, part_all, gd, bd, 1e-5, True, ys2[r], Cc,
-                                        fold_ranks=R, totals=tot_all))
+    import ctypes as C
+    bad = ops.gn_params(xd[0], Cc, Cc, B * rps_loc, rps_loc, part, gd, bd, 1e-5, True, ys[0], Cc, fold_ranks=R)    # shards without records
+    assert S.lib.vmv_groupnorm_apply(C.byref(bad), None) == -1
+
+
+@pytest.mark.parametrize("kind", ["tiny", "offset", "huge", "mixed"])
+@pytest.mark.parametrize("path", ["partial", "totals", "fused"])
+def test_groupnorm_statistics_are_shift_and_scale_safe(kind, path):
+    """the statistics must survive activations that are tiny (1e-3 N(0,1): round 2's single 2^-12 fixed-point limb lost
+    the variance), far from zero (100 + N(0,1): E[x^2] - mean^2 cancels in fp32) or huge (3e3 N(0,1); 1e6-sized in the bf16
+    build, whose range allows it) — on all three forms (per-chunk partial sums, integer totals, the one-launch LDS form).
+    Checked against fp64 group statistics of the SAME 16-bit inputs: normalised output within 2e-3 (storage rounding included)."""
+    rows, rps, Cc = 2 * 4800, 4800, 320
+    base = torch.randn(rows, Cc, generator=g(31))
+    if kind == "tiny":
+        x = 1e-3 * base
+    elif kind == "offset":
+        x = 100.0 + base
+    elif kind == "huge":
+        x = (1e6 if BF == torch.bfloat16 else 3e3) * base
+    else:       # groups of very different scale side by side in one tensor (per-group pilots / exponents)
+        x = base * torch.logspace(-3, 3, Cc)[None, :]
+    x = x.to(BF)
+    if path == "fused":
+        rows, rps = 2 * 160, 160
+        x = x[:rows].contiguous()
+    xd = x.cuda()
+    gamma, beta = torch.ones(Cc), torch.zeros(Cc)
+    y = torch.zeros(rows, Cc, dtype=BF, device="cuda")
+    part = torch.zeros(ops.gn_partial_floats(rows, rps, Cc) + 64, device="cuda")
+    tot = torch.zeros(2, 64 * 32 * ops.GN_REC, dtype=torch.int64, device="cuda")
+    S = ops.Stream(record=False)
+    pr = ops.gn_params(xd, Cc, Cc, rows, rps, part, gamma.cuda(), beta.cuda(), 1e-12, False, y, Cc,
+                       **(dict(totals=tot[0], totals_clear=tot[1], clear_count=tot[1].numel()) if path == "totals" else {}))
+    if path == "fused":
+        S.groupnorm_fused(pr, ops.gn_fused_cols(rps, Cc))
+    else:
+        S.groupnorm_stats(pr); S.groupnorm_apply(pr)
     torch.cuda.synchronize()
-    got2 = torch.cat([y.view(B, rps_loc, Cc) for y in ys2], dim=1)
-    check(got2, ref.to(BF), tol_l2=5e-3, tol_max=3e-2)
+    xg = x.double().view(rows // rps, rps, 32, Cc // 32)
+    mean = xg.mean(dim=(1, 3), keepdim=True)
+    var = ((xg - mean) ** 2).mean(dim=(1, 3), keepdim=True)
+    ref = ((xg - mean) / torch.sqrt(var + 1e-12)).view(rows, Cc)
+    got = y.double().cpu()
+    assert torch.isfinite(got).all()
+    err = float((got - ref).abs().max())
+    assert err < (2e-3 if BF == torch.float16 else 1.6e-2) * float(ref.abs().max()), (kind, path, err)
 
 
 def test_permute_copy_matches_torch():

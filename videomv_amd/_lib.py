@@ -139,6 +139,7 @@ SYMBOLS = {
     "vmv_gemm": (C.c_int, [C.POINTER(GemmParams), _P]),
     "vmv_gemm_ln_inline_ok": (C.c_int, [C.POINTER(GemmParams)]),
     "vmv_gemm_rs_ok": (C.c_int, [C.POINTER(GemmParams)]),
+    "vmv_has_experiments": (C.c_int, []),
     "vmv_gemm_pick_tile": (C.c_int, [C.POINTER(GemmParams)]),
     "vmv_groupnorm_stats": (C.c_int, [C.POINTER(GroupNormParams), _P]),
     "vmv_groupnorm_apply": (C.c_int, [C.POINTER(GroupNormParams), _P]),
@@ -190,7 +191,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the ABI drifted
         fn.restype = res
         fn.argtypes = args
-    if lib.vmv_abi_version() != 6:
+    if lib.vmv_abi_version() != 7:
         raise RuntimeError(f"{LIB_PATH}: ABI version mismatch")
     if lib.vmv_elem_type() != (ELEM_F16 if _elem == "f16" else ELEM_BF16):
         raise RuntimeError(f"{LIB_PATH} was built for another element type")

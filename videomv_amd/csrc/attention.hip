@@ -61,6 +61,20 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
     const uint16_t* kp = reinterpret_cast<const uint16_t*>(p.k) + seq_base(p.km, o / p.kv_div) + h * D;
     const uint16_t* vp = reinterpret_cast<const uint16_t*>(p.v) + seq_base(p.vm, o / p.kv_div) + h * D;
     uint16_t* op = reinterpret_cast<uint16_t*>(p.o) + seq_base(p.om, o) + h * D;
+    // (o, h) are wave-uniform (block indices, or blockIdx * 4 + wave), so the four problem base pointers are too — but not
+    // provably so for the compiler (threadIdx >> 6), which kept them in 8 VGPRs and spilled four of them across the main loop of
+    // <4, 4, 64>.  Through readfirstlane they live in SGPRs and every access becomes scalar base + 32-bit lane offset.
+    auto uniform_ptr = [](auto* ptr) {
+        const uint64_t a = reinterpret_cast<uint64_t>(ptr);
+        // (the builtin returns a signed int: widen through uint32_t, or a low word with bit 31 set smears into the high half)
+        const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) << 32) |
+                           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a);
+        return reinterpret_cast<decltype(ptr)>(u);
+    };
+    qp = uniform_ptr(qp); kp = uniform_ptr(kp); vp = uniform_ptr(vp); op = uniform_ptr(op);
+    // row offsets inside one problem fit 32 bits (vmv_attention checks (N - 1) * s_row + head_dim < 2^30 elements): 64-bit
+    // products of the row index kept their sign-extension registers alive across the main loop (three more spilled pairs)
+    const int qs_row = (int)p.qm.s_row, ks_row = (int)p.km.s_row, vs_row = (int)p.vm.s_row, os_row = (int)p.om.s_row;
 
     // ---- staging group
     constexpr int NT = (WPP == 4) ? 256 : 64;
@@ -76,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             u32x4_t v = {0u, 0u, 0u, 0u};
-            if (wvalid && q < p.Nq) v = *reinterpret_cast<const u32x4_t*>(qp + (long)q * p.qm.s_row + kk * 32 + g * 8);
+            if (wvalid && q < p.Nq) v = *reinterpret_cast<const u32x4_t*>(qp + q * qs_row + kk * 32 + g * 8);
             qf[qt][kk] = __builtin_bit_cast(elem8_t, v);
         }
     }
@@ -106,8 +120,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
                 const int key = kt2 * 64 + row;
                 u32x4_t kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
                 if (key < p.Nk) {
-                    kv = *reinterpret_cast<const u32x4_t*>(kp + (long)key * p.km.s_row + slot * 8);
-                    vv = *reinterpret_cast<const u32x4_t*>(vp + (long)key * p.vm.s_row + slot * 8);
+                    kv = *reinterpret_cast<const u32x4_t*>(kp + key * ks_row + slot * 8);
+                    vv = *reinterpret_cast<const u32x4_t*>(vp + key * vs_row + slot * 8);
                 }
                 kreg[i] = kv; vreg[i] = vv;
             }
@@ -177,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
                 const int idx = stid + i * NT;
                 const int key = key0 + (idx >> 3);
                 vvr[i] = u32x4_t{0u, 0u, 0u, 0u};
-                if (wvalid && key < p.Nk) vvr[i] = *reinterpret_cast<const u32x4_t*>(vp + (long)key * p.vm.s_row + (idx & 7) * 8);
+                if (wvalid && key < p.Nk) vvr[i] = *reinterpret_cast<const u32x4_t*>(vp + key * vs_row + (idx & 7) * 8);
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) write_vt(Vtd, stid + i * NT, vvr[i]);
@@ -199,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
                 } else {
                     u32x4_t kv = {0u, 0u, 0u, 0u};
                     const int key = key0 + krow;
-                    if (wvalid && key < p.Nk) kv = *reinterpret_cast<const u32x4_t*>(kp + (long)key * p.km.s_row + kk * 32 + g * 8);
+                    if (wvalid && key < p.Nk) kv = *reinterpret_cast<const u32x4_t*>(kp + key * ks_row + kk * 32 + g * 8);
                     kf[t][kk] = __builtin_bit_cast(elem8_t, kv);
                 }
             }
@@ -355,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
         const float inv = 1.0f / l;
         const int q = q0 + qt * 16 + u;
         if (wvalid && q < p.Nq) {
-            uint16_t* orow = op + (long)q * p.om.s_row + 4 * g;
+            uint16_t* orow = op + q * os_row + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 const f32x4_t a = oacc[qt][dt] * inv;
@@ -510,6 +524,11 @@ extern "C" int vmv_attention(const VmvAttnParams* pp, void* stream) {
     const VmvAttnParams& p = *pp;
     if (!p.q || !p.k || !p.v || !p.o) return VMV_ENULL;
     if (p.n_outer <= 0 || p.heads <= 0 || p.Nq <= 0 || p.Nk <= 0 || p.kv_div <= 0) return VMV_EINVAL;
+    {   // the kernels index the rows of one problem with 32-bit element offsets
+        const long lim = 1L << 30;
+        if ((long)(p.Nq - 1) * p.qm.s_row + 64 >= lim || (long)(p.Nq - 1) * p.om.s_row + 64 >= lim || (long)(p.Nk - 1) * p.km.s_row + 64 >= lim ||
+            (long)(p.Nk - 1) * p.vm.s_row + 64 >= lim || p.qm.s_row < 0 || p.km.s_row < 0 || p.vm.s_row < 0 || p.om.s_row < 0) return VMV_ERANGE;
+    }
     if (!map_ok(p.qm) || !map_ok(p.km) || !map_ok(p.vm) || !map_ok(p.om)) return VMV_EALIGN;
     if ((p.qm.s_row & 7) || (p.km.s_row & 7) || (p.vm.s_row & 7)) return VMV_EALIGN;
     if (!vmv_aligned16(p.q) || !vmv_aligned16(p.k) || !vmv_aligned16(p.v) || (((uintptr_t)p.o) & 7)) return VMV_EALIGN;

@@ -23,12 +23,22 @@ int vmv_gemm_glds_launch(const VmvGemmParams& p, int total_steps, int tile, hipS
 int vmv_gemm_pglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st);  // gemm_pglds.hip
 bool vmv_gemm_pglds_supported(const VmvGemmParams& p);
 int vmv_gemm_xglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st);  // gemm_xglds.hip
+#if defined(VMV_EXPERIMENTS)
 int vmv_gemm_sglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st);  // gemm_sglds.hip
 int vmv_gemm_astat_launch(const VmvGemmParams& p, int tile, hipStream_t st);                   // gemm_astat.hip
+#else      // production build: the measured-and-rejected kernels are not in the library (make EXPERIMENTS=1)
+constexpr int VMV_NOT_BUILT = -101;
+static int vmv_gemm_sglds_launch(const VmvGemmParams&, int, int, hipStream_t) { return VMV_NOT_BUILT; }
+static int vmv_gemm_astat_launch(const VmvGemmParams&, int, hipStream_t) { return VMV_NOT_BUILT; }
+#endif
 int vmv_gemm_rs_launch(const VmvGemmParams& p, int tile, hipStream_t st);                      // gemm_rs.hip
 bool vmv_gemm_rs_supported(const VmvGemmParams& p);
 bool vmv_gemm_rs_preferred(const VmvGemmParams& p);
+#if defined(VMV_EXPERIMENTS)
 bool vmv_gemm_astat_eligible(const VmvGemmParams& p);
+#else
+static bool vmv_gemm_astat_eligible(const VmvGemmParams&) { return false; }
+#endif
 
 namespace {
 
@@ -336,8 +346,10 @@ int pick_tile(const VmvGemmParams& p, int total_steps) {
             if (o > 0) return o;
         }
     }
+#if defined(VMV_EXPERIMENTS)
     if (gemm_policy() >= 2 && astat_policy() && p.N >= 640 && p.M >= 128 * 256 && vmv_gemm_astat_eligible(p))
         return (!geglu && p.N % 160 == 0) ? VMV_TILE_A128x160 : VMV_TILE_A128x128;
+#endif
     auto padded = [&](int bn) { return ((p.N + bn - 1) / bn) * bn; };
     int best = VMV_TILE_128x128, best_pad = padded(128);
     if (!geglu && padded(160) <= best_pad) { best = VMV_TILE_128x160; best_pad = padded(160); }
@@ -346,6 +358,7 @@ int pick_tile(const VmvGemmParams& p, int total_steps) {
     if (gemm_policy() >= 1 && p.ksplit > 1 && p.M > 64 && (best == VMV_TILE_128x128 || best == VMV_TILE_128x160))
         // split-K (small-M levels): the 4-wave LDS-DMA kernel instead of the register-staged one (same 128-row tiles)
         best = best == VMV_TILE_128x128 ? VMV_TILE_G128x128 : VMV_TILE_G128x160;
+#if defined(VMV_EXPERIMENTS)
     if (gemm_policy() >= 3 && p.ksplit <= 1 && !geglu && p.N % 160 == 0) {
         // wave-specialised persistent kernel (gemm_sglds.hip): 8 MFMA waves + 4 loader waves per CU.  Measured against every
         // other variant (tools/gemm_bench.py) it wins wherever its static round-robin over the 256 CUs is
@@ -357,6 +370,7 @@ int pick_tile(const VmvGemmParams& p, int total_steps) {
         for (int i = 0; i < p.nseg; ++i) any_gather = any_gather || p.seg[i].mode != VMV_SEG_LINEAR;
         if (items >= 256 && (double)items / (double)(rounds * 256) >= 0.8 && (gemm_policy() == 3 || any_gather)) return VMV_TILE_S192x160;
     }
+#endif
     if (gemm_policy() >= 1 && p.ksplit <= 1 && (best == VMV_TILE_128x128 || best == VMV_TILE_128x160)) {
         // the 256-row kernel runs one block per CU: use it when its grid still fills the 256 CUs well
         const int bn = best == VMV_TILE_128x128 ? 128 : 160;
@@ -385,6 +399,10 @@ int pick_tile(const VmvGemmParams& p, int total_steps) {
 // configuration vmv_gemm launches first, or a negative VMV_E* code for a forced tile that cannot serve the request
 int final_tile(const VmvGemmParams& p, int total_steps) {
     int picked = pick_tile(p, total_steps);
+#if !defined(VMV_EXPERIMENTS)
+    if (picked == VMV_TILE_S256x128 || picked == VMV_TILE_S192x160 || picked == VMV_TILE_S256x160 || picked == VMV_TILE_A128x160 ||
+        picked == VMV_TILE_A128x128) return VMV_EINVAL;
+#endif
     const bool rs_tile = picked == VMV_TILE_RS || picked == VMV_TILE_RS512 || picked == VMV_TILE_RS256;
     if (rs_tile) return vmv_gemm_rs_supported(p) ? picked : VMV_EINVAL;      // (handles rowstat / colsum / grouped weights itself)
     if (vmv_gemm_ln_inline(p) && p.tile == VMV_TILE_AUTO)
@@ -419,6 +437,14 @@ bool ln_inline_ok(const VmvGemmParams& p) {
 }
 
 }  // namespace
+
+extern "C" int vmv_has_experiments(void) {
+#if defined(VMV_EXPERIMENTS)
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 extern "C" int vmv_gemm_ln_inline_ok(const VmvGemmParams* pp) { return pp && ln_inline_ok(*pp) ? 1 : 0; }
 

@@ -462,6 +462,7 @@ int launch_glds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
         return VMV_OK;
     };
     int rc;
+#if defined(VMV_EXPERIMENTS)       // (the ablation instantiations are not in the production library)
     switch (ablate) {
         case 1: rc = go(std::integral_constant<int, 1>{}); break;
         case 2: rc = go(std::integral_constant<int, 2>{}); break;
@@ -471,6 +472,9 @@ int launch_glds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
         case 6: rc = go(std::integral_constant<int, 6>{}); break;
         default: rc = go(std::integral_constant<int, 0>{}); break;
     }
+#else
+    rc = go(std::integral_constant<int, 0>{});
+#endif
     if (rc != VMV_OK) return rc;
     return vmv_launch_status();
 }

@@ -684,7 +684,9 @@ int launch_pglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
         return VMV_OK;
     };
     auto go = [&](auto tag) -> int {
+#if defined(VMV_EXPERIMENTS)
         if constexpr (NWM == 4) { if (il_env == 1) return go_il(tag, std::true_type{}); }
+#endif
         return go_il(tag, std::false_type{});
     };
     int rc;
@@ -704,6 +706,7 @@ int launch_pglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
             return VMV_EINVAL;
         }
     }
+#if defined(VMV_EXPERIMENTS)       // (the ablation / stamp instantiations are not in the production library)
     switch (ablate) {
         case 1: rc = go(std::integral_constant<int, 1>{}); break;
         case 2: rc = go(std::integral_constant<int, 2>{}); break;
@@ -713,6 +716,9 @@ int launch_pglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
         case 8: rc = go(std::integral_constant<int, 8>{}); break;
         default: rc = go(std::integral_constant<int, 0>{}); break;
     }
+#else
+    rc = go(std::integral_constant<int, 0>{});
+#endif
     if (rc != VMV_OK) return rc;
     return vmv_launch_status();
 }

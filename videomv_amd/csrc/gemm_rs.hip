@@ -182,6 +182,11 @@ __global__ __launch_bounds__(512, 1) void gemm_rs_kernel(const VmvGemmParams p, 
             }
             const float rstd = __builtin_amdgcn_rsqf(xor16_32_sum(s2) * inv_k + p.ln_eps);
             const float nm = -mean * rstd;
+            // (the normalisation pass unpacks the same registers as the variance pass: left visible, the compiler keeps the 80
+            //  unpacked fp32 values of the row tile alive in between — the bf16 build, whose unpack is a shift, spilled 300
+            //  registers that way — so the packed registers are made opaque here)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) asm volatile("" : "+v"(a[i][kk].x), "+v"(a[i][kk].y), "+v"(a[i][kk].z), "+v"(a[i][kk].w));
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
                 a[i][kk].x = pack_elem2(fmaf(elem_lo(a[i][kk].x), rstd, nm), fmaf(elem_hi(a[i][kk].x), rstd, nm));

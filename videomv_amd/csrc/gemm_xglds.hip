@@ -48,7 +48,8 @@ struct WgCfg {
     static constexpr int NWX = WGROUPS % NW;                // ... and one more for the waves < NWX
     static constexpr int LPT = NAI + NWI;                   // loads per lane per chunk (waves < NWX: LPT + 1)
     static constexpr int HALF_ROWS = 128;                   // epilogue staging: half a tile at a time
-    static_assert(HALF_ROWS * (BN * 2 + 16) <= LDS_BYTES && LDS_BYTES <= 160 * 1024, "LDS budget");
+    static constexpr int XG_MAXG = 8;                       // row groups (rowvec rows) one tile's rows may span
+    static_assert(HALF_ROWS * (BN * 2 + 16) + XG_MAXG * BN * 4 <= LDS_BYTES && LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
 struct WRow {        // gather state of one A row of the lane beyond its index m (recomputed: it lives beside 160 accumulators)
@@ -266,7 +267,6 @@ __global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams 
 
     // ---- epilogue
     const int mbase = m0 + wave_m * 16 * WM + frow;
-    const int nbase = n0 + wave_n * 16 * WN + 4 * fgrp;
     // (the launcher only sends GEMMs whose outputs can be staged: 16-bit, 16-byte aligned rows)
     // 16-bit outputs go through LDS (whole rows, 16-byte lanes, residual read the same way), half a tile (the two waves of
     // one wave row) at a time: the ring holds 128 rows of BN outputs
@@ -275,24 +275,40 @@ __global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams 
     uint16_t* outp = reinterpret_cast<uint16_t*>(p.out);
     const uint16_t* resp = reinterpret_cast<const uint16_t*>(p.residual);
     const float rs = p.res_scale != 0.f ? p.res_scale : 1.f;
+    // Column vectors of the epilogue — bias plus, for conv1 of a ResBlock, the per-image embedding row (rowvec) — are staged
+    // once per tile in LDS behind the staging area, one [BN] vector per row group the tile's rows span (<= XG_MAXG, launcher).
+    // (Round 2 loaded them from global memory inside the (column tile, row tile) loops: exec-masked loads that the compiler
+    //  follows with vmcnt(0) each — 40 dependent L2 round trips per wave — and whose hoisted 64-bit row pointers were the
+    //  kernel's 10 spilled registers.)
+    float* cvec = reinterpret_cast<float*>(smem + Cfg::HALF_ROWS * row_bytes);
+    const int rv_div = p.rowvec ? p.rowvec_div : (1 << 30);
+    const int g0 = m0 / rv_div;
+    const int m_last = (m0 + BM < p.M ? m0 + BM : p.M) - 1;
+    const int ng = m_last / rv_div - g0 + 1;
+    __syncthreads();                                // ring no longer read by anyone
+    for (int idx = tid; idx < ng * BN; idx += Cfg::NT) {
+        const int gq = idx / BN, n = n0 + (idx - gq * BN);
+        float v = 0.f;
+        if (n < p.N) {
+            if (p.bias) v = p.bias[n];
+            if (p.rowvec) v += p.rowvec[(size_t)(g0 + gq) * p.rowvec_ld + n];
+        }
+        cvec[idx] = v;
+    }
+    int gi[WM];                                     // row group (relative to g0) of this lane's row in each row tile
+#pragma unroll
+    for (int i = 0; i < WM; ++i) { const int m = mbase + 16 * i; gi[i] = ((m < p.M ? m : m_last) / rv_div - g0) * BN; }
 #pragma unroll 1
     for (int hh = 0; hh < 2; ++hh) {
-        __syncthreads();                            // ring (or the previous half's slab) no longer read by anyone
+        __syncthreads();                            // column vectors written / the previous half's slab no longer read by anyone
         if ((wave_m >> 1) == hh) {
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
-                const int n = nbase + 16 * j;
-                f32x4_t bias = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                if (p.bias && n < p.N) bias = *reinterpret_cast<const f32x4_t*>(p.bias + n);
+                const int nl = wave_n * 16 * WN + 16 * j + 4 * fgrp;       // column inside the tile
 #pragma unroll
                 for (int i = 0; i < WM; ++i) {
-                    const int m = mbase + 16 * i;
-                    f32x4_t v = acc[j][i] + bias;
-                    if (n < p.N) {
-                        if (p.rowvec && m < p.M)
-                            v += *reinterpret_cast<const f32x4_t*>(p.rowvec + (size_t)(m / p.rowvec_div) * p.rowvec_ld + n);
-                        if (p.act == VMV_ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
-                    }
+                    f32x4_t v = acc[j][i] + *reinterpret_cast<const f32x4_t*>(cvec + gi[i] + nl);
+                    if (p.act == VMV_ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
                     u32x2_t o;
                     o.x = pack_elem2(v.x, v.y); o.y = pack_elem2(v.z, v.w);
                     *reinterpret_cast<u32x2_t*>(smem + ((wave_m & 1) * 16 * WM + 16 * i + frow) * row_bytes + (wave_n * 16 * WN + 16 * j + 4 * fgrp) * 2) = o;
@@ -345,6 +361,7 @@ int launch_xglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
     for (int i = 0; i < p.nseg; ++i) nsteps += (p.seg[i].k + WBK - 1) / WBK;
     (void)total_steps;
     if (nsteps < Cfg::STAGES || (nsteps & 1)) return VMV_GLDS_UNSUPPORTED;
+    if (p.rowvec && (Cfg::BM - 1) / p.rowvec_div + 2 > Cfg::XG_MAXG) return VMV_GLDS_UNSUPPORTED;      // column vectors staged per row group
     hipLaunchKernelGGL((gemm_xglds_kernel<NH, WH>), dim3(tiles_m * tiles_n), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n, nsteps);
     return vmv_launch_status();
 }

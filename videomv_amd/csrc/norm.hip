@@ -11,7 +11,27 @@ namespace {
 // grid = (nchunk, nstat).  Block (256 threads) owns `chunk_rows` rows of one stat group and ALL channels.
 // Thread -> fixed column slot (8 channels) so sums stay in registers; lanes that share a column are combined
 // through an LDS [lane_rows][C] array in fixed order; then 32 threads produce the per-group (sum, sumsq).
-constexpr float GN_FX = 4096.0f;          // fixed-point scale of the integer stat-group accumulators (VmvGroupNormParams.totals)
+// Statistics are taken of d = x - pilot, the pilot of (stat group, channel group) being the group's first element (first row of the
+// stat group, first channel of the group): shift-invariant — E[d^2] - E[d]^2 has nothing to cancel when |mean| >> sigma (x = 100 +
+// N(0, 1)) — at the price of 32 extra 2-byte loads per block.  Stat-group totals (VmvGroupNormParams.totals) are TWO-LIMB 64-bit
+// fixed point per value: an integer limb (quantum 1, |sum| < 2^63: fp16's largest squares times a whole sample fit) and a fraction
+// limb (quantum 2^-40), so a block's fp32 partial sum is represented exactly whether the activations are 1e-3 or 3e3 (round 2's
+// single limb had a fixed 2^-12 quantum: a group of 1e-3-sized activations lost its variance).  Integer addition
+// commutes: the totals are bitwise reproducible whatever the arrival order.  Record per (stat, group): GN_REC int64 =
+// { sum_hi, sumsq_hi, sum_lo, sumsq_lo, pilot (fp32 bits), pad x3 }.
+constexpr int GN_REC = 8;
+constexpr float GN_LO = 1099511627776.0f;       // 2^40
+
+VMV_DEV void gn_add2(unsigned long long* rec, int which, float v) {
+    const float fl = floorf(v);
+    atomicAdd(rec + which, (unsigned long long)(long long)fl);
+    atomicAdd(rec + 2 + which, (unsigned long long)(long long)((v - fl) * GN_LO));
+}
+VMV_DEV float gn_pilot(const VmvGroupNormParams& p, long row, int c) {          // element (row, channel c) of the (two-source) input
+    const bool first = c < p.C0;
+    const uint16_t* b = reinterpret_cast<const uint16_t*>(first ? p.x : p.x1);
+    return elem_to_f32(b[row * (long)(first ? p.ld : p.ld1) + (first ? c : c - p.C0)]);
+}
 
 __global__ __launch_bounds__(256) void gn_stats_kernel(const VmvGroupNormParams p, const int nchunk) {
     extern __shared__ __attribute__((aligned(16))) float sh[];
@@ -30,12 +50,16 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const VmvGroupNormParams 
     if (row_end > stat_end) row_end = stat_end;
     float* lsum = sh;                            // [RPP][C]
     float* lsq = sh + RPP * C;
+    float* pil = sh + 2 * RPP * C;               // [32] pilots of this stat group
     const uint16_t* x0 = reinterpret_cast<const uint16_t*>(p.x);
     const uint16_t* x1 = reinterpret_cast<const uint16_t*>(p.x1);
+    const int cpg_ = C >> 5;
+    if (tid < 32) pil[tid] = gn_pilot(p, (long)stat * p.rows_per_stat, tid * cpg_);
+    __syncthreads();
     for (int cs = cl; cs < CS; cs += TPR) {
-        float s[8], q[8];
+        float s[8], q[8], pl[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+        for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; pl[e] = pil[(cs * 8 + e) / cpg_]; }
         if (active) {
             const int c = cs * 8;
             const bool first = c < p.C0;
@@ -51,7 +75,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const VmvGroupNormParams 
                     float f[8];
                     unpack8(v[k], f);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+                    for (int e = 0; e < 8; ++e) { const float d = f[e] - pl[e]; s[e] += d; q[e] += d * d; }
                 }
             }
             for (; r + 3L * RPP < row_end; r += 4L * RPP) {
@@ -63,7 +87,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const VmvGroupNormParams 
                     float f[8];
                     unpack8(v[k], f);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+                    for (int e = 0; e < 8; ++e) { const float d = f[e] - pl[e]; s[e] += d; q[e] += d * d; }
                 }
             }
             for (; r < row_end; r += RPP) {
@@ -71,7 +95,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const VmvGroupNormParams 
                 float f[8];
                 unpack8(v, f);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+                for (int e = 0; e < 8; ++e) { const float d = f[e] - pl[e]; s[e] += d; q[e] += d * d; }
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) { lsum[rl * C + cs * 8 + e] = s[e]; lsq[rl * C + cs * 8 + e] = q[e]; }
@@ -83,10 +107,11 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const VmvGroupNormParams 
         float s = 0.f, q = 0.f;
         for (int r = 0; r < RPP; ++r)
             for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { s += lsum[r * C + c]; q += lsq[r * C + c]; }
-        if (p.totals) {        // fixed-point 64-bit atomics: order-independent, hence deterministic (vmv.h)
-            unsigned long long* t = reinterpret_cast<unsigned long long*>(p.totals) + ((long)stat * 32 + tid) * 2;
-            atomicAdd(t, (unsigned long long)__float2ll_rn(s * GN_FX));
-            atomicAdd(t + 1, (unsigned long long)__float2ll_rn(q * GN_FX));
+        if (p.totals) {        // two-limb fixed-point 64-bit atomics: order-independent, hence deterministic (vmv.h)
+            unsigned long long* rec = reinterpret_cast<unsigned long long*>(p.totals) + ((long)stat * 32 + tid) * GN_REC;
+            gn_add2(rec, 0, s);
+            gn_add2(rec, 1, q);
+            if (chunk == 0) rec[4] = (unsigned long long)__float_as_uint(pil[tid]);
         } else {
             float* out = p.partial + (((long)stat * nchunk + chunk) * 32 + tid) * 2;
             out[0] = s; out[1] = q;
@@ -115,30 +140,41 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const VmvGroupNormParams 
         float s = 0.f, q = 0.f;
         // fold_ranks R > 1: partial = [R][nstat][nchunk][64] (all-gathered shards); every rank folds in the same order
         const int R = p.fold_ranks > 1 ? p.fold_ranks : 1;
-        if (p.totals) {      // integer totals: one (sum, sumsq) pair per (rank, stat, group), exact integer sum over the ranks
+        if (p.totals) {      // two-limb integer totals per (rank, stat, group), each relative to that rank's pilot: moved to rank 0's
+                             // pilot and summed in fp64 (R shards of equal size: frame-parallel pixel shards)
             if (sub == 0) {
-                long long si = 0, qi = 0;
+                const double nr = (double)p.rows_per_stat * (double)cpg;
+                double S = 0.0, Q = 0.0, P0 = 0.0;
                 for (int r = 0; r < R; ++r) {
-                    const long long* pp = reinterpret_cast<const long long*>(p.totals) + (((long)r * nstat + stat) * 32 + g) * 2;
-                    si += pp[0]; qi += pp[1];
+                    const long long* rec = reinterpret_cast<const long long*>(p.totals) + (((long)r * nstat + stat) * 32 + g) * GN_REC;
+                    const double sr = (double)rec[0] + (double)rec[2] * (1.0 / (double)GN_LO);
+                    const double qr = (double)rec[1] + (double)rec[3] * (1.0 / (double)GN_LO);
+                    const double P = (double)__uint_as_float((uint32_t)rec[4]);
+                    if (r == 0) P0 = P;
+                    const double d = P - P0;
+                    S += sr + nr * d;
+                    Q += qr + 2.0 * d * sr + nr * d * d;
                 }
-                s = (float)((double)si * (1.0 / GN_FX)); q = (float)((double)qi * (1.0 / GN_FX));
+                const double n = nr * (double)R;
+                const double m = S / n;
+                double var = Q / n - m * m;
+                var = var < 0.0 ? 0.0 : var;
+                s_mean[g] = (float)(P0 + m);
+                s_rstd[g] = (float)(1.0 / sqrt(var + (double)p.eps));
             }
-        } else {
-            for (int r = 0; r < R; ++r) {
-                const float* pp = p.partial + (((long)r * nstat + stat) * nchunk * 32 + g) * 2;
-                for (int c = sub; c < nchunk; c += 8) { s += pp[(long)c * 64]; q += pp[(long)c * 64 + 1]; }
-            }
-        }
+        } else {             // per-chunk fp32 partial sums of x - pilot (the pilot is re-read: the same element the statistics pass used)
+            const float* pp = p.partial + ((long)stat * nchunk * 32 + g) * 2;
+            for (int c = sub; c < nchunk; c += 8) { s += pp[(long)c * 64]; q += pp[(long)c * 64 + 1]; }
 #pragma unroll
-        for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-        if (sub == 0) {
-            const float n = (float)p.rows_per_stat * (float)cpg * (float)R;
-            const float mean = s / n;
-            float var = q / n - mean * mean;
-            var = var < 0.f ? 0.f : var;
-            s_mean[g] = mean;
-            s_rstd[g] = rsqrtf(var + p.eps);
+            for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+            if (sub == 0) {
+                const float n = (float)p.rows_per_stat * (float)cpg;
+                const float m = s / n;
+                float var = q / n - m * m;
+                var = var < 0.f ? 0.f : var;
+                s_mean[g] = gn_pilot(p, (long)stat * p.rows_per_stat, g * cpg) + m;
+                s_rstd[g] = rsqrtf(var + p.eps);
+            }
         }
     }
     __syncthreads();
@@ -460,7 +496,7 @@ extern "C" int vmv_groupnorm_stats(const VmvGroupNormParams* pp, void* stream) {
     const int RPP = 256 / TPR;
     const int nstat = p.rows / p.rows_per_stat;
     const int nchunk = (p.rows_per_stat + p.chunk_rows - 1) / p.chunk_rows;
-    const size_t shbytes = (size_t)2 * RPP * C * sizeof(float);
+    const size_t shbytes = ((size_t)2 * RPP * C + 32) * sizeof(float);
     if (p.totals && (((uintptr_t)p.totals) & 7)) return VMV_EALIGN;
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, nstat), dim3(256), shbytes, reinterpret_cast<hipStream_t>(stream), p, nchunk);
     return vmv_launch_status();
@@ -473,6 +509,7 @@ extern "C" int vmv_groupnorm_apply(const VmvGroupNormParams* pp, void* stream) {
     if (rc != VMV_OK) return rc;
     if (!p.y || !p.gamma || !p.beta) return VMV_ENULL;
     if (!vmv_aligned16(p.y) || (p.ldy & 7) || !vmv_aligned16(p.gamma) || !vmv_aligned16(p.beta)) return VMV_EALIGN;
+    if (p.fold_ranks > 1 && !p.totals) return VMV_EINVAL;      // shards are folded through the totals records (they carry the pilots)
     const int C = p.C0 + p.C1;
     const int nstat = p.rows / p.rows_per_stat;
     const int nchunk = (p.rows_per_stat + p.chunk_rows - 1) / p.chunk_rows;

@@ -13,6 +13,7 @@ import torch
 from . import _lib as L
 
 TAPS3x3 = [(dy, dx) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+GN_REC = 8      # int64 per (stat group, channel group) record of VmvGroupNormParams.totals (include/vmv.h)
 
 
 def _ptr(t):
@@ -81,8 +82,9 @@ def gemm_params(M, N, segs: Sequence[Seg], W, out, ldo, bias=None, rowvec=None, 
 
 def gn_params(x, ld, C0, rows, rows_per_stat, partial, gamma, beta, eps, silu, y, ldy, x1=None, ld1=0, C1=0,
               chunk_rows=None, fold_ranks=0, totals=None, totals_clear=None, clear_count=0) -> L.GroupNormParams:
-    """totals / totals_clear: int64 fixed-point stat-group accumulators (include/vmv.h): `totals` must be zero when the
-    statistics pass starts; the apply pass zeroes `clear_count` entries of `totals_clear` (the next norm's accumulators)."""
+    """totals / totals_clear: int64 two-limb fixed-point stat-group accumulators, GN_REC int64 per (stat, group) (include/vmv.h):
+    `totals` must be zero when the statistics pass starts; the apply pass zeroes `clear_count` entries of `totals_clear` (the
+    next norm's accumulators)."""
     p = L.GroupNormParams()
     p.x, p.x1, p.ld, p.ld1, p.C0, p.C1 = _ptr(x), _ptr(x1), int(ld), int(ld1), int(C0), int(C1)
     p.rows, p.rows_per_stat = int(rows), int(rows_per_stat)

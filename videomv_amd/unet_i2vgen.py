@@ -252,11 +252,13 @@ class UNetSD_I2VGen(nn.Module, LgmMixin):
         L_ctx = kc["y"].shape[1] + 64 + self.num_tokens
         # (local_image / fps / camera are checked to be the same for both branches below: the CFG pair shares its prefix)
         eng, front = self._get(2, f, h, w, L_ctx, dev, n_t=1, share_prefix=True)
-        same_for_both_branches("local_image", kc.get("local_image"), ku.get("local_image"))
-        same_for_both_branches("fps", kc.get("fps"), ku.get("fps"))
-        same_for_both_branches("camera_data", kc.get("camera_data"), ku.get("camera_data"))
         cache = eng.__dict__.setdefault("_cond", CondCache())
-        if not cache.hit(kc["y"], ku["y"], kc["image"], ku["image"], kc["local_image"], kc["fps"], kc.get("camera_data")):
+        if not cache.hit(kc["y"], ku["y"], kc["image"], ku["image"], kc["local_image"], kc["fps"], kc.get("camera_data"),
+                         ku.get("local_image"), ku.get("fps"), ku.get("camera_data")):
+            # (once per sample, not per step: each comparison is a device-to-host sync — ADVICE r2)
+            same_for_both_branches("local_image", kc.get("local_image"), ku.get("local_image"))
+            same_for_both_branches("fps", kc.get("fps"), ku.get("fps"))
+            same_for_both_branches("camera_data", kc.get("camera_data"), ku.get("camera_data"))
             li = self._first_frame(kc["local_image"]).to(dev)
             front.run(eng, torch.cat([li, li], dim=0), torch.cat([kc["y"], ku["y"]], dim=0).to(dev).float(),
                       torch.cat([kc["image"], ku["image"]], dim=0).to(dev).float(), kc["fps"][:1])

@@ -280,9 +280,7 @@ class UNetSD_T2VBase(nn.Module, LgmMixin):
             if os.environ.get("VMV_FP_PIPELINE", "1") != "0":
                 return self._forward_cfg_rows_pipelined(xt, t, cond_kwargs, uncond_kwargs)
             f = f * self.frame_comm.world
-        cam_shared = (not self.use_camera_condition) or cam_u is camera_data or (
-            cam_u is not None and camera_data is not None and cam_u.shape == camera_data.shape
-            and torch.equal(cam_u.to(camera_data.device), camera_data))
+        cam_shared = self._cameras_agree(camera_data, cam_u)
         eng = self.engine_for(2, f, h, w, y_cond.shape[1], dev, n_t=1, share_prefix=cam_shared)
         cache = eng.__dict__.setdefault("_cond", CondCache())
         if not cache.hit(y_cond, y_uncond, camera_data, cam_u, cond_kwargs.get("fps")):      # context / camera are step-invariant: once per sample
@@ -296,10 +294,25 @@ class UNetSD_T2VBase(nn.Module, LgmMixin):
             eng.set_context(torch.cat([y_cond.to(dev).float(), y_uncond.to(dev).float()], dim=0))
             eng.set_camera(cam)
             fps = cond_kwargs.get("fps") if self.use_fps_condition else None
-            if fps is not None:
+            if self.use_fps_condition:      # (either branch alone having an fps is a disagreement too)
                 same_for_both_branches("fps", fps, uncond_kwargs.get("fps"))
             eng.set_fps(fps)
         return eng, eng.forward_rows(xt.float(), t.to(dev))
+
+    def _cameras_agree(self, cam_c, cam_u) -> bool:
+        """Do the two CFG branches carry the same camera_data (=> shared-prefix engine)?  The comparison is a device-to-host
+        sync, so it is evaluated once per pair of tensors (identity + in-place version, strong references held), not on every
+        denoising step."""
+        if not self.use_camera_condition or cam_u is cam_c:
+            return True
+        if cam_u is None or cam_c is None:
+            return False
+        key = (id(cam_c), cam_c._version, id(cam_u), cam_u._version)
+        memo = getattr(self, "_cam_agree", None)
+        if memo is None or memo[0] != key:
+            same = cam_u.shape == cam_c.shape and bool(torch.equal(cam_u.to(cam_c.device), cam_c))
+            self._cam_agree = memo = (key, same, (cam_c, cam_u))
+        return memo[1]
 
     def begin_sample(self):
         """Drop the per-sample conditioning caches (called by the sampler at the start of every ddim_sample_loop)."""
