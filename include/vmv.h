@@ -167,6 +167,34 @@ int vmv_gemm_rs_ok(const VmvGemmParams* p);
 int vmv_gemm_pick_tile(const VmvGemmParams* p);
 
 /* ------------------------------------------------------------------------------------------------------
+ * FeedForward of a BasicTransformerBlock in one launch (util.py:536-540 `x = ff(norm3(x)) + x`, FeedForward :553-578,
+ * GEGLU :541-550), for C = 320 (the UNet's largest level):
+ *     out = residual + W2 . ( (W1x LN(x) + b1x) * gelu(W1g LN(x) + b1g) ) + b2
+ * The 4C-wide hidden activation stays in registers (csrc/gemm_ff.hip); rounding points are those of the two-GEMM form
+ * (hidden rounded to elem before the down projection).  W1 / b1: the GEGLU up projection packed as for vmv_gemm with
+ * VMV_EPI_GEGLU (x | gate rows interleaved in 16-row blocks; LayerNorm gamma / beta folded in when ln_eps > 0, as for
+ * VmvGemmParams.colsum); W2: elem [C][4C] whose K axis is permuted inside every block of 32 channels to
+ * [0-3, 16-19, 4-7, 20-23, 8-11, 24-27, 12-15, 28-31] (position -> channel), the order in which the kernel's MFMA outputs form
+ * the next MFMA's operand.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t M, C;            /* rows; channels (320)                                               */
+    const void* x; int32_t ldx;          /* elem rows [M][ldx]                                      */
+    int32_t _pad0;
+    const void* w1;          /* elem [8C][C]                                                       */
+    const float* b1;         /* [8C] or NULL                                                       */
+    const void* w2;          /* elem [C][4C], K-permuted (see above)                               */
+    const float* b2;         /* [C] or NULL                                                        */
+    const void* residual; int32_t ldr;   /* optional elem [M][ldr] (may alias x)                    */
+    float ln_eps;            /* > 0: LayerNorm (no affine: folded) of each row of x first; 0: x as is */
+    void* out; int32_t ldo;  /* elem [M][ldo]                                                      */
+    int32_t _pad1;
+} VmvFfParams;
+int vmv_ff_fused(const VmvFfParams* p, void* stream);
+/* 1 if vmv_ff_fused serves *p (host logic only) */
+int vmv_ff_fused_ok(const VmvFfParams* p);
+
+/* ------------------------------------------------------------------------------------------------------
  * GroupNorm(32 groups) over row blocks + optional SiLU (torch group_norm + silu: util.py:329,649,673,1014,
  * 1358-1373; unet_t2v.py:262; autoencoder.py Normalize).  A "stat group" is `rows_per_stat` consecutive rows:
  * H*W rows for the per-frame 4-D norms, F*H*W rows for the 5-D norms whose statistics span all frames
@@ -408,6 +436,7 @@ typedef struct VmvPlan VmvPlan;
 #define VMV_OP_SOFTMAX     6
 #define VMV_OP_COPY        7
 #define VMV_OP_GN_FUSED    8   /* args: VmvGroupNormParams with chunk_rows = cols of vmv_groupnorm_fused */
+#define VMV_OP_FF          9   /* args: VmvFfParams */
 VmvPlan* vmv_plan_create(void);
 void     vmv_plan_destroy(VmvPlan* plan);
 int      vmv_plan_add(VmvPlan* plan, int op, const void* params, size_t nbytes);

@@ -224,6 +224,30 @@ def softmax_rows(p: L.SoftmaxParams):
     _rows(p.p, p.rows, p.ldp)[:, : p.n] = torch.softmax(s * p.scale, dim=-1).to(L.elem())
 
 
+def ff_fused(p: L.FfParams):
+    """vmv_ff_fused: out = residual + W2 (x' * gelu(gate')) + b2 with (x' | gate') = W1 LN(x) + b1, hidden rounded to elem; W1 rows
+    interleaved x | gate in 16-row blocks, W2's K axis permuted per 32-channel block (packing.FF_DOWN_ORDER)."""
+    from videomv_amd.packing import FF_DOWN_ORDER
+    M, Cc = p.M, p.C
+    x = _rows(p.x, M, p.ldx)[:, :Cc].float()
+    if p.ln_eps > 0:
+        mean = x.mean(dim=1, keepdim=True)
+        x = ((x - mean) * torch.rsqrt(((x - mean) ** 2).mean(dim=1, keepdim=True) + p.ln_eps)).to(L.elem()).float()
+    h = x @ _rows(p.w1, 8 * Cc, Cc).float().t()
+    if p.b1:
+        h = h + _view(p.b1, 8 * Cc, "f32")
+    h = h.view(M, 8 * Cc // 32, 2, 16)
+    h = (h[:, :, 0] * torch.nn.functional.gelu(h[:, :, 1])).reshape(M, 4 * Cc).to(L.elem()).float()
+    idx = torch.tensor(FF_DOWN_ORDER, dtype=torch.long)
+    hp = h.view(M, 4 * Cc // 32, 32)[:, :, idx].reshape(M, 4 * Cc)          # natural -> the order W2's K axis is stored in
+    acc = hp @ _rows(p.w2, Cc, 4 * Cc).float().t()
+    if p.b2:
+        acc = acc + _view(p.b2, Cc, "f32")
+    if p.residual:
+        acc = acc + _rows(p.residual, M, p.ldr)[:, :Cc].float()
+    _rows(p.out, M, p.ldo)[:, :Cc] = acc.to(L.elem())
+
+
 def run_recorded(recorded):
     for op, params in recorded:
         if op == L.OP_GEMM:
@@ -242,6 +266,8 @@ def run_recorded(recorded):
             permute_copy(params)
         elif op == L.OP_GN_FUSED:
             groupnorm_fused(params)
+        elif op == L.OP_FF:
+            ff_fused(params)
         else:
             raise ValueError(op)
 

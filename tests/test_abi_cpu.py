@@ -28,7 +28,7 @@ def test_struct_layouts_match_c():
     lib = L.load()
     for which, st in ((L.OP_GEMM, L.GemmParams), (L.OP_GN_STATS, L.GroupNormParams), (L.OP_GN_APPLY, L.GroupNormParams),
                       (L.OP_LAYERNORM, L.LayerNormParams), (L.OP_ATTENTION, L.AttnParams), (L.OP_SOFTMAX, L.SoftmaxParams),
-                      (100, L.DdimParams),
+                      (L.OP_COPY, L.CopyParams), (L.OP_FF, L.FfParams), (100, L.DdimParams),
                       (101, L.GemmSeg), (102, L.SeqMap)):
         assert lib.vmv_sizeof(which) == C.sizeof(st), st.__name__
 

@@ -109,3 +109,30 @@ def test_attention_maps_contract():
     q, k, v = (q5[:, :, :, i].permute(0, 2, 3, 1, 4) for i in range(3))          # b p h f d
     ref = Fn.scaled_dot_product_attention(q, k, v).permute(0, 3, 1, 2, 4).reshape(T, inner)
     close(o2, ref)
+
+
+def test_ff_fused_argument_block_equals_the_two_gemm_form():
+    """The fused FeedForward's argument block (interleaved W1, K-permuted W2: packing.ff_down_permute) through the interpreter
+    against the two-GEMM form (LayerNorm-folded GEGLU GEMM with in-kernel statistics, then the down projection with the
+    residual) on the same weights: same rounding points, so equal to accumulation order."""
+    from videomv_amd import _lib as L, ops, packing as P
+    torch.manual_seed(0)
+    M, Cc = 96, 320
+    BF = L.elem()
+    x = (torch.randn(M, Cc) * 1.5 + 2.0).to(BF)
+    w1 = torch.randn(8 * Cc, Cc) * Cc ** -0.5
+    b1 = torch.randn(8 * Cc)
+    w2 = torch.randn(Cc, 4 * Cc) * (4 * Cc) ** -0.5
+    b2 = torch.randn(Cc)
+    gamma, beta = 1 + 0.2 * torch.randn(Cc), 0.2 * torch.randn(Cc)
+    wf, bf, cs = P.fold_layernorm(w1, b1, gamma, beta)
+    w1p, b1p, csp = P.geglu_interleave(wf).contiguous(), P.geglu_interleave(bf).contiguous(), P.geglu_interleave(cs).contiguous()
+    w2n, w2p = w2.to(BF).contiguous(), P.ff_down_permute(w2).to(BF).contiguous()
+    hid = torch.zeros(M, 4 * Cc, dtype=BF)
+    out_a, out_b = torch.zeros(M, Cc, dtype=BF), torch.zeros(M, Cc, dtype=BF)
+    I.gemm(ops.gemm_params(M, 8 * Cc, ops.linear_segs([(x, Cc, Cc)]), w1p, hid, 4 * Cc, bias=b1p, colsum=csp, ln_eps=1e-5,
+                                     epilogue=L.EPI_GEGLU))
+    I.gemm(ops.gemm_params(M, Cc, ops.linear_segs([(hid, 4 * Cc, 4 * Cc)]), w2n, out_a, Cc, bias=b2, residual=x, ldr=Cc))
+    I.ff_fused(ops.ff_params(M, Cc, x, Cc, w1p, b1p, w2p, b2, out_b, Cc, residual=x, ldr=Cc, ln_eps=1e-5))
+    err = float((out_a.float() - out_b.float()).norm() / out_a.float().norm())
+    assert err < 2e-3, err

@@ -781,6 +781,53 @@ def test_gemm_rs_eligibility():
     assert lib.vmv_gemm_rs_ok(C.byref(small)) == 0 and lib.vmv_gemm_pick_tile(C.byref(small)) != L.TILE_RS
 
 
+# ------------------------------------------------------------------------------------------------- fused FeedForward
+@pytest.mark.parametrize("M,ln,res", [(1000, True, True), (128, False, False), (33000, True, True), (257, True, False), (70000, False, True)])
+def test_ff_fused(M, ln, res):
+    """csrc/gemm_ff.hip: out = res + W2 . ((W1x LN(x) + b1x) * gelu(W1g LN(x) + b1g)) + b2 at C = 320 in one launch (hidden in
+    registers, W2's K axis permuted per 32-channel block) against the unfused definition in fp32 on the same 16-bit operands,
+    and — small M — against the interpreter's restatement of the argument block; M tails, many blocks, two runs bitwise equal."""
+    Cc = 320
+    x = (rnd((M, Cc), 1, 1.5).float() + (3.0 * torch.randn(M, 1, generator=g(9)) if ln else 0.0)).to(BF)
+    w1 = torch.randn(8 * Cc, Cc, generator=g(2)) * Cc ** -0.5
+    b1 = torch.randn(8 * Cc, generator=g(3))
+    w2 = torch.randn(Cc, 4 * Cc, generator=g(4)) * (4 * Cc) ** -0.5
+    b2 = torch.randn(Cc, generator=g(5))
+    gamma, beta = 1 + 0.2 * torch.randn(Cc, generator=g(6)), 0.2 * torch.randn(Cc, generator=g(7))
+    if ln:
+        w1f, b1f, _ = P.fold_layernorm(w1, b1, gamma, beta)
+    else:
+        w1f, b1f = w1.to(BF), b1
+    w1p, b1p = P.geglu_interleave(w1f.float()).to(BF), P.geglu_interleave(b1f)
+    w2p = P.ff_down_permute(w2).to(BF)
+    rs = rnd((M, Cc), 8)
+    c = Case(x=x, w1=w1p, b1=b1p, w2=w2p, b2=b2, res=rs, out=torch.zeros(M, Cc, dtype=BF))
+
+    def build(t):
+        return ops.ff_params(M, Cc, t["x"], Cc, t["w1"], t["b1"], t["w2"], t["b2"], t["out"], Cc,
+                             residual=t["res"] if res else None, ldr=Cc, ln_eps=1e-5 if ln else 0.0)
+    dev = c.on("cuda")
+    S = ops.Stream(record=False)
+    import ctypes as C
+    assert S.lib.vmv_ff_fused_ok(C.byref(build(dev))) == 1
+    S.ff(build(dev))
+    torch.cuda.synchronize()
+    xin = torch.nn.functional.layer_norm(x.float(), (Cc,), gamma, beta, 1e-5) if ln else x.float()
+    h = xin @ (w1 if ln else w1f.float()).t() + b1
+    a, gate = h.chunk(2, dim=-1)
+    hid = (a * torch.nn.functional.gelu(gate)).to(BF).float()
+    ref = hid @ w2.to(BF).float().t() + b2 + (rs.float() if res else 0.0)
+    check(dev["out"], ref, tol_l2=6e-3, tol_max=2e-2)
+    if M <= 1000:
+        cpu = c.on("cpu")
+        I.ff_fused(build(cpu))
+        check(dev["out"], cpu["out"], tol_l2=6e-3, tol_max=2e-2)
+    dev2 = c.on("cuda")
+    S.ff(build(dev2))
+    torch.cuda.synchronize()
+    assert torch.equal(dev2["out"], dev["out"])
+
+
 def test_gemm_layernorm_folded_rejects_split_k_and_gathers():
     import ctypes as C
     lib = L.load()

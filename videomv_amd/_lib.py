@@ -51,7 +51,7 @@ TILE_S256x128, TILE_S192x160, TILE_S256x160 = 15, 16, 17
 TILE_A128x160, TILE_A128x128 = 18, 19
 TILE_X256x320, TILE_X256x256, TILE_X256x128 = 20, 21, 22
 TILE_RS, TILE_RS512, TILE_RS256 = 23, 24, 25
-OP_GEMM, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTENTION, OP_SOFTMAX, OP_COPY, OP_GN_FUSED = 1, 2, 3, 4, 5, 6, 7, 8
+OP_GEMM, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTENTION, OP_SOFTMAX, OP_COPY, OP_GN_FUSED, OP_FF = 1, 2, 3, 4, 5, 6, 7, 8, 9
 GN_FUSED_BYTES = 131072
 
 
@@ -82,6 +82,13 @@ class GroupNormParams(C.Structure):
                 ("chunk_rows", C.c_int32), ("partial", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
                 ("eps", C.c_float), ("silu", C.c_int32), ("y", C.c_void_p), ("ldy", C.c_int32), ("fold_ranks", C.c_int32),
                 ("totals", C.c_void_p), ("totals_clear", C.c_void_p), ("clear_count", C.c_int32), ("_pad", C.c_int32)]
+
+
+class FfParams(C.Structure):
+    _fields_ = [("M", C.c_int32), ("C", C.c_int32), ("x", C.c_void_p), ("ldx", C.c_int32), ("_pad0", C.c_int32),
+                ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+                ("residual", C.c_void_p), ("ldr", C.c_int32), ("ln_eps", C.c_float),
+                ("out", C.c_void_p), ("ldo", C.c_int32), ("_pad1", C.c_int32)]
 
 
 class GsParams(C.Structure):
@@ -140,6 +147,8 @@ SYMBOLS = {
     "vmv_gemm_ln_inline_ok": (C.c_int, [C.POINTER(GemmParams)]),
     "vmv_gemm_rs_ok": (C.c_int, [C.POINTER(GemmParams)]),
     "vmv_has_experiments": (C.c_int, []),
+    "vmv_ff_fused": (C.c_int, [C.POINTER(FfParams), _P]),
+    "vmv_ff_fused_ok": (C.c_int, [C.POINTER(FfParams)]),
     "vmv_gemm_pick_tile": (C.c_int, [C.POINTER(GemmParams)]),
     "vmv_groupnorm_stats": (C.c_int, [C.POINTER(GroupNormParams), _P]),
     "vmv_groupnorm_apply": (C.c_int, [C.POINTER(GroupNormParams), _P]),

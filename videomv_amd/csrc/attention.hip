@@ -71,7 +71,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
                            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a);
         return reinterpret_cast<decltype(ptr)>(u);
     };
+#ifndef VMV_ATTN_VGPR_PTRS      // (A/B hook: -DVMV_ATTN_VGPR_PTRS keeps the round-2 form)
     qp = uniform_ptr(qp); kp = uniform_ptr(kp); vp = uniform_ptr(vp); op = uniform_ptr(op);
+#endif
     // row offsets inside one problem fit 32 bits (vmv_attention checks (N - 1) * s_row + head_dim < 2^30 elements): 64-bit
     // products of the row index kept their sign-extension registers alive across the main loop (three more spilled pairs)
     const int qs_row = (int)p.qm.s_row, ks_row = (int)p.km.s_row, vs_row = (int)p.vm.s_row, os_row = (int)p.om.s_row;

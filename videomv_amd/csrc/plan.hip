@@ -22,6 +22,7 @@ int run_op(const VmvPlan::Op& o, void* stream) {
         case VMV_OP_ATTENTION: return vmv_attention(reinterpret_cast<const VmvAttnParams*>(o.args.data()), stream);
         case VMV_OP_SOFTMAX: return vmv_softmax_rows(reinterpret_cast<const VmvSoftmaxParams*>(o.args.data()), stream);
         case VMV_OP_COPY: return vmv_permute_copy(reinterpret_cast<const VmvCopyParams*>(o.args.data()), stream);
+        case VMV_OP_FF: return vmv_ff_fused(reinterpret_cast<const VmvFfParams*>(o.args.data()), stream);
         case VMV_OP_GN_FUSED: {
             const VmvGroupNormParams* g = reinterpret_cast<const VmvGroupNormParams*>(o.args.data());
             return vmv_groupnorm_fused(g, g->chunk_rows, stream);
@@ -37,6 +38,7 @@ size_t op_size(int op) {
         case VMV_OP_ATTENTION: return sizeof(VmvAttnParams);
         case VMV_OP_SOFTMAX: return sizeof(VmvSoftmaxParams);
         case VMV_OP_COPY: return sizeof(VmvCopyParams);
+        case VMV_OP_FF: return sizeof(VmvFfParams);
         default: return 0;
     }
 }

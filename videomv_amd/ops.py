@@ -160,6 +160,15 @@ def ln_params(x, ldx, y, ldy, gamma, beta, rows, Cc, eps=1e-5, stats_out=None) -
     return p
 
 
+def ff_params(M, Cc, x, ldx, w1, b1, w2, b2, out, ldo, residual=None, ldr=0, ln_eps=0.0) -> L.FfParams:
+    """Fused FeedForward (vmv_ff_fused): w1 / b1 GEGLU-interleaved (+ LayerNorm folded when ln_eps > 0), w2 = packing.ff_down_permute."""
+    p = L.FfParams()
+    p.M, p.C, p.x, p.ldx = int(M), int(Cc), _ptr(x), int(ldx)
+    p.w1, p.b1, p.w2, p.b2 = _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2)
+    p.residual, p.ldr, p.ln_eps, p.out, p.ldo = _ptr(residual), int(ldr), float(ln_eps), _ptr(out), int(ldo)
+    return p
+
+
 def seq_map(s_outer, s_inner, s_row, inner=1) -> L.SeqMap:
     m = L.SeqMap()
     m.s_outer, m.s_inner, m.s_row, m.inner = int(s_outer), int(s_inner), int(s_row), int(inner)
@@ -248,6 +257,9 @@ class Stream:
 
     def copy(self, params, label="copy"):
         self._go(L.OP_COPY, params, self.lib.vmv_permute_copy, label)
+
+    def ff(self, params, label="ff"):
+        self._go(L.OP_FF, params, self.lib.vmv_ff_fused, label)
 
     def layernorm(self, params, label="ln"):
         self._go(L.OP_LAYERNORM, params, self.lib.vmv_layernorm, label)

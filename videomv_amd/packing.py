@@ -61,6 +61,19 @@ def geglu_interleave(t: torch.Tensor) -> torch.Tensor:
     return torch.cat([x, g], dim=1).reshape((two_i,) + rest)
 
 
+# position -> channel inside every block of 32 hidden channels: the order in which gemm_ff.hip's FF1 MFMA outputs (two 16-channel
+# tiles, lane group g holding channels 4g..4g+3 of each) form the B operand of its FF2 MFMAs (include/vmv.h, VmvFfParams.w2)
+FF_DOWN_ORDER = [4 * g + e if e < 4 else 16 + 4 * g + (e - 4) for g in range(4) for e in range(8)]
+
+
+def ff_down_permute(w2: torch.Tensor) -> torch.Tensor:
+    """FF down-projection weight [C, 4C] (util.py:573) with its K axis reordered per 32-channel block for the fused FeedForward."""
+    n, k = w2.shape
+    assert k % 32 == 0
+    idx = torch.tensor(FF_DOWN_ORDER, dtype=torch.long)
+    return w2.reshape(n, k // 32, 32)[:, :, idx].reshape(n, k).contiguous()
+
+
 def fold_layernorm(w: torch.Tensor, b, gamma: torch.Tensor, beta: torch.Tensor):
     """LayerNorm folded into the Linear that consumes it (include/vmv.h, VmvGemmParams.rowstat): for
     y = W LN(x) + b, LN(x) = (x - mean) * rstd * gamma + beta, returns (W', b', colsum) with W' = W diag(gamma) already

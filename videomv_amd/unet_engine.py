@@ -241,6 +241,10 @@ class UNetEngine:
         # (round 2, same box): 99 launches / 1.2 ms of statistics passes go away, but the 48-64 dot2c per chunk
         # cost the short-K GEMMs 7-15 % and the step gets 0.5 ms SLOWER — off by default.
         self.ln_inline = os.environ.get("VMV_LN_INLINE", "0") == "1"
+        # VMV_FF_FUSED=1 (default 0): the FeedForward of the C = 320 transformer blocks as ONE launch (csrc/gemm_ff.hip).
+        # Opt-in: 383 us against 379 us for the two gemm_rs launches inside a step (51.61 / 51.52 ms, same box) — see the
+        # kernel's header for why (one 1-KB LDS fragment per MFMA)
+        self.ff_fused = os.environ.get("VMV_FF_FUSED", "0") == "1" and self.fold_ln
         # packed weights are immutable and shape-independent: engines of one model (other B / resolution / frame count, the
         # two branch engines of the pipelined frame-parallel mode) share ONE copy (`packed` = another engine's .packed)
         if packed is not None and packed.get("fold_ln") == self.fold_ln and packed.get("device") == str(device):
@@ -303,6 +307,8 @@ class UNetEngine:
             w[f"{p}.ff.net.0.proj.bias"] = P.pack_bias(P.geglu_interleave(sd[f"{p}.ff.net.0.proj.bias"]), dev)
             folded(f"{p}.ff.net.0.proj", sd[f"{p}.ff.net.0.proj.weight"], sd[f"{p}.ff.net.0.proj.bias"], f"{p}.norm3", geglu=True)
             lin(f"{p}.ff.net.2")
+            if self.fold_ln and sd[f"{p}.ff.net.2.weight"].shape[0] == 320:      # fused FeedForward (csrc/gemm_ff.hip: C = 320)
+                w[f"{p}.ff.net.2.weight.ffperm"] = P.pack_linear(P.ff_down_permute(sd[f"{p}.ff.net.2.weight"]), dev)
             for n in ("norm1", "norm2", "norm3"):
                 norm(f"{p}.{n}")
 
@@ -645,10 +651,19 @@ class UNetEngine:
         a2 = cross_attn("attn2", a1, "norm2") if cross_ctx else self_attn("attn2", a1, "norm2")
         if phase != "post":
             self.release(a1)
+        a3 = self.act(T, inner)
+        if self.ff_fused and f"{p}.ff.net.2.weight.ffperm" in self.w and T >= 16384:
+            # the whole FeedForward in one launch, hidden activation in registers (gemm_ff.hip; the UNet's largest level)
+            fp = ops.ff_params(T, inner, a2.ptr, a2.C, self.w[f"{p}.ff.net.0.proj.ln.weight"], self.w[f"{p}.ff.net.0.proj.ln.bias"],
+                               self.w[f"{p}.ff.net.2.weight.ffperm"], self.w[f"{p}.ff.net.2.bias"], a3.ptr, a3.C,
+                               residual=a2.ptr, ldr=a2.C, ln_eps=1e-5)
+            if self.S.lib.vmv_ff_fused_ok(C.byref(fp)):
+                self.S.ff(fp, f"{p}.ff.fused")
+                self.release(a2)
+                return a3
         ff = self.act(T, 4 * inner)
         self._ln_linear(f"{p}.ff.geglu", a2, f"{p}.norm3", 8 * inner, f"{p}.ff.net.0.proj.weight", ff,
                         bias=self.w[f"{p}.ff.net.0.proj.bias"], epilogue=L.EPI_GEGLU)
-        a3 = self.act(T, inner)
         self._gemm(f"{p}.ff.down", T, inner, ops.linear_segs([(ff.ptr, ff.C, ff.C)]), f"{p}.ff.net.2.weight", a3,
                    bias=self.w[f"{p}.ff.net.2.bias"], residual=a2.ptr, ldr=a2.C)
         self.release(ff); self.release(a2)
