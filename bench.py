@@ -221,7 +221,7 @@ def main():
         fam = {}
         for i, (op, p) in enumerate(rec):
             kind = {L.OP_GEMM: "gemm", L.OP_GN_STATS: "gn_stats", L.OP_GN_APPLY: "gn_apply", L.OP_LAYERNORM: "layernorm",
-                    L.OP_ATTENTION: "attention", L.OP_GN_FUSED: "gn_fused", L.OP_COPY: "copy"}[op]
+                    L.OP_ATTENTION: "attention", L.OP_GN_FUSED: "gn_fused", L.OP_COPY: "copy", L.OP_FF: "ff_fused"}[op]
             fl = gemm_flops(p) if op == L.OP_GEMM else (attn_flops(p) if op == L.OP_ATTENTION else 0.0)
             f = fam.setdefault(kind, dict(ms=0.0, flops=0.0, n=0))
             f["ms"] += ms[i]; f["flops"] += fl; f["n"] += 1
@@ -231,14 +231,14 @@ def main():
         # HBM bytes per launch of the same family from the committed PMC passes of this command (tools/gemm_traffic.py;
         # FETCH_SIZE doubled as the microarch guide prescribes for gfx950) — counters cannot be read from inside the run
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r2_gemm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r3_gemm_traffic.json")
         if (H, W) == (40, 64) and args.frames == 24 and os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
             traffic = round(tj["bytes_per_launch"])
-            traffic_src = (f"profiles/r2_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+            traffic_src = (f"profiles/r3_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
                            f"separate runs, commit {tj.get('commit', '?')}, dtype {tj.get('dtype', '?')})")
-        roof = dict(bound="mfma", kernel="16-bit MFMA implicit-GEMM family (gemm_xglds_kernel / gemm_glds_kernel / gemm_pglds_kernel / gemm_kernel: "
+        roof = dict(bound="mfma", kernel="16-bit MFMA implicit-GEMM family (gemm_xglds_kernel / gemm_rs_kernel / gemm_glds_kernel / gemm_pglds_kernel / gemm_kernel: "
                     "conv3x3, temporal conv, linear)",
                     achieved=round(ach, 1), peak=PEAK_MFMA16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_MFMA16_TFLOPS, 4),
                     traffic=traffic, traffic_source=traffic_src,

@@ -33,7 +33,7 @@ def main(fetch_dir, write_dir, out):
     nw, write = family_sum(write_dir, "WRITE_SIZE")
     if not nf or not nw:
         raise SystemExit("no GEMM launches found in the counter files")
-    d = dict(kernel_family="gemm_xglds_kernel / gemm_glds_kernel / gemm_pglds_kernel / gemm_kernel (all 16-bit MFMA implicit-GEMM launches)",
+    d = dict(kernel_family="gemm_xglds_kernel / gemm_rs_kernel / gemm_glds_kernel / gemm_pglds_kernel / gemm_kernel (all 16-bit MFMA implicit-GEMM launches)",
              commit=os.environ.get("VMV_COMMIT", "unknown"), dtype=os.environ.get("VMV_DTYPE", "fp16"),
              launches_fetch_pass=nf, launches_write_pass=nw,
              fetch_kib_per_launch_reported=fetch / nf, write_kib_per_launch_reported=write / nw,
