@@ -221,11 +221,12 @@ typedef struct {
      * group, first channel of the group): shift-invariant, no E[x^2] - mean^2 cancellation for |mean| >> sigma.
      * Optional stat-group totals (long stat groups: the all-frame norms have up to 256 chunks, which every apply block would
      * otherwise re-fold).  With `totals` set, every _stats block ADDS its 32 (sum, sumsq) pairs to the records
-     * totals[stat][32][VMV_GN_REC] = { sum_hi, sumsq_hi, sum_lo, sumsq_lo, pilot (fp32 bits), 3 x pad } with 64-bit integer atomics:
+     * totals[stat][32][VMV_GN_NREP][VMV_GN_REC] = { sum_hi, sumsq_hi, sum_lo, sumsq_lo, pilot (fp32 bits), 3 x pad } with 64-bit
+     * integer atomics (chunk c adds into replica c % VMV_GN_NREP — atomics on one record serialise — replica 0 holds the pilot):
      * two-limb fixed point (integer limb + 2^-40 fraction limb: a block's fp32 partial sum is represented exactly for 1e-3-sized
      * and for 3e3-sized activations alike, |sum| < 2^63).  Integer addition commutes, so the result is bitwise reproducible
      * whatever the arrival order, and no fold launch and no release fence is needed.  The accumulators must be ZERO when _stats
-     * starts.  _apply reads totals instead of partial ([nstat][32][VMV_GN_REC], or [R][nstat][32][VMV_GN_REC] gathered when
+     * starts.  _apply reads totals instead of partial ([nstat][32][NREP][REC], or [R][nstat][32][NREP][REC] gathered when
      * fold_ranks = R > 1: each rank's sums are relative to ITS pilot and are moved to rank 0's in fp64; fold_ranks > 1 requires
      * totals) and, when `totals_clear` is set, zeroes `clear_count` int64 entries there — the accumulators of the NEXT norm (two
      * buffers used alternately: the buffer being cleared was last read one norm ago).                                          */
@@ -236,6 +237,7 @@ typedef struct {
 } VmvGroupNormParams;
 
 #define VMV_GN_REC 8
+#define VMV_GN_NREP 8
 int vmv_groupnorm_stats(const VmvGroupNormParams* p, void* stream);
 int vmv_groupnorm_apply(const VmvGroupNormParams* p, void* stream);
 /* One-launch GroupNorm for stat groups that fit on chip: a block stages all rows_per_stat rows of `cols` channels (a

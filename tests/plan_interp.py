@@ -100,7 +100,7 @@ def _gn_input(p):
     return x, Cc
 
 
-GN_REC = 8          # int64 per (stat, group) record of VmvGroupNormParams.totals (include/vmv.h)
+GN_REC, GN_NREP = 8, 8          # int64 per record of VmvGroupNormParams.totals, replicas per (stat, group) (include/vmv.h)
 
 
 def _gn_pilots(x, nstat, rps, Cc):
@@ -121,13 +121,14 @@ def groupnorm_stats(p: L.GroupNormParams):
         part[:, c, :, 0] = blk.sum(dim=(1, 3))
         part[:, c, :, 1] = (blk * blk).sum(dim=(1, 3))
     if p.totals:       # two-limb fixed-point integer accumulation (order-independent), as the kernel does
-        tot = _view(p.totals, nstat * 32 * GN_REC, "i64").view(nstat, 32, GN_REC)
+        tot = _view(p.totals, nstat * 32 * GN_NREP * GN_REC, "i64").view(nstat, 32, GN_NREP, GN_REC)
         v = part.float()                                             # [nstat][nchunk][32][2]
         hi = torch.floor(v)
         lo = ((v - hi) * float(2 ** 40)).to(torch.int64)
-        tot[:, :, 0:2] += hi.to(torch.int64).sum(dim=1)
-        tot[:, :, 2:4] += lo.sum(dim=1)
-        tot[:, :, 4] = pil.view(torch.int32).to(torch.int64) & 0xffffffff
+        for c in range(nchunk):                                      # chunk c -> replica c % NREP
+            tot[:, :, c % GN_NREP, 0:2] += hi[:, c].to(torch.int64)
+            tot[:, :, c % GN_NREP, 2:4] += lo[:, c]
+        tot[:, :, 0, 4] = pil.view(torch.int32).to(torch.int64) & 0xffffffff
 
 
 def groupnorm(p: L.GroupNormParams):
@@ -138,9 +139,10 @@ def groupnorm(p: L.GroupNormParams):
     R = max(1, p.fold_ranks)
     nr = float(p.rows_per_stat) * (Cc // 32)
     if p.totals:
-        rec = _view(p.totals, R * nstat * 32 * GN_REC, "i64").view(R, nstat, 32, GN_REC)
-        sr = rec[..., 0:2].double() + rec[..., 2:4].double() / float(2 ** 40)            # [R][nstat][32][2]
-        pil = (rec[..., 4] & 0xffffffff).to(torch.int32).view(torch.float32).double()      # [R][nstat][32]
+        rec = _view(p.totals, R * nstat * 32 * GN_NREP * GN_REC, "i64").view(R, nstat, 32, GN_NREP, GN_REC)
+        lim = rec[..., 0:4].sum(dim=3)                                                        # exact integer fold of the replicas
+        sr = lim[..., 0:2].double() + lim[..., 2:4].double() / float(2 ** 40)            # [R][nstat][32][2]
+        pil = (rec[..., 0, 4] & 0xffffffff).to(torch.int32).view(torch.float32).double()   # [R][nstat][32]
         d = pil - pil[0:1]
         S = (sr[..., 0] + nr * d).sum(dim=0)
         Q = (sr[..., 1] + 2.0 * d * sr[..., 0] + nr * d * d).sum(dim=0)

@@ -362,12 +362,12 @@ def test_groupnorm(rows, rps, C0, C1, silu, eps):
 @pytest.mark.parametrize("rows,rps,Cc,silu", [(2 * 61440, 61440, 320, True), (2 * 960, 960, 1280, False), (3 * 500, 500, 64, True)])
 def test_groupnorm_prefolded_totals(rows, rps, Cc, silu):
     """Long stat groups (the all-frame norms): the stats blocks add their sums to two-limb 64-bit fixed-point integer accumulators
-    totals[stat][32][GN_REC] (order-independent => deterministic, no fold launch); apply reads them and clears the next norm's.
+    totals[stat][32][GN_NREP][GN_REC] (order-independent => deterministic, no fold launch); apply reads them and clears the next norm's.
     Same statistics as the plain two-launch path up to summation order (the two limbs hold each block's fp32 sum exactly)."""
     x = rnd((rows, Cc), 21, 1.3).cuda() + 0.1
     gamma, beta = (1 + 0.1 * torch.randn(Cc, generator=g(3))).cuda(), (0.1 * torch.randn(Cc, generator=g(4))).cuda()
     part = torch.zeros(ops.gn_partial_floats(rows, rps, Cc) + 64, device="cuda")
-    tot = torch.zeros(2, 64 * 32 * ops.GN_REC, dtype=torch.int64, device="cuda")
+    tot = torch.zeros(2, 64 * ops.GN_TOT, dtype=torch.int64, device="cuda")
     y0, y1 = torch.zeros(rows, Cc, dtype=BF, device="cuda"), torch.zeros(rows, Cc, dtype=BF, device="cuda")
     S = ops.Stream(record=False)
     p0 = ops.gn_params(x, Cc, Cc, rows, rps, part, gamma, beta, 1e-5, silu, y0, Cc)
@@ -399,9 +399,9 @@ def test_groupnorm_sharded_statistics(R, B, rps_loc, Cc):
     S = ops.Stream(record=False)
     xd = [x.cuda() for x in xs]
     gd, bd = gamma.cuda(), beta.cuda()
-    # every "rank" folds its own chunks into its records; the [R][B][32][GN_REC] records are "gathered" (each relative to the
+    # every "rank" folds its own chunks into its records; the [R][B][32][GN_NREP][GN_REC] records are "gathered" (each relative to the
     # rank's own pilot — the shards' first elements differ — and moved to rank 0's by the apply pass)
-    nrec = B * 32 * ops.GN_REC
+    nrec = B * ops.GN_TOT
     tot_all = torch.zeros(R * nrec, dtype=torch.int64, device="cuda")
     ys = [torch.zeros(B * rps_loc, Cc, dtype=BF, device="cuda") for _ in range(R)]
     for r in range(R):
@@ -443,7 +443,7 @@ def test_groupnorm_statistics_are_shift_and_scale_safe(kind, path):
     gamma, beta = torch.ones(Cc), torch.zeros(Cc)
     y = torch.zeros(rows, Cc, dtype=BF, device="cuda")
     part = torch.zeros(ops.gn_partial_floats(rows, rps, Cc) + 64, device="cuda")
-    tot = torch.zeros(2, 64 * 32 * ops.GN_REC, dtype=torch.int64, device="cuda")
+    tot = torch.zeros(2, 64 * ops.GN_TOT, dtype=torch.int64, device="cuda")
     S = ops.Stream(record=False)
     pr = ops.gn_params(xd, Cc, Cc, rows, rps, part, gamma.cuda(), beta.cuda(), 1e-12, False, y, Cc,
                        **(dict(totals=tot[0], totals_clear=tot[1], clear_count=tot[1].numel()) if path == "totals" else {}))

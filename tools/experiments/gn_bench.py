@@ -1,7 +1,14 @@
-import torch, sys, os
-sys.path.insert(0, os.getcwd())
+#!/usr/bin/env python
+"""GroupNorm statistics pass at the UNet's L0 shapes: all-frame (2 stat groups of 61 440 rows) against per-frame (48 x 2560), the
+int64 totals against per-chunk partials, over the chunk size.  us per launch."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
 from videomv_amd import _lib as L, ops
-S = ops.Stream(record=False)
+
+BF = L.elem()
+
+
 def bench(fn, reps=30):
     for _ in range(3): fn()
     torch.cuda.synchronize()
@@ -10,14 +17,24 @@ def bench(fn, reps=30):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1000
-for rows, rps, C in ((122880, 2560, 320), (122880, 61440, 320), (30720, 640, 640), (30720, 15360, 640)):
-    x = torch.randn(rows, C, device="cuda").to(L.elem())
+
+
+dev = "cuda"
+for C, HW in ((320, 2560), (640, 640)):
+    rows = 2 * 24 * HW
+    x = torch.randn(rows, C, device=dev).to(BF)
     y = torch.empty_like(x)
-    g, b = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
-    part = torch.zeros(ops.gn_partial_floats(rows, rps, C) + 64, device="cuda")
-    tot = torch.zeros(64 * 64, device="cuda")
-    allf = rps > 10000
-    p = ops.gn_params(x, C, C, rows, rps, part, g, b, 1e-5, True, y, C, totals=tot if allf else None)
-    ts = bench(lambda: S.groupnorm_stats(p)); ta = bench(lambda: S.groupnorm_apply(p))
-    mb = rows * C * 2 / 1e6
-    print(f"rows {rows} rps {rps} C {C}: stats {ts:.1f} us ({mb/ts/1e0:.2f} GB/ms = {mb/ts:.2f} TB/s) apply {ta:.1f} us ({2*mb/ta:.2f} TB/s)")
+    g, b = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    S = ops.Stream(record=False)
+    for rps in (24 * HW, HW):
+        for cr in (None, 120, 60, 30):
+            cr_ = cr or ops.gn_chunk_rows(rps, C)
+            if cr_ > rps: continue
+            part = torch.zeros(ops.gn_partial_floats(rows, rps, C, cr_) + 64, device=dev)
+            tot = torch.zeros(64 * ops.GN_TOT, device=dev, dtype=torch.int64)
+            pp = ops.gn_params(x, C, C, rows, rps, part, g, b, 1e-5, True, y, C, chunk_rows=cr_)
+            pt = ops.gn_params(x, C, C, rows, rps, part, g, b, 1e-5, True, y, C, chunk_rows=cr_, totals=tot)
+            tp = bench(lambda: S.groupnorm_stats(pp))
+            tt = bench(lambda: S.groupnorm_stats(pt)) if (rps + cr_ - 1) // cr_ <= 4096 else float("nan")
+            ta = bench(lambda: S.groupnorm_apply(pp))
+            print(f"C={C} rows/stat={rps:6d} chunk_rows={cr_:4d} nchunk={(rps + cr_ - 1) // cr_:5d}: stats(partials) {tp:6.1f}  stats(totals) {tt:6.1f}  apply(partials) {ta:6.1f} us", flush=True)

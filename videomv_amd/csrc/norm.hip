@@ -18,8 +18,9 @@ namespace {
 // limb (quantum 2^-40), so a block's fp32 partial sum is represented exactly whether the activations are 1e-3 or 3e3 (round 2's
 // single limb had a fixed 2^-12 quantum: a group of 1e-3-sized activations lost its variance).  Integer addition
 // commutes: the totals are bitwise reproducible whatever the arrival order.  Record per (stat, group): GN_REC int64 =
-// { sum_hi, sumsq_hi, sum_lo, sumsq_lo, pilot (fp32 bits), pad x3 }.
+// { sum_hi, sumsq_hi, sum_lo, sumsq_lo, pilot (fp32 bits), pad x3 }, kept GN_NREP times (see the atomics below).
 constexpr int GN_REC = 8;
+constexpr int GN_NREP = 8;                      // replicas of a record: chunk c adds into replica c % 8 (below)
 constexpr float GN_LO = 1099511627776.0f;       // 2^40
 
 VMV_DEV void gn_add2(unsigned long long* rec, int which, float v) {
@@ -54,7 +55,11 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const VmvGroupNormParams 
     const uint16_t* x0 = reinterpret_cast<const uint16_t*>(p.x);
     const uint16_t* x1 = reinterpret_cast<const uint16_t*>(p.x1);
     const int cpg_ = C >> 5;
+#if defined(VMV_GN_ABLATE_PILOT)
+    if (tid < 32) pil[tid] = 0.f;
+#else
     if (tid < 32) pil[tid] = gn_pilot(p, (long)stat * p.rows_per_stat, tid * cpg_);
+#endif
     __syncthreads();
     for (int cs = cl; cs < CS; cs += TPR) {
         float s[8], q[8], pl[8];
@@ -108,10 +113,14 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const VmvGroupNormParams 
         for (int r = 0; r < RPP; ++r)
             for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { s += lsum[r * C + c]; q += lsq[r * C + c]; }
         if (p.totals) {        // two-limb fixed-point 64-bit atomics: order-independent, hence deterministic (vmv.h)
-            unsigned long long* rec = reinterpret_cast<unsigned long long*>(p.totals) + ((long)stat * 32 + tid) * GN_REC;
+            // Atomics on one 64-B record serialise at ~20 ns each wherever they are resolved (measured: 256 chunks x 4 adds on
+            // one record = +20 us on a 17-us pass, linear in the chunk count: tools/experiments/gn_bench.py), so a record is
+            // kept GN_NREP times and consecutive chunks take consecutive replicas; integer adds: the fold stays exact
+            unsigned long long* rec = reinterpret_cast<unsigned long long*>(p.totals) +
+                                      (((long)stat * 32 + tid) * GN_NREP + (chunk & (GN_NREP - 1))) * GN_REC;
             gn_add2(rec, 0, s);
             gn_add2(rec, 1, q);
-            if (chunk == 0) rec[4] = (unsigned long long)__float_as_uint(pil[tid]);
+            if (chunk == 0) rec[4] = (unsigned long long)__float_as_uint(pil[tid]);       // (replica 0 carries the pilot)
         } else {
             float* out = p.partial + (((long)stat * nchunk + chunk) * 32 + tid) * 2;
             out[0] = s; out[1] = q;
@@ -142,19 +151,28 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const VmvGroupNormParams 
         const int R = p.fold_ranks > 1 ? p.fold_ranks : 1;
         if (p.totals) {      // two-limb integer totals per (rank, stat, group), each relative to that rank's pilot: moved to rank 0's
                              // pilot and summed in fp64 (R shards of equal size: frame-parallel pixel shards)
-            if (sub == 0) {
-                const double nr = (double)p.rows_per_stat * (double)cpg;
-                double S = 0.0, Q = 0.0, P0 = 0.0;
-                for (int r = 0; r < R; ++r) {
-                    const long long* rec = reinterpret_cast<const long long*>(p.totals) + (((long)r * nstat + stat) * 32 + g) * GN_REC;
-                    const double sr = (double)rec[0] + (double)rec[2] * (1.0 / (double)GN_LO);
-                    const double qr = (double)rec[1] + (double)rec[3] * (1.0 / (double)GN_LO);
-                    const double P = (double)__uint_as_float((uint32_t)rec[4]);
-                    if (r == 0) P0 = P;
-                    const double d = P - P0;
-                    S += sr + nr * d;
-                    Q += qr + 2.0 * d * sr + nr * d * d;
+            static_assert(GN_NREP == 8, "one replica per sub-lane");
+            const double nr = (double)p.rows_per_stat * (double)cpg;
+            double S = 0.0, Q = 0.0, P0 = 0.0;
+            for (int r = 0; r < R; ++r) {
+                const long long* rec = reinterpret_cast<const long long*>(p.totals) +
+                                       ((((long)r * nstat + stat) * 32 + g) * GN_NREP + sub) * GN_REC;
+                long long l0 = rec[0], l1 = rec[1], l2 = rec[2], l3 = rec[3];
+                const long long pb = __shfl(rec[4], tid & 56, 64);         // replica 0's
+#pragma unroll
+                for (int o = 1; o < 8; o <<= 1) {       // the 8 replicas: exact integer sums
+                    l0 += __shfl_xor(l0, o, 64); l1 += __shfl_xor(l1, o, 64);
+                    l2 += __shfl_xor(l2, o, 64); l3 += __shfl_xor(l3, o, 64);
                 }
+                const double sr = (double)l0 + (double)l2 * (1.0 / (double)GN_LO);
+                const double qr = (double)l1 + (double)l3 * (1.0 / (double)GN_LO);
+                const double P = (double)__uint_as_float((uint32_t)pb);
+                if (r == 0) P0 = P;
+                const double d = P - P0;
+                S += sr + nr * d;
+                Q += qr + 2.0 * d * sr + nr * d * d;
+            }
+            if (sub == 0) {
                 const double n = nr * (double)R;
                 const double m = S / n;
                 double var = Q / n - m * m;

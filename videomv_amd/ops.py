@@ -14,6 +14,8 @@ from . import _lib as L
 
 TAPS3x3 = [(dy, dx) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
 GN_REC = 8      # int64 per (stat group, channel group) record of VmvGroupNormParams.totals (include/vmv.h)
+GN_NREP = 8     # replicas of every record (chunk c adds into replica c % 8)
+GN_TOT = 32 * GN_NREP * GN_REC      # int64 per stat group
 
 
 def _ptr(t):
@@ -82,7 +84,7 @@ def gemm_params(M, N, segs: Sequence[Seg], W, out, ldo, bias=None, rowvec=None, 
 
 def gn_params(x, ld, C0, rows, rows_per_stat, partial, gamma, beta, eps, silu, y, ldy, x1=None, ld1=0, C1=0,
               chunk_rows=None, fold_ranks=0, totals=None, totals_clear=None, clear_count=0) -> L.GroupNormParams:
-    """totals / totals_clear: int64 two-limb fixed-point stat-group accumulators, GN_REC int64 per (stat, group) (include/vmv.h):
+    """totals / totals_clear: int64 two-limb fixed-point stat-group accumulators, GN_TOT int64 per stat group (include/vmv.h):
     `totals` must be zero when the statistics pass starts; the apply pass zeroes `clear_count` entries of `totals_clear` (the
     next norm's accumulators)."""
     p = L.GroupNormParams()

@@ -225,10 +225,10 @@ class UNetEngine:
         # pre-folded statistics of the all-frame norms: [nstat][32][2] per rank (+ the gathered [R][nstat][32][2]), tickets
         # two buffers used alternately by consecutive all-frame norms (the apply pass of one clears the other's)
         # (records of ops.GN_REC int64 per (stat group, channel group): two-limb sums of x - pilot, sums of squares, the pilot)
-        self._gn_tot2 = torch.zeros(2, 64 * 32 * ops.GN_REC, dtype=torch.int64, device=device)
-        self._gn_zero = torch.zeros(2, 64 * 32 * ops.GN_REC, dtype=torch.int64, device=device)   # source of the plan's own clearing copy
+        self._gn_tot2 = torch.zeros(2, 64 * ops.GN_TOT, dtype=torch.int64, device=device)
+        self._gn_zero = torch.zeros(2, 64 * ops.GN_TOT, dtype=torch.int64, device=device)   # source of the plan's own clearing copy
         self._gn_tot_k = 0
-        self._gn_tot_all = torch.zeros(64 * 32 * ops.GN_REC * self.R, dtype=torch.int64, device=device) if comm is not None else None
+        self._gn_tot_all = torch.zeros(64 * ops.GN_TOT * self.R, dtype=torch.int64, device=device) if comm is not None else None
         self.taps = taps            # optional dict: prefix -> Act (buffers are then never recycled)
         self.n_t = n_t
         self.dim = cfg["dim"]
@@ -439,12 +439,12 @@ class UNetEngine:
         assert nstat <= 64
         tot, nxt = self._gn_tot2[self._gn_tot_k & 1], self._gn_tot2[(self._gn_tot_k + 1) & 1]
         self._gn_tot_k += 1
-        clr = dict(totals_clear=nxt, clear_count=nxt.numel())
+        clr = dict(totals_clear=nxt, clear_count=nstat * ops.GN_TOT)      # (every all-frame norm of an engine has nstat = B)
         if self.comm is None:
             self.S.groupnorm(ops.gn_params(*args, totals=tot, **clr, **base), label)
             return y
         self.S.groupnorm_stats(ops.gn_params(*args, totals=tot, **base), label)
-        loc, allr = tot[: nstat * 32 * ops.GN_REC], self._gn_tot_all[: nstat * 32 * ops.GN_REC * self.R]
+        loc, allr = tot[: nstat * ops.GN_TOT], self._gn_tot_all[: nstat * ops.GN_TOT * self.R]
         self._break(lambda: self.comm.all_gather(allr, loc))
         self.S.groupnorm_apply(ops.gn_params(*args, totals=self._gn_tot_all, fold_ranks=self.R, **clr, **base), label)
         return y
