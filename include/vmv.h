@@ -77,6 +77,7 @@ typedef struct {
 #define VMV_EPI_GEGLU  1   /* N counts x|gate pairs interleaved in 16-column blocks; writes N/2 columns: x*gelu_erf(gate) */
 #define VMV_ACT_NONE   0
 #define VMV_ACT_SILU   1
+#define VMV_ACT_GELU   2   /* exact (erf) GELU: nn.GELU() of the CLIP text tower's MLP */
 
 typedef struct {
     int32_t M, N;            /* output rows / weight rows (N multiple of 4)                         */
@@ -274,8 +275,8 @@ typedef struct {
 int vmv_softmax_rows(const VmvSoftmaxParams* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
- * Softmax attention, head_dim 64, no mask/bias, scale given (xformers memory_efficient_attention at
- * util.py:253,258).  One kernel for the three uses, selected by the index maps:
+ * Softmax attention, head_dim 64, no bias, scale given (xformers memory_efficient_attention at
+ * util.py:253,258); optional causal mask (key index <= query index: the text tower of clip_embedder.py:192-201).  One kernel for the three uses, selected by the index maps:
  *   spatial self  : problems (b f, head), Nq = Nk = H*W
  *   spatial cross : same queries, Nk = 77 text tokens shared by all frames of a batch item (kv_div = F)
  *   temporal      : problems (b, pixel, head), Nq = Nk = F, rows strided by H*W   
@@ -296,7 +297,7 @@ typedef struct {
     int32_t Nq, Nk;
     float scale;
     int32_t head_dim;      /* 64 (0 = 64) or 32; 32 only for long sequences (LGM MVAttention, core/attention.py:67-84) */
-    int32_t _pad;
+    int32_t causal;        /* != 0: scores of keys j > query i are masked out (requires Nq == Nk, head_dim 64)         */
 } VmvAttnParams;
 int vmv_attention(const VmvAttnParams* p, void* stream);
 

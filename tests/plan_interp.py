@@ -86,6 +86,8 @@ def gemm(p: L.GemmParams):
         acc = acc + rv[m // p.rowvec_div]
     if p.act == L.ACT_SILU:
         acc = torch.nn.functional.silu(acc)
+    elif p.act == L.ACT_GELU:
+        acc = torch.nn.functional.gelu(acc)
     if p.residual:
         acc = acc + (p.res_scale if p.res_scale != 0.0 else 1.0) * _rows(p.residual, M, p.ldr)[:, :No].float()
     out = _rows(p.out, M, p.ldo, "f32" if p.out_fp32 else "elem")
@@ -215,8 +217,10 @@ def attention(p: L.AttnParams):
             kf, ki = _seq_rows(p.k, p.km, o // p.kv_div, h, p.Nk, hd)
             vf, vi = _seq_rows(p.v, p.vm, o // p.kv_div, h, p.Nk, hd)
             q, k, v = qf[qi].float(), kf[ki].float(), vf[vi].float()
-            s = torch.softmax(q @ k.t() * p.scale, dim=-1)
-            out = (s @ v).to(L.elem())
+            s = q @ k.t() * p.scale
+            if p.causal:
+                s = s.masked_fill(torch.ones_like(s, dtype=torch.bool).triu(1), float("-inf"))
+            out = (torch.softmax(s, dim=-1) @ v).to(L.elem())
             of, oi = _seq_rows(p.o, p.om, o, h, p.Nq, hd)
             of[oi.reshape(-1)] = out.reshape(-1)
 

@@ -917,6 +917,50 @@ def test_attention_head_dim_32(T, heads):
     check(dev["o"], cpu["o"], tol_l2=6e-3, tol_max=2e-2)
 
 
+@pytest.mark.parametrize("B,T,heads", [(2, 77, 16), (1, 77, 2), (3, 130, 1), (1, 300, 2)])
+def test_attention_causal(B, T, heads):
+    """VmvAttnParams.causal (the CLIP text tower, clip_embedder.py:192-201): keys j > i masked out, fused q|k|v rows; 77 tokens
+    = two key tiles with a partial second one, 130 / 300 = several query blocks with fully masked key tiles above the diagonal."""
+    Cc = heads * 64
+    c = Case(qkv=rnd((B * T, 3 * Cc), 5), o=torch.zeros(B * T, Cc, dtype=BF))
+
+    def build(t, causal=True):
+        m = lambda: ops.seq_map(T * 3 * Cc, 0, 3 * Cc, inner=1)
+        base = t["qkv"].data_ptr()
+        return ops.attn_params(base, base + 2 * Cc, base + 4 * Cc, t["o"], m(), m(), m(), ops.seq_map(T * Cc, 0, Cc, inner=1),
+                               B, heads, T, T, 64 ** -0.5, causal=causal)
+    cpu = c.on("cpu")
+    I.attention(build(cpu))
+    dev = c.on("cuda")
+    S = ops.Stream(record=False)
+    S.attention(build(dev), "t")
+    torch.cuda.synchronize()
+    check(dev["o"], cpu["o"], tol_l2=6e-3, tol_max=2e-2)
+    full = c.on("cuda")
+    S.attention(build(full, causal=False), "t")
+    torch.cuda.synchronize()
+    assert not torch.equal(full["o"], dev["o"])                      # the mask is really applied
+    assert torch.equal(full["o"].view(B, T, Cc)[:, -1], dev["o"].view(B, T, Cc)[:, -1]) or T > 64     # (last row sees every key; same tile walk for T <= 64 only)
+    import ctypes as C
+    bad = build(dev); bad.Nk = T - 1
+    assert S.lib.vmv_attention(C.byref(bad), None) == -1              # causal needs Nq == Nk
+
+
+@pytest.mark.parametrize("M,K,N", [(154, 1024, 4096), (77, 128, 512), (3000, 320, 640)])
+def test_gemm_gelu_activation(M, K, N):
+    """VMV_ACT_GELU: exact-erf GELU after bias (the CLIP text tower's c_fc, nn.GELU())."""
+    c = Case(x=rnd((M, K), 1), w=rnd((N, K), 2, K ** -0.5), b=torch.randn(N, generator=g(3)), o=torch.zeros(M, N, dtype=BF))
+
+    def build(t):
+        return ops.gemm_params(M, N, ops.linear_segs([(t["x"], K, K)]), t["w"], t["o"], N, bias=t["b"], act=L.ACT_GELU)
+    cpu = c.on("cpu")
+    I.gemm(build(cpu))
+    dev = c.on("cuda")
+    ops.Stream(record=False).gemm(build(dev), "t")
+    torch.cuda.synchronize()
+    check(dev["o"], cpu["o"])
+
+
 # ------------------------------------------------------------------------------------------------- sampler glue
 def test_layout_and_ddim_kernels():
     nb, Cc, F_, H, W = 1, 4, 5, 6, 7

@@ -38,3 +38,19 @@ for C, HW in ((320, 2560), (640, 640)):
             tt = bench(lambda: S.groupnorm_stats(pt)) if (rps + cr_ - 1) // cr_ <= 4096 else float("nan")
             ta = bench(lambda: S.groupnorm_apply(pp))
             print(f"C={C} rows/stat={rps:6d} chunk_rows={cr_:4d} nchunk={(rps + cr_ - 1) // cr_:5d}: stats(partials) {tp:6.1f}  stats(totals) {tt:6.1f}  apply(partials) {ta:6.1f} us", flush=True)
+
+print("one-launch form (vmv_groupnorm_fused): us, GB/s of read + write")
+for name, (rps, C, nstat) in {"L1 frame 640": (640, 640, 48), "L1 frame concat 1280": (640, 1280, 48), "L2 frame 1280": (160, 1280, 48),
+                              "L2 concat 2560": (160, 2560, 48), "L3 frame 1280": (40, 1280, 48), "L3 all-frame 1280": (960, 1280, 2)}.items():
+    rows = rps * nstat
+    x = torch.randn(rows, C, device=dev).to(BF)
+    y = torch.empty_like(x)
+    g, b = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    part = torch.zeros(ops.gn_partial_floats(rows, rps, C) + 64, device=dev)
+    S = ops.Stream(record=False)
+    cols = ops.gn_fused_cols(rps, C)
+    pf = ops.gn_params(x, C, C, rows, rps, part, g, b, 1e-5, True, y, C)
+    tf = bench(lambda: S.groupnorm_fused(pf, cols))
+    p2 = ops.gn_params(x, C, C, rows, rps, part, g, b, 1e-5, True, y, C)
+    t2 = bench(lambda: (S.groupnorm_stats(p2), S.groupnorm_apply(p2)))
+    print(f"{name:22s} cols={cols:3d} fused {tf:6.1f} us ({2 * rows * C * 2 / tf / 1e3:6.0f} GB/s)   stats+apply {t2:6.1f} us", flush=True)

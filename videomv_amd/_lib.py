@@ -43,7 +43,7 @@ def lib_path() -> str:
 VMV_MAX_SEGS = 24
 SEG_LINEAR, SEG_SPATIAL, SEG_TEMPORAL = 0, 1, 2
 EPI_NONE, EPI_GEGLU = 0, 1
-ACT_NONE, ACT_SILU = 0, 1
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 TILE_AUTO, TILE_128x128, TILE_128x160, TILE_128x64, TILE_64x64, TILE_256x128, TILE_256x160 = 0, 1, 2, 3, 4, 5, 6
 TILE_G128x128, TILE_G128x160, TILE_P256x128, TILE_P256x160, TILE_PP256x128, TILE_PP256x160 = 7, 8, 9, 10, 11, 12
 TILE_Q128x128, TILE_Q96x160 = 13, 14
@@ -121,7 +121,7 @@ class AttnParams(C.Structure):
     _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p),
                 ("qm", SeqMap), ("km", SeqMap), ("vm", SeqMap), ("om", SeqMap),
                 ("n_outer", C.c_int32), ("kv_div", C.c_int32), ("heads", C.c_int32),
-                ("Nq", C.c_int32), ("Nk", C.c_int32), ("scale", C.c_float), ("head_dim", C.c_int32), ("_pad", C.c_int32)]
+                ("Nq", C.c_int32), ("Nk", C.c_int32), ("scale", C.c_float), ("head_dim", C.c_int32), ("causal", C.c_int32)]
 
 
 class SoftmaxParams(C.Structure):

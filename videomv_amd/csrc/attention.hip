@@ -36,7 +36,8 @@ constexpr float NEG_BIG = -1.0e30f;
 // 128-query version at long sequences)
 // D = head dimension: 64 (the video UNet) or 32 (the LGM U-Net's 512-channel / 16-head MVAttention; WPP = 4 only): the
 // same kernel with D / 32 k-steps in S^T = K Q^T, D / 16 output tiles in O^T = V^T P^T and D / 8 16-byte slots per staged K row.
-template <int WPP, int QT, int D = 64>
+// CAUSAL: keys j > query i masked out (own instantiation: the test costs <4, 4, 64> two spilled registers)
+template <int WPP, int QT, int D = 64, bool CAUSAL = false>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, const int nproblems) {
     static_assert(D == 64 || (D == 32 && WPP == 4), "head_dim 64, or 32 on the 4-waves-per-problem variant");
     constexpr int KK = D / 32, DT = D / 16, SLOTS = D / 8, SLOG = (D == 64) ? 3 : 2;
@@ -244,13 +245,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
     #pragma unroll
             for (int q2 = 0; q2 < 2; ++q2) {
                 const int qt = 2 * qp + q2;
-                if (partial) {
+                if (partial || CAUSAL) {         // (causal: key <= query — the CLIP text tower; key 0 is visible to every query, so the
+                                                 //  running max is real from the first tile on and masked scores exponentiate to 0)
+                    const int qlim = CAUSAL ? q0 + qt * 16 + u : 0x7fffffff;
     #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int kb = key0 + 32 * (t >> 1) + 8 * g + 4 * (t & 1);
     #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            if (kb + r >= p.Nk) s[q2][t][r] = NEG_BIG;
+                            if (kb + r >= p.Nk || kb + r > qlim) s[q2][t][r] = NEG_BIG;
                     }
                 }
                 // (v_max3 through asm: fmaxf() is llvm.maxnum, which in IEEE mode first quiets every MFMA result with a
@@ -536,6 +539,7 @@ extern "C" int vmv_attention(const VmvAttnParams* pp, void* stream) {
     if (!vmv_aligned16(p.q) || !vmv_aligned16(p.k) || !vmv_aligned16(p.v) || (((uintptr_t)p.o) & 7)) return VMV_EALIGN;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int hd = p.head_dim ? p.head_dim : 64;
+    if (p.causal && (hd != 64 || p.Nq != p.Nk)) return VMV_EINVAL;          // causal: self-attention on the general head_dim-64 kernel
     if (hd == 32) {                  // LGM MVAttention (core/attention.py:67-84): long sequences only
         if (p.n_outer > 65535 || p.heads > 65535) return VMV_ERANGE;
         hipLaunchKernelGGL((attn_kernel<4, 2, 32>), dim3((p.Nq + 127) / 128, p.heads, p.n_outer), dim3(256), 32768, st, p, 0);
@@ -544,10 +548,10 @@ extern "C" int vmv_attention(const VmvAttnParams* pp, void* stream) {
     if (hd != 64) return VMV_EINVAL;
     static int short_env = -1;
     if (short_env < 0) { const char* e = getenv("VMV_ATTN_SHORT"); short_env = e ? atoi(e) : 1; }
-    if (p.Nq <= 32 && p.Nk <= 32 && short_env) {
+    if (p.Nq <= 32 && p.Nk <= 32 && short_env && !p.causal) {
         const int nproblems = p.n_outer * p.heads;
         hipLaunchKernelGGL(attn_short_kernel, dim3((nproblems + 3) / 4), dim3(256), 0, st, p, nproblems);
-    } else if (p.Nq <= 32) {
+    } else if (p.Nq <= 32 && !p.causal) {
         const int nproblems = p.n_outer * p.heads;
         static bool attr1 = false;
         if (!attr1) {
@@ -564,7 +568,8 @@ extern "C" int vmv_attention(const VmvAttnParams* pp, void* stream) {
         // 256-query blocks when that still leaves >= 2 blocks per CU and the key loop is long enough to matter
         const long blocks256 = (long)((p.Nq + 255) / 256) * p.heads * p.n_outer;
         const bool big = qt_env == 4 || (qt_env == 0 && p.Nk >= 512 && blocks256 >= 512 && (p.Nq % 256 == 0 || p.Nq >= 2048));
-        if (big) hipLaunchKernelGGL((attn_kernel<4, 4>), dim3((p.Nq + 255) / 256, p.heads, p.n_outer), dim3(256), 32768, st, p, 0);
+        if (p.causal) hipLaunchKernelGGL((attn_kernel<4, 2, 64, true>), dim3((p.Nq + 127) / 128, p.heads, p.n_outer), dim3(256), 32768, st, p, 0);
+        else if (big) hipLaunchKernelGGL((attn_kernel<4, 4>), dim3((p.Nq + 255) / 256, p.heads, p.n_outer), dim3(256), 32768, st, p, 0);
         else hipLaunchKernelGGL((attn_kernel<4, 2>), dim3((p.Nq + 127) / 128, p.heads, p.n_outer), dim3(256), 32768, st, p, 0);
     }
     return vmv_launch_status();

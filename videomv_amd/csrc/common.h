@@ -122,6 +122,12 @@ VMV_DEV float gelu_erf_f(float x) {
     return fmaf(-a, q, m);
 }
 
+// VMV_ACT_* on four accumulator values (bias / rowvec already added): SiLU (the UNet's convs), exact-erf GELU (the CLIP text tower's MLP)
+VMV_DEV void act_apply(f32x4_t& v, const int act) {
+    if (act == VMV_ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+    else if (act == VMV_ACT_GELU) { v.x = gelu_erf_f(v.x); v.y = gelu_erf_f(v.y); v.z = gelu_erf_f(v.z); v.w = gelu_erf_f(v.w); }
+}
+
 VMV_DEV float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

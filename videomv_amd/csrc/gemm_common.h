@@ -61,7 +61,7 @@ VMV_DEV void epilogue_store(const VmvGemmParams& p, int m, int n, f32x4_t v, f32
         const f32x4_t rv = *reinterpret_cast<const f32x4_t*>(p.rowvec + (size_t)(m / p.rowvec_div) * p.rowvec_ld + no);
         v += rv;
     }
-    if (p.act == VMV_ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+    act_apply(v, p.act);
     if (p.residual) {
         const u32x2_t r = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const uint16_t*>(p.residual) + (size_t)m * p.ldr + no);
         const float rs = p.res_scale != 0.f ? p.res_scale : 1.f;

@@ -391,7 +391,7 @@ __global__ __launch_bounds__(128 * WMW, WMW == 2 ? 2 : 1) void gemm_glds_kernel(
                     }
                     if (p.rowvec && m < p.M)
                         v += *reinterpret_cast<const f32x4_t*>(p.rowvec + (size_t)(m / p.rowvec_div) * p.rowvec_ld + no);
-                    if (p.act == VMV_ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+                    act_apply(v, p.act);
                 } else if (geglu) {
                     tc = (tc >> 5) * 16 + (tc & 15);
                 }

@@ -406,7 +406,7 @@ __global__ __launch_bounds__(768, 3) void gemm_sglds_kernel(const VmvGemmParams 
                     }
                 }
                 if (p.rowvec) v += rv[j];
-                if (p.act == VMV_ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+                act_apply(v, p.act);
                 packed[j].x = pack_elem2(v.x, v.y); packed[j].y = pack_elem2(v.z, v.w);
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams 
 #pragma unroll
                 for (int i = 0; i < WM; ++i) {
                     f32x4_t v = acc[j][i] + *reinterpret_cast<const f32x4_t*>(cvec + gi[i] + nl);
-                    if (p.act == VMV_ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+                    act_apply(v, p.act);
                     u32x2_t o;
                     o.x = pack_elem2(v.x, v.y); o.y = pack_elem2(v.z, v.w);
                     *reinterpret_cast<u32x2_t*>(smem + ((wave_m & 1) * 16 * WM + 16 * i + frow) * row_bytes + (wave_n * 16 * WN + 16 * j + 4 * fgrp) * 2) = o;

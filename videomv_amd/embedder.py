@@ -1,9 +1,17 @@
-"""Text-conditioning inputs.  The OpenCLIP ViT-H/14 text tower (tools/modules/clip_embedder.py) is OUT OF SCOPE for the
-hot path (it runs once per prompt) and its package/weights are not available offline; the sampler only needs
-its output ``y_words`` [1, 77, 1024].  ``SyntheticTextEmbedder`` produces a deterministic, prompt-seeded stand-in of that
-shape so the drop-in entrance, the benchmark and CI can run end-to-end; recorded CLIP features can be fed instead via
-``cfg.text_features`` (a .pt file mapping prompt -> tensor)."""
+"""Text-conditioning inputs.  The sampler needs ``y_words`` [B, 77, 1024] (and, for I2VGen, ``y_visual`` [B, 1024]) — the outputs
+of ``FrozenOpenCLIPTtxtVisualEmbedder`` (tools/modules/clip_embedder.py:144-227), which runs once per prompt, upstream of the hot
+path.
+
+* TEXT tower: ``clip_text.ClipTextEngine`` runs open_clip's ViT-H/14 text transformer on the HIP kernels when ``pretrained``
+  names an open_clip checkpoint (a state dict holding ``token_embedding.weight`` ...).  Tokenisation needs open_clip's BPE
+  vocabulary, which is not available offline: token ids come from ``open_clip.tokenize`` when that package is importable, from a
+  ``tokenizer=`` callable, or are passed directly (``forward(tokens=...)``).
+* IMAGE tower (ViT-H/14 visual, head_dim 80) is not built: ``y_visual`` is a recorded feature or the synthetic stand-in.
+* Without a checkpoint (this container: no weights, no network) ``SyntheticTextEmbedder`` produces deterministic, prompt-seeded
+  stand-ins of the right shapes so the drop-in entrance, the benchmark and CI run end-to-end; recorded CLIP features can be fed
+  through ``features_path`` (a .pt file mapping prompt -> tensor)."""
 import hashlib
+import os
 
 import torch
 
@@ -47,11 +55,50 @@ class SyntheticTextEmbedder(_TextFeatures):
 
 @EMBEDDER.register_class()
 class FrozenOpenCLIPTtxtVisualEmbedder(_TextFeatures):
-    """Registered under the reference's name so unchanged YAMLs build; produces synthetic / recorded features (see the
-    module docstring) — the real CLIP towers are not part of this implementation."""
+    """Registered under the reference's name so unchanged YAMLs build.  ``pretrained`` = an open_clip checkpoint -> the real text
+    tower on the HIP kernels (module docstring); otherwise synthetic / recorded features."""
 
-    def __init__(self, pretrained=None, layer="penultimate", vit_resolution=(224, 224), **kwargs):
+    def __init__(self, pretrained=None, layer="penultimate", vit_resolution=(224, 224), tokenizer=None, device="cuda", **kwargs):
         super().__init__(features_path=kwargs.pop("features_path", None))
+        if layer not in ("last", "penultimate"):
+            raise NotImplementedError(layer)                                   # (clip_embedder.py:165-170)
+        self.layer_idx = 1 if layer == "penultimate" else 0
+        self.tokenizer, self.tower_device = tokenizer, device
+        self.tower_sd, self._towers = None, {}
+        if pretrained and os.path.isfile(str(pretrained)):
+            sd = torch.load(pretrained, map_location="cpu")
+            sd = sd.get("state_dict", sd)
+            if "token_embedding.weight" in sd:
+                self.tower_sd = {k: v for k, v in sd.items() if not k.startswith("visual.")}
+        if self.tokenizer is None:
+            try:
+                import open_clip                                               # absent in this image
+                self.tokenizer = open_clip.tokenize
+            except ImportError:
+                pass
+
+    def _tower(self, B):
+        from .clip_text import ClipTextEngine, ClipTextOptions
+        if B not in self._towers:
+            sd = self.tower_sd
+            o = ClipTextOptions(vocab_size=sd["token_embedding.weight"].shape[0], context_length=sd["positional_embedding"].shape[0],
+                                width=sd["positional_embedding"].shape[1], heads=sd["positional_embedding"].shape[1] // 64,
+                                layers=1 + max(int(k.split(".")[2]) for k in sd if k.startswith("transformer.resblocks.")),
+                                embed_dim=sd["text_projection"].shape[1])
+            self._towers[B] = ClipTextEngine(o, sd, B, torch.device(self.tower_device), layer_idx=self.layer_idx)
+        return self._towers[B]
+
+    def forward(self, text=None, image=None, tokens=None):
+        if self.tower_sd is None:
+            return super().forward(text=text, image=image)
+        if tokens is None:
+            if self.tokenizer is None:
+                raise RuntimeError("CLIP weights are loaded but there is no tokenizer (open_clip's BPE vocabulary is not bundled): "
+                                   "pass tokens=open_clip.tokenize(text) or construct the embedder with tokenizer=")
+            tokens = self.tokenizer([text] if isinstance(text, str) else list(text))
+        xt, x = self._tower(tokens.shape[0]).forward(tokens)
+        y_visual = super().forward(text=[""] * tokens.shape[0], image=image)[0] if image is not None else None
+        return y_visual, xt, x
 
 
 @EMBEDDER.register_class()

@@ -177,12 +177,12 @@ def seq_map(s_outer, s_inner, s_row, inner=1) -> L.SeqMap:
     return m
 
 
-def attn_params(q, k, v, o, qm, km, vm, om, n_outer, heads, Nq, Nk, scale, kv_div=1, head_dim=64) -> L.AttnParams:
+def attn_params(q, k, v, o, qm, km, vm, om, n_outer, heads, Nq, Nk, scale, kv_div=1, head_dim=64, causal=False) -> L.AttnParams:
     p = L.AttnParams()
     p.q, p.k, p.v, p.o = _ptr(q), _ptr(k), _ptr(v), _ptr(o)
     p.qm, p.km, p.vm, p.om = qm, km, vm, om
     p.n_outer, p.kv_div, p.heads, p.Nq, p.Nk, p.scale = int(n_outer), int(kv_div), int(heads), int(Nq), int(Nk), float(scale)
-    p.head_dim = int(head_dim)
+    p.head_dim, p.causal = int(head_dim), 1 if causal else 0
     return p
 
 
