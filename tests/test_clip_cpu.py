@@ -15,15 +15,15 @@ from videomv_amd.clip_text import ClipTextOptions, clip_text_shapes
 SMALL = ClipTextOptions(vocab_size=300, context_length=77, width=128, heads=2, layers=4, embed_dim=96)
 
 
-def random_sd(o, seed):
+def random_sd(o, seed, shapes=None):
     g = torch.Generator().manual_seed(seed)
     sd = {}
-    for k, shp in clip_text_shapes(o).items():
-        if k.endswith("ln_1.weight") or k.endswith("ln_2.weight") or k == "ln_final.weight":
+    for k, shp in (shapes or clip_text_shapes(o)).items():
+        if ".ln_" in k and k.endswith(".weight") or k == "ln_final.weight":
             sd[k] = 1 + 0.1 * torch.randn(shp, generator=g)
         elif k.endswith("bias"):
             sd[k] = 0.05 * torch.randn(shp, generator=g)
-        elif k in ("token_embedding.weight", "positional_embedding"):
+        elif k in ("token_embedding.weight", "positional_embedding", "visual.positional_embedding", "visual.class_embedding"):
             sd[k] = 0.5 * torch.randn(shp, generator=g)
         else:
             sd[k] = torch.randn(shp, generator=g) * shp[-1] ** -0.5
@@ -126,7 +126,7 @@ def test_embedder_uses_the_tower_when_a_checkpoint_is_given(monkeypatch, tmp_pat
     from videomv_amd.embedder import FrozenOpenCLIPTtxtVisualEmbedder
     o = SMALL
     sd = random_sd(o, 9)
-    sd["visual.proj"] = torch.zeros(4, 4)                                      # (the image side of the checkpoint is ignored)
+    sd["visual.proj"] = torch.zeros(4, 4)                                      # (an image side without conv1: ignored)
     path = tmp_path / "open_clip_pytorch_model.bin"
     torch.save(sd, path)
     tok = tokens_for(o, 1, 10)
@@ -141,3 +141,79 @@ def test_embedder_uses_the_tower_when_a_checkpoint_is_given(monkeypatch, tmp_pat
     with pytest.raises(RuntimeError, match="tokenizer"):
         none(text=["a chair"])
     assert torch.equal(none(tokens=tok)[2], x)
+
+
+# ------------------------------------------------------------------------------------------------------- image tower
+from oracle.clip_vision import image_tower
+from videomv_amd.clip_vision import ClipVisionOptions, clip_vision_shapes
+
+VSMALL = ClipVisionOptions(image_size=56, patch_size=14, width=160, heads=2, layers=3, mlp_ratio=2.0, embed_dim=48)      # head_dim 80 like ViT-H/14
+
+
+def test_vision_oracle_matches_torch_modules():
+    o = VSMALL
+    sd = random_sd(o, 31, clip_vision_shapes(o))
+    img = torch.randn(2, 3, o.image_size, o.image_size, generator=torch.Generator().manual_seed(32))
+    blocks = torch.nn.ModuleList([_Block(o.width, o.heads) for _ in range(o.layers)])
+    pre = "visual.transformer.resblocks."
+    bsd = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+    hid = int(o.width * o.mlp_ratio)
+    for b in blocks:                                              # (_Block builds a 4x MLP; this config uses mlp_ratio 2)
+        b.mlp.c_fc, b.mlp.c_proj = torch.nn.Linear(o.width, hid), torch.nn.Linear(hid, o.width)
+    blocks.load_state_dict(bsd)
+    with torch.no_grad():
+        x = torch.nn.functional.conv2d(img, sd["visual.conv1.weight"], stride=o.patch_size).reshape(2, o.width, -1).permute(0, 2, 1)
+        x = torch.cat([sd["visual.class_embedding"].expand(2, 1, o.width), x], dim=1) + sd["visual.positional_embedding"]
+        x = torch.nn.functional.layer_norm(x, (o.width,), sd["visual.ln_pre.weight"], sd["visual.ln_pre.bias"])
+        x = x.permute(1, 0, 2)
+        for r in blocks:
+            x = r(x, None)
+        x = x.permute(1, 0, 2)
+        ref = torch.nn.functional.layer_norm(x[:, 0], (o.width,), sd["visual.ln_post.weight"], sd["visual.ln_post.bias"]) @ sd["visual.proj"]
+    got = image_tower(sd, img, o.width, o.heads, o.layers, o.patch_size)
+    assert float((ref - got).abs().max()) < 2e-5
+
+
+def test_vision_plan_matches_oracle(monkeypatch):
+    """head_dim 80 packed as 128 (zero rows / columns), patch GEMM with K padded 588 -> 592, class token, ln_pre / ln_post."""
+    plan_interp.install(monkeypatch)
+    from videomv_amd.clip_vision import ClipVisionEngine
+    o = VSMALL
+    sd = random_sd(o, 33, clip_vision_shapes(o))
+    B = 2
+    img = torch.randn(B, 3, o.image_size, o.image_size, generator=torch.Generator().manual_seed(34))
+    taps, taps_ref = {}, {}
+    eng = ClipVisionEngine(o, sd, B, torch.device("cpu"), taps=taps)
+    assert eng.hd == 80 and eng.hdp == 128 and eng.T == 17
+    out = eng.forward(img)
+    ref = image_tower(sd, img, o.width, o.heads, o.layers, o.patch_size, taps=taps_ref)
+    tol = 6e-3 if L.elem() == torch.float16 else 3e-2
+    for k, a in taps.items():
+        assert rel_l2(a.tensor().view(B, eng.T, o.width), taps_ref[k]) < tol, k
+    assert out.shape == ref.shape and rel_l2(out, ref) < tol, rel_l2(out, ref)
+    with pytest.raises(ValueError):
+        eng.forward(img[:, :, :-14])
+
+
+def test_vision_full_size_shapes():
+    import math
+    s = clip_vision_shapes(ClipVisionOptions())
+    assert s["visual.positional_embedding"] == (257, 1280) and s["visual.proj"] == (1280, 1024)
+    assert sum(math.prod(v) for v in s.values()) == 632_076_800
+
+
+def test_embedder_runs_both_towers(monkeypatch, tmp_path):
+    plan_interp.install(monkeypatch)
+    from videomv_amd.embedder import FrozenOpenCLIPTtxtVisualEmbedder
+    ot, ov = SMALL, dataclasses.replace(VSMALL, width=128, heads=2, embed_dim=96)      # width 128 -> the embedder's head_dim-64 rule
+    sd = random_sd(ot, 41)
+    sd.update(random_sd(ov, 42, clip_vision_shapes(ov)))
+    path = tmp_path / "open_clip_pytorch_model.bin"
+    torch.save({"state_dict": sd}, path)
+    tok = tokens_for(ot, 1, 43)
+    img = torch.randn(1, 3, ov.image_size, ov.image_size, generator=torch.Generator().manual_seed(44))
+    emb = FrozenOpenCLIPTtxtVisualEmbedder(pretrained=str(path), tokenizer=lambda t: tok, device="cpu")
+    y_visual, xt, x = emb(text=[""], image=img)
+    ref = image_tower(sd, img, ov.width, ov.heads, ov.layers, ov.patch_size)
+    assert y_visual.shape == (1, 96) and rel_l2(y_visual, ref) < 3e-2
+    assert x.shape == (1, 77, 128)

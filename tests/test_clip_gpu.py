@@ -46,3 +46,41 @@ def test_vit_h14_text_tower_matches_oracle():
         eng.S.run()
     e1.record(); torch.cuda.synchronize()
     print(f"\nViT-H/14 text tower, {B} prompts: {e0.elapsed_time(e1) / 5:.3f} ms per forward ({eng.S.nops} launches)")
+
+
+# ------------------------------------------------------------------------------------------------------- image tower
+from oracle.clip_vision import image_tower
+from tests.test_clip_cpu import VSMALL
+from videomv_amd.clip_vision import ClipVisionEngine, ClipVisionOptions, clip_vision_shapes
+
+
+def test_small_vision_tower_matches_oracle():
+    o, B = VSMALL, 3
+    sd = random_sd(o, 51, clip_vision_shapes(o))
+    img = torch.randn(B, 3, o.image_size, o.image_size, generator=torch.Generator().manual_seed(52))
+    taps, taps_ref = {}, {}
+    eng = ClipVisionEngine(o, sd, B, torch.device("cuda"), taps=taps)
+    out = eng.forward(img)
+    ref = image_tower(sd, img, o.width, o.heads, o.layers, o.patch_size, taps=taps_ref)
+    for k, a in taps.items():
+        assert rel_l2(a.tensor().float().cpu().view(B, eng.T, o.width), taps_ref[k]) < TOL, k
+    assert rel_l2(out.cpu(), ref) < TOL
+    assert torch.equal(out, eng.forward(img))
+
+
+def test_vit_h14_image_tower_matches_oracle():
+    o, B = ClipVisionOptions(), 1
+    sd = random_sd(o, 61, clip_vision_shapes(o))
+    img = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(62))
+    eng = ClipVisionEngine(o, sd, B, torch.device("cuda"))
+    out = eng.forward(img)
+    ref = image_tower(sd, img, o.width, o.heads, o.layers, o.patch_size)
+    assert out.shape == (B, 1024) and torch.isfinite(out).all()
+    assert rel_l2(out.cpu(), ref) < 3 * TOL, rel_l2(out.cpu(), ref)          # 32 blocks of 16-bit residual stream, one pooled token
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        eng.S.run()
+    e1.record(); torch.cuda.synchronize()
+    print(f"\nViT-H/14 image tower, {B} image: {e0.elapsed_time(e1) / 5:.3f} ms per forward ({eng.S.nops} launches)")

@@ -946,6 +946,29 @@ def test_attention_causal(B, T, heads):
     assert S.lib.vmv_attention(C.byref(bad), None) == -1              # causal needs Nq == Nk
 
 
+@pytest.mark.parametrize("B,T,heads", [(2, 257, 16), (1, 17, 2), (1, 700, 3)])
+def test_attention_head_dim_128(B, T, heads):
+    """head_dim 128 (the CLIP image tower's 80-wide heads packed to 128 with zeros, clip_vision.py): four k-steps per S^T tile,
+    eight output tiles, 32-KB stages; fused q|k|v rows, query and key tails."""
+    Cc = heads * 128
+    qkv = rnd((B * T, 3 * Cc), 5)
+    qkv.view(B * T, 3, heads, 128)[..., 80:] = 0
+    c = Case(qkv=qkv, o=torch.zeros(B * T, Cc, dtype=BF))
+
+    def build(t):
+        m = lambda: ops.seq_map(T * 3 * Cc, 0, 3 * Cc, inner=1)
+        base = t["qkv"].data_ptr()
+        return ops.attn_params(base, base + 2 * Cc, base + 4 * Cc, t["o"], m(), m(), m(), ops.seq_map(T * Cc, 0, Cc, inner=1),
+                               B, heads, T, T, 80 ** -0.5, head_dim=128)
+    cpu = c.on("cpu")
+    I.attention(build(cpu))
+    dev = c.on("cuda")
+    ops.Stream(record=False).attention(build(dev), "t")
+    torch.cuda.synchronize()
+    check(dev["o"], cpu["o"], tol_l2=6e-3, tol_max=2e-2)
+    assert float(dev["o"].view(B * T, heads, 128)[..., 80:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("M,K,N", [(154, 1024, 4096), (77, 128, 512), (3000, 320, 640)])
 def test_gemm_gelu_activation(M, K, N):
     """VMV_ACT_GELU: exact-erf GELU after bias (the CLIP text tower's c_fc, nn.GELU())."""

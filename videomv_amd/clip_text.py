@@ -50,7 +50,85 @@ def clip_text_shapes(o: ClipTextOptions) -> Dict[str, tuple]:
     return s
 
 
-class ClipTextEngine:
+class _ClipTower:
+    """Shared by the text and image towers: pooled activations, the recorded stream, and open_clip's ResidualAttentionBlock
+    (``x = x + attn(ln_1(x))``, ``x = x + c_proj(gelu(c_fc(ln_2(x))))``) as 7 launches."""
+
+    def _init_common(self, device, taps):
+        self.device, self.taps = device, taps
+        self.pool = Pool(device)
+        self.S = ops.Stream(record=True)
+        self._splitk = ops.SplitK(device, cap=8)
+        self.wt: Dict[str, torch.Tensor] = {}
+
+    def act(self, rows, C, dtype=None) -> Act:
+        return Act(self.pool.get(rows * C * (4 if dtype == torch.float32 else 2)), rows, C, dtype)
+
+    def rel(self, a: Act):
+        if self.taps is None and not getattr(a, "_pinned", False):
+            self.pool.put(a.buf)
+
+    def _gemm(self, label, x: Act, wkey, out: Act, **kw):
+        Wt = self.wt[wkey + ".weight"]
+        segs = ops.linear_segs([(x.ptr, x.C, x.C)])
+        ks, ws = self._splitk.pick(x.rows, Wt.shape[0], segs)
+        self.S.gemm(ops.gemm_params(x.rows, Wt.shape[0], segs, Wt, out.ptr, out.C, bias=self.wt.get(wkey + ".bias"),
+                                    ksplit=ks, workspace=ws, **kw), label)
+
+    def _ln(self, label, x: Act, key) -> Act:
+        y = self.act(x.rows, x.C)
+        self.S.layernorm(ops.ln_params(x.ptr, x.C, y.ptr, x.C, self.wt[key + ".weight"], self.wt[key + ".bias"], x.rows, x.C, 1e-5), label)
+        return y
+
+    def _pack_block(self, sd, src, p, heads, hd, hdp):
+        """src: state-dict prefix of the block, p: packed-key prefix.  hdp > hd: every head's q / k / v rows (and the matching
+        out_proj columns) are laid out hdp wide with zeros behind the hd real ones — scores and outputs are unchanged and the
+        flash kernel sees a head_dim it has (80 -> 128)."""
+        dev, w = self.device, self.wt
+        for n in ("ln_1", "ln_2"):
+            w[p + n + ".weight"], w[p + n + ".bias"] = P.f32(sd[src + n + ".weight"], dev), P.f32(sd[src + n + ".bias"], dev)
+        W = heads * hd
+        wi, bi = sd[src + "attn.in_proj_weight"].detach().float(), sd[src + "attn.in_proj_bias"].detach().float()
+        wo = sd[src + "attn.out_proj.weight"].detach().float()
+        if hdp != hd:
+            wi_p = wi.new_zeros(3, heads, hdp, W); wi_p[:, :, :hd] = wi.view(3, heads, hd, W)
+            bi_p = bi.new_zeros(3, heads, hdp); bi_p[:, :, :hd] = bi.view(3, heads, hd)
+            wo_p = wo.new_zeros(W, heads, hdp); wo_p[:, :, :hd] = wo.view(W, heads, hd)
+            wi, bi, wo = wi_p.view(3 * heads * hdp, W), bi_p.view(-1), wo_p.view(W, heads * hdp)
+        w[p + "qkv.weight"], w[p + "qkv.bias"] = P.pack_linear(wi, dev), P.pack_bias(bi, dev)
+        w[p + "out.weight"], w[p + "out.bias"] = P.pack_linear(wo, dev), P.pack_bias(sd[src + "attn.out_proj.bias"], dev)
+        w[p + "fc.weight"], w[p + "fc.bias"] = P.pack_linear(sd[src + "mlp.c_fc.weight"], dev), P.pack_bias(sd[src + "mlp.c_fc.bias"], dev)
+        w[p + "proj.weight"], w[p + "proj.bias"] = P.pack_linear(sd[src + "mlp.c_proj.weight"], dev), P.pack_bias(sd[src + "mlp.c_proj.bias"], dev)
+
+    def _block(self, p, x: Act, B, T, heads, hd, hdp, causal, release_x=True) -> Act:
+        rows, W, A = x.rows, x.C, heads * hdp
+        h = self._ln(p + "ln_1", x, p + "ln_1")
+        qkv = self.act(rows, 3 * A)
+        self._gemm(p + "qkv", h, p + "qkv", qkv)
+        self.rel(h)
+        ao = self.act(rows, A)
+        m = lambda: ops.seq_map(T * 3 * A, 0, 3 * A, inner=1)
+        self.S.attention(ops.attn_params(qkv.ptr, qkv.ptr + 2 * A, qkv.ptr + 4 * A, ao.ptr, m(), m(), m(), ops.seq_map(T * A, 0, A, inner=1),
+                                         B, heads, T, T, hd ** -0.5, head_dim=hdp, causal=causal), p + "attn")
+        self.rel(qkv)
+        y = self.act(rows, W)
+        self._gemm(p + "out", ao, p + "out", y, residual=x.ptr, ldr=W)
+        self.rel(ao)
+        if release_x:
+            self.rel(x)
+        x = y
+        h = self._ln(p + "ln_2", x, p + "ln_2")
+        f = self.act(rows, self.wt[p + "fc.weight"].shape[0])
+        self._gemm(p + "fc", h, p + "fc", f, act=L.ACT_GELU)
+        self.rel(h)
+        y = self.act(rows, W)
+        self._gemm(p + "proj", f, p + "proj", y, residual=x.ptr, ldr=W)
+        self.rel(f)
+        self.rel(x)
+        return y
+
+
+class ClipTextEngine(_ClipTower):
     """Plan for ``B`` prompts: token ids [B, T] -> (xt fp32 [B, embed_dim], x fp32 [B, T, width])."""
 
     def __init__(self, opt: ClipTextOptions, sd: Dict[str, torch.Tensor], B: int, device, layer_idx: int = 1, taps: Optional[dict] = None):
@@ -58,11 +136,8 @@ class ClipTextEngine:
             raise NotImplementedError("the flash kernel's causal path is head_dim 64 (ViT-H/14 text: 1024 / 16)")
         if not 0 <= layer_idx < opt.layers:
             raise ValueError("layer_idx")
-        self.o, self.B, self.device, self.layer_idx, self.taps = opt, int(B), device, int(layer_idx), taps
-        self.pool = Pool(device)
-        self.S = ops.Stream(record=True)
-        self._splitk = ops.SplitK(device, cap=8)
-        self.wt: Dict[str, torch.Tensor] = {}
+        self.o, self.B, self.layer_idx = opt, int(B), int(layer_idx)
+        self._init_common(device, taps)
         self._pack(sd)
         self._build()
 
@@ -71,42 +146,11 @@ class ClipTextEngine:
         dev, w, o = self.device, self.wt, self.o
         self.tok = sd["token_embedding.weight"].detach().float().to(dev)
         self.pos = sd["positional_embedding"].detach().float().to(dev)
-
-        def lin(key, wkey, bkey):
-            w[key + ".weight"], w[key + ".bias"] = P.pack_linear(sd[wkey], dev), P.pack_bias(sd[bkey], dev)
-
-        def ln(key, src):
-            w[key + ".weight"], w[key + ".bias"] = P.f32(sd[src + ".weight"], dev), P.f32(sd[src + ".bias"], dev)
-
         for i in range(o.layers - self.layer_idx):
             p = f"transformer.resblocks.{i}."
-            ln(p + "ln_1", p + "ln_1"); ln(p + "ln_2", p + "ln_2")
-            lin(p + "qkv", p + "attn.in_proj_weight", p + "attn.in_proj_bias")
-            lin(p + "out", p + "attn.out_proj.weight", p + "attn.out_proj.bias")
-            lin(p + "fc", p + "mlp.c_fc.weight", p + "mlp.c_fc.bias")
-            lin(p + "proj", p + "mlp.c_proj.weight", p + "mlp.c_proj.bias")
-        ln("ln_final", "ln_final")
+            self._pack_block(sd, p, p, o.heads, 64, 64)
+        w["ln_final.weight"], w["ln_final.bias"] = P.f32(sd["ln_final.weight"], dev), P.f32(sd["ln_final.bias"], dev)
         w["text_projection"] = P.pack_linear(sd["text_projection"].detach().float().t().contiguous(), dev)      # x @ P = x . (P^T)^T
-
-    # ------------------------------------------------------------------ helpers
-    def act(self, rows, C, dtype=None) -> Act:
-        return Act(self.pool.get(rows * C * (4 if dtype == torch.float32 else 2)), rows, C, dtype)
-
-    def rel(self, a: Act):
-        if self.taps is None:
-            self.pool.put(a.buf)
-
-    def _gemm(self, label, x: Act, wkey, out: Act, **kw):
-        Wt = self.wt[wkey + ".weight"]
-        segs = ops.linear_segs([(x.ptr, x.C, x.C)])
-        ks, ws = self._splitk.pick(x.rows, Wt.shape[0], segs)
-        self.S.gemm(ops.gemm_params(x.rows, Wt.shape[0], segs, Wt, out.ptr, out.C, bias=self.wt[wkey + ".bias"],
-                                    ksplit=ks, workspace=ws, **kw), label)
-
-    def _ln(self, label, x: Act, key) -> Act:
-        y = self.act(x.rows, x.C)
-        self.S.layernorm(ops.ln_params(x.ptr, x.C, y.ptr, x.C, self.wt[key + ".weight"], self.wt[key + ".bias"], x.rows, x.C, 1e-5), label)
-        return y
 
     # ------------------------------------------------------------------ plan
     def _build(self):
@@ -116,31 +160,7 @@ class ClipTextEngine:
         self.x_rows = torch.zeros(rows, W, dtype=L.elem(), device=self.device)
         x = Act(self.x_rows.view(torch.uint8).view(-1), rows, W)
         for i in range(o.layers - self.layer_idx):
-            p = f"transformer.resblocks.{i}."
-            h = self._ln(p + "ln_1", x, p + "ln_1")
-            qkv = self.act(rows, 3 * W)
-            self._gemm(p + "qkv", h, p + "qkv", qkv)
-            self.rel(h)
-            ao = self.act(rows, W)
-            m = lambda: ops.seq_map(T * 3 * W, 0, 3 * W, inner=1)
-            self.S.attention(ops.attn_params(qkv.ptr, qkv.ptr + 2 * W, qkv.ptr + 4 * W, ao.ptr, m(), m(), m(), ops.seq_map(T * W, 0, W, inner=1),
-                                             B, o.heads, T, T, 64 ** -0.5, causal=True), p + "attn")
-            self.rel(qkv)
-            y = self.act(rows, W)
-            self._gemm(p + "out", ao, p + "out", y, residual=x.ptr, ldr=W)
-            self.rel(ao)
-            if i > 0:
-                self.rel(x)
-            x = y
-            h = self._ln(p + "ln_2", x, p + "ln_2")
-            f = self.act(rows, 4 * W)
-            self._gemm(p + "fc", h, p + "fc", f, act=L.ACT_GELU)
-            self.rel(h)
-            y = self.act(rows, W)
-            self._gemm(p + "proj", f, p + "proj", y, residual=x.ptr, ldr=W)
-            self.rel(f)
-            self.rel(x)
-            x = y
+            x = self._block(f"transformer.resblocks.{i}.", x, B, T, o.heads, 64, 64, True, release_x=i > 0)
             if self.taps is not None:
                 self.taps[f"resblocks.{i}"] = x
         self.out = self._ln("ln_final", x, "ln_final")

@@ -39,8 +39,9 @@ constexpr float NEG_BIG = -1.0e30f;
 // CAUSAL: keys j > query i masked out (own instantiation: the test costs <4, 4, 64> two spilled registers)
 template <int WPP, int QT, int D = 64, bool CAUSAL = false>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, const int nproblems) {
-    static_assert(D == 64 || (D == 32 && WPP == 4), "head_dim 64, or 32 on the 4-waves-per-problem variant");
-    constexpr int KK = D / 32, DT = D / 16, SLOTS = D / 8, SLOG = (D == 64) ? 3 : 2;
+    static_assert(D == 64 || ((D == 32 || D == 128) && WPP == 4), "head_dim 64, or 32 / 128 on the 4-waves-per-problem variant");
+    constexpr int KK = D / 32, DT = D / 16, SLOTS = D / 8, SLOG = (D == 128) ? 4 : (D == 64) ? 3 : 2;
+    constexpr int KBYTES = (D == 128) ? 16384 : 8192, STAGE = 2 * KBYTES;       // staged K tile (then the V tile) / one stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -156,8 +157,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
     };
     auto store_tile = [&](int buf) {
         if constexpr (WPP == 4) {
-            u32x4_t* Ksd = reinterpret_cast<u32x4_t*>(region + buf * 16384);
-            uint16_t* Vtd = reinterpret_cast<uint16_t*>(region + buf * 16384 + 8192);
+            u32x4_t* Ksd = reinterpret_cast<u32x4_t*>(region + buf * STAGE);
+            uint16_t* Vtd = reinterpret_cast<uint16_t*>(region + buf * STAGE + KBYTES);
 #pragma unroll
             for (int i = 0; i < NPIECE; ++i) write_piece(Ksd, Vtd, stid + i * NT, kreg[i], vreg[i]);
         }
@@ -174,11 +175,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
         if constexpr (WPP == 4) {
 #if VMV_ATTN_ABLATE == 4 || VMV_ATTN_ABLATE == 5
             Ks = reinterpret_cast<const u32x4_t*>(region);
-            Vt = reinterpret_cast<const uint16_t*>(region + 8192);
+            Vt = reinterpret_cast<const uint16_t*>(region + KBYTES);
 #else
             if (kt + 1 < ntile) load_tile(kt + 1);
-            Ks = reinterpret_cast<const u32x4_t*>(region + (kt & 1) * 16384);
-            Vt = reinterpret_cast<const uint16_t*>(region + (kt & 1) * 16384 + 8192);
+            Ks = reinterpret_cast<const u32x4_t*>(region + (kt & 1) * STAGE);
+            Vt = reinterpret_cast<const uint16_t*>(region + (kt & 1) * STAGE + KBYTES);
 #endif
         } else {
             // One short problem per wave (the 24-frame temporal attention: HBM-bound).  Only V^T goes through LDS — the K
@@ -543,6 +544,17 @@ extern "C" int vmv_attention(const VmvAttnParams* pp, void* stream) {
     if (hd == 32) {                  // LGM MVAttention (core/attention.py:67-84): long sequences only
         if (p.n_outer > 65535 || p.heads > 65535) return VMV_ERANGE;
         hipLaunchKernelGGL((attn_kernel<4, 2, 32>), dim3((p.Nq + 127) / 128, p.heads, p.n_outer), dim3(256), 32768, st, p, 0);
+        return vmv_launch_status();
+    }
+    if (hd == 128) {                 // zero-padded wide heads (the CLIP image tower's head_dim 80 packed to 128: clip_vision.py)
+        if (p.n_outer > 65535 || p.heads > 65535) return VMV_ERANGE;
+        static bool attr128 = false;
+        if (!attr128) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<4, 2, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+            if (e != hipSuccess) return (int)e;
+            attr128 = true;
+        }
+        hipLaunchKernelGGL((attn_kernel<4, 2, 128>), dim3((p.Nq + 127) / 128, p.heads, p.n_outer), dim3(256), 65536, st, p, 0);
         return vmv_launch_status();
     }
     if (hd != 64) return VMV_EINVAL;

@@ -6,7 +6,8 @@ path.
   names an open_clip checkpoint (a state dict holding ``token_embedding.weight`` ...).  Tokenisation needs open_clip's BPE
   vocabulary, which is not available offline: token ids come from ``open_clip.tokenize`` when that package is importable, from a
   ``tokenizer=`` callable, or are passed directly (``forward(tokens=...)``).
-* IMAGE tower (ViT-H/14 visual, head_dim 80) is not built: ``y_visual`` is a recorded feature or the synthetic stand-in.
+* IMAGE tower: ``clip_vision.ClipVisionEngine`` (ViT-H/14 visual, head_dim 80 packed 128 wide for the flash kernel) when the
+  checkpoint holds the ``visual.*`` keys: ``y_visual = encode_image(image)`` for I2VGen (inference_i2vgen_entrance.py:246).
 * Without a checkpoint (this container: no weights, no network) ``SyntheticTextEmbedder`` produces deterministic, prompt-seeded
   stand-ins of the right shapes so the drop-in entrance, the benchmark and CI run end-to-end; recorded CLIP features can be fed
   through ``features_path`` (a .pt file mapping prompt -> tensor)."""
@@ -64,12 +65,14 @@ class FrozenOpenCLIPTtxtVisualEmbedder(_TextFeatures):
             raise NotImplementedError(layer)                                   # (clip_embedder.py:165-170)
         self.layer_idx = 1 if layer == "penultimate" else 0
         self.tokenizer, self.tower_device = tokenizer, device
-        self.tower_sd, self._towers = None, {}
+        self.tower_sd, self.visual_sd, self._towers = None, None, {}
         if pretrained and os.path.isfile(str(pretrained)):
             sd = torch.load(pretrained, map_location="cpu")
             sd = sd.get("state_dict", sd)
             if "token_embedding.weight" in sd:
                 self.tower_sd = {k: v for k, v in sd.items() if not k.startswith("visual.")}
+            if "visual.conv1.weight" in sd and "visual.proj" in sd:
+                self.visual_sd = {k: v for k, v in sd.items() if k.startswith("visual.")}
         if self.tokenizer is None:
             try:
                 import open_clip                                               # absent in this image
@@ -88,6 +91,20 @@ class FrozenOpenCLIPTtxtVisualEmbedder(_TextFeatures):
             self._towers[B] = ClipTextEngine(o, sd, B, torch.device(self.tower_device), layer_idx=self.layer_idx)
         return self._towers[B]
 
+    def _vision(self, B):
+        from .clip_vision import ClipVisionEngine, ClipVisionOptions
+        if ("v", B) not in self._towers:
+            sd = self.visual_sd
+            W = sd["visual.conv1.weight"].shape[0]
+            ps = sd["visual.conv1.weight"].shape[-1]
+            g = int(round((sd["visual.positional_embedding"].shape[0] - 1) ** 0.5))
+            hd = 80 if W == 1280 else 64                                       # (ViT-H/14: 16 heads of 80; the B / L families use 64)
+            o = ClipVisionOptions(image_size=g * ps, patch_size=ps, width=W, heads=W // hd,
+                                  layers=1 + max(int(k.split(".")[3]) for k in sd if k.startswith("visual.transformer.resblocks.")),
+                                  mlp_ratio=sd["visual.transformer.resblocks.0.mlp.c_fc.weight"].shape[0] / W, embed_dim=sd["visual.proj"].shape[1])
+            self._towers[("v", B)] = ClipVisionEngine(o, sd, B, torch.device(self.tower_device))
+        return self._towers[("v", B)]
+
     def forward(self, text=None, image=None, tokens=None):
         if self.tower_sd is None:
             return super().forward(text=text, image=image)
@@ -97,7 +114,10 @@ class FrozenOpenCLIPTtxtVisualEmbedder(_TextFeatures):
                                    "pass tokens=open_clip.tokenize(text) or construct the embedder with tokenizer=")
             tokens = self.tokenizer([text] if isinstance(text, str) else list(text))
         xt, x = self._tower(tokens.shape[0]).forward(tokens)
-        y_visual = super().forward(text=[""] * tokens.shape[0], image=image)[0] if image is not None else None
+        y_visual = None
+        if image is not None:                                                  # (clip_embedder.py:187)
+            y_visual = self._vision(image.shape[0]).forward(image) if self.visual_sd is not None else \
+                super().forward(text=[""] * tokens.shape[0], image=image)[0]
         return y_visual, xt, x
 
 
