@@ -376,6 +376,47 @@ def main():
                       samples_per_s=round(1.0 / (t3 - t1), 5), video_shape=list(vid.shape),
                       finite=bool(torch.isfinite(vid).all() and torch.isfinite(x0_lat).all()))
 
+    # ---- the once-per-prompt conditioning upstream of the loop: open_clip ViT-H/14 text (2 prompts: caption + negative) and image
+    #      towers on the same kernels (clip_embedder.py:187-201); full-size, random-init on the device
+    clip = None
+    if rank == 0 and world == 1 and not args.no_sample:
+        try:
+            from videomv_amd.clip_text import ClipTextEngine, ClipTextOptions, clip_text_shapes
+            from videomv_amd.clip_vision import ClipVisionEngine, ClipVisionOptions, clip_vision_shapes
+
+            def rand_sd(shapes, seed):
+                gg = torch.Generator(device=dev).manual_seed(seed)
+                sd = {}
+                for k, shp in shapes.items():
+                    t = torch.randn(shp, device=dev, generator=gg)
+                    is_ln = (".ln_" in k or k.startswith("ln_") or "ln_p" in k) and k.endswith(".weight")
+                    sd[k] = 1 + 0.1 * t if is_ln else 0.05 * t if k.endswith("bias") else 0.5 * t if "embedding" in k else t * shp[-1] ** -0.5
+                return sd
+
+            def time_plan(eng, reps=5):
+                eng.S.run(); torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(reps):
+                    eng.S.run()
+                b.record(); torch.cuda.synchronize()
+                return a.elapsed_time(b) / reps
+            ot, ov = ClipTextOptions(), ClipVisionOptions()
+            te = ClipTextEngine(ot, rand_sd(clip_text_shapes(ot), 5), 2, dev, layer_idx=1)
+            tok = torch.zeros(2, 77, dtype=torch.long, device=dev); tok[:, 0] = 49406; tok[0, 1:6] = torch.arange(320, 325, device=dev); tok[0, 6] = 49407; tok[1, 1] = 49407
+            xt, xw = te.forward(tok)
+            t_text = time_plan(te)
+            ve = ClipVisionEngine(ov, rand_sd(clip_vision_shapes(ov), 6), 1, dev)
+            yv = ve.forward(torch.randn(1, 3, 224, 224, device=dev))
+            t_img = time_plan(ve)
+            clip = dict(text_tower_ms=round(t_text, 3), text_prompts=2, text_launches=te.S.nops, image_tower_ms=round(t_img, 3), image_launches=ve.S.nops,
+                        arch="open_clip ViT-H-14 (text 354 M, penultimate layer; visual 632 M), random-init", y_words=list(xw.shape), y_visual=list(yv.shape),
+                        finite=bool(torch.isfinite(xw).all() and torch.isfinite(yv).all()))
+            del te, ve
+            torch.cuda.empty_cache()
+        except Exception as e:      # (reported, never fatal to the headline)
+            clip = {"error": f"{type(e).__name__}: {e}"}
+
     # ---- BASELINE configs[4]: one LGM-refined sample at the reference's own 256-px shape (latent 24x32x32): 50 DDIM steps,
     #      of which steps 20/30/40 send each CFG branch through VAE decode (4 views) -> LGM U-Net (415 M) -> 65 536
     #      Gaussians -> 24 renders at 512^2 -> VAE encode (24 views); full-size LGM, random weights
@@ -476,7 +517,7 @@ def main():
 
     if rank == 0:
         out = headline()
-        out.update({"sample_24view": sample, "lgm_refined_sample": lgm, "frame_parallel": fpar, "cpu_baseline": cpu})
+        out.update({"sample_24view": sample, "clip_towers": clip, "lgm_refined_sample": lgm, "frame_parallel": fpar, "cpu_baseline": cpu})
         if alt is not None:
             out["other_dtype"] = alt
         print(json.dumps(out), flush=True)

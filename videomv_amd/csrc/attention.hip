@@ -17,6 +17,7 @@
 //   WPP = 1: every wave owns a whole short problem (Nq <= 32, e.g. the 24-frame temporal attention) with a
 //            private 16-KB stage.
 #include "common.h"
+#include "gemm_glds_common.h"       // LDS-DMA helper, buffer descriptor constants
 #include <cstdlib>
 
 namespace {
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = (WPP == 4) ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
     const int u = lane & 15, g = lane >> 4;
 
     // ---- which problem / query rows does this wave own?
@@ -113,21 +114,35 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
     // K/V staging.  WPP = 4: two LDS stages; the next tile's global loads are issued BEFORE the current tile's MFMAs
     // and written to the other stage after them (one barrier per tile, HBM/L2 latency hidden under the math).
     // WPP = 1 (one short problem per wave, a single tile in practice): plain load -> write -> barrier.
+    // K / V tiles (WPP = 4) go global -> LDS by DMA (round 3; was global -> registers -> ds_write, 21 % of the kernel by ablation):
+    // a wave-instruction fills 1 KB of the stage lane-linearly, so the lane FETCHES the piece whose place it writes — the swizzled
+    // K image and the transpose-read V image below are both permutations of 16-byte pieces.  Rows >= Nk fall outside the
+    // descriptors and arrive as zeros (0 x NaN from a recycled buffer would poison P.V).
     constexpr int NPIECE = (64 * SLOTS) / NT;      // 16-byte pieces of K (and of V) per lane per tile
-    u32x4_t kreg[(WPP == 4) ? NPIECE : 1], vreg[(WPP == 4) ? NPIECE : 1];
-    auto load_tile = [&](int kt2) {
+    uint32_t k_off[(WPP == 4) ? NPIECE : 1], v_off[(WPP == 4) ? NPIECE : 1];
+    __amdgpu_buffer_rsrc_t k_rsrc, v_rsrc;
+    if constexpr (WPP == 4) {
+        k_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(kp), 0, (uint32_t)((p.Nk - 1) * ks_row + D) * 2u, vmvg::SRD_FLAGS);
+        v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(vp), 0, (uint32_t)((p.Nk - 1) * vs_row + D) * 2u, vmvg::SRD_FLAGS);
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) {
+            const int q = (wave * NPIECE + i) * 64 + lane;                   // piece of the tile image this lane fills
+            const int krow = q >> SLOG, ksl = (q & (SLOTS - 1)) ^ (k_swz(krow) & (SLOTS - 1));
+            k_off[i] = (uint32_t)(krow * ks_row + ksl * 8) * 2u;
+            const int dt = q >> 7, r = q & 127;                              // V image: 2 KB (128 pieces) per 16-d subtile
+            const int pos = (r >> 3) ^ (dt & 1);
+            const int vrow = (((pos >> 3) & 1) << 5) | ((pos & 3) << 3) | (((pos >> 2) & 1) << 2) | ((r >> 1) & 3);
+            v_off[i] = (uint32_t)(vrow * vs_row + (dt * 2 + (r & 1)) * 8) * 2u;
+        }
+    }
+    auto issue_tile = [&](int kt2, int buf) {
         if constexpr (WPP == 4) {
+            unsigned char* kd = region + buf * STAGE + wave * (NPIECE * 1024);
+            const uint32_t kb = (uint32_t)(kt2 * 64 * ks_row) * 2u, vb = (uint32_t)(kt2 * 64 * vs_row) * 2u;
 #pragma unroll
             for (int i = 0; i < NPIECE; ++i) {
-                const int idx = stid + i * NT;
-                const int row = idx >> SLOG, slot = idx & (SLOTS - 1);
-                const int key = kt2 * 64 + row;
-                u32x4_t kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-                if (key < p.Nk) {
-                    kv = *reinterpret_cast<const u32x4_t*>(kp + key * ks_row + slot * 8);
-                    vv = *reinterpret_cast<const u32x4_t*>(vp + key * vs_row + slot * 8);
-                }
-                kreg[i] = kv; vreg[i] = vv;
+                vmvg::blds16(k_rsrc, kd + i * 1024, k_off[i] + kb, 0);
+                vmvg::blds16(v_rsrc, kd + KBYTES + i * 1024, v_off[i] + vb, 0);
             }
         }
     };
@@ -142,30 +157,17 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
             Vtd[d * 64 + (row ^ fk)] = val;
         }
     };
-    // V (WPP = 4) stays ROW-major in LDS — one 16-byte write per piece instead of eight scattered 2-byte writes of a
+    // V (WPP = 4) stays ROW-major in LDS — one 16-byte piece per (key, 8 d) instead of eight scattered 2-byte writes of a
     // transposed image — and the PV fragments come from gfx950's transpose read: ds_read_b64_tr_b16 hands lane j of a
     // 16-lane group column j of the [4 rows][16 columns] block whose row j / 4, columns 4 (j % 4)..+3 the lanes address
     // (tools/experiments/tr_probe.hip).  Image: per 16-d subtile (2 KB) sixteen 128-byte blocks of [4 keys][16 d]; the
     // block of keys 32 kk + 8 g + 4 h + 0..3 sits at position (8 kk + 4 h + g) ^ (dt & 1), so that the two lane groups
-    // of a half-wave (g, g + 1) read different 128-byte bank halves.
-    auto write_piece = [&](u32x4_t* Ksd, uint16_t* Vtd, int idx, const u32x4_t& kv, const u32x4_t& vv) {
-        const int row = idx >> SLOG, slot = idx & (SLOTS - 1);
-        Ksd[row * SLOTS + (slot ^ (k_swz(row) & (SLOTS - 1)))] = kv;
-        const int dt = slot >> 1;
-        const int pos = (((row >> 5) << 3) + (((row >> 2) & 1) << 2) + ((row >> 3) & 3)) ^ (dt & 1);
-        *reinterpret_cast<u32x4_t*>(reinterpret_cast<unsigned char*>(Vtd) + dt * 2048 + (pos << 7) + ((row & 3) << 5) + ((slot & 1) << 4)) = vv;
-    };
-    auto store_tile = [&](int buf) {
-        if constexpr (WPP == 4) {
-            u32x4_t* Ksd = reinterpret_cast<u32x4_t*>(region + buf * STAGE);
-            uint16_t* Vtd = reinterpret_cast<uint16_t*>(region + buf * STAGE + KBYTES);
-#pragma unroll
-            for (int i = 0; i < NPIECE; ++i) write_piece(Ksd, Vtd, stid + i * NT, kreg[i], vreg[i]);
-        }
-    };
+    // of a half-wave (g, g + 1) read different 128-byte bank halves: piece (key, slot) at dt * 2048 + (pos << 7) + ((key & 3) << 5)
+    // + ((slot & 1) << 4), dt = slot >> 1, pos = (((key >> 5) << 3) + (((key >> 2) & 1) << 2) + ((key >> 3) & 3)) ^ (dt & 1)
+    // (issue_tile above inverts this).  K image: [key][slot ^ swizzle(key)].
     if constexpr (WPP == 4) {
-        load_tile(0);
-        store_tile(0);
+        issue_tile(0, 0);
+        vmvg::wait_vmcnt<0>();
         __syncthreads();
     }
     for (int kt = 0; kt < ntile; ++kt) {
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
             Ks = reinterpret_cast<const u32x4_t*>(region);
             Vt = reinterpret_cast<const uint16_t*>(region + KBYTES);
 #else
-            if (kt + 1 < ntile) load_tile(kt + 1);
+            if (kt + 1 < ntile) issue_tile(kt + 1, (kt + 1) & 1);        // the other stage: last read one tile ago, behind a barrier
             Ks = reinterpret_cast<const u32x4_t*>(region + (kt & 1) * STAGE);
             Vt = reinterpret_cast<const uint16_t*>(region + (kt & 1) * STAGE + KBYTES);
 #endif
@@ -362,8 +364,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
             __syncthreads();
 #elif VMV_ATTN_ABLATE == 5
 #else
-            if (kt + 1 < ntile) store_tile((kt + 1) & 1);     // the other stage: last read two tiles ago
-            __syncthreads();
+            vmvg::wait_vmcnt<0>();                             // my pieces of tile kt + 1 have landed ...
+            __syncthreads();                                   // ... and everyone's; everyone is done reading tile kt
 #endif
         }
     }
