@@ -184,6 +184,26 @@ def test_vae_decode_matches_reference_golden(golden_dir):
     assert e < TOL_AUX, e
 
 
+def test_non_finite_outputs_are_an_error_not_a_video(golden_dir, monkeypatch):
+    """the fp16 store epilogues do not saturate, so weights / latents that drive activations past 65504 used to give
+    inf / NaN frames silently.  ``decode`` (and the sampling loop) now check their result once per call and name the bf16 build."""
+    from videomv_amd.registry import AUTO_ENCODER
+    from oracle.weights import vae_decoder_param_shapes
+    if _L.elem_name() != "fp16":
+        pytest.skip("range test of the fp16 build")
+    g = load_file(os.path.join(golden_dir, "vae_tiny.safetensors"))
+    dd = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 4, 4],
+              num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    sd = random_state_dict(vae_decoder_param_shapes(ch=32), 77)
+    sd["decoder.conv_in.weight"] = sd["decoder.conv_in.weight"] * 3.0e4          # the first activation leaves fp16's range
+    vae = AUTO_ENCODER.build(dict(type="AutoencoderKL", ddconfig=dd, embed_dim=4))
+    vae.load_state_dict(sd, strict=False)
+    with pytest.raises(FloatingPointError, match="bf16"):
+        vae.decode(g["z"].cuda() * 50.0)
+    monkeypatch.setenv("VMV_CHECK_FINITE", "0")
+    assert not bool(torch.isfinite(vae.decode(g["z"].cuda() * 50.0)).all())
+
+
 def test_inference_py_entry_on_gpu(tmp_path):
     """`python inference.py --cfg configs/t2v_infer.yaml ...` end to end on the GPU (random weights, 4 views, 2 steps,
     latent 32x32 = the reference's real shape): config layering -> registries -> HIP UNet -> fused CFG/DDIM -> HIP VAE."""

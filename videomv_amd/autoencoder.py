@@ -465,7 +465,10 @@ class AutoencoderKL(nn.Module):
                   if k.startswith("decoder.") or k.startswith("post_quant_conv.")}
             eng = VaeDecoderEngine(self.ddconfig, sd, n, h, w, z.device, packed=self._packed_of(VaeDecoderEngine, z.device))
             self._engines[key] = eng
-        return eng.decode(z.float())
+        out = eng.decode(z.float())
+        from .diffusion_ddim import _check_finite
+        _check_finite(out, "the decoded frames")
+        return out
 
     @torch.no_grad()
     def encode(self, x):

@@ -550,12 +550,8 @@ extern "C" int vmv_attention(const VmvAttnParams* pp, void* stream) {
     }
     if (hd == 128) {                 // zero-padded wide heads (the CLIP image tower's head_dim 80 packed to 128: clip_vision.py)
         if (p.n_outer > 65535 || p.heads > 65535) return VMV_ERANGE;
-        static bool attr128 = false;
-        if (!attr128) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<4, 2, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-            if (e != hipSuccess) return (int)e;
-            attr128 = true;
-        }
+        static std::atomic<unsigned long long> attr128{0};
+        if (const int rc_attr = vmv_lds_attr_once(attr128, reinterpret_cast<const void*>(&attn_kernel<4, 2, 128>), 65536)) return rc_attr;
         hipLaunchKernelGGL((attn_kernel<4, 2, 128>), dim3((p.Nq + 127) / 128, p.heads, p.n_outer), dim3(256), 65536, st, p, 0);
         return vmv_launch_status();
     }
@@ -567,13 +563,8 @@ extern "C" int vmv_attention(const VmvAttnParams* pp, void* stream) {
         hipLaunchKernelGGL(attn_short_kernel, dim3((nproblems + 3) / 4), dim3(256), 0, st, p, nproblems);
     } else if (p.Nq <= 32 && !p.causal) {
         const int nproblems = p.n_outer * p.heads;
-        static bool attr1 = false;
-        if (!attr1) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<1, 2>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 32768);
-            if (e != hipSuccess) return (int)e;
-            attr1 = true;
-        }
+        static std::atomic<unsigned long long> attr1{0};
+        if (const int rc_attr = vmv_lds_attr_once(attr1, reinterpret_cast<const void*>(&attn_kernel<1, 2>), 32768)) return rc_attr;
         hipLaunchKernelGGL((attn_kernel<1, 2>), dim3((nproblems + 3) / 4), dim3(256), 32768, st, p, nproblems);
     } else {
         if (p.n_outer > 65535 || p.heads > 65535) return VMV_ERANGE;

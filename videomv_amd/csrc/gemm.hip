@@ -260,13 +260,8 @@ int launch_cfg(const VmvGemmParams& p, int total_steps, hipStream_t st) {
     const int tiles_n = (p.N + Cfg::BN - 1) / Cfg::BN;
     const int ks = p.ksplit > 1 ? p.ksplit : 1;
     const int sps = (total_steps + ks - 1) / ks;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<WM, WN>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_set{0};
+    if (const int rc_attr = vmv_lds_attr_once(attr_set, reinterpret_cast<const void*>(&gemm_kernel<WM, WN>), Cfg::LDS_BYTES)) return rc_attr;
     dim3 grid(tiles_m * tiles_n, ks, 1);
     hipLaunchKernelGGL((gemm_kernel<WM, WN>), grid, dim3(256), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n, total_steps, sps);
     return vmv_launch_status();

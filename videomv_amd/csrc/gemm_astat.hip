@@ -349,13 +349,8 @@ int launch_astat(const VmvGemmParams& p, hipStream_t st) {
     const int G = npanels < ncu ? npanels : ncu;
     auto go = [&](auto tag) -> int {
         constexpr int AB = decltype(tag)::value;
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_astat_kernel<WN, KC, GEGLU, AB>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_TOTAL);
-            if (e != hipSuccess) return (int)e;
-            attr_set = true;
-        }
+        static std::atomic<unsigned long long> attr_set{0};
+        if (const int rc_attr = vmv_lds_attr_once(attr_set, reinterpret_cast<const void*>(&gemm_astat_kernel<WN, KC, GEGLU, AB>), Cfg::LDS_TOTAL)) return rc_attr;
         hipLaunchKernelGGL((gemm_astat_kernel<WN, KC, GEGLU, AB>), dim3(G), dim3(Cfg::NT), Cfg::LDS_TOTAL, st, p, npanels, ntn);
         return VMV_OK;
     };

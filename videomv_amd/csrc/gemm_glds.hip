@@ -450,13 +450,8 @@ int launch_glds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
     dim3 grid(tiles_m * tiles_n, ks, 1);
     auto go = [&](auto tag) -> int {
         constexpr int AB = decltype(tag)::value;
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<WMW, WN, STAGES, AB, PP>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-            if (e != hipSuccess) return (int)e;
-            attr_set = true;
-        }
+        static std::atomic<unsigned long long> attr_set{0};
+        if (const int rc_attr = vmv_lds_attr_once(attr_set, reinterpret_cast<const void*>(&gemm_glds_kernel<WMW, WN, STAGES, AB, PP>), Cfg::LDS_BYTES)) return rc_attr;
         hipLaunchKernelGGL((gemm_glds_kernel<WMW, WN, STAGES, AB, PP>), grid, dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n,
                            total_steps, sps);
         return VMV_OK;

@@ -672,13 +672,8 @@ int launch_pglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
     auto go_il = [&](auto tag, auto il_tag) -> int {
         constexpr int AB = decltype(tag)::value;
         constexpr bool IL = decltype(il_tag)::value;
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pglds_kernel<NWM, WM, WN, AB, IL>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_TOTAL);
-            if (e != hipSuccess) return (int)e;
-            attr_set = true;
-        }
+        static std::atomic<unsigned long long> attr_set{0};
+        if (const int rc_attr = vmv_lds_attr_once(attr_set, reinterpret_cast<const void*>(&gemm_pglds_kernel<NWM, WM, WN, AB, IL>), Cfg::LDS_TOTAL)) return rc_attr;
         hipLaunchKernelGGL((gemm_pglds_kernel<NWM, WM, WN, AB, IL>), grid, dim3(Cfg::NT), Cfg::LDS_TOTAL, st, p, tiles_n, total_steps,
                            nitems, order);
         return VMV_OK;
@@ -692,13 +687,8 @@ int launch_pglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
     int rc;
     if (vmv_gemm_ln_inline(p)) {               // row statistics in the main loop: the one-block-per-CU configurations only
         if constexpr (NWM == 4) {
-            static bool attr_set_lns = false;
-            if (!attr_set_lns) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pglds_kernel<NWM, WM, WN, 0, false, true>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_TOTAL);
-                if (e != hipSuccess) return (int)e;
-                attr_set_lns = true;
-            }
+            static std::atomic<unsigned long long> attr_set_lns{0};
+            if (const int rc_attr = vmv_lds_attr_once(attr_set_lns, reinterpret_cast<const void*>(&gemm_pglds_kernel<NWM, WM, WN, 0, false, true>), Cfg::LDS_TOTAL)) return rc_attr;
             hipLaunchKernelGGL((gemm_pglds_kernel<NWM, WM, WN, 0, false, true>), grid, dim3(Cfg::NT), Cfg::LDS_TOTAL, st, p, tiles_n,
                                total_steps, nitems, order);
             return vmv_launch_status();

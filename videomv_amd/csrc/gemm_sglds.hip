@@ -557,13 +557,8 @@ int launch_sglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
     if (ablate < 0) { const char* e = getenv("VMV_GEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
     auto go = [&](auto dbg_tag) -> int {
         constexpr bool DBG = decltype(dbg_tag)::value;
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sglds_kernel<WM, WN, DBG>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_TOTAL);
-            if (e != hipSuccess) return (int)e;
-            attr_set = true;
-        }
+        static std::atomic<unsigned long long> attr_set{0};
+        if (const int rc_attr = vmv_lds_attr_once(attr_set, reinterpret_cast<const void*>(&gemm_sglds_kernel<WM, WN, DBG>), Cfg::LDS_TOTAL)) return rc_attr;
         hipLaunchKernelGGL((gemm_sglds_kernel<WM, WN, DBG>), dim3(G), dim3(Cfg::NT), Cfg::LDS_TOTAL, st, p, tiles_n, total_steps, nitems,
                            fast);
         return VMV_OK;

@@ -350,13 +350,8 @@ int launch_xglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
     using Cfg = WgCfg<NH, WH>;
     const int tiles_m = (p.M + Cfg::BM - 1) / Cfg::BM;
     const int tiles_n = (p.N + Cfg::BN - 1) / Cfg::BN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_xglds_kernel<NH, WH>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_set{0};
+    if (const int rc_attr = vmv_lds_attr_once(attr_set, reinterpret_cast<const void*>(&gemm_xglds_kernel<NH, WH>), Cfg::LDS_BYTES)) return rc_attr;
     int nsteps = 0;                                          // chunks of WBK = 32 (total_steps counts the other kernels' 64)
     for (int i = 0; i < p.nseg; ++i) nsteps += (p.seg[i].k + WBK - 1) / WBK;
     (void)total_steps;

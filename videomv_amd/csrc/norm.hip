@@ -551,17 +551,14 @@ extern "C" int vmv_groupnorm_fused(const VmvGroupNormParams* pp, int32_t cols, v
     if (!vmv_aligned16(p.y) || (p.ldy & 7) || !vmv_aligned16(p.gamma) || !vmv_aligned16(p.beta)) return VMV_EALIGN;
     const int C = p.C0 + p.C1, cpg = C >> 5;
     if (cols <= 0 || (cols & 7) || (cols % cpg) || (C % cols)) return VMV_EINVAL;
+    if (cols > 256) return VMV_ERANGE;              // the column fold is one thread per column of a 256-thread block
     if (p.fold_ranks > 1) return VMV_EINVAL;
     if ((long)p.rows_per_stat * cols * 2 > VMV_GN_FUSED_BYTES) return VMV_ERANGE;
     const int SW = cols >> 3;
     const int TPR = SW < 256 ? SW : 256, RPP = 256 / TPR;
     const size_t shbytes = (size_t)p.rows_per_stat * cols * 2 + (size_t)(RPP * cols + 2 * cols + 64) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr = true;
-    }
+    static std::atomic<unsigned long long> attr{0};
+    if (const int rc_attr = vmv_lds_attr_once(attr, reinterpret_cast<const void*>(&gn_fused_kernel), 160 * 1024)) return rc_attr;
     if (shbytes > 160 * 1024) return VMV_ERANGE;
     hipLaunchKernelGGL(gn_fused_kernel, dim3(C / cols, p.rows / p.rows_per_stat), dim3(256), shbytes,
                        reinterpret_cast<hipStream_t>(stream), p, cols);

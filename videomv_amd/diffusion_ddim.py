@@ -39,6 +39,19 @@ def beta_schedule(schedule="cosine", num_timesteps=1000, zero_terminal_snr=False
     return betas
 
 
+def _check_finite(t, what):
+    """the fp16 stores of the default build do not saturate (v_cvt_pk_f16_f32 gives inf above 65504), so a checkpoint whose
+    activations leave fp16's range would produce inf / NaN frames silently.  One reduction per SAMPLE (not per step) turns that into
+    an error that names the way out.  ``VMV_CHECK_FINITE=0`` disables."""
+    import os
+    if os.environ.get("VMV_CHECK_FINITE", "1") == "0" or not t.is_cuda:
+        return
+    if not bool(torch.isfinite(t).all()):
+        from . import _lib as L
+        raise FloatingPointError(f"{what} holds inf / NaN after the {L.elem_name()} kernels: activations left the 16-bit range"
+                                 + (" — rerun with hip_dtype: bf16 (VMV_DTYPE=bf16), the wide-range build" if L.elem_name() == "fp16" else ""))
+
+
 def _unwrap(model):
     return getattr(model, "module", model)      # DistributedDataParallel / DataParallel
 
@@ -151,6 +164,7 @@ class DiffusionDDIM(object):
         if comm is not None:
             from .unet_t2v import gather_frames
             xt = gather_frames(comm, xt)
+        _check_finite(xt, "the denoised latent")
         return xt
 
     # ------------------------------------------------------------------ generic path (foreign models / CPU)
