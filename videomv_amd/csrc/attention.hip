@@ -28,6 +28,10 @@ VMV_DEV long seq_base(const VmvSeqMap& m, int o) {
 VMV_DEV int k_swz(int key) { return (((key >> 3) & 3) << 1) | ((key >> 1) & 1); }
 
 constexpr float NEG_BIG = -1.0e30f;
+#ifndef VMV_ATTN_STAGES
+#define VMV_ATTN_STAGES 2   // K / V ring depth of the 4-waves-per-problem kernels (head_dim 32 / 64).  3 (DMA of tile kt + 2 issued in tile kt's
+                            // softmax phase, a tile to land) measured SLOWER on one box: L0 self 592 -> 617-627 us, L1 80 -> 96, cross 47 -> 56
+#endif
 #ifndef VMV_ATTN_ABLATE
 #define VMV_ATTN_ABLATE 0   // experiments (tools/experiments/run_attn_ablate.sh): 1 no exp, 2 no softmax VALU, 3 no PV MFMAs, 4 no K/V restaging, 5 = 4 + no barrier
 #endif
@@ -43,6 +47,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
     static_assert(D == 64 || ((D == 32 || D == 128) && WPP == 4), "head_dim 64, or 32 / 128 on the 4-waves-per-problem variant");
     constexpr int KK = D / 32, DT = D / 16, SLOTS = D / 8, SLOG = (D == 128) ? 4 : (D == 64) ? 3 : 2;
     constexpr int KBYTES = (D == 128) ? 16384 : 8192, STAGE = 2 * KBYTES;       // staged K tile (then the V tile) / one stage
+    // WPP = 4 ring depth (VMV_ATTN_STAGES, default 2).  Three stages (48 KB): the DMA of tile kt + 2 goes out after tile kt's softmax
+    // and has a whole tile to land; with two stages it goes out at the top of the tile, among the S^T MFMAs — which measured faster.
+    constexpr int NST = (WPP == 4 && D != 128) ? VMV_ATTN_STAGES : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -168,6 +175,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
     if constexpr (WPP == 4) {
         issue_tile(0, 0);
         vmvg::wait_vmcnt<0>();
+        if constexpr (NST > 2) { if (ntile > 1) issue_tile(1, 1); }
         __syncthreads();
     }
     for (int kt = 0; kt < ntile; ++kt) {
@@ -179,9 +187,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
             Ks = reinterpret_cast<const u32x4_t*>(region);
             Vt = reinterpret_cast<const uint16_t*>(region + KBYTES);
 #else
-            if (kt + 1 < ntile) issue_tile(kt + 1, (kt + 1) & 1);        // the other stage: last read one tile ago, behind a barrier
-            Ks = reinterpret_cast<const u32x4_t*>(region + (kt & 1) * STAGE);
-            Vt = reinterpret_cast<const uint16_t*>(region + (kt & 1) * STAGE + KBYTES);
+            if constexpr (NST == 2) { if (kt + 1 < ntile) issue_tile(kt + 1, (kt + 1) & 1); }      // the other stage: last read one tile ago, behind a barrier
+            Ks = reinterpret_cast<const u32x4_t*>(region + (kt % NST) * STAGE);
+            Vt = reinterpret_cast<const uint16_t*>(region + (kt % NST) * STAGE + KBYTES);
 #endif
         } else {
             // One short problem per wave (the 24-frame temporal attention: HBM-bound).  Only V^T goes through LDS — the K
@@ -316,6 +324,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
             }
         }
         // ---- O^T += V^T P^T
+        if constexpr (WPP == 4 && NST > 2) {     // stage (kt + 2) % 3 was last read in tile kt - 1, behind that tile's barrier
+            if (kt + 2 < ntile) issue_tile(kt + 2, (kt + 2) % NST);
+        }
         if constexpr (WPP == 4) {
             typedef short s16x4_t __attribute__((ext_vector_type(4)));
             typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_p;
@@ -364,7 +375,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
             __syncthreads();
 #elif VMV_ATTN_ABLATE == 5
 #else
-            vmvg::wait_vmcnt<0>();                             // my pieces of tile kt + 1 have landed ...
+            // my pieces of tile kt + 1 have landed (three stages: those of tile kt + 2, issued above, may still be in flight) ...
+            if (NST > 2 && kt + 2 < ntile) vmvg::wait_vmcnt<2 * NPIECE>(); else vmvg::wait_vmcnt<0>();
             __syncthreads();                                   // ... and everyone's; everyone is done reading tile kt
 #endif
         }
@@ -545,7 +557,7 @@ extern "C" int vmv_attention(const VmvAttnParams* pp, void* stream) {
     if (p.causal && (hd != 64 || p.Nq != p.Nk)) return VMV_EINVAL;          // causal: self-attention on the general head_dim-64 kernel
     if (hd == 32) {                  // LGM MVAttention (core/attention.py:67-84): long sequences only
         if (p.n_outer > 65535 || p.heads > 65535) return VMV_ERANGE;
-        hipLaunchKernelGGL((attn_kernel<4, 2, 32>), dim3((p.Nq + 127) / 128, p.heads, p.n_outer), dim3(256), 32768, st, p, 0);
+        hipLaunchKernelGGL((attn_kernel<4, 2, 32>), dim3((p.Nq + 127) / 128, p.heads, p.n_outer), dim3(256), VMV_ATTN_STAGES * 16384, st, p, 0);
         return vmv_launch_status();
     }
     if (hd == 128) {                 // zero-padded wide heads (the CLIP image tower's head_dim 80 packed to 128: clip_vision.py)
@@ -573,9 +585,9 @@ extern "C" int vmv_attention(const VmvAttnParams* pp, void* stream) {
         // 256-query blocks when that still leaves >= 2 blocks per CU and the key loop is long enough to matter
         const long blocks256 = (long)((p.Nq + 255) / 256) * p.heads * p.n_outer;
         const bool big = qt_env == 4 || (qt_env == 0 && p.Nk >= 512 && blocks256 >= 512 && (p.Nq % 256 == 0 || p.Nq >= 2048));
-        if (p.causal) hipLaunchKernelGGL((attn_kernel<4, 2, 64, true>), dim3((p.Nq + 127) / 128, p.heads, p.n_outer), dim3(256), 32768, st, p, 0);
-        else if (big) hipLaunchKernelGGL((attn_kernel<4, 4>), dim3((p.Nq + 255) / 256, p.heads, p.n_outer), dim3(256), 32768, st, p, 0);
-        else hipLaunchKernelGGL((attn_kernel<4, 2>), dim3((p.Nq + 127) / 128, p.heads, p.n_outer), dim3(256), 32768, st, p, 0);
+        if (p.causal) hipLaunchKernelGGL((attn_kernel<4, 2, 64, true>), dim3((p.Nq + 127) / 128, p.heads, p.n_outer), dim3(256), VMV_ATTN_STAGES * 16384, st, p, 0);
+        else if (big) hipLaunchKernelGGL((attn_kernel<4, 4>), dim3((p.Nq + 255) / 256, p.heads, p.n_outer), dim3(256), VMV_ATTN_STAGES * 16384, st, p, 0);
+        else hipLaunchKernelGGL((attn_kernel<4, 2>), dim3((p.Nq + 127) / 128, p.heads, p.n_outer), dim3(256), VMV_ATTN_STAGES * 16384, st, p, 0);
     }
     return vmv_launch_status();
 }
