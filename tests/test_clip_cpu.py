@@ -217,3 +217,30 @@ def test_embedder_runs_both_towers(monkeypatch, tmp_path):
     ref = image_tower(sd, img, ov.width, ov.heads, ov.layers, ov.patch_size)
     assert y_visual.shape == (1, 96) and rel_l2(y_visual, ref) < 3e-2
     assert x.shape == (1, 77, 128)
+
+
+# ------------------------------------------------------------------------------------------------------- tokenizer
+def test_bpe_tokenizer_on_a_synthetic_merges_file(tmp_path):
+    """The published CLIP BPE on a small merges file: vocabulary layout, merge priority, '</w>' word ends, lower-casing and
+    whitespace collapse, apostrophe / digit / punctuation splitting, byte-level fallback for non-ASCII, framing, truncation."""
+    import gzip
+    from videomv_amd.clip_tokenizer import ClipBpeTokenizer, byte_symbols
+    merges = ["c h", "ch a", "i r</w>", "cha ir</w>", "a n", "t h", "th e</w>", "an d</w>", "Ã ©</w>"]
+    path = tmp_path / "bpe.txt.gz"
+    with gzip.open(path, "wb") as f:
+        f.write(("#version: synthetic\n" + "\n".join(merges) + "\n").encode("utf-8"))
+    tok = ClipBpeTokenizer(str(path), context_length=12, vocab_size=512 + len(merges) + 2)
+    assert len(tok.ids) == 512 + len(merges) + 2 and tok.sot == 512 + len(merges) and tok.eot == tok.sot + 1
+    sym = byte_symbols()
+    assert len(set(sym.values())) == 256 and sym[ord("a")] == "a" and sym[ord(" ")] == chr(256 + 32)      # space is remapped
+    assert tok.encode("Chair") == [tok.ids["chair</w>"]]                                   # c h -> ch a -> (i r</w>) -> cha ir</w>
+    assert tok.encode("  the   CHAIR and\tthe chairs ") == [tok.ids["the</w>"], tok.ids["chair</w>"], tok.ids["and</w>"], tok.ids["the</w>"],
+                                                            tok.ids["cha"], tok.ids["i"], tok.ids["r"], tok.ids["s</w>"]]
+    assert tok.encode("it's 42!") == [tok.ids["i"], tok.ids["t</w>"], tok.ids["'"], tok.ids["s</w>"], tok.ids["4</w>"], tok.ids["2</w>"], tok.ids["!</w>"]]
+    assert tok.encode("\u00e9") == [tok.ids["\u00c3\u00a9</w>"]]                            # UTF-8 bytes C3 A9, merged by the last rule
+    assert tok.encode("a &amp;amp; b") == [tok.ids["a</w>"], tok.ids["&</w>"], tok.ids["b</w>"]]     # html.unescape twice
+    t = tok(["the chair", "and " * 20])
+    assert t.shape == (2, 12) and t.dtype == torch.long
+    assert t[0].tolist() == [tok.sot, tok.ids["the</w>"], tok.ids["chair</w>"], tok.eot] + [0] * 8
+    assert t[1, 0] == tok.sot and t[1, -1] == tok.eot and (t[1, 1:-1] == tok.ids["and</w>"]).all()      # cut, <end> kept last
+    assert t.argmax(dim=-1).tolist() == [3, 11]                                              # what the pooled feature indexes

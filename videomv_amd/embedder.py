@@ -4,8 +4,9 @@ path.
 
 * TEXT tower: ``clip_text.ClipTextEngine`` runs open_clip's ViT-H/14 text transformer on the HIP kernels when ``pretrained``
   names an open_clip checkpoint (a state dict holding ``token_embedding.weight`` ...).  Tokenisation needs open_clip's BPE
-  vocabulary, which is not available offline: token ids come from ``open_clip.tokenize`` when that package is importable, from a
-  ``tokenizer=`` callable, or are passed directly (``forward(tokens=...)``).
+  vocabulary, which is not available offline: token ids come from ``clip_tokenizer.ClipBpeTokenizer`` when ``bpe_path`` names the
+  merges file, from ``open_clip.tokenize`` when that package is importable, from a ``tokenizer=`` callable, or are passed directly
+  (``forward(tokens=...)``).
 * IMAGE tower: ``clip_vision.ClipVisionEngine`` (ViT-H/14 visual, head_dim 80 packed 128 wide for the flash kernel) when the
   checkpoint holds the ``visual.*`` keys: ``y_visual = encode_image(image)`` for I2VGen (inference_i2vgen_entrance.py:246).
 * Without a checkpoint (this container: no weights, no network) ``SyntheticTextEmbedder`` produces deterministic, prompt-seeded
@@ -59,7 +60,7 @@ class FrozenOpenCLIPTtxtVisualEmbedder(_TextFeatures):
     """Registered under the reference's name so unchanged YAMLs build.  ``pretrained`` = an open_clip checkpoint -> the real text
     tower on the HIP kernels (module docstring); otherwise synthetic / recorded features."""
 
-    def __init__(self, pretrained=None, layer="penultimate", vit_resolution=(224, 224), tokenizer=None, device="cuda", **kwargs):
+    def __init__(self, pretrained=None, layer="penultimate", vit_resolution=(224, 224), tokenizer=None, device="cuda", bpe_path=None, **kwargs):
         super().__init__(features_path=kwargs.pop("features_path", None))
         if layer not in ("last", "penultimate"):
             raise NotImplementedError(layer)                                   # (clip_embedder.py:165-170)
@@ -73,6 +74,9 @@ class FrozenOpenCLIPTtxtVisualEmbedder(_TextFeatures):
                 self.tower_sd = {k: v for k, v in sd.items() if not k.startswith("visual.")}
             if "visual.conv1.weight" in sd and "visual.proj" in sd:
                 self.visual_sd = {k: v for k, v in sd.items() if k.startswith("visual.")}
+        if self.tokenizer is None and bpe_path:                                # open_clip's merges file, wherever the deployment keeps it
+            from .clip_tokenizer import ClipBpeTokenizer
+            self.tokenizer = ClipBpeTokenizer(bpe_path)
         if self.tokenizer is None:
             try:
                 import open_clip                                               # absent in this image
