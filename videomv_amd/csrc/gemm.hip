@@ -350,9 +350,17 @@ int pick_tile(const VmvGemmParams& p, int total_steps) {
     if (!geglu && padded(160) <= best_pad) { best = VMV_TILE_128x160; best_pad = padded(160); }
     if (padded(64) < best_pad) { best = VMV_TILE_128x64; best_pad = padded(64); }
     if (p.M <= 64 && best == VMV_TILE_128x64) best = VMV_TILE_64x64;
-    if (gemm_policy() >= 1 && p.ksplit > 1 && p.M > 64 && (best == VMV_TILE_128x128 || best == VMV_TILE_128x160))
-        // split-K (small-M levels): the 4-wave LDS-DMA kernel instead of the register-staged one (same 128-row tiles)
+    if (gemm_policy() >= 1 && p.ksplit > 1 && p.M > 64 && (best == VMV_TILE_128x128 || best == VMV_TILE_128x160)) {
+        // split-K (small-M levels): the 4-wave LDS-DMA kernel instead of the register-staged one (same 128-row tiles) ...
+        const int bn = best == VMV_TILE_128x128 ? 128 : 160;
         best = best == VMV_TILE_128x128 ? VMV_TILE_G128x128 : VMV_TILE_G128x160;
+        // ... unless the 8-wave 256-row tiles times the split make one round of the chip (one block per CU): twice the FLOPs per
+        // LDS-DMA byte.  M = 1920, N = 1280 (the UNet's fourth level): 64 tiles x 4 splits = 256 blocks — conv 749 -> 805,
+        // conv 2560 -> 1280 893 -> 987, FF-down 559 -> 578 TFLOP/s (tools/experiments/run_l3_matrix.sh, same box)
+        const long blocks256 = (long)((p.M + 255) / 256) * ((p.N + bn - 1) / bn) * p.ksplit;
+        if (gemm_policy() >= 2 && p.M >= 1024 && blocks256 >= 192 && blocks256 <= 272)
+            best = bn == 128 ? VMV_TILE_256x128 : VMV_TILE_256x160;
+    }
 #if defined(VMV_EXPERIMENTS)
     if (gemm_policy() >= 3 && p.ksplit <= 1 && !geglu && p.N % 160 == 0) {
         // wave-specialised persistent kernel (gemm_sglds.hip): 8 MFMA waves + 4 loader waves per CU.  Measured against every
