@@ -331,7 +331,8 @@ int pick_tile(const VmvGemmParams& p, int total_steps) {
         const int bx = p.N % 320 == 0 ? 320 : 256;
         const long tm = (p.M + 255) / 256;
         const long rounds_x = (tm * (p.N / bx) + 255) / 256, rounds_g = (tm * (p.N / (bx / 2)) + 255) / 256;
-        if (any_gather && 20 * rounds_x <= 11 * rounds_g) return bx == 320 ? VMV_TILE_X256x320 : VMV_TILE_X256x256;
+        // (plain rows too once the reduction is long: FF-down of the second level, K = 2560 — 937 -> 1008 TFLOP/s)
+        if ((any_gather || total_steps >= 32) && 20 * rounds_x <= 11 * rounds_g) return bx == 320 ? VMV_TILE_X256x320 : VMV_TILE_X256x256;
     }
     {
         bool lin = p.ksplit <= 1 && total_steps <= 24 && p.M >= 16384;
