@@ -221,7 +221,7 @@ def main():
         fam = {}
         for i, (op, p) in enumerate(rec):
             kind = {L.OP_GEMM: "gemm", L.OP_GN_STATS: "gn_stats", L.OP_GN_APPLY: "gn_apply", L.OP_LAYERNORM: "layernorm",
-                    L.OP_ATTENTION: "attention", L.OP_GN_FUSED: "gn_fused", L.OP_COPY: "copy", L.OP_FF: "ff_fused"}[op]
+                    L.OP_ATTENTION: "attention", L.OP_GN_FUSED: "gn_fused", L.OP_COPY: "copy", L.OP_FF: "ff_fused", L.OP_GN_TABLE: "gn_table"}[op]
             fl = gemm_flops(p) if op == L.OP_GEMM else (attn_flops(p) if op == L.OP_ATTENTION else 0.0)
             f = fam.setdefault(kind, dict(ms=0.0, flops=0.0, n=0))
             f["ms"] += ms[i]; f["flops"] += fl; f["n"] += 1

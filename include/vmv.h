@@ -125,6 +125,15 @@ typedef struct {
      * LDS-DMA kernels (vmv_gemm returns VMV_EINVAL for other forced tiles).                                          */
     int32_t wgroup_rows;
     int64_t wgroup_stride;
+    /* GroupNorm folded into the GEMM's A rows (SpatialTransformer / TemporalTransformer: norm -> proj_in, util.py:354-360, 1043-1050):
+     * gn_table = fp32 [nstat][2][ktot] — per stat group (rows [s * gn_rows_per_stat, (s + 1) * gn_rows_per_stat)) the per-channel
+     * scale then shift of the norm, written by vmv_groupnorm_table — and the GEMM multiplies elem(x * scale + shift), the very
+     * values vmv_groupnorm_apply would have stored: the normalised tensor is never written or re-read.  Row-stationary kernel
+     * only (ask vmv_gemm_rs_ok; K = 320 / 640, one linear segment, no folded LayerNorm), gn_rows_per_stat a multiple of 16 and
+     * >= 512; vmv_gemm returns VMV_EINVAL otherwise.  NULL = off.                                                       */
+    const float* gn_table;
+    int32_t gn_rows_per_stat;
+    int32_t _pad_gn;
 } VmvGemmParams;
 
 #define VMV_TILE_AUTO     0
@@ -240,6 +249,9 @@ typedef struct {
 #define VMV_GN_REC 8
 #define VMV_GN_NREP 8
 int vmv_groupnorm_stats(const VmvGroupNormParams* p, void* stream);
+/* The per-channel scale / shift of the norm instead of its output: p->y is an fp32 table [nstat][2][C] (scale[c] = rstd * gamma[c],
+ * shift[c] = beta[c] - mean * scale[c]; silu must be 0) for VmvGemmParams.gn_table.  Same statistics inputs as _apply. */
+int vmv_groupnorm_table(const VmvGroupNormParams* p, void* stream);
 int vmv_groupnorm_apply(const VmvGroupNormParams* p, void* stream);
 /* One-launch GroupNorm for stat groups that fit on chip: a block stages all rows_per_stat rows of `cols` channels (a
  * whole number of groups, cols % 8 == 0, rows_per_stat * cols * 2 <= VMV_GN_FUSED_BYTES) in LDS, computes the statistics
@@ -440,6 +452,7 @@ typedef struct VmvPlan VmvPlan;
 #define VMV_OP_COPY        7
 #define VMV_OP_GN_FUSED    8   /* args: VmvGroupNormParams with chunk_rows = cols of vmv_groupnorm_fused */
 #define VMV_OP_FF          9   /* args: VmvFfParams */
+#define VMV_OP_GN_TABLE    10  /* args: VmvGroupNormParams, y = the fp32 table (vmv_groupnorm_table) */
 VmvPlan* vmv_plan_create(void);
 void     vmv_plan_destroy(VmvPlan* plan);
 int      vmv_plan_add(VmvPlan* plan, int op, const void* params, size_t nbytes);

@@ -57,6 +57,11 @@ def gemm(p: L.GemmParams):
         a[~valid] = 0
         cols.append(a)
     A = torch.cat(cols, dim=1)
+    if p.gn_table:            # GroupNorm folded into the A rows: elem(x * scale + shift) per (stat group, channel)
+        nstat = (M + p.gn_rows_per_stat - 1) // p.gn_rows_per_stat
+        tab = _view(p.gn_table, nstat * 2 * p.ktot, "f32").view(nstat, 2, p.ktot)
+        st = m // p.gn_rows_per_stat
+        A = (A * tab[st, 0] + tab[st, 1]).to(L.elem()).float()
     if p.wgroup_rows > 0:     # grouped weights (vmv.h): rows [g R, (g + 1) R) multiply the matrix at W + g * stride elements
         R = p.wgroup_rows
         acc = torch.empty(M, N)
@@ -133,7 +138,11 @@ def groupnorm_stats(p: L.GroupNormParams):
         tot[:, :, 0, 4] = pil.view(torch.int32).to(torch.int64) & 0xffffffff
 
 
-def groupnorm(p: L.GroupNormParams):
+def groupnorm_table(p: L.GroupNormParams):
+    groupnorm(p, table=True)
+
+
+def groupnorm(p: L.GroupNormParams, table=False):
     """apply: fold the partial sums (of `fold_ranks` gathered shards when > 1), normalise, affine, optional SiLU."""
     x, Cc = _gn_input(p)
     nstat = p.rows // p.rows_per_stat
@@ -160,6 +169,14 @@ def groupnorm(p: L.GroupNormParams):
         m = part[..., 0] / nr
         mean = _gn_pilots(x, nstat, p.rows_per_stat, Cc).double() + m
         var = (part[..., 1] / nr - m * m).clamp_min(0.0)
+    if table:          # vmv_groupnorm_table: y is the fp32 [nstat][2][C] scale / shift table
+        gamma, beta = _view(p.gamma, Cc, "f32"), _view(p.beta, Cc, "f32")
+        rstd = torch.rsqrt(var.float() + p.eps)                                  # [nstat][32]
+        sc = rstd[:, :, None] * gamma.view(1, 32, Cc // 32)
+        sh = beta.view(1, 32, Cc // 32) - mean.float()[:, :, None] * sc
+        tab = _view(p.y, nstat * 2 * Cc, "f32").view(nstat, 2, Cc)
+        tab[:, 0], tab[:, 1] = sc.reshape(nstat, Cc), sh.reshape(nstat, Cc)
+        return
     xg = x.view(nstat, p.rows_per_stat, 32, Cc // 32)
     y = ((xg - mean.float()[:, None, :, None]) * torch.rsqrt(var.float() + p.eps)[:, None, :, None]).view(p.rows, Cc)
     y = y * _view(p.gamma, Cc, "f32") + _view(p.beta, Cc, "f32")
@@ -274,6 +291,8 @@ def run_recorded(recorded):
             groupnorm_fused(params)
         elif op == L.OP_FF:
             ff_fused(params)
+        elif op == L.OP_GN_TABLE:
+            groupnorm_table(params)
         else:
             raise ValueError(op)
 

@@ -136,3 +136,26 @@ def test_ff_fused_argument_block_equals_the_two_gemm_form():
     I.ff_fused(ops.ff_params(M, Cc, x, Cc, w1p, b1p, w2p, b2, out_b, Cc, residual=x, ldr=Cc, ln_eps=1e-5))
     err = float((out_a.float() - out_b.float()).norm() / out_a.float().norm())
     assert err < 2e-3, err
+
+
+def test_groupnorm_fold_argument_block_equals_apply_then_gemm():
+    """vmv_groupnorm_table + VmvGemmParams.gn_table (the GroupNorm -> proj_in fold of the transformers, gemm_rs.hip): the interpreter's
+    reading of the two argument blocks gives bitwise what stats + apply + plain GEMM gives — the contract the GPU test holds the
+    kernels to."""
+    nstat, rps, K, N = 3, 32, 64, 48
+    M = nstat * rps
+    x = (torch.randn(M, K, generator=g(1)) * 1.5 + 0.3).to(BF)
+    gamma, beta = 1 + 0.2 * torch.randn(K, generator=g(2)), 0.1 * torch.randn(K, generator=g(3))
+    w, b = (torch.randn(N, K, generator=g(4)) * K ** -0.5).to(BF), torch.randn(N, generator=g(5))
+    part = torch.zeros(ops.gn_partial_floats(M, rps, K) + 64)
+    y, tab = torch.zeros(M, K, dtype=BF), torch.zeros(nstat, 2, K)
+    o_ref, o_new = torch.zeros(M, N, dtype=BF), torch.zeros(M, N, dtype=BF)
+    gp = ops.gn_params(x, K, K, M, rps, part, gamma, beta, 1e-6, False, y, K)
+    I.groupnorm_stats(gp); I.groupnorm(gp)
+    I.gemm(ops.gemm_params(M, N, ops.linear_segs([(y, K, K)]), w, o_ref, N, bias=b))
+    gt = ops.gn_params(x, K, K, M, rps, part, gamma, beta, 1e-6, False, tab, K)
+    I.groupnorm_stats(gt); I.groupnorm_table(gt)
+    I.gemm(ops.gemm_params(M, N, ops.linear_segs([(x, K, K)]), w, o_new, N, bias=b, gn_table=tab, gn_rows_per_stat=rps))
+    ref = torch.nn.functional.group_norm(x.float().view(nstat, rps, K).permute(0, 2, 1), 32, gamma, beta, 1e-6).permute(0, 2, 1).reshape(M, K)
+    close(y, ref, 1e-2)
+    assert float((o_new.float() - o_ref.float()).abs().max()) <= 2 ** -6 * float(o_ref.float().abs().max())      # (one rounding of x_hat apart at most)

@@ -782,6 +782,48 @@ def test_gemm_rs_eligibility():
 
 
 # ------------------------------------------------------------------------------------------------- fused FeedForward
+@pytest.mark.parametrize("nstat,rps,K,N,totals", [(6, 2560, 320, 320, False), (5, 2576, 320, 320, False), (12, 640, 640, 640, False),
+                                                  (7, 656, 640, 640, False), (2, 7680, 320, 320, True)])
+def test_gemm_rs_groupnorm_fold(nstat, rps, K, N, totals):
+    """GroupNorm -> proj_in with the apply pass folded into the row-stationary GEMM (vmv.h gn_table, vmv_groupnorm_table): the GEMM
+    multiplies elem(x * scale + shift) — exactly what vmv_groupnorm_apply stores — so the result is BITWISE the two-kernel one.
+    rps = 2576 / 656: blocks that straddle two stat groups; totals: the all-frame form (integer accumulators)."""
+    M = nstat * rps
+    x = (rnd((M, K), 3, 1.5) + 0.3).cuda()
+    gamma, beta = (1 + 0.2 * torch.randn(K, generator=g(4))).cuda(), (0.1 * torch.randn(K, generator=g(5))).cuda()
+    w, b = rnd((N, K), 6, K ** -0.5).cuda(), torch.randn(N, generator=g(7)).cuda()
+    part = torch.zeros(ops.gn_partial_floats(M, rps, K) + 64, device="cuda")
+    tot = torch.zeros(2, 64 * ops.GN_TOT, dtype=torch.int64, device="cuda")
+    kw = dict(totals=tot[0], totals_clear=tot[1], clear_count=nstat * ops.GN_TOT) if totals else {}
+    S = ops.Stream(record=False)
+    y = torch.zeros(M, K, dtype=BF, device="cuda")
+    o_ref, o_new = torch.zeros(M, N, dtype=BF, device="cuda"), torch.zeros(M, N, dtype=BF, device="cuda")
+    gp = ops.gn_params(x, K, K, M, rps, part, gamma, beta, 1e-6, False, y, K, **kw)
+    S.groupnorm_stats(gp); S.groupnorm_apply(gp)
+    p_ref = ops.gemm_params(M, N, ops.linear_segs([(y, K, K)]), w, o_ref, N, bias=b)
+    S.gemm(p_ref, "ref")
+    tab = torch.zeros(nstat, 2, K, device="cuda")
+    tot.zero_()
+    gt = ops.gn_params(x, K, K, M, rps, part, gamma, beta, 1e-6, False, tab, K, **kw)
+    S.groupnorm_stats(gt); S.groupnorm_table(gt)
+    p_new = ops.gemm_params(M, N, ops.linear_segs([(x, K, K)]), w, o_new, N, bias=b, gn_table=tab, gn_rows_per_stat=rps)
+    import ctypes as C
+    assert S.lib.vmv_gemm_pick_tile(C.byref(p_new)) == L.TILE_RS
+    S.gemm(p_new, "fold")
+    torch.cuda.synchronize()
+    assert torch.equal(o_new, o_ref)
+    if totals:
+        assert int(tot[1].abs().sum()) == 0 and int(tot[0].abs().sum()) > 0          # the table launch cleared the other buffer too
+    cpu = Case(x=x.cpu(), w=w.cpu(), b=b.cpu(), tab=tab.cpu(), o=torch.zeros(M, N, dtype=BF)).on("cpu")
+    I.gemm(ops.gemm_params(M, N, ops.linear_segs([(cpu["x"], K, K)]), cpu["w"], cpu["o"], N, bias=cpu["b"], gn_table=cpu["tab"], gn_rows_per_stat=rps))
+    check(o_new, cpu["o"])
+    # not eligible -> an error, not a silently unnormalised product
+    bad = ops.gemm_params(M, N, ops.linear_segs([(x, K, K)]), w, o_new, N, bias=b, gn_table=tab, gn_rows_per_stat=rps, tile=L.TILE_256x128)
+    assert S.lib.vmv_gemm(C.byref(bad), None) == -1
+    bad2 = ops.gemm_params(M, N, ops.linear_segs([(x, K, K)]), w, o_new, N, bias=b, gn_table=tab, gn_rows_per_stat=264)
+    assert S.lib.vmv_gemm(C.byref(bad2), None) == -1
+
+
 @pytest.mark.parametrize("M,ln,res", [(1000, True, True), (128, False, False), (33000, True, True), (257, True, False), (70000, False, True)])
 def test_ff_fused(M, ln, res):
     """csrc/gemm_ff.hip: out = res + W2 . ((W1x LN(x) + b1x) * gelu(W1g LN(x) + b1g)) + b2 at C = 320 in one launch (hidden in

@@ -51,7 +51,7 @@ TILE_S256x128, TILE_S192x160, TILE_S256x160 = 15, 16, 17
 TILE_A128x160, TILE_A128x128 = 18, 19
 TILE_X256x320, TILE_X256x256, TILE_X256x128 = 20, 21, 22
 TILE_RS, TILE_RS512, TILE_RS256 = 23, 24, 25
-OP_GEMM, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTENTION, OP_SOFTMAX, OP_COPY, OP_GN_FUSED, OP_FF = 1, 2, 3, 4, 5, 6, 7, 8, 9
+OP_GEMM, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTENTION, OP_SOFTMAX, OP_COPY, OP_GN_FUSED, OP_FF, OP_GN_TABLE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 GN_FUSED_BYTES = 131072
 
 
@@ -73,7 +73,8 @@ class GemmParams(C.Structure):
                 ("F", C.c_int32), ("P", C.c_int32),
                 ("ksplit", C.c_int32), ("workspace", C.c_void_p),
                 ("tile", C.c_int32), ("res_scale", C.c_float), ("rowstat", C.c_void_p), ("colsum", C.c_void_p),
-                ("ln_eps", C.c_float), ("wgroup_rows", C.c_int32), ("wgroup_stride", C.c_int64)]
+                ("ln_eps", C.c_float), ("wgroup_rows", C.c_int32), ("wgroup_stride", C.c_int64),
+                ("gn_table", C.c_void_p), ("gn_rows_per_stat", C.c_int32), ("_pad_gn", C.c_int32)]
 
 
 class GroupNormParams(C.Structure):
@@ -152,6 +153,7 @@ SYMBOLS = {
     "vmv_gemm_pick_tile": (C.c_int, [C.POINTER(GemmParams)]),
     "vmv_groupnorm_stats": (C.c_int, [C.POINTER(GroupNormParams), _P]),
     "vmv_groupnorm_apply": (C.c_int, [C.POINTER(GroupNormParams), _P]),
+    "vmv_groupnorm_table": (C.c_int, [C.POINTER(GroupNormParams), _P]),
     "vmv_groupnorm_fused": (C.c_int, [C.POINTER(GroupNormParams), C.c_int32, _P]),
     "vmv_layernorm": (C.c_int, [C.POINTER(LayerNormParams), _P]),
     "vmv_attention": (C.c_int, [C.POINTER(AttnParams), _P]),

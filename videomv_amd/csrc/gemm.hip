@@ -321,6 +321,7 @@ int pick_tile(const VmvGemmParams& p, int total_steps) {
     const int geglu = p.epilogue == VMV_EPI_GEGLU;
     // the short-K linears of the two large levels: rows resident in registers, W streamed, outputs per column pair (gemm_rs.hip)
     if (gemm_policy() >= 2 && vmv_gemm_rs_preferred(p)) return VMV_TILE_RS;
+    if (p.gn_table) return VMV_TILE_RS;             // a folded GroupNorm lives in that kernel's prologue only (vmv_gemm checks eligibility)
     if (gemm_policy() >= 2 && xglds_policy() && !geglu && p.ksplit <= 1 && !p.rowstat && !vmv_gemm_ln_inline(p) && total_steps >= 12 &&
         (p.N % 320 == 0 || p.N % 256 == 0)) {
         bool any_gather = false;
@@ -409,6 +410,7 @@ int final_tile(const VmvGemmParams& p, int total_steps) {
 #endif
     const bool rs_tile = picked == VMV_TILE_RS || picked == VMV_TILE_RS512 || picked == VMV_TILE_RS256;
     if (rs_tile) return vmv_gemm_rs_supported(p) ? picked : VMV_EINVAL;      // (handles rowstat / colsum / grouped weights itself)
+    if (p.gn_table) return VMV_EINVAL;                                       // (a forced tile that cannot fold the GroupNorm)
     if (vmv_gemm_ln_inline(p) && p.tile == VMV_TILE_AUTO)
         picked = vmv_gemm_rs_supported(p) ? VMV_TILE_RS
                                           : (p.epilogue != VMV_EPI_GEGLU && p.N % 160 == 0) ? VMV_TILE_P256x160 : VMV_TILE_P256x128;
@@ -504,6 +506,7 @@ extern "C" int vmv_gemm(const VmvGemmParams* pp, void* stream) {
         const long groups = ((long)p.M + p.wgroup_rows - 1) / p.wgroup_rows;
         if (((groups - 1) * p.wgroup_stride + (long)p.N * p.ktot) * 2 >= (1L << 31) - 65536) return VMV_ERANGE;
     }
+    if (p.gn_table && !vmv_gemm_rs_supported(p)) return VMV_EINVAL;      // folded GroupNorm: the row-stationary kernel's prologue only
     const bool ln_inline = vmv_gemm_ln_inline(p);
     if (ln_inline) {       // statistics in the main loop: the persistent one-block-per-CU kernel, staged 16-bit output
         if (!ln_inline_ok(p)) return VMV_EINVAL;

@@ -40,7 +40,8 @@ struct RsCfg {
     static constexpr int STAGES = 3;
     static constexpr int PIECES = CHUNK_BYTES / 1024 / NW;     // LDS-DMA wave-instructions per wave per chunk (5)
     static constexpr int MAX_COLS = 5120;                      // W rows one block walks (bias strip: 20 KB)
-    static constexpr int LDS_BYTES = STAGES * CHUNK_BYTES + MAX_COLS * 4;
+    static constexpr int TAB_BYTES = 2 * 2 * K * 4;            // folded GroupNorm: (scale | shift)[K] fp32 of the two stat groups a block can touch
+    static constexpr int LDS_BYTES = STAGES * CHUNK_BYTES + MAX_COLS * 4 + TAB_BYTES;
     static_assert(CROWS * RB == CHUNK_BYTES && (G == 2 || G == 4) && PIECES * NW * 1024 == CHUNK_BYTES, "chunk geometry");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
@@ -58,7 +59,7 @@ VMV_DEV u32x4_t swap16_xz_yw(u32x4_t v) {
     return u32x4_t{x, y, z, w};
 }
 
-constexpr int RS_GEGLU = 1, RS_LN = 2, RS_RES = 4;
+constexpr int RS_GEGLU = 1, RS_LN = 2, RS_RES = 4, RS_GN = 8;
 #ifndef VMV_RS_STAGGER
 #define VMV_RS_STAGGER 0        // experiments: 1 = waves 4-7 take the chunk barrier between the MFMAs and the epilogue of a chunk's last pair
 #endif
@@ -75,7 +76,7 @@ constexpr int RS_GEGLU = 1, RS_LN = 2, RS_RES = 4;
 template <int RT, int KS, int MODE>
 __global__ __launch_bounds__(512, 1) void gemm_rs_kernel(const VmvGemmParams p, const int tiles_m, const int nsplit, const int cols_per_split) {
     using Cfg = RsCfg<RT, KS>;
-    constexpr bool GEGLU = (MODE & RS_GEGLU) != 0, LN = (MODE & RS_LN) != 0, RES = (MODE & RS_RES) != 0;
+    constexpr bool GEGLU = (MODE & RS_GEGLU) != 0, LN = (MODE & RS_LN) != 0, RES = (MODE & RS_RES) != 0, GN = (MODE & RS_GN) != 0;
     constexpr int RB = Cfg::RB, G = Cfg::G, P = Cfg::PIECES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -135,6 +136,17 @@ __global__ __launch_bounds__(512, 1) void gemm_rs_kernel(const VmvGemmParams p, 
         for (int q = wave; q * 256 < ncols; q += Cfg::NW)      // 256 floats per wave-instruction; columns >= N / no bias: zeros
             VMV_BLDS16(b_rsrc, reinterpret_cast<unsigned char*>(bias_lds) + q * 1024, (uint32_t)(n_begin + q * 256 + 4 * lane) * 4u, 0);
     }
+    // folded GroupNorm (vmv.h: gn_table): a block's rows lie in at most two consecutive stat groups (gn_rows_per_stat >= BM); their
+    // scale / shift rows — 2 x 2 x K floats, contiguous in the table — go to LDS behind the bias strip, before the W ring
+    float* tab_lds = bias_lds + Cfg::MAX_COLS;
+    int gn_first = 0;
+    if constexpr (GN) {
+        gn_first = (mt * Cfg::BM) / p.gn_rows_per_stat;
+        const uint32_t nstat = (uint32_t)((p.M + p.gn_rows_per_stat - 1) / p.gn_rows_per_stat);
+        const __amdgpu_buffer_rsrc_t t_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gn_table), 0, nstat * (uint32_t)(2 * Cfg::K * 4), SRD_FLAGS);
+        for (int q = wave; q * 1024 < Cfg::TAB_BYTES; q += Cfg::NW)
+            VMV_BLDS16(t_rsrc, reinterpret_cast<unsigned char*>(tab_lds) + q * 1024, (uint32_t)(gn_first * 2 * Cfg::K * 4 + q * 1024 + 16 * lane), 0);
+    }
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, (uint32_t)p.N * (uint32_t)p.ktot * 2u, SRD_FLAGS);
     auto issue_chunk = [&](int c, int slot) {
         unsigned char* base = smem + slot * Cfg::CHUNK_BYTES + wave * (P * 1024);
@@ -153,6 +165,46 @@ __global__ __launch_bounds__(512, 1) void gemm_rs_kernel(const VmvGemmParams p, 
     };
     const int pro = NC < Cfg::STAGES ? NC : Cfg::STAGES;
     for (int c = 0; c < pro; ++c) issue_chunk(c, c);
+
+    // ---- folded GroupNorm: x <- elem(x * scale[c] + shift[c]) — the values vmv_groupnorm_apply would have stored — on the resident rows
+    if constexpr (GN) {
+        wait_vmcnt_rt(pro * P);                      // everything issued before the W ring has landed (in-order): my A rows, my table pieces
+        __syncthreads();                             // ... and every wave's table pieces
+        // per row tile the LDS address of its stat group's table (scalar select), per (row tile, k-step) 16 table values; the loop is
+        // fenced per step and reads one step ahead: left to itself the scheduler hoists every step's reads (600 spilled registers)
+        const float* tbase[RT];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const int l = __builtin_amdgcn_readfirstlane((m_wave + 16 * i) / p.gn_rows_per_stat - gn_first);      // 0 or 1
+            tbase[i] = tab_lds + (l ? 2 * Cfg::K : 0) + 8 * fgrp;
+        }
+        constexpr int GPF = 1, GNB = GPF + 1;        // table reads run GPF steps ahead (16 registers per step in flight; 2 measured the same)
+        f32x4_t tv[GNB][4];
+        int chain = 0;                               // always 0; ties each read to an earlier step's result (see the asm below)
+        auto rd = [&](int idx, f32x4_t (&t)[4]) {
+            const float* tb = tbase[idx / KS] + (idx % KS) * 32 + chain;
+            t[0] = *reinterpret_cast<const f32x4_t*>(tb); t[1] = *reinterpret_cast<const f32x4_t*>(tb + 4);
+            t[2] = *reinterpret_cast<const f32x4_t*>(tb + Cfg::K); t[3] = *reinterpret_cast<const f32x4_t*>(tb + Cfg::K + 4);
+        };
+#pragma unroll
+        for (int idx = 0; idx < GPF; ++idx) rd(idx, tv[idx % GNB]);
+#pragma unroll
+        for (int idx = 0; idx < RT * KS; ++idx) {
+            if (idx + GPF < RT * KS) rd(idx + GPF, tv[(idx + GPF) % GNB]);
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4_t sc0 = tv[idx % GNB][0], sc1 = tv[idx % GNB][1], sh0 = tv[idx % GNB][2], sh1 = tv[idx % GNB][3];
+            u32x4_t v = a[idx / KS][idx % KS];
+            v.x = pack_elem2(fmaf(elem_lo(v.x), sc0.x, sh0.x), fmaf(elem_hi(v.x), sc0.y, sh0.y));
+            v.y = pack_elem2(fmaf(elem_lo(v.y), sc0.z, sh0.z), fmaf(elem_hi(v.y), sc0.w, sh0.w));
+            v.z = pack_elem2(fmaf(elem_lo(v.z), sc1.x, sh1.x), fmaf(elem_hi(v.z), sc1.y, sh1.y));
+            v.w = pack_elem2(fmaf(elem_lo(v.w), sc1.z, sh1.z), fmaf(elem_hi(v.w), sc1.w, sh1.w));
+            a[idx / KS][idx % KS] = v;
+            // (a fence for the optimiser, not only the scheduler: without a data dependency every step's table reads are issued up
+            //  front — 640 live registers; the empty asm makes a later read's address "depend" on this step's result)
+            asm volatile("" : "+v"(chain) : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
 
     // ---- LayerNorm of the resident rows (two-pass, fp32): lanes frow, frow + 16, + 32, + 48 hold the four k-quarters of a row
     if constexpr (LN && VMV_RS_ABLATE != 5) {
@@ -460,6 +512,7 @@ int launch_rs_mode(const VmvGemmParams& p, const RsPlan& pl, int mode, hipStream
         case RS_LN: return launch_rs<RT, KS, RS_LN>(p, pl, st);
         case RS_LN | RS_GEGLU: return launch_rs<RT, KS, RS_LN | RS_GEGLU>(p, pl, st);
         case RS_RES: return launch_rs<RT, KS, RS_RES>(p, pl, st);
+        case RS_GN: return launch_rs<RT, KS, RS_GN>(p, pl, st);
         default: return VMV_GLDS_UNSUPPORTED;
     }
 }
@@ -479,6 +532,10 @@ bool vmv_gemm_rs_supported(const VmvGemmParams& p) {
     if (ln && !(p.ln_eps > 0.f)) return false;
     if (ln && p.residual) return false;
     if (geglu && p.residual) return false;
+    if (p.gn_table) {            // folded GroupNorm: the plain projection only (proj_in), stat groups of whole 16-row tiles, >= a block's rows
+        if (ln || geglu || p.residual) return false;
+        if (p.gn_rows_per_stat < 512 || (p.gn_rows_per_stat & 15) || (((uintptr_t)p.gn_table) & 15)) return false;
+    }
     const int n_out = geglu ? p.N / 2 : p.N;
     if ((p.ldo & 7) || (n_out & 7) || !vmv_aligned16(p.out)) return false;
     if (p.residual && ((p.ldr & 7) || !vmv_aligned16(p.residual))) return false;
@@ -504,7 +561,7 @@ int vmv_gemm_rs_launch(const VmvGemmParams& p, int tile, hipStream_t st) {
     RsPlan pl;
     const int force_rt = tile == VMV_TILE_RS512 ? 4 : tile == VMV_TILE_RS256 ? 2 : 0;
     if (!rs_plan(p, force_rt, pl, ncu_whole_xcds())) return VMV_GLDS_UNSUPPORTED;
-    const int mode = (p.epilogue == VMV_EPI_GEGLU ? RS_GEGLU : 0) | (p.colsum ? RS_LN : 0) | (p.residual ? RS_RES : 0);
+    const int mode = (p.epilogue == VMV_EPI_GEGLU ? RS_GEGLU : 0) | (p.colsum ? RS_LN : 0) | (p.residual ? RS_RES : 0) | (p.gn_table ? RS_GN : 0);
     if (p.ktot == 320) return pl.rt == 4 ? launch_rs_mode<4, 10>(p, pl, mode, st) : launch_rs_mode<2, 10>(p, pl, mode, st);
     return launch_rs_mode<2, 20>(p, pl, mode, st);
 }

@@ -132,8 +132,9 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const VmvGroupNormParams 
 // grid = (nblk, nstat).  Every block first folds the partial sums of its stat group (fixed order) into
 // mean / rstd for the 32 groups and expands them to per-channel scale/shift tables in LDS, then streams its
 // rows: y = [silu](x * scale[c] + shift[c]).
+// table != nullptr (vmv_groupnorm_table, grid = (1, nstat)): the block writes its scale / shift tables there and stops.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const VmvGroupNormParams p, const int nchunk,
-                                                       const int apply_rows, const int nstat) {
+                                                       const int apply_rows, const int nstat, float* const table) {
     extern __shared__ __attribute__((aligned(16))) float sh[];
     const int C = p.C0 + p.C1;
     const int CS = C >> 3;
@@ -205,6 +206,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const VmvGroupNormParams 
         shift[c] = p.beta[c] - s_mean[g] * sc;
     }
     __syncthreads();
+    if (table) {
+        for (int c = tid; c < C; c += 256) {
+            table[((long)stat * 2 + 0) * C + c] = scale[c];
+            table[((long)stat * 2 + 1) * C + c] = shift[c];
+        }
+        return;
+    }
     const long row0 = (long)stat * p.rows_per_stat + (long)blockIdx.x * apply_rows;
     long row_end = row0 + apply_rows;
     const long stat_end = (long)(stat + 1) * p.rows_per_stat;
@@ -536,7 +544,24 @@ extern "C" int vmv_groupnorm_apply(const VmvGroupNormParams* pp, void* stream) {
     if (apply_rows < 1) apply_rows = 1;
     const int nblk = (p.rows_per_stat + apply_rows - 1) / apply_rows;
     hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, nstat), dim3(256), (size_t)(2 * C + 64) * sizeof(float),
-                       reinterpret_cast<hipStream_t>(stream), p, nchunk, apply_rows, nstat);
+                       reinterpret_cast<hipStream_t>(stream), p, nchunk, apply_rows, nstat, nullptr);
+    return vmv_launch_status();
+}
+
+extern "C" int vmv_groupnorm_table(const VmvGroupNormParams* pp, void* stream) {
+    if (!pp) return VMV_ENULL;
+    const VmvGroupNormParams& p = *pp;
+    int rc = gn_check(p);
+    if (rc != VMV_OK) return rc;
+    if (!p.y || !p.gamma || !p.beta) return VMV_ENULL;
+    if (p.silu) return VMV_EINVAL;                         // an activation cannot ride in an affine table
+    if ((((uintptr_t)p.y) & 15) || !vmv_aligned16(p.gamma) || !vmv_aligned16(p.beta)) return VMV_EALIGN;
+    if (p.fold_ranks > 1 && !p.totals) return VMV_EINVAL;
+    const int C = p.C0 + p.C1;
+    const int nstat = p.rows / p.rows_per_stat;
+    const int nchunk = (p.rows_per_stat + p.chunk_rows - 1) / p.chunk_rows;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(1, nstat), dim3(256), (size_t)(2 * C + 64) * sizeof(float),
+                       reinterpret_cast<hipStream_t>(stream), p, nchunk, 1, nstat, reinterpret_cast<float*>(p.y));
     return vmv_launch_status();
 }
 

@@ -23,6 +23,7 @@ int run_op(const VmvPlan::Op& o, void* stream) {
         case VMV_OP_SOFTMAX: return vmv_softmax_rows(reinterpret_cast<const VmvSoftmaxParams*>(o.args.data()), stream);
         case VMV_OP_COPY: return vmv_permute_copy(reinterpret_cast<const VmvCopyParams*>(o.args.data()), stream);
         case VMV_OP_FF: return vmv_ff_fused(reinterpret_cast<const VmvFfParams*>(o.args.data()), stream);
+        case VMV_OP_GN_TABLE: return vmv_groupnorm_table(reinterpret_cast<const VmvGroupNormParams*>(o.args.data()), stream);
         case VMV_OP_GN_FUSED: {
             const VmvGroupNormParams* g = reinterpret_cast<const VmvGroupNormParams*>(o.args.data());
             return vmv_groupnorm_fused(g, g->chunk_rows, stream);
@@ -33,7 +34,7 @@ int run_op(const VmvPlan::Op& o, void* stream) {
 size_t op_size(int op) {
     switch (op) {
         case VMV_OP_GEMM: return sizeof(VmvGemmParams);
-        case VMV_OP_GN_STATS: case VMV_OP_GN_APPLY: case VMV_OP_GN_FUSED: return sizeof(VmvGroupNormParams);
+        case VMV_OP_GN_STATS: case VMV_OP_GN_APPLY: case VMV_OP_GN_FUSED: case VMV_OP_GN_TABLE: return sizeof(VmvGroupNormParams);
         case VMV_OP_LAYERNORM: return sizeof(VmvLayerNormParams);
         case VMV_OP_ATTENTION: return sizeof(VmvAttnParams);
         case VMV_OP_SOFTMAX: return sizeof(VmvSoftmaxParams);

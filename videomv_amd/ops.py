@@ -58,7 +58,8 @@ class Geom:
 
 def gemm_params(M, N, segs: Sequence[Seg], W, out, ldo, bias=None, rowvec=None, rowvec_div=1, rowvec_ld=0,
                 residual=None, ldr=0, epilogue=L.EPI_NONE, act=L.ACT_NONE, out_fp32=False, geom: Optional[Geom] = None,
-                ksplit=0, workspace=None, tile=L.TILE_AUTO, res_scale=0.0, rowstat=None, colsum=None, ln_eps=0.0, wgroup_rows=0, wgroup_stride=0) -> L.GemmParams:
+                ksplit=0, workspace=None, tile=L.TILE_AUTO, res_scale=0.0, rowstat=None, colsum=None, ln_eps=0.0, wgroup_rows=0, wgroup_stride=0,
+                gn_table=None, gn_rows_per_stat=0) -> L.GemmParams:
     p = L.GemmParams()
     p.M, p.N, p.nseg = int(M), int(N), len(segs)
     if len(segs) > L.VMV_MAX_SEGS:
@@ -79,6 +80,7 @@ def gemm_params(M, N, segs: Sequence[Seg], W, out, ldo, bias=None, rowvec=None, 
     p.ksplit, p.workspace, p.tile, p.res_scale = int(ksplit), _ptr(workspace), tile, float(res_scale)
     p.rowstat, p.colsum, p.ln_eps = _ptr(rowstat), _ptr(colsum), float(ln_eps)
     p.wgroup_rows, p.wgroup_stride = int(wgroup_rows), int(wgroup_stride)
+    p.gn_table, p.gn_rows_per_stat = _ptr(gn_table), int(gn_rows_per_stat)       # GroupNorm folded into the A rows (vmv.h; gemm_rs only)
     return p
 
 
@@ -256,6 +258,10 @@ class Stream:
 
     def groupnorm_apply(self, params, label="gn"):
         self._go(L.OP_GN_APPLY, params, self.lib.vmv_groupnorm_apply, label + ".apply")
+
+    def groupnorm_table(self, params, label="gn"):
+        """scale / shift table of the norm (params.y = fp32 [nstat][2][C]) for a GEMM that folds it (gemm_params(gn_table=...))."""
+        self._go(L.OP_GN_TABLE, params, self.lib.vmv_groupnorm_table, label + ".table")
 
     def copy(self, params, label="copy"):
         self._go(L.OP_COPY, params, self.lib.vmv_permute_copy, label)

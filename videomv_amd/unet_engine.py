@@ -245,6 +245,8 @@ class UNetEngine:
         # Opt-in: 383 us against 379 us for the two gemm_rs launches inside a step (51.61 / 51.52 ms, same box) — see the
         # kernel's header for why (one 1-KB LDS fragment per MFMA)
         self.ff_fused = os.environ.get("VMV_FF_FUSED", "0") == "1" and self.fold_ln
+        # VMV_GN_FOLD (default 1): the transformers' GroupNorm -> proj_in with the apply pass folded into the GEMM (_gn_folded_proj_in)
+        self.gn_fold = os.environ.get("VMV_GN_FOLD", "1") != "0"
         # packed weights are immutable and shape-independent: engines of one model (other B / resolution / frame count, the
         # two branch engines of the pipelined frame-parallel mode) share ONE copy (`packed` = another engine's .packed)
         if packed is not None and packed.get("fold_ln") == self.fold_ln and packed.get("device") == str(device):
@@ -448,6 +450,39 @@ class UNetEngine:
         self._break(lambda: self.comm.all_gather(allr, loc))
         self.S.groupnorm_apply(ops.gn_params(*args, totals=self._gn_tot_all, fold_ranks=self.R, **clr, **base), label)
         return y
+
+    def _gn_folded_proj_in(self, p, x: Act, T, rps, out: Act, all_frames) -> bool:
+        """SpatialTransformer / TemporalTransformer head (util.py:354-360, 1043-1050): GroupNorm -> proj_in with the norm's apply
+        pass folded into the GEMM (the row-stationary kernel scales / shifts its resident rows from a per-(stat group, channel)
+        table, vmv.h gn_table): statistics + a one-block-per-group table launch instead of statistics + a read-modify-write of
+        the whole tensor; the GEMM multiplies the values the apply pass would have stored.  The two large levels only (K = 320 /
+        640); VMV_GN_FOLD=0 disables; not on the frame-parallel plans (their totals are gathered between the two launches)."""
+        if not self.gn_fold or self.comm is not None or rps < 512 or rps % 16:
+            return False
+        Cc = x.C
+        nstat = T // rps
+        tab = self.act(nstat * 2, Cc, dtype=torch.float32)
+        W = self.w[f"{p}.proj_in.weight"]
+        gp = ops.gemm_params(T, W.shape[0], ops.linear_segs([(x.ptr, Cc, Cc)]), W, out.ptr, out.C, bias=self.w[f"{p}.proj_in.bias"],
+                             gn_table=tab.ptr, gn_rows_per_stat=rps)
+        if not self.S.lib.vmv_gemm_rs_ok(C.byref(gp)):
+            self.release(tab)
+            return False
+        label = p + ".norm"
+        args = (x.ptr, Cc, Cc, T, rps, self._gnws, self.w[f"{p}.norm.weight"], self.w[f"{p}.norm.bias"], 1e-6, False, tab.ptr, Cc)
+        assert ops.gn_partial_floats(T, rps, Cc) <= self._gnws.numel()
+        if all_frames:          # long stat groups: integer totals (as _gn)
+            assert nstat <= 64
+            tot, nxt = self._gn_tot2[self._gn_tot_k & 1], self._gn_tot2[(self._gn_tot_k + 1) & 1]
+            self._gn_tot_k += 1
+            gnp = ops.gn_params(*args, totals=tot, totals_clear=nxt, clear_count=nstat * ops.GN_TOT)
+        else:
+            gnp = ops.gn_params(*args)
+        self.S.groupnorm_stats(gnp, label)
+        self.S.groupnorm_table(gnp, label)
+        self.S.gemm(gp, p + ".proj_in")
+        self.release(tab)
+        return True
 
     # ------------------------------------------------------------------ frame-parallel layout switches
     def _break(self, fn):
@@ -682,12 +717,13 @@ class UNetEngine:
         sharded = temporal and self.comm is not None
         if sharded:        # the whole TemporalTransformer is pixel-local: run it on the pixel-major shard
             x = self._switch(x, h * w, to_pixel=True, release_in=False)
-        n0 = self._gn(p + ".norm", [x], T, (F * h * w) if temporal else (h * w), f"{p}.norm", 1e-6, False,
-                      all_frames=temporal)
+        rps = (F * h * w) if temporal else (h * w)
         a = self.act(T, inner)
-        self._gemm(p + ".proj_in", T, inner, ops.linear_segs([(n0.ptr, n0.C, n0.C)]), f"{p}.proj_in.weight", a,
-                   bias=self.w[f"{p}.proj_in.bias"])
-        self.release(n0)
+        if not self._gn_folded_proj_in(p, x, T, rps, a, temporal):
+            n0 = self._gn(p + ".norm", [x], T, rps, f"{p}.norm", 1e-6, False, all_frames=temporal)
+            self._gemm(p + ".proj_in", T, inner, ops.linear_segs([(n0.ptr, n0.C, n0.C)]), f"{p}.proj_in.weight", a,
+                       bias=self.w[f"{p}.proj_in.bias"])
+            self.release(n0)
         if cut:
             assert not temporal and self.B == 1
             a1 = self._tblock(f"{p}.transformer_blocks.0", a, m["heads"], temporal, h, w, cross_ctx=True, phase="pre")
