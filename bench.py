@@ -345,6 +345,19 @@ def main():
                 fpar["cfg_x_frame"] = dict(cfgp, parallelism=f"2 branch groups x {comm2.world} frame shards")
                 if cfgp["steps_per_s"] > fpar["steps_per_s"]:
                     fpar.update(cfgp, mode="cfg-parallel x frame-parallel")
+            # BASELINE's north-star form of configs[2], measured beside the default: frames stay sharded through the temporal
+            # transformers, one all-gather of [K | V] before each temporal attention (VMV_FP_TEMPORAL=kv_gather; branch-pipelined
+            # B = 1 plans).  Last, inside its own try: nothing above depends on it.
+            state["partial"] = dict(fpar)
+            try:
+                os.environ["VMV_FP_TEMPORAL"], os.environ["VMV_FP_PIPELINE"] = "kv_gather", "1"
+                model.set_frame_parallel(comm)
+                kvg = timed_leg("kv-gather")
+                fpar["kv_gather_temporal"] = dict(kvg, parallelism=f"frames x{world}, K|V all-gather per temporal attention (north-star form)")
+            except Exception as e:
+                fpar["kv_gather_temporal"] = dict(error=f"{type(e).__name__}: {e}")
+            finally:
+                os.environ.pop("VMV_FP_TEMPORAL", None)
         except Exception as e:      # the headline (replicas) line must survive any problem in this leg
             fpar = dict(state.get("partial") or {}, error=f"{type(e).__name__}: {e}")
         finally:

@@ -378,3 +378,72 @@ def test_world_8_three_frames_per_rank(tmp_path):
         assert r["fl"] == 3 and r["pipe_plans"] == 2 and r["fp_world"] == 4 and r["branch"] == r["rank"] // 4
         assert r["e_plan"] < 3e-2 and r["e_pipe"] < 6e-2 and r["e_cfgpar"] < 6e-2, r
         assert r["a2a"] >= 2 * (3 + 4) and r["ag"] >= 4 * 3 + 4, r
+
+
+# ------------------------------------------------------------------------------------------------------- north-star KV all-gather
+def _kvg_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        torch.set_num_threads(2)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from tests import plan_interp
+        plan_interp.install(_Patch)
+        from oracle.weights import random_state_dict, unet_param_shapes
+        from oracle.unet_ref import UNetCfg
+        from videomv_amd.comm import FrameComm
+        from videomv_amd.unet_engine import UNetEngine
+        ocfg = UNetCfg(**{k: v for k, v in CFG.items() if k in {f.name for f in dataclasses.fields(UNetCfg)}})
+        sd = random_state_dict(unet_param_shapes(ocfg), 99)
+        B, F_, H, W, L = 1, 8, 8, 8, 5
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(1, 4, F_, H, W, generator=g)
+        t = torch.tensor([501])
+        y = torch.randn(B, L, 1024, generator=g)
+        cam = torch.randn(1, F_, 16, generator=g)
+        dev = torch.device("cpu")
+        ref = UNetEngine(CFG, sd, B, F_, H, W, L, dev, n_t=1)
+        ref.set_context(y); ref.set_camera(cam)
+        ref.forward_rows(x, t)
+        eps_single = ref.eps_ncfhw()
+        fl = F_ // world
+        sl = slice(rank * fl, (rank + 1) * fl)
+        res = {}
+        for mode in ("switch", "kv_gather"):
+            os.environ["VMV_FP_TEMPORAL"] = mode
+            comm = FrameComm()
+            eng = UNetEngine(CFG, sd, B, F_, H, W, L, dev, n_t=1, comm=comm)
+            eng.set_context(y); eng.set_camera(cam)
+            eng.forward_rows(x[:, :, sl].contiguous(), t)
+            res[mode] = dict(e=rel_l2(eng.eps_ncfhw(), eps_single[:, :, sl]), a2a=comm.n_all_to_all, ag=comm.n_all_gather,
+                             packs=sum(1 for l in eng.S.labels if l.endswith(".kv.pack")))
+        q.put(dict(rank=rank, **res))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put(dict(rank=rank, error=traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_kv_all_gather_temporal_mode(world):
+    """BASELINE's north-star form of configs[2] (VMV_FP_TEMPORAL=kv_gather): the frames stay sharded through the
+    TemporalTransformers and every temporal attention all-gathers [K | V] (Nq = F / R local frames against Nk = F keys per pixel)
+    instead of the two layout switches around the block — same eps as the single-rank plan and as the default 'switch' mode; the
+    collective COUNT is the same (2 per TemporalTransformer either way), the bytes are not."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_kvg_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert "error" not in r, r["error"]
+    for r in res:
+        sw, kv = r["switch"], r["kv_gather"]
+        assert sw["e"] < 3e-2 and kv["e"] < 3e-2, r
+        assert kv["packs"] > 0 and sw["packs"] == 0
+        assert kv["a2a"] == sw["a2a"] - kv["packs"] and kv["ag"] == sw["ag"] + kv["packs"], r      # 2 switches -> 2 gathers per block

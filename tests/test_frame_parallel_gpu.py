@@ -82,6 +82,32 @@ def test_world1_sharded_plan_equals_the_unsharded_plan(monkeypatch, same_gn_form
         dist.destroy_process_group()
 
 
+def test_world1_kv_gather_temporal_mode_on_the_gpu(monkeypatch):
+    """VMV_FP_TEMPORAL=kv_gather (BASELINE's north-star form: an all-gather of K | V before each temporal attention) through the HIP
+    kernels at world 1: B = 1 plan, short-sequence attention with Nq = Nk = F here, the K | V pack copy, the gather through the
+    communicator — against the unsharded B = 1 plan."""
+    monkeypatch.setenv("VMV_FP_TEMPORAL", "kv_gather")
+    from videomv_amd.comm import FrameComm
+    from videomv_amd.unet_engine import UNetEngine
+    from videomv_amd import _lib as L
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
+    try:
+        ocfg, sd, x, t, y, cam = _case(4, 16, 16)
+        dev = torch.device("cuda", 0)
+        outs = []
+        for comm in (None, FrameComm()):
+            eng = UNetEngine(CFG, sd, 1, 4, 16, 16, y.shape[1], dev, n_t=1, comm=comm)
+            eng.set_context(y[:1].to(dev)); eng.set_camera(cam.to(dev))
+            eng.forward_rows(x.to(dev), t.to(dev))
+            outs.append(eng.eps_ncfhw().cpu())
+            if comm is not None:
+                assert sum(1 for l in eng.S.labels if l.endswith(".kv.pack")) > 0
+        tol = 5e-3 if L.elem_name() == "fp16" else 3e-2
+        assert torch.isfinite(outs[0]).all() and rel_l2(outs[1], outs[0]) < tol, rel_l2(outs[1], outs[0])
+    finally:
+        dist.destroy_process_group()
+
+
 def _worker(rank, world, port, F_, H, W, q):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"

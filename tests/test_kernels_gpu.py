@@ -959,6 +959,27 @@ def test_attention_head_dim_32(T, heads):
     check(dev["o"], cpu["o"], tol_l2=6e-3, tol_max=2e-2)
 
 
+@pytest.mark.parametrize("Fl,Fg,hw,heads", [(3, 24, 40, 5), (12, 24, 17, 2), (1, 8, 64, 1)])
+def test_attention_temporal_kv_gathered(Fl, Fg, hw, heads):
+    """The north-star form of frame-parallel temporal attention (VMV_FP_TEMPORAL=kv_gather): per (pixel, head) Nq = Fl local frames
+    attend to Nk = Fg gathered frames; q rows live in the fused q|k|v buffer of the local frames, K | V in the gathered [Fg][hw][2C]
+    buffer — the short-sequence kernel with Nq != Nk and different row strides per operand."""
+    Cc = heads * 64
+    c = Case(qkv=rnd((Fl * hw, 3 * Cc), 5), kv=rnd((Fg * hw, 2 * Cc), 6), o=torch.zeros(Fl * hw, Cc, dtype=BF))
+
+    def build(t):
+        qm = ops.seq_map(0, 3 * Cc, hw * 3 * Cc, inner=hw)
+        km = ops.seq_map(0, 2 * Cc, hw * 2 * Cc, inner=hw)
+        kv = t["kv"].data_ptr()
+        return ops.attn_params(t["qkv"], kv, kv + 2 * Cc, t["o"], qm, km, km, ops.seq_map(0, Cc, hw * Cc, inner=hw), hw, heads, Fl, Fg, 64 ** -0.5)
+    cpu = c.on("cpu")
+    I.attention(build(cpu))
+    dev = c.on("cuda")
+    ops.Stream(record=False).attention(build(dev), "t")
+    torch.cuda.synchronize()
+    check(dev["o"], cpu["o"], tol_l2=6e-3, tol_max=2e-2)
+
+
 @pytest.mark.parametrize("B,T,heads", [(2, 77, 16), (1, 77, 2), (3, 130, 1), (1, 300, 2)])
 def test_attention_causal(B, T, heads):
     """VmvAttnParams.causal (the CLIP text tower, clip_embedder.py:192-201): keys j > i masked out, fused q|k|v rows; 77 tokens

@@ -247,6 +247,12 @@ class UNetEngine:
         self.ff_fused = os.environ.get("VMV_FF_FUSED", "0") == "1" and self.fold_ln
         # VMV_GN_FOLD (default 1): the transformers' GroupNorm -> proj_in with the apply pass folded into the GEMM (_gn_folded_proj_in)
         self.gn_fold = os.environ.get("VMV_GN_FOLD", "1") != "0"
+        # VMV_FP_TEMPORAL (frame-parallel plans): "switch" (default) = the TemporalTransformer runs on the pixel-major shard between two
+        # all-to-all layout switches; "kv_gather" = BASELINE's north-star form — frames stay sharded, ONE all-gather of [K | V] before
+        # each temporal attention (B = 1 plans, i.e. the branch-pipelined / CFG-parallel modes; 16x the bytes of the switches)
+        self.fp_temporal = os.environ.get("VMV_FP_TEMPORAL", "switch")
+        if self.fp_temporal not in ("switch", "kv_gather"):
+            raise ValueError("VMV_FP_TEMPORAL must be 'switch' or 'kv_gather'")
         # packed weights are immutable and shape-independent: engines of one model (other B / resolution / frame count, the
         # two branch engines of the pipelined frame-parallel mode) share ONE copy (`packed` = another engine's .packed)
         if packed is not None and packed.get("fold_ln") == self.fold_ln and packed.get("device") == str(device):
@@ -618,7 +624,7 @@ class UNetEngine:
             cur = self._switch(cur, h * w, to_pixel=False)
         return cur
 
-    def _tblock(self, p, a: Act, heads, temporal: bool, h, w, cross_ctx: bool, phase: str = "all") -> Act:
+    def _tblock(self, p, a: Act, heads, temporal: bool, h, w, cross_ctx: bool, phase: str = "all", kv_gather: bool = False) -> Act:
         """phase "pre": stop after the first (self-)attention and return a1; "post": `a` IS a1, continue from the second
         attention (the shared-prefix cut, see __init__); "all": the whole block."""
         B, F = self.B, self.F
@@ -627,7 +633,7 @@ class UNetEngine:
         hw = h * w
         scale = 64 ** -0.5
 
-        if temporal:       # frame-parallel: `a` is the pixel-major shard — all Fg frames of hw / R pixels
+        if temporal and not kv_gather:       # frame-parallel: `a` is the pixel-major shard — all Fg frames of hw / R pixels
             hw, F = hw // self.R, self.Fg
 
         def maps(ld, col0=0):
@@ -643,9 +649,27 @@ class UNetEngine:
             self._ln_linear(f"{p}.{tag}.qkv", x, f"{p}.{normkey}", 3 * inner, f"{p}.{tag}.qkv", qkv)
             ao = self.act(T, inner)
             ld = 3 * inner
-            self.S.attention(ops.attn_params(qkv.ptr, qkv.ptr + 2 * inner, qkv.ptr + 4 * inner, ao.ptr,
-                                             maps(ld), maps(ld), maps(ld), maps(inner), n_outer, heads, Nq, Nq, scale),
-                             f"{p}.{tag}.attn")
+            if kv_gather:
+                # north-star form: my F frames of every pixel attend to ALL Fg frames — [K | V] of the local rows is made contiguous
+                # (one strided copy), all-gathered (rank r's chunk = frames [r F, (r + 1) F): frame-major since B = 1), and the
+                # short-sequence kernel runs with Nq = F queries against Nk = Fg keys per (pixel, head)
+                cv = inner // 8
+                kvloc = self.act(T, 2 * inner)
+                self.S.copy(ops.copy_params(qkv.ptr + 2 * inner, kvloc.ptr, T, 1, 1, 2 * cv, 3 * cv, 0), f"{p}.{tag}.kv.pack")
+                kvall = self.act(self.R * T, 2 * inner)
+                out_t, in_t = kvall.tensor().view(-1), kvloc.tensor().view(-1)
+                self._break(lambda: self.comm.all_gather(out_t, in_t))
+                self.release(kvloc)
+                qm = ops.seq_map(0, ld, hw * ld, inner=hw)
+                km = ops.seq_map(0, 2 * inner, hw * 2 * inner, inner=hw)
+                self.S.attention(ops.attn_params(qkv.ptr, kvall.ptr, kvall.ptr + 2 * inner, ao.ptr, qm, km, km,
+                                                 ops.seq_map(0, inner, hw * inner, inner=hw), hw, heads, F, self.Fg, scale),
+                                 f"{p}.{tag}.attn")
+                self.release(kvall)
+            else:
+                self.S.attention(ops.attn_params(qkv.ptr, qkv.ptr + 2 * inner, qkv.ptr + 4 * inner, ao.ptr,
+                                                 maps(ld), maps(ld), maps(ld), maps(inner), n_outer, heads, Nq, Nq, scale),
+                                 f"{p}.{tag}.attn")
             self.release(qkv)
             y = self.act(T, inner)
             self._gemm(f"{p}.{tag}.out", T, inner, ops.linear_segs([(ao.ptr, ao.C, ao.C)]), f"{p}.{tag}.to_out.0.weight", y,
@@ -715,7 +739,8 @@ class UNetEngine:
             raise NotImplementedError("the HIP attention kernel is specialised for head_dim 64")
         temporal = kind == "tt"
         sharded = temporal and self.comm is not None
-        if sharded:        # the whole TemporalTransformer is pixel-local: run it on the pixel-major shard
+        kvg = sharded and self.fp_temporal == "kv_gather" and self.B == 1 and not cut
+        if sharded and not kvg:        # the whole TemporalTransformer is pixel-local: run it on the pixel-major shard
             x = self._switch(x, h * w, to_pixel=True, release_in=False)
         rps = (F * h * w) if temporal else (h * w)
         a = self.act(T, inner)
@@ -735,7 +760,7 @@ class UNetEngine:
             a3 = self._tblock(f"{p}.transformer_blocks.0", a1_full, m["heads"], temporal, h, w, cross_ctx=True, phase="post")
             self.release(a1_full)
         else:
-            a3 = self._tblock(f"{p}.transformer_blocks.0", a, m["heads"], temporal, h, w, cross_ctx=not temporal)
+            a3 = self._tblock(f"{p}.transformer_blocks.0", a, m["heads"], temporal, h, w, cross_ctx=not temporal, kv_gather=kvg)
             self.release(a)
         y = self.act(T, C)
         self._gemm(p + ".proj_out", T, C, ops.linear_segs([(a3.ptr, a3.C, a3.C)]), f"{p}.proj_out.weight", y,
@@ -743,7 +768,7 @@ class UNetEngine:
         self.release(a3)
         if cut:
             self.release(x)
-        if sharded:
+        if sharded and not kvg:
             self.release(x)
             y = self._switch(y, h * w, to_pixel=False)
         return y
