@@ -60,7 +60,23 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
     int o, h, q0;
     bool wvalid = true;
     if constexpr (WPP == 4) {
+#ifndef VMV_ATTN_XCD_MAP
+#define VMV_ATTN_XCD_MAP 1
+#endif
+#if VMV_ATTN_XCD_MAP
+        // XCD-aware block map: workgroups are handed out round-robin over the 8 XCDs in linear block order, so with the natural map
+        // the query tiles that share one (problem, head)'s K / V land on eight different L2s and each re-fetches them from the fabric
+        // (FETCH_SIZE: 1.2 GB per L0 self-attention launch for 236 MB of operands).  Bijection: the blocks of one XCD, in issue
+        // order, walk consecutive logical ids = the query tiles of one (problem, head), then the next pair.
+        const int nqt = gridDim.x, nh = gridDim.y;
+        const int lin = blockIdx.x + nqt * (blockIdx.y + nh * blockIdx.z), nblk = nqt * nh * gridDim.z;
+        const int qq = nblk >> 3, rr = nblk & 7, xcd = lin & 7, idx = lin >> 3;
+        const int logical = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+        const int pair = logical / nqt, qtile = logical - pair * nqt;
+        o = pair / nh; h = pair - o * nh; q0 = (qtile * 4 + wave) * (16 * QT);
+#else
         o = blockIdx.z; h = blockIdx.y; q0 = (blockIdx.x * 4 + wave) * (16 * QT);
+#endif
     } else {
         const int pidx = blockIdx.x * 4 + wave;
         wvalid = pidx < nproblems;
