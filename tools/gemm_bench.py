@@ -61,6 +61,10 @@ def main():
                 kw["epilogue"] = L.EPI_GEGLU; No = N // 2
         elif kind == "conv":
             K = 9 * C; segs = ops.conv3x3_segs([(x, C, C)])
+            G = int(os.environ.get("VMV_BENCH_CGROUPS", "1"))       # experiment: channel-group-major K order (G groups x 9 taps)
+            if G > 1 and C % (8 * G) == 0:
+                cg = C // G
+                segs = [ops.Seg(x.data_ptr() + 2 * g_ * cg, C, cg, L.SEG_SPATIAL, dy, dx) for g_ in range(G) for (dy, dx) in ops.TAPS3x3]
             hw = {M0: (40, 64), M1: (20, 32), M2: (10, 16), 1920: (5, 8), 24 * 80 * 128: (80, 128), 24 * 160 * 256: (160, 256),
                   24 * 320 * 512: (320, 512)}[M]
             geom = ops.Geom(OH=hw[0], OW=hw[1], IH=hw[0], IW=hw[1])
