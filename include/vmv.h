@@ -165,6 +165,8 @@ typedef struct {
                                   split picked by the launcher — the short-K linears of the two large UNet levels */
 #define VMV_TILE_RS512    24   /* the same, forced to 64 rows per wave (512-row blocks; K = 320 only) */
 #define VMV_TILE_RS256    25   /* the same, forced to 32 rows per wave (256-row blocks) */
+#define VMV_TILE_HALO     26   /* halo-resident 3 x 3 convolution for N <= 8 output channels (conv_halo.hip): 8 x 16 pixel tiles, the 10 x 18 halo and
+                                  the weights in LDS — the VAE / UNet output heads */
 
 int vmv_gemm(const VmvGemmParams* p, void* stream);
 /* 1 if vmv_gemm accepts *p (rowstat ignored) with in-loop LayerNorm statistics (VmvGemmParams.ln_eps), else 0 */

@@ -213,6 +213,42 @@ def test_gemm_splitk(ks, tile):
     check(dev["out"], cpu["out"])
 
 
+@pytest.mark.parametrize("n,H,W,Cin,N,fp32,ldo", [(2, 20, 37, 128, 4, True, 4), (3, 9, 16, 320, 4, False, 8), (2, 8, 8, 512, 8, True, 8),
+                                                   (1, 33, 50, 192, 4, True, 4), (2, 16, 17, 160, 4, True, 4), (1, 5, 3, 32, 8, False, 8),
+                                                   (24, 40, 64, 320, 4, True, 4)])
+def test_conv_halo_few_output_channels(n, H, W, Cin, N, fp32, ldo):
+    """The halo-resident 3 x 3 convolution for N <= 8 output channels (conv_halo.hip; the VAE's conv_out 128 -> 3, the encoder's
+    512 -> 8, the UNet's eps head 320 -> 4): ragged tiles at the right / bottom edge, several images, channel chunks of 128 + a 64- or
+    32-channel tail, fp32 and 16-bit outputs (vmv_gemm takes N % 4 == 0: 3 channels are a zero-padded fourth row) — against F.conv2d and
+    the tile kernels; the dispatcher picks it."""
+    M = n * H * W
+    wt = torch.randn(N, Cin, 3, 3, generator=g(2)) * (9 * Cin) ** -0.5
+    wp = torch.zeros((N + 3) // 4 * 4, 9 * Cin)
+    wp[:N] = wt.permute(0, 2, 3, 1).reshape(N, -1)
+    c = Case(x=rnd((M, Cin), 1), w=wp.to(BF), b=torch.cat([torch.randn(N, generator=g(3)), torch.zeros(8)])[: (N + 3) // 4 * 4],
+             out=torch.full((M, ldo), 7.0, dtype=torch.float32 if fp32 else BF))
+
+    def build(t, tile=L.TILE_AUTO):
+        return ops.gemm_params(M, N, ops.conv3x3_segs([(t["x"], Cin, Cin)]), t["w"], t["out"], ldo, bias=t["b"], out_fp32=fp32,
+                               geom=ops.Geom(OH=H, OW=W, IH=H, IW=W), tile=tile)
+    import ctypes as C
+    dev = c.on("cuda")
+    S = ops.Stream(record=False)
+    assert S.lib.vmv_gemm_pick_tile(C.byref(build(dev))) == L.TILE_HALO
+    S.gemm(build(dev), "halo")
+    torch.cuda.synchronize()
+    x = c.t["x"].float().view(n, H, W, Cin).permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(x, wt.to(BF).float(), c.t["b"][:N], padding=1).permute(0, 2, 3, 1).reshape(M, N)
+    got = dev["out"].float().cpu()
+    assert float((got[:, :N] - ref).abs().max()) <= (2e-3 if fp32 else 2e-2) * float(ref.abs().max()), float((got[:, :N] - ref).abs().max())
+    if ldo > (N + 3) // 4 * 4:
+        assert bool((got[:, (N + 3) // 4 * 4:] == 7.0).all())              # columns beyond the (4-padded) outputs are not touched
+    old = c.on("cuda")                                                        # the tile kernels on the same argument block
+    S.gemm(build(old, tile=L.TILE_128x64), "tile")
+    torch.cuda.synchronize()
+    assert float((old["out"].float()[:, :N] - dev["out"].float()[:, :N]).abs().max().cpu()) <= (2e-3 if fp32 else 2e-2) * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("tile", [L.TILE_S256x128, L.TILE_S192x160, L.TILE_S256x160, L.TILE_256x160, L.TILE_X256x320, L.TILE_X256x256, L.TILE_X256x128])
 def test_gemm_conv3x3_many_tiles(tile):
     """>= 2 tiles per persistent block (M = 2*24*40*64/2 rows), residual + per-image row vector, two sources + 1x1 skip."""

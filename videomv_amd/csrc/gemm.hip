@@ -33,6 +33,8 @@ static int vmv_gemm_astat_launch(const VmvGemmParams&, int, hipStream_t) { retur
 #endif
 int vmv_gemm_rs_launch(const VmvGemmParams& p, int tile, hipStream_t st);                      // gemm_rs.hip
 bool vmv_gemm_rs_supported(const VmvGemmParams& p);
+int vmv_conv_halo_launch(const VmvGemmParams& p, hipStream_t st);                             // conv_halo.hip
+bool vmv_conv_halo_supported(const VmvGemmParams& p);
 bool vmv_gemm_rs_preferred(const VmvGemmParams& p);
 #if defined(VMV_EXPERIMENTS)
 bool vmv_gemm_astat_eligible(const VmvGemmParams& p);
@@ -316,11 +318,20 @@ int xglds_policy() {
     return pol;
 }
 
+int conv_halo_policy() {
+    // VMV_CONV_HALO (A/B experiments): 1 (default) = the halo-resident kernel takes the eligible few-channel 3 x 3 convolutions
+    static int pol = -1;
+    if (pol < 0) { const char* e = getenv("VMV_CONV_HALO"); pol = e ? atoi(e) : 1; }
+    return pol;
+}
+
 int pick_tile(const VmvGemmParams& p, int total_steps) {
     if (p.tile != VMV_TILE_AUTO) return p.tile;
     const int geglu = p.epilogue == VMV_EPI_GEGLU;
     // the short-K linears of the two large levels: rows resident in registers, W streamed, outputs per column pair (gemm_rs.hip)
     if (gemm_policy() >= 2 && vmv_gemm_rs_preferred(p)) return VMV_TILE_RS;
+    // 3 x 3 convolutions with N <= 8 output channels (the VAE / UNet heads): halo tile + weights in LDS (conv_halo.hip)
+    if (gemm_policy() >= 2 && conv_halo_policy() && vmv_conv_halo_supported(p)) return VMV_TILE_HALO;
     if (p.gn_table) return VMV_TILE_RS;             // a folded GroupNorm lives in that kernel's prologue only (vmv_gemm checks eligibility)
     if (gemm_policy() >= 2 && xglds_policy() && !geglu && p.ksplit <= 1 && !p.rowstat && !vmv_gemm_ln_inline(p) && total_steps >= 12 &&
         (p.N % 320 == 0 || p.N % 256 == 0)) {
@@ -408,6 +419,7 @@ int final_tile(const VmvGemmParams& p, int total_steps) {
     if (picked == VMV_TILE_S256x128 || picked == VMV_TILE_S192x160 || picked == VMV_TILE_S256x160 || picked == VMV_TILE_A128x160 ||
         picked == VMV_TILE_A128x128) return VMV_EINVAL;
 #endif
+    if (picked == VMV_TILE_HALO) return vmv_conv_halo_supported(p) ? picked : VMV_EINVAL;
     const bool rs_tile = picked == VMV_TILE_RS || picked == VMV_TILE_RS512 || picked == VMV_TILE_RS256;
     if (rs_tile) return vmv_gemm_rs_supported(p) ? picked : VMV_EINVAL;      // (handles rowstat / colsum / grouped weights itself)
     if (p.gn_table) return VMV_EINVAL;                                       // (a forced tile that cannot fold the GroupNorm)
@@ -549,6 +561,10 @@ extern "C" int vmv_gemm(const VmvGemmParams* pp, void* stream) {
                 rc = vmv_gemm_glds_launch(p, total_steps, p.N % 160 == 0 ? VMV_TILE_256x160 : VMV_TILE_256x128, st);
                 if (rc == VMV_GLDS_UNSUPPORTED) rc = p.N % 160 == 0 ? launch_cfg<4, 5>(p, total_steps, st) : launch_cfg<4, 4>(p, total_steps, st);
             }
+            break;
+        case VMV_TILE_HALO:
+            rc = vmv_conv_halo_launch(p, st);
+            if (rc == VMV_GLDS_UNSUPPORTED) return VMV_EINVAL;
             break;
         case VMV_TILE_RS:
         case VMV_TILE_RS512:
