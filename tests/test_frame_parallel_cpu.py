@@ -425,7 +425,7 @@ def _kvg_worker(rank, world, port, q):
         q.put(dict(rank=rank, error=traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_kv_all_gather_temporal_mode(world):
     """BASELINE's north-star form of configs[2] (VMV_FP_TEMPORAL=kv_gather): the frames stay sharded through the
     TemporalTransformers and every temporal attention all-gathers [K | V] (Nq = F / R local frames against Nk = F keys per pixel)
