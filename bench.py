@@ -22,6 +22,7 @@ launch with events on the launch stream in a separate pass) and `cpu_baseline` (
 host cores, bounded sample, FLOP-scaled to the metric's unit).
 """
 import argparse
+import ctypes
 import json
 import math
 import os
@@ -130,6 +131,11 @@ def main():
     ap.add_argument("--frame-parallel-budget", type=float, default=300.0, help="seconds before the watchdog abandons that leg")
     ap.add_argument("--no-lgm", action="store_true", help="skip the LGM-refined sample (BASELINE configs[4])")
     ap.add_argument("--no-sample", action="store_true", help="skip the (untimed-region) full 50-step + VAE-decode sample")
+    ap.add_argument("--simulate-rank", type=int, default=8, metavar="W", help="N = 1 only: also build rank 0's plan of a W-GPU frame-parallel run "
+                    "(BASELINE configs[2]: 24 / W views, HW / W pixels per temporal block) on THIS GPU with the W - 1 peers simulated — every "
+                    "collective a local copy of the same bytes — and report its GPU and host ms per step; 0 = skip")
+    ap.add_argument("--dump-ops-sim", type=str, default="", help="per-launch timing table of the simulated rank's plan")
+    ap.add_argument("--no-i2vgen", action="store_true", help="skip the UNetSD_I2VGen leg (BASELINE configs[3])")
     ap.add_argument("--no-alt-dtype", action="store_true", help="(default since round 3; kept for old command lines)")
     ap.add_argument("--alt-dtype", action="store_true", help="also time the other 16-bit element type's library in a child process "
                     "(bf16 is the range fallback — DESIGN.md §6 — and not part of the headline line)")
@@ -193,22 +199,26 @@ def main():
         one_step(args.warmup + i)
     fence()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt[0])
+    from videomv_amd.dist import max_over_ranks
+    dt = max_over_ranks(dt, dev)                 # the slowest rank defines the job time (no-op at N = 1)
     finite = bool(torch.isfinite(xt).all())
     steps_per_s = world * args.steps / dt
     ms_per_step = 1000.0 * dt / args.steps
     step_tflop = STEP_TFLOP.get((H, W))
 
     # ---- per-launch timing pass (events on the launch stream = torch's current stream)
-    roof = None
-    if rank == 0 and not args.no_op_profile:
-        eng = model.engine_for(2, args.frames, H, W, 77, dev, n_t=1, share_prefix=True)     # the plan the timed steps replayed
+    KIND = {L.OP_GEMM: "gemm", L.OP_GN_STATS: "gn_stats", L.OP_GN_APPLY: "gn_apply", L.OP_LAYERNORM: "layernorm",
+            L.OP_ATTENTION: "attention", L.OP_GN_FUSED: "gn_fused", L.OP_COPY: "copy", L.OP_FF: "ff_fused", L.OP_GN_TABLE: "gn_table",
+            L.OP_COMM: "collective"}
+
+    def op_flops(op, p):
+        return gemm_flops(p) if op == L.OP_GEMM else (attn_flops(p) if op == L.OP_ATTENTION else 0.0)
+
+    def profile_plan(eng, reps=3, dump=""):
+        """Every recorded launch of `eng`'s plan timed on its own (events on the launch stream, min of `reps`).  Returns
+        (per-family dict, per-launch ms list)."""
         rec, labels = eng.S.recorded, eng.S.labels
         n = len(rec)
-        reps = 3
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(n + 1)] for _ in range(reps)]
         for r in range(reps):
             torch.cuda.synchronize()
@@ -220,23 +230,40 @@ def main():
         ms = [min(ev[r][i].elapsed_time(ev[r][i + 1]) for r in range(reps)) for i in range(n)]
         fam = {}
         for i, (op, p) in enumerate(rec):
-            kind = {L.OP_GEMM: "gemm", L.OP_GN_STATS: "gn_stats", L.OP_GN_APPLY: "gn_apply", L.OP_LAYERNORM: "layernorm",
-                    L.OP_ATTENTION: "attention", L.OP_GN_FUSED: "gn_fused", L.OP_COPY: "copy", L.OP_FF: "ff_fused", L.OP_GN_TABLE: "gn_table"}[op]
-            fl = gemm_flops(p) if op == L.OP_GEMM else (attn_flops(p) if op == L.OP_ATTENTION else 0.0)
-            f = fam.setdefault(kind, dict(ms=0.0, flops=0.0, n=0))
-            f["ms"] += ms[i]; f["flops"] += fl; f["n"] += 1
+            f = fam.setdefault(KIND[op], dict(ms=0.0, flops=0.0, n=0))
+            f["ms"] += ms[i]; f["flops"] += op_flops(op, p); f["n"] += 1
+        if dump:
+            os.makedirs(os.path.dirname(os.path.abspath(dump)), exist_ok=True)
+            with open(dump, "w") as f:
+                f.write("idx\tlabel\tms\tGFLOP\tTFLOP/s\ttile\n")
+                for i, (op, p) in enumerate(rec):
+                    fl = op_flops(op, p)
+                    tile = eng.S.lib.vmv_gemm_pick_tile(ctypes.byref(p)) if op == L.OP_GEMM else ""
+                    f.write(f"{i}\t{labels[i]}\t{ms[i]:.4f}\t{fl / 1e9:.2f}\t{(fl / (ms[i] * 1e-3) / 1e12) if fl else 0:.1f}\t{tile}\n")
+        return fam, ms
+
+    def fam_table(fam):
         tot_ms = sum(f["ms"] for f in fam.values())
+        return {k: dict(ms=round(v["ms"], 3), share=round(v["ms"] / tot_ms, 4), launches=v["n"],
+                        tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None) for k, v in fam.items()}, tot_ms
+
+    roof = None
+    if rank == 0 and not args.no_op_profile:
+        eng = model.engine_for(2, args.frames, H, W, 77, dev, n_t=1, share_prefix=True)     # the plan the timed steps replayed
+        rec = eng.S.recorded
+        fam, _ = profile_plan(eng, dump=args.dump_ops)
+        families, tot_ms = fam_table(fam)
         gm = fam["gemm"]
         ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
         # HBM bytes per launch of the same family from the committed PMC passes of this command (tools/gemm_traffic.py;
         # FETCH_SIZE doubled as the microarch guide prescribes for gfx950) — counters cannot be read from inside the run
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r3_gemm_traffic.json")
-        if (H, W) == (40, 64) and args.frames == 24 and os.path.exists(tpath):
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_gemm_traffic.json") for r in (4, 3)) if os.path.exists(q)), None)
+        if (H, W) == (40, 64) and args.frames == 24 and tpath:
             with open(tpath) as f:
                 tj = json.load(f)
             traffic = round(tj["bytes_per_launch"])
-            traffic_src = (f"profiles/r3_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+            traffic_src = (f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
                            f"separate runs, commit {tj.get('commit', '?')}, dtype {tj.get('dtype', '?')})")
         roof = dict(bound="mfma", kernel="16-bit MFMA implicit-GEMM family (gemm_xglds_kernel / gemm_rs_kernel / gemm_glds_kernel / gemm_pglds_kernel / gemm_kernel: "
                     "conv3x3, temporal conv, linear)",
@@ -244,21 +271,10 @@ def main():
                     traffic=traffic, traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=round(sum(gemm_bytes(p) for op, p in rec if op == L.OP_GEMM) / gm["n"]),
                     launches=gm["n"], avg_launch_us=round(1000.0 * gm["ms"] / gm["n"], 2),
-                    flop_per_launch=gm["flops"] / gm["n"],
-                    families={k: dict(ms=round(v["ms"], 3), share=round(v["ms"] / tot_ms, 4), launches=v["n"],
-                                      tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None)
-                              for k, v in fam.items()},
-                    serial_forward_ms=round(tot_ms, 3))
+                    flop_per_launch=gm["flops"] / gm["n"], families=families, serial_forward_ms=round(tot_ms, 3))
         if step_tflop:
             roof["whole_step"] = dict(algorithmic_tflop=step_tflop, achieved=round(step_tflop * steps_per_s / world, 1),
                                       frac=round(step_tflop * steps_per_s / world / PEAK_MFMA16_TFLOPS, 4))
-        if args.dump_ops:
-            os.makedirs(os.path.dirname(os.path.abspath(args.dump_ops)), exist_ok=True)
-            with open(args.dump_ops, "w") as f:
-                f.write("idx\tlabel\tms\tGFLOP\tTFLOP/s\n")
-                for i, (op, p) in enumerate(rec):
-                    fl = gemm_flops(p) if op == L.OP_GEMM else (attn_flops(p) if op == L.OP_ATTENTION else 0.0)
-                    f.write(f"{i}\t{labels[i]}\t{ms[i]:.4f}\t{fl / 1e9:.2f}\t{(fl / (ms[i] * 1e-3) / 1e12) if fl else 0:.1f}\n")
 
     def headline():
         return {"metric": "denoise-steps/sec, t2v %dx%dx%d (latent %dx%dx%d), CFG 9.0, 50-step DDIM schedule" % (8 * H, 8 * W, args.frames, args.frames, H, W),
@@ -326,8 +342,9 @@ def main():
             os.environ["VMV_FP_PIPELINE"] = "0"
             single = timed_leg("single-plan")
             eng = model.engine_for(2, args.frames, H, W, 77, dev, n_t=1)
-            common = dict(scaling="strong", views_per_gpu=fl, collectives_per_branch_plan=len(eng.breaks),
-                          all_to_all_per_step=sum(1 for i, _ in eng.breaks if eng.S.labels[i].endswith(".unpack")),
+            common = dict(scaling="strong", views_per_gpu=fl, collectives_per_branch_plan=len(eng.breaks) + eng.n_comm_ops,
+                          collectives_issued_by=("C plan replay (VMV_OP_COMM, RCCL)" if eng.n_comm_ops else "Python (torch.distributed) between plan segments"),
+                          all_to_all_per_step=sum(1 for lb in eng.S.labels if lb.endswith(".all_to_all")) + sum(1 for i, _ in eng.breaks if eng.S.labels[i].endswith(".unpack")),
                           parallelism=f"frames x{world} (frame-major <-> pixel-major all-to-all, DESIGN.md §8)")
             state["partial"] = dict(common, mode="single-plan", **single)
             os.environ["VMV_FP_PIPELINE"] = "1"
@@ -487,6 +504,148 @@ def main():
                    finite=bool(torch.isfinite(x0_l).all()))
         del model_l
 
+    # ---- the rasteriser alone on the last refined step's Gaussians (BASELINE configs[4]'s only new kernel family): HBM-bound,
+    #      DESIGN.md §4.4's algorithmic bytes = 48 B per Gaussian (14 fp32 attributes read once, the per-Gaussian screen-space
+    #      record written) + 12 B per (tile, Gaussian) instance (64-bit key + index written; sort passes and blend reads not
+    #      counted) + 16 B per pixel written, per view
+    if lgm is not None and ref_l.last_gaussians is not None:
+        try:
+            gsn = ref_l.last_gaussians.unsqueeze(0).contiguous()
+            cv, cvp = gs_data["cam_view"].to(dev), gs_data["cam_view_proj"].to(dev)
+            ref_l.renderer.render(gsn, cv, cvp, None)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                ref_l.renderer.render(gsn, cv, cvp, None)
+            torch.cuda.synchronize()
+            t_r = (time.perf_counter() - t1) / 3
+            nview, S_out = cv.shape[1], ref_l.renderer.size
+            inst = sum(ref_l.renderer.last_num_rendered)
+            by = nview * (gsn.shape[1] * 48 + S_out * S_out * 16) + inst * 12
+            lgm["rasteriser"] = dict(views=nview, gaussians=int(gsn.shape[1]), instances=int(inst), ms_per_24_views=round(1000 * t_r, 3),
+                                     ms_per_view=round(1000 * t_r / nview, 4), algorithmic_bytes=int(by),
+                                     achieved_gb_s=round(by / t_r / 1e9, 1), peak_gb_s=8000.0, frac=round(by / t_r / 8e12, 4),
+                                     note="wall time of GaussianRenderer.render incl. its one host round trip per view (the instance count); "
+                                          "rocprim radix sort passes are traffic on top of the algorithmic bytes")
+        except Exception as e:
+            lgm["rasteriser"] = {"error": f"{type(e).__name__}: {e}"}
+    if lgm is not None:
+        del ref_l
+
+    # ---- BASELINE configs[3]: the full-size UNetSD_I2VGen (1.422 B parameters: the T2V trunk with an 8-channel input conv + the image
+    #      front-end), 24 views, 77 text + 64 local-image + 4 CLIP-image = 145 context tokens, v-prediction on the cosine /
+    #      zero-terminal-SNR schedule, guide 6 (i2vgen_xl_infer.yaml) — at the config's own 256-px shape (latent 32x32) and at the
+    #      headline's 320x512 (latent 40x64)
+    i2v = None
+    if rank == 0 and world == 1 and not args.no_sample and not args.no_i2vgen:
+        try:
+            import videomv_amd.unet_i2vgen  # noqa: F401
+            with torch.device(dev):
+                m_i = MODEL.build(dict(type="UNetSD_I2VGen", y_dim=1024, concat_dim=4, use_camera_condition=True, use_lgm_refine=False, **FULL))
+            randomize_(m_i, 4242)
+            m_i.eval()
+            dif_v = DIFFUSION.build(dict(type="DiffusionDDIM", schedule="cosine",
+                                         schedule_param=dict(num_timesteps=1000, cosine_s=0.008, zero_terminal_snr=True),
+                                         mean_type="v", var_type="fixed_small"))
+            steps_v = [int(v) for v in dif_v.ddim_steps(50)]
+            gi = torch.Generator(device=dev).manual_seed(9999)          # i2vgen_xl_infer.yaml seed
+            img, img0 = torch.randn(1, 1, 1024, generator=gi, device=dev), torch.zeros(1, 1, 1024, device=dev)
+            fps = torch.tensor([8], device=dev)
+            i2v = dict(workload="i2vgen_xl_infer.yaml UNetSD_I2VGen, 24 views, 145 ctx tokens (77 text + 64 local-image + 4 CLIP-image), "
+                                "v-prediction, cosine schedule with zero terminal SNR, CFG 6.0, cond + uncond batched",
+                       params=int(sum(p_.numel() for p_ in m_i.parameters())), shapes={})
+            for hh, ww in ((32, 32), (H, W)):
+                noise_i = torch.randn(1, 4, args.frames, hh, ww, generator=gi, device=dev)
+                li = torch.randn(1, 4, hh, ww, generator=gi, device=dev).unsqueeze(2).repeat_interleave(args.frames, dim=2)
+                kci = dict(y=y, image=img, local_image=li, fps=fps, camera_data=cam)
+                kui = dict(y=y0, image=img0, local_image=li, fps=fps, camera_data=cam)
+                xi = noise_i.clone()
+                for i in range(max(2, args.warmup)):
+                    dif_v.ddim_step_hip(xi, steps_v[1 + i], m_i, kci, kui, 6.0, stride)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(args.steps):
+                    dif_v.ddim_step_hip(xi, steps_v[(3 + i) % 49 + 1], m_i, kci, kui, 6.0, stride)
+                torch.cuda.synchronize()
+                t_i = (time.perf_counter() - t1) / args.steps
+                r = dict(ms_per_step=round(1000 * t_i, 3), steps_per_s=round(1.0 / t_i, 4), finite=bool(torch.isfinite(xi).all()))
+                tf = STEP_TFLOP.get((hh, ww))
+                if tf:       # (the T2V trunk's algorithmic FLOPs: the 8-channel input conv and the 68 extra context tokens add < 1 %)
+                    r["whole_step"] = dict(algorithmic_tflop=tf, achieved=round(tf / t_i, 1), frac=round(tf / t_i / PEAK_MFMA16_TFLOPS, 4))
+                i2v["shapes"][f"{args.frames}x{hh}x{ww}"] = r
+            del m_i
+            torch.cuda.empty_cache()
+        except Exception as e:
+            i2v = dict(i2v or {}, error=f"{type(e).__name__}: {e}")
+
+    # ---- BASELINE configs[2] on ONE GPU: rank 0's plan of a W-GPU frame-parallel run with the W - 1 peers simulated (comm.SimComm:
+    #      every collective a device-local copy of the same bytes, issued from the C replay loop like the RCCL ones).  GPU ms per
+    #      step = this rank's kernels + local copies (no wire time: the xGMI floor of its bytes is reported beside it); host ms per
+    #      step = the time the Python thread needs to enqueue one step.  NOT a sample (peers' data = this rank's own).
+    simr = None
+    if rank == 0 and world == 1 and args.simulate_rank > 1 and args.frames % args.simulate_rank == 0:
+        Wn = args.simulate_rank
+        try:
+            from videomv_amd.comm import SimComm
+            fl = args.frames // Wn
+            xs0 = noise[:, :, :fl].clone().contiguous()
+            simr = dict(world=Wn, rank=0, views_per_gpu=fl, plain_step_ms_this_box=round(ms_per_step, 3),
+                        note="peers simulated on one GPU: kernels, tiles, local copies and host time are the real rank's; wire time is not included "
+                             "and the output is not a sample", modes={})
+
+            def sim_leg(pipeline, graph):
+                os.environ["VMV_FP_PIPELINE"], os.environ["VMV_GRAPH"] = ("1" if pipeline else "0"), ("1" if graph else "0")
+                model.set_frame_parallel(SimComm(Wn, 0))
+                xs = xs0.clone()
+                for i in range(3):                                   # eager, capture, first graph launch
+                    dif.ddim_step_hip(xs, steps[i % len(steps)], model, kw_c, kw_u, 9.0, stride)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(args.steps):
+                    dif.ddim_step_hip(xs, steps[(3 + i) % len(steps)], model, kw_c, kw_u, 9.0, stride)
+                t_host_all = time.perf_counter() - t1
+                torch.cuda.synchronize()
+                t_all = time.perf_counter() - t1
+                hs = []
+                for i in range(5):                                   # host time of ONE step's enqueue on an idle queue
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    dif.ddim_step_hip(xs, steps[(7 + i) % len(steps)], model, kw_c, kw_u, 9.0, stride)
+                    hs.append(time.perf_counter() - t1)
+                torch.cuda.synchronize()
+                engs = model._pipe["engs"] if (pipeline and model._pipe) else [model.engine_for(2, args.frames, H, W, 77, dev, n_t=1, share_prefix=True)]
+                e0 = engs[0]
+                ncoll = sum(e.n_comm_ops for e in engs)
+                bytes_in = sum(e.comm_bytes_in for e in engs)
+                r = dict(gpu_ms_per_step=round(1000 * t_all / args.steps, 3), host_ms_per_step=round(1000 * sorted(hs)[len(hs) // 2], 3),
+                         host_ms_per_step_queued=round(1000 * t_host_all / args.steps, 3),
+                         launches_per_step=sum(e.S.nops for e in engs), collectives_per_step=ncoll, python_collectives_per_step=sum(len(e.breaks) for e in engs),
+                         bytes_received_per_step=int(bytes_in),
+                         xgmi_floor_ms=round(1000 * bytes_in / (7 * 76.8e9), 3),
+                         graph=bool(graph and all(e.S.graph for e in engs)), graph_nodes=[e.graph_nodes for e in engs] if graph else None,
+                         finite=bool(torch.isfinite(xs).all()))
+                if step_tflop:
+                    r["frac_of_peak_if_all_ranks_equal"] = round(step_tflop / Wn / (t_all / args.steps) / PEAK_MFMA16_TFLOPS, 4)
+                return r, e0
+
+            for tag, pl, gr in (("single-plan", 0, 0), ("single-plan+graph", 0, 1), ("branch-pipelined", 1, 0), ("branch-pipelined+graph", 1, 1)):
+                try:
+                    simr["modes"][tag], e0 = sim_leg(pl, gr)
+                    if tag == "single-plan":          # per-family table of the rank-local B = 2 plan (tile policy at M / W)
+                        fam_s, _ = profile_plan(e0, dump=args.dump_ops_sim)
+                        simr["families_single_plan"], simr["serial_forward_ms"] = fam_table(fam_s)
+                        simr["serial_forward_ms"] = round(simr["serial_forward_ms"], 3)
+                except Exception as e:
+                    simr["modes"][tag] = {"error": f"{type(e).__name__}: {e}"}
+            best = min((v["gpu_ms_per_step"], k) for k, v in simr["modes"].items() if "gpu_ms_per_step" in v)
+            simr["best_mode"], simr["best_gpu_ms_per_step"] = best[1], best[0]
+            simr["projected_speedup_vs_1gpu_no_wire"] = round(ms_per_step / best[0], 2)
+        except Exception as e:
+            simr = dict(simr or {}, error=f"{type(e).__name__}: {e}")
+        finally:
+            os.environ.pop("VMV_FP_PIPELINE", None); os.environ.pop("VMV_GRAPH", None)
+            model.set_frame_parallel(None)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cores = os.cpu_count() or 1
@@ -530,7 +689,8 @@ def main():
 
     if rank == 0:
         out = headline()
-        out.update({"sample_24view": sample, "clip_towers": clip, "lgm_refined_sample": lgm, "frame_parallel": fpar, "cpu_baseline": cpu})
+        out.update({"sample_24view": sample, "clip_towers": clip, "lgm_refined_sample": lgm, "i2vgen": i2v, "frame_parallel": fpar,
+                    "simulated_rank": simr, "cpu_baseline": cpu})
         if alt is not None:
             out["other_dtype"] = alt
         print(json.dumps(out), flush=True)

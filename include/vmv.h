@@ -28,8 +28,9 @@ extern "C" {
 #define VMV_EALIGN       -2   /* pointer or leading dimension not 16-byte aligned */
 #define VMV_ENULL        -3   /* required pointer is NULL */
 #define VMV_ERANGE       -4   /* size outside what the kernel supports */
+#define VMV_ECOMM        -5   /* an RCCL call of vmv_comm_* failed */
 
-#define VMV_ABI_VERSION   7
+#define VMV_ABI_VERSION   8
 int vmv_abi_version(void);
 /* The 16-bit storage / MFMA operand type ("elem") this build of the library computes in.  The same sources are
  * compiled once per type: libvmv_hip_f16.so (VMV_ELEM_F16: IEEE fp16 — the default; the reference's own half mode,
@@ -165,7 +166,7 @@ typedef struct {
                                   split picked by the launcher — the short-K linears of the two large UNet levels */
 #define VMV_TILE_RS512    24   /* the same, forced to 64 rows per wave (512-row blocks; K = 320 only) */
 #define VMV_TILE_RS256    25   /* the same, forced to 32 rows per wave (256-row blocks) */
-#define VMV_TILE_HALO     26   /* halo-resident 3 x 3 convolution for N <= 8 output channels (conv_halo.hip): 8 x 16 pixel tiles, the 10 x 18 halo and
+#define VMV_TILE_HALO     26   /* halo-resident 3 x 3 convolution for N <= 8 output channels (conv_halo.hip): 4 x 16 pixel tiles, the 6 x 18 halo and
                                   the weights in LDS — the VAE / UNet output heads */
 
 int vmv_gemm(const VmvGemmParams* p, void* stream);
@@ -441,6 +442,46 @@ typedef struct {
 int vmv_permute_copy(const VmvCopyParams* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * Collectives of the frame-sharded sampler (SURVEY §8b "vmv_comm_* wrappers, RCCL communicator handle injected
+ * from Python", §8e).  The reference has no counterpart: its multi-GPU mode is replicas (inference_text2video_entrance.py:79,
+ * 152-156).  One process per GPU; the host creates the communicator ONCE — rank 0 draws an id with vmv_comm_unique_id(), ships its
+ * 128 bytes to the other ranks by any means (the Python host broadcasts it over torch.distributed), every rank calls
+ * vmv_comm_create() — and records VMV_OP_COMM ops into its plans, so the 183 collectives of a branch forward are issued from the
+ * C replay loop on the replay's stream (and captured into its hipGraph) instead of from Python between plan segments.
+ * RCCL is resolved at run time: vmv_comm_load(path) dlopen()s the librccl.so the process already uses (path NULL / "" =
+ * "librccl.so" through the loader's search path); libvmv itself does not link against it.
+ *   VMV_COMM_ALL_TO_ALL : send = [world][bytes] (chunk j goes to rank j), recv = [world][bytes] (chunk i came from rank i) — the
+ *                         frame-major <-> pixel-major layout switch;
+ *   VMV_COMM_ALL_GATHER : send = [bytes], recv = [world][bytes] — the GroupNorm totals of the all-frame norms, K | V of the
+ *                         north-star temporal-attention form.
+ * vmv_comm_create_sim(world, rank): a communicator whose W - 1 peers are absent — every collective becomes a device-local copy of
+ * the same byte count (all-to-all: recv = send; all-gather: recv[j] = send for all j), so the rank-local plan of a W-GPU run can be
+ * replayed and timed on ONE GPU (bench.py --simulate-rank).  Its output is not a sample.
+ * ---------------------------------------------------------------------------------------------------- */
+#define VMV_COMM_ALL_TO_ALL 0
+#define VMV_COMM_ALL_GATHER 1
+#define VMV_COMM_ID_BYTES   128
+typedef struct VmvComm VmvComm;
+typedef struct {
+    const VmvComm* comm;
+    int32_t kind;            /* VMV_COMM_*                                                          */
+    int32_t _pad;
+    const void* send;
+    void* recv;
+    int64_t bytes;           /* per-rank chunk, > 0                                                 */
+} VmvCommParams;
+int      vmv_comm_load(const char* rccl_path);
+int      vmv_comm_loaded(void);
+int      vmv_comm_unique_id(void* id128);                               /* rank 0: VMV_COMM_ID_BYTES bytes out */
+VmvComm* vmv_comm_create(const void* id128, int world, int rank);       /* collective over the `world` ranks; NULL on failure */
+VmvComm* vmv_comm_create_sim(int world, int rank);
+void     vmv_comm_destroy(VmvComm* comm);
+int      vmv_comm_world(const VmvComm* comm);
+int      vmv_comm_rank(const VmvComm* comm);
+int      vmv_comm_is_sim(const VmvComm* comm);
+int      vmv_comm_run(const VmvCommParams* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
  * Plan: a recorded sequence of the launches above, replayed with one call (host-side launch overhead of
  * >1000 kernels per forward would otherwise dominate).
  * ---------------------------------------------------------------------------------------------------- */
@@ -455,6 +496,7 @@ typedef struct VmvPlan VmvPlan;
 #define VMV_OP_GN_FUSED    8   /* args: VmvGroupNormParams with chunk_rows = cols of vmv_groupnorm_fused */
 #define VMV_OP_FF          9   /* args: VmvFfParams */
 #define VMV_OP_GN_TABLE    10  /* args: VmvGroupNormParams, y = the fp32 table (vmv_groupnorm_table) */
+#define VMV_OP_COMM        11  /* args: VmvCommParams — a collective of the frame-sharded sampler, issued on the replay's stream */
 VmvPlan* vmv_plan_create(void);
 void     vmv_plan_destroy(VmvPlan* plan);
 int      vmv_plan_add(VmvPlan* plan, int op, const void* params, size_t nbytes);
@@ -462,6 +504,16 @@ int      vmv_plan_size(const VmvPlan* plan);
 int      vmv_plan_run(const VmvPlan* plan, void* stream);
 /* run ops [first, last) only — used by tests and profiling */
 int      vmv_plan_run_range(const VmvPlan* plan, int first, int last, void* stream);
+/* The plan as a hipGraph: vmv_plan_capture() records ONE replay of the whole plan on `stream` in stream-capture mode and
+ * instantiates it (nothing executes; every launcher takes the stream explicitly and allocates nothing, so all of them — the RCCL
+ * collectives of VMV_OP_COMM included — are capturable); vmv_graph_launch() enqueues the instantiated graph: one host call and one
+ * submission per forward instead of ~800 launches.  Run the plan once eagerly first (kernels set their LDS-size attribute on first
+ * use).  The argument blocks are baked in: re-capture after editing the plan.  Returns NULL / an error code on failure. */
+typedef struct VmvGraph VmvGraph;
+VmvGraph* vmv_plan_capture(const VmvPlan* plan, void* stream);
+int       vmv_graph_launch(const VmvGraph* graph, void* stream);
+int       vmv_graph_nodes(const VmvGraph* graph);
+void      vmv_graph_destroy(VmvGraph* graph);
 
 #ifdef __cplusplus
 }

@@ -271,6 +271,20 @@ def ff_fused(p: L.FfParams):
     _rows(p.out, M, p.ldo)[:, :Cc] = acc.to(L.elem())
 
 
+def comm_sim(p: L.CommParams):
+    """VMV_OP_COMM on a SIMULATED communicator (vmv_comm_create_sim: the only kind a CPU test can hold): all-to-all recv = send,
+    all-gather recv[j] = send for every j."""
+    lib = L.load()
+    assert lib.vmv_comm_is_sim(p.comm) == 1
+    W, n = lib.vmv_comm_world(p.comm), int(p.bytes)
+    src = torch.from_numpy(np.ctypeslib.as_array((C.c_uint8 * (n * (W if p.kind == L.COMM_ALL_TO_ALL else 1))).from_address(p.send)))
+    dst = torch.from_numpy(np.ctypeslib.as_array((C.c_uint8 * (n * W)).from_address(p.recv)))
+    if p.kind == L.COMM_ALL_TO_ALL:
+        dst.copy_(src)
+    else:
+        dst.view(W, n).copy_(src.view(1, n).expand(W, n))
+
+
 def run_recorded(recorded):
     for op, params in recorded:
         if op == L.OP_GEMM:
@@ -293,6 +307,8 @@ def run_recorded(recorded):
             ff_fused(params)
         elif op == L.OP_GN_TABLE:
             groupnorm_table(params)
+        elif op == L.OP_COMM:
+            comm_sim(params)
         else:
             raise ValueError(op)
 
@@ -437,7 +453,7 @@ def install(monkeypatch):
         self.lib = L.load()      # symbols only; nothing is launched
         self.record = record
         self.plan = None
-        self.keep, self.nops, self.labels, self.recorded = [], 0, [], []
+        self.keep, self.nops, self.labels, self.recorded, self.graph = [], 0, [], [], None
 
     from videomv_amd import gs as _gs
 

@@ -447,3 +447,72 @@ def test_kv_all_gather_temporal_mode(world):
         assert sw["e"] < 3e-2 and kv["e"] < 3e-2, r
         assert kv["packs"] > 0 and sw["packs"] == 0
         assert kv["a2a"] == sw["a2a"] - kv["packs"] and kv["ag"] == sw["ag"] + kv["packs"], r      # 2 switches -> 2 gathers per block
+
+
+def test_simulated_rank_plan_records_its_collectives(monkeypatch):
+    """comm.SimComm (vmv_comm_create_sim): rank 0's plan of a 4-GPU frame-parallel run built in ONE process.  The collectives are
+    plan ops (VMV_OP_COMM) — no Python break points — with the same count and per-rank byte sizes as the gloo plans' break points
+    (2 layout switches per temporal block + one totals gather per all-frame GroupNorm), the plan replays through the interpreter
+    (sim semantics: recv = this rank's own bytes) to finite values, and the branch-pipelined sampler path runs on it.  With every
+    rank holding the SAME frames and a pixel-periodic image the simulated exchange IS the real one — but zero-padded convolutions
+    break pixel periodicity, so exactness is only asserted at world 1 (where sim == real == identity)."""
+    from tests import plan_interp
+    plan_interp.install(monkeypatch)
+    import ctypes as C
+    from oracle.unet_ref import UNetCfg
+    from oracle.weights import random_state_dict, unet_param_shapes
+    from videomv_amd import _lib as L
+    from videomv_amd.comm import SimComm
+    from videomv_amd.unet_engine import UNetEngine
+    from videomv_amd.registry import MODEL, DIFFUSION
+    import videomv_amd  # noqa: F401
+    ocfg = UNetCfg(**{k: v for k, v in CFG.items() if k in {f.name for f in dataclasses.fields(UNetCfg)}})
+    sd = random_state_dict(unet_param_shapes(ocfg), 99)
+    B, F_, H, W, Lc, R = 2, 4, 8, 8, 5, 4
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 4, F_, H, W, generator=g)
+    t = torch.tensor([501])
+    y = torch.randn(B, Lc, 1024, generator=g)
+    cam = torch.randn(1, F_, 16, generator=g)
+    dev = torch.device("cpu")
+    sc = SimComm(R, 0)
+    lib = L.load()
+    assert lib.vmv_comm_world(sc.handle) == R and lib.vmv_comm_rank(sc.handle) == 0 and lib.vmv_comm_is_sim(sc.handle) == 1
+    eng = UNetEngine(CFG, sd, B, F_, H, W, Lc, dev, n_t=1, comm=sc)
+    assert eng.F == 1 and not eng.breaks                                   # nothing left for Python to issue
+    comm_ops = [(lb, p) for lb, (op, p) in zip(eng.S.labels, eng.S.recorded) if op == L.OP_COMM]
+    n_a2a = sum(1 for lb, p in comm_ops if p.kind == L.COMM_ALL_TO_ALL)
+    n_ag = sum(1 for lb, p in comm_ops if p.kind == L.COMM_ALL_GATHER)
+    blocks = [k for blk in eng.inp + [eng.mid] + eng.outb for k, _, _ in blk]
+    n_res, n_tt = blocks.count("res"), blocks.count("tt")                   # (tiny net: 8 ResBlocks, 8 TemporalTransformers)
+    assert n_a2a == 2 * (n_res + n_tt) and n_ag == 4 * n_res + n_tt and eng.n_comm_ops == n_a2a + n_ag
+    for lb, p in comm_ops:
+        assert p.comm == sc.handle and p.bytes > 0 and p.bytes % 16 == 0, lb
+        if p.kind == L.COMM_ALL_GATHER:
+            assert p.bytes == B * 2048 * 8                                  # B stat groups x GN_TOT int64
+    # first layout switch: the [B][1 frame][64 pixels][64 ch] shard in 4 chunks
+    first = next(p for lb, p in comm_ops if p.kind == L.COMM_ALL_TO_ALL)
+    assert first.bytes == B * 1 * (H * W // R) * 64 * 2
+    assert eng.comm_bytes_in == sum(p.bytes * (R - 1) for _, p in comm_ops)
+    eng.set_context(y); eng.set_camera(cam)
+    eng.forward_rows(x[:, :, :1].contiguous(), t)
+    assert torch.isfinite(eng.eps_ncfhw()).all()
+    # world 1: the simulated collectives are the identity, and so are the real ones -> the sharded plan equals the plain plan
+    ref = UNetEngine(CFG, sd, B, F_, H, W, Lc, dev, n_t=1)
+    ref.set_context(y); ref.set_camera(cam); ref.forward_rows(x, t)
+    one = UNetEngine(CFG, sd, B, F_, H, W, Lc, dev, n_t=1, comm=SimComm(1, 0))
+    one.set_context(y); one.set_camera(cam); one.forward_rows(x, t)
+    assert one.n_comm_ops == n_a2a + n_ag and rel_l2(one.eps_ncfhw(), ref.eps_ncfhw()) < 3e-2
+    # the sampler on the simulated rank (branch-pipelined: two B = 1 plans)
+    m = MODEL.build(dict(type="UNetSD_T2VBase", **{k: v for k, v in CFG.items()}))
+    m.load_state_dict(sd, strict=False)
+    m.set_frame_parallel(sc)
+    dif = DIFFUSION.build(dict(type="DiffusionDDIM", schedule="linear_sd",
+                               schedule_param=dict(num_timesteps=1000, init_beta=0.00085, last_beta=0.0120),
+                               mean_type="eps", var_type="fixed_small"))
+    xt = x[:, :, :1].clone().contiguous()
+    dif.ddim_step_hip(xt, 501, m, dict(y=y[:1], camera_data=cam), dict(y=y[1:], camera_data=cam), 9.0, 500)
+    assert torch.isfinite(xt).all()
+    pe = m._pipe["engs"]
+    assert len(pe) == 2 and all(not e.breaks and e.n_comm_ops == n_a2a + n_ag for e in pe)
+    assert pe[0].comm.handle != pe[1].comm.handle                            # a communicator per branch stream

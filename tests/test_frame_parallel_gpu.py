@@ -158,3 +158,87 @@ def test_two_ranks_one_gpu_host_staged_collectives(F_, H, W):
         assert r["e_oracle"] < 3e-2, r
         assert abs(r["e_oracle"] - r["e_single_oracle"]) < 5e-3, r
         assert r["e_single"] < 3e-2, r
+
+
+def _rccl_world1_worker(port, q):
+    """Child process: an RCCL group of ONE rank (the only RCCL configuration a 1-GPU box can run), VMV_COMM_FORCE=1 so that the
+    collectives are issued although world == 1.  The communicator then holds a VmvComm handle (comm.native_comm: unique id from
+    rank 0, broadcast over torch.distributed, ncclCommInitRank inside libvmv), the plan carries its collectives as VMV_OP_COMM and
+    one C call replays it; the same plan captured into a hipGraph must give the same bits."""
+    try:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        os.environ["VMV_COMM_FORCE"], os.environ["VMV_GN_FUSED"] = "1", "0"
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        from videomv_amd import _lib as L
+        from videomv_amd.comm import FrameComm
+        from videomv_amd.unet_engine import UNetEngine
+        ocfg, sd, x, t, y, cam = _case(4, 16, 16)
+        out = {}
+        ref = UNetEngine(CFG, sd, 2, 4, 16, 16, y.shape[1], dev, n_t=1)
+        ref.set_context(y.to(dev)); ref.set_camera(cam.to(dev)); ref.forward_rows(x.to(dev), t.to(dev))
+        eps_ref = ref.eps_ncfhw().cpu()
+        comm = FrameComm()
+        out["handle"] = bool(comm.handle)
+        eng = UNetEngine(CFG, sd, 2, 4, 16, 16, y.shape[1], dev, n_t=1, comm=comm)
+        out["breaks"], out["comm_ops"] = len(eng.breaks), eng.n_comm_ops
+        eng.set_context(y.to(dev)); eng.set_camera(cam.to(dev)); eng.forward_rows(x.to(dev), t.to(dev))
+        torch.cuda.synchronize()
+        eps_c = eng.eps_ncfhw().cpu()
+        out["bitwise_vs_unsharded"] = bool(torch.equal(eps_c, eps_ref))
+        out["err"] = rel_l2(eps_c, eps_ref)
+        # the same plan as a hipGraph (RCCL collectives captured with the kernels)
+        try:
+            out["graph_nodes"] = eng.S.capture_graph()
+            eng.eps_rows.zero_()
+            eng.forward_rows(x.to(dev), t.to(dev))
+            torch.cuda.synchronize()
+            out["graph_bitwise"] = bool(torch.equal(eng.eps_ncfhw().cpu(), eps_c))
+        except Exception as e:
+            out["graph_error"] = f"{type(e).__name__}: {e}"
+        q.put(out)
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put(dict(error=traceback.format_exc()))
+
+
+def test_rccl_collectives_inside_the_plan_world1():
+    """vmv_comm_* (SURVEY §8b last row): the frame-parallel plan with its collectives issued by the C replay loop through RCCL."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1_worker, args=(_free_port(), q))
+    p.start()
+    r = q.get(timeout=420)
+    p.join(timeout=60)
+    assert "error" not in r, r["error"]
+    assert r["handle"] and r["breaks"] == 0 and r["comm_ops"] > 30, r
+    assert r["bitwise_vs_unsharded"], r                      # identity permutations + the rank's own totals: same bits (same GroupNorm form)
+    assert r.get("graph_bitwise"), r                         # RCCL collectives captured into the hipGraph with the kernels
+    print("RCCL world-1 plan:", r)
+
+
+def test_simulated_rank_and_graph_replay_on_the_gpu(monkeypatch):
+    """comm.SimComm on the GPU: rank 0 of an 8-GPU run of a 24-view sample (3 views, HW / 8 pixels) — collectives recorded into the
+    plan as device-local copies — replayed eagerly and as a hipGraph: identical bits, finite values; and the plain (unsharded) plan
+    as a hipGraph equals its eager replay."""
+    from videomv_amd.comm import SimComm
+    from videomv_amd.unet_engine import UNetEngine
+    ocfg, sd, x, t, y, cam = _case(24, 16, 16)
+    dev = torch.device("cuda", 0)
+    for comm, xs in ((None, x), (SimComm(8, 0), x[:, :, :3].contiguous())):
+        eng = UNetEngine(CFG, sd, 2, 24, 16, 16, y.shape[1], dev, n_t=1, comm=comm)
+        eng.set_context(y.to(dev)); eng.set_camera(cam.to(dev))
+        eng.forward_rows(xs.to(dev), t.to(dev))
+        torch.cuda.synchronize()
+        e1 = eng.eps_ncfhw().clone()
+        assert torch.isfinite(e1).all()
+        if comm is not None:
+            assert eng.F == 3 and not eng.breaks and eng.n_comm_ops > 30
+        nodes = eng.S.capture_graph()
+        assert nodes >= eng.S.nops                     # every launch a node (RCCL-free plans: exactly one kernel node per op)
+        eng.eps_rows.zero_()
+        eng.forward_rows(xs.to(dev), t.to(dev))
+        torch.cuda.synchronize()
+        assert torch.equal(eng.eps_ncfhw(), e1)

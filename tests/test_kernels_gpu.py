@@ -1176,3 +1176,45 @@ def test_lgm_render_to_vae_matches_interpolate(S_in, S):
     torch.cuda.synchronize()
     ref = (torch.nn.functional.interpolate(img, size=(S, S), mode="nearest") - 0.5) / 0.5
     assert torch.allclose(out.cpu(), ref, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------- fp16 stores saturate
+@pytest.mark.skipif(BF != torch.float16, reason="bf16 has fp32's exponent range: nothing to saturate")
+@pytest.mark.parametrize("tile,M,N,K", [(L.TILE_64x64, 128, 64, 64), (L.TILE_128x128, 256, 128, 128), (L.TILE_256x160, 512, 320, 320),
+                                        (L.TILE_G128x160, 512, 320, 320), (L.TILE_P256x160, 66000, 320, 320), (L.TILE_X256x320, 1024, 320, 320),
+                                        (L.TILE_RS, 70000, 320, 320)])
+def test_fp16_stores_saturate(tile, M, N, K):
+    """a finite fp32 result beyond the fp16 range must be STORED as +-65504, not +-inf (csrc/common.h: the MODE.FP16_OVFL
+    bit set at kernel entry).  x = +-256, w = 8 over K >= 64 -> |acc| >= 131072 > 65504; one row stays in range (exact)."""
+    sign = torch.where(torch.arange(M) % 2 == 0, 1.0, -1.0)[:, None]
+    a = (256.0 * sign).expand(M, K).clone().to(BF)
+    a[5] = 2.0 ** -8                                              # row 5 stays in range: 2^-8 * 8 * K = K / 32, exact in fp16
+    w = torch.full((N, K), 8.0, dtype=BF)
+    out = torch.zeros(M, N, dtype=BF, device="cuda")
+    S = ops.Stream(record=False)
+    S.gemm(ops.gemm_params(M, N, ops.linear_segs([(a.cuda(), K, K)]), w.cuda(), out, N, tile=tile), "sat")
+    torch.cuda.synchronize()
+    o = out.float().cpu()
+    assert torch.isfinite(o).all()
+    keep = torch.ones(M, dtype=torch.bool); keep[5] = False
+    assert torch.equal(o[keep], (65504.0 * sign).expand(M, N)[keep])
+    assert torch.equal(o[5], torch.full((N,), float(a[5, 0]) * 8.0 * K))
+
+
+@pytest.mark.skipif(BF != torch.float16, reason="bf16 has fp32's exponent range: nothing to saturate")
+def test_fp16_norm_and_glue_stores_saturate_and_keep_infinities():
+    """The same store rule outside the GEMMs: LayerNorm with a huge gamma saturates; a true infinity in the INPUT still comes out
+    non-finite (saturation must not hide a broken forward from the finite check)."""
+    rows, Cc = 64, 320
+    x = torch.randn(rows, Cc, generator=g(1)).to(BF).cuda()
+    y = torch.zeros(rows, Cc, dtype=BF, device="cuda")
+    gam, bet = torch.full((Cc,), 1e6).cuda(), torch.zeros(Cc).cuda()
+    S = ops.Stream(record=False)
+    S.layernorm(ops.ln_params(x, Cc, y, Cc, gam, bet, rows, Cc, 1e-5), "sat.ln")
+    torch.cuda.synchronize()
+    o = y.float().cpu()
+    assert torch.isfinite(o).all() and float(o.abs().max()) == 65504.0 and float((o.abs() == 65504.0).float().mean()) > 0.9
+    x[3, 7] = float("inf")
+    S.layernorm(ops.ln_params(x, Cc, y, Cc, torch.ones(Cc).cuda(), bet, rows, Cc, 1e-5), "inf.ln")
+    torch.cuda.synchronize()
+    assert not torch.isfinite(y[3].float()).all()

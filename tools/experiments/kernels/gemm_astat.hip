@@ -74,6 +74,7 @@ VMV_DEV void wait_vmcnt_n(int n) {
 
 template <int WN, int KC, bool GEGLU, int ablate = 0>
 __global__ __launch_bounds__(512) void gemm_astat_kernel(const VmvGemmParams p, const int npanels, const int ntn) {
+    VMV_KERNEL_ENTER();
     using Cfg = AsCfg<WN, KC>;
     constexpr int NW = Cfg::NW, WM = Cfg::WM, BN = Cfg::BN;
     static_assert(!GEGLU || (WN % 2) == 0, "GEGLU pairs x / gate column tiles");

@@ -60,6 +60,7 @@ template <int N> VMV_DEV void wait_vm() {
 
 template <int WM, int WN, bool DBG>
 __global__ __launch_bounds__(768, 3) void gemm_sglds_kernel(const VmvGemmParams p, const int tiles_n_, const int total_steps_, const int nitems_, const int fast_) {
+    VMV_KERNEL_ENTER();
     // (kernel arguments are uniform, but once the segment table is indexed inside the loader's nested loops the compiler
     //  stops believing it and spills "divergent" loop bounds: pin them to SGPRs)
     const int tiles_n = __builtin_amdgcn_readfirstlane(tiles_n_);

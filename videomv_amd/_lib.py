@@ -51,7 +51,9 @@ TILE_S256x128, TILE_S192x160, TILE_S256x160 = 15, 16, 17
 TILE_A128x160, TILE_A128x128 = 18, 19
 TILE_X256x320, TILE_X256x256, TILE_X256x128 = 20, 21, 22
 TILE_RS, TILE_RS512, TILE_RS256, TILE_HALO = 23, 24, 25, 26
-OP_GEMM, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTENTION, OP_SOFTMAX, OP_COPY, OP_GN_FUSED, OP_FF, OP_GN_TABLE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+OP_GEMM, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTENTION, OP_SOFTMAX, OP_COPY, OP_GN_FUSED, OP_FF, OP_GN_TABLE, OP_COMM = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
+COMM_ALL_TO_ALL, COMM_ALL_GATHER, COMM_ID_BYTES = 0, 1, 128
+ABI_VERSION = 8
 GN_FUSED_BYTES = 131072
 
 
@@ -105,6 +107,11 @@ class GsParams(C.Structure):
 class CopyParams(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("n0", C.c_int32), ("n1", C.c_int32), ("n2", C.c_int32),
                 ("inner16", C.c_int32), ("ss0", C.c_int64), ("ss1", C.c_int64), ("ss2", C.c_int64)]
+
+
+class CommParams(C.Structure):
+    _fields_ = [("comm", C.c_void_p), ("kind", C.c_int32), ("_pad", C.c_int32), ("send", C.c_void_p), ("recv", C.c_void_p),
+                ("bytes", C.c_int64)]
 
 
 class LayerNormParams(C.Structure):
@@ -182,6 +189,20 @@ SYMBOLS = {
     "vmv_plan_size": (C.c_int, [_P]),
     "vmv_plan_run": (C.c_int, [_P, _P]),
     "vmv_plan_run_range": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "vmv_plan_capture": (_P, [_P, _P]),
+    "vmv_graph_launch": (C.c_int, [_P, _P]),
+    "vmv_graph_nodes": (C.c_int, [_P]),
+    "vmv_graph_destroy": (None, [_P]),
+    "vmv_comm_load": (C.c_int, [C.c_char_p]),
+    "vmv_comm_loaded": (C.c_int, []),
+    "vmv_comm_unique_id": (C.c_int, [_P]),
+    "vmv_comm_create": (_P, [_P, C.c_int, C.c_int]),
+    "vmv_comm_create_sim": (_P, [C.c_int, C.c_int]),
+    "vmv_comm_destroy": (None, [_P]),
+    "vmv_comm_world": (C.c_int, [_P]),
+    "vmv_comm_rank": (C.c_int, [_P]),
+    "vmv_comm_is_sim": (C.c_int, [_P]),
+    "vmv_comm_run": (C.c_int, [C.POINTER(CommParams), _P]),
 }
 
 _lib = None
@@ -202,12 +223,12 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the ABI drifted
         fn.restype = res
         fn.argtypes = args
-    if lib.vmv_abi_version() != 7:
+    if lib.vmv_abi_version() != ABI_VERSION:
         raise RuntimeError(f"{LIB_PATH}: ABI version mismatch")
     if lib.vmv_elem_type() != (ELEM_F16 if _elem == "f16" else ELEM_BF16):
         raise RuntimeError(f"{LIB_PATH} was built for another element type")
     for which, st in ((OP_GEMM, GemmParams), (OP_GN_STATS, GroupNormParams), (OP_LAYERNORM, LayerNormParams),
-                      (OP_ATTENTION, AttnParams), (OP_SOFTMAX, SoftmaxParams), (OP_COPY, CopyParams), (103, GsParams), (100, DdimParams), (101, GemmSeg), (102, SeqMap)):
+                      (OP_ATTENTION, AttnParams), (OP_SOFTMAX, SoftmaxParams), (OP_COPY, CopyParams), (OP_FF, FfParams), (OP_COMM, CommParams), (103, GsParams), (100, DdimParams), (101, GemmSeg), (102, SeqMap)):
         if lib.vmv_sizeof(which) != C.sizeof(st):
             raise RuntimeError(f"struct layout drift for {st.__name__}: C {lib.vmv_sizeof(which)} vs ctypes "
                                f"{C.sizeof(st)}")

@@ -10,10 +10,46 @@
 With a "gloo" group the same calls work on CPU tensors (the world_size-2 CPU tests) and, for device tensors, stage
 through host memory — a debugging aid that lets two processes share one GPU; it is never the fast path.
 """
+import ctypes as C
 import os
 
 import torch
 import torch.distributed as dist
+
+
+def _rccl_path() -> str:
+    """The librccl this process already uses (PyTorch ships its own copy): libvmv must talk to THAT instance, not to a second
+    copy from /opt/rocm.  Found in the process's memory map, else next to torch's libraries, else left to the loader."""
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "librccl" in line:
+                    return line.split()[-1]
+    except OSError:
+        pass
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return cand if os.path.exists(cand) else ""
+
+
+def native_comm(group, device):
+    """A VmvComm* over the ranks of `group` (include/vmv.h vmv_comm_*): rank 0 draws the RCCL id, torch.distributed carries its 128
+    bytes to the others, every rank joins.  Collective: all ranks of the group call it at the same point."""
+    from . import _lib as L
+    lib = L.load()
+    L.check(lib.vmv_comm_load(_rccl_path().encode()), "vmv_comm_load")
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    idb = (C.c_uint8 * L.COMM_ID_BYTES)()
+    if rank == 0:
+        L.check(lib.vmv_comm_unique_id(idb), "vmv_comm_unique_id")
+    t = torch.tensor(list(idb), dtype=torch.uint8, device=device)
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    dist.broadcast(t, src=src, group=group)
+    idb = (C.c_uint8 * L.COMM_ID_BYTES)(*[int(v) for v in t.cpu()])
+    with torch.cuda.device(device):
+        h = lib.vmv_comm_create(idb, world, rank)
+    if not h:
+        raise L.VmvError("vmv_comm_create failed (ncclCommInitRank)")
+    return h
 
 
 class FrameComm:
@@ -29,6 +65,26 @@ class FrameComm:
         self.n_all_to_all = 0
         self.n_all_gather = 0
         self._twin = None
+        # handle (VmvComm*): with RCCL underneath the collectives are recorded INTO the plans (VMV_OP_COMM) and issued by the C
+        # replay loop on the replay's stream — one host call per forward instead of one Python collective per plan segment
+        # (DESIGN.md §8).  VMV_COMM_NATIVE=0 keeps the torch.distributed calls (the gloo path always does).
+        self.handle = None
+        if self.backend == "nccl" and not self.local_only and os.environ.get("VMV_COMM_NATIVE", "1") != "0" and torch.cuda.is_available():
+            try:
+                self.handle = native_comm(group, torch.device("cuda", torch.cuda.current_device()))
+            except Exception as e:          # (the torch.distributed path below needs nothing from libvmv: keep going on it)
+                import warnings
+                warnings.warn(f"vmv_comm_* unavailable ({type(e).__name__}: {e}); collectives stay in Python")
+                self.handle = None
+
+    def __del__(self):
+        try:
+            if self.handle:
+                from . import _lib as L
+                L.load().vmv_comm_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
 
     def twin(self) -> "FrameComm":
         """A second communicator over the same ranks (its own process group, so that its collectives can be in flight on
@@ -65,6 +121,48 @@ class FrameComm:
             out.copy_(o)
         else:
             dist.all_gather_into_tensor(out, inp, group=self.group)
+
+
+class SimComm:
+    """Rank `rank` of a `world`-GPU frame-parallel run with the other W - 1 ranks ABSENT (include/vmv.h vmv_comm_create_sim): every
+    collective is a device-local copy of the bytes the real one would deliver, recorded into the plan like the RCCL ones.  Lets ONE
+    GPU build, replay, time and profile the rank-local plan of BASELINE configs[2] (3 of 24 views, HW / 8 pixels per temporal block):
+    launch sequence, tile choices, local HBM traffic and host time are the real rank's; the OUTPUT is not a sample (peers' data is
+    this rank's own) and the wire time is absent — bench.py --simulate-rank reports both facts next to the numbers."""
+
+    def __init__(self, world: int, rank: int = 0):
+        from . import _lib as L
+        self.world, self.rank = int(world), int(rank)
+        self.backend, self.local_only, self.group = "sim", False, None
+        self.n_all_to_all = self.n_all_gather = 0
+        self._twin = None
+        self.handle = L.load().vmv_comm_create_sim(self.world, self.rank)
+        if not self.handle:
+            raise ValueError(f"bad simulated communicator {rank}/{world}")
+
+    def __del__(self):
+        try:
+            if self.handle:
+                from . import _lib as L
+                L.load().vmv_comm_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def twin(self) -> "SimComm":
+        if self._twin is None:
+            self._twin = SimComm(self.world, self.rank)
+            self._twin._twin = self
+        return self._twin
+
+    # (eager forms, for callers outside a plan: gather_frames at the end of a sample)
+    def all_to_all(self, out, inp):
+        self.n_all_to_all += 1
+        out.copy_(inp)
+
+    def all_gather(self, out, inp):
+        self.n_all_gather += 1
+        out.view(self.world, -1).copy_(inp.view(1, -1).expand(self.world, -1))
 
 
 class CfgFrameComm:

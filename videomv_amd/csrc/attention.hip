@@ -44,6 +44,7 @@ constexpr float NEG_BIG = -1.0e30f;
 // CAUSAL: keys j > query i masked out (own instantiation: the test costs <4, 4, 64> two spilled registers)
 template <int WPP, int QT, int D = 64, bool CAUSAL = false>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, const int nproblems) {
+    VMV_KERNEL_ENTER();
     static_assert(D == 64 || ((D == 32 || D == 128) && WPP == 4), "head_dim 64, or 32 / 128 on the 4-waves-per-problem variant");
     constexpr int KK = D / 32, DT = D / 16, SLOTS = D / 8, SLOG = (D == 128) ? 4 : (D == 64) ? 3 : 2;
     constexpr int KBYTES = (D == 128) ? 16384 : 8192, STAGE = 2 * KBYTES;       // staged K tile (then the V tile) / one stage
@@ -427,6 +428,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, con
 //   * the stage is private to the wave: no block barrier anywhere.
 // Same transposed formulation and key permutation as attn_kernel (header of this file).
 __global__ __launch_bounds__(256, 4) void attn_short_kernel(const VmvAttnParams p, const int nproblems) {
+    VMV_KERNEL_ENTER();
     __shared__ __attribute__((aligned(16))) unsigned char smem_s[4 * 4096];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -560,10 +562,14 @@ extern "C" int vmv_attention(const VmvAttnParams* pp, void* stream) {
     const VmvAttnParams& p = *pp;
     if (!p.q || !p.k || !p.v || !p.o) return VMV_ENULL;
     if (p.n_outer <= 0 || p.heads <= 0 || p.Nq <= 0 || p.Nk <= 0 || p.kv_div <= 0) return VMV_EINVAL;
-    {   // the kernels index the rows of one problem with 32-bit element offsets
+    {   // the kernels index the rows of one problem with 32-bit element offsets; the 4-waves-per-problem kernels issue K / V DMA
+        // offsets for the whole last 64-row tile (rows >= Nk must land OUTSIDE the descriptor, i.e. must not wrap), and a row is
+        // head_dim elements wide: validate the PADDED counts with the actual head_dim
         const long lim = 1L << 30;
-        if ((long)(p.Nq - 1) * p.qm.s_row + 64 >= lim || (long)(p.Nq - 1) * p.om.s_row + 64 >= lim || (long)(p.Nk - 1) * p.km.s_row + 64 >= lim ||
-            (long)(p.Nk - 1) * p.vm.s_row + 64 >= lim || p.qm.s_row < 0 || p.km.s_row < 0 || p.vm.s_row < 0 || p.om.s_row < 0) return VMV_ERANGE;
+        const long hdw = p.head_dim ? p.head_dim : 64;
+        const long nq_pad = ((long)p.Nq + 255) / 256 * 256, nk_pad = ((long)p.Nk + 63) / 64 * 64;
+        if ((nq_pad - 1) * p.qm.s_row + hdw >= lim || (nq_pad - 1) * p.om.s_row + hdw >= lim || (nk_pad - 1) * p.km.s_row + hdw >= lim ||
+            (nk_pad - 1) * p.vm.s_row + hdw >= lim || p.qm.s_row < 0 || p.km.s_row < 0 || p.vm.s_row < 0 || p.om.s_row < 0) return VMV_ERANGE;
     }
     if (!map_ok(p.qm) || !map_ok(p.km) || !map_ok(p.vm) || !map_ok(p.om)) return VMV_EALIGN;
     if ((p.qm.s_row & 7) || (p.km.s_row & 7) || (p.vm.s_row & 7)) return VMV_EALIGN;

@@ -46,7 +46,31 @@ VMV_DEV float elem_lo(uint32_t w) { return (float)__builtin_bit_cast(elem2_t, w)
 VMV_DEV float elem_hi(uint32_t w) { return (float)__builtin_bit_cast(elem2_t, w).y; }
 VMV_DEV float elem_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
 #endif
+// ---- fp16 stores SATURATE ("fp16 epilogues do not saturate; the only guard is a post-hoc finite check").  A finite fp32
+// value beyond +-65504 becomes +-65504 in the 16-bit store instead of +-inf (true infinities and NaNs are preserved, so a genuinely
+// broken forward still trips the finite check); bf16 has fp32's exponent range and needs nothing.  Two implementations, same result
+// (tests/test_kernels_gpu.py::test_fp16_stores_saturate; tools/experiments/f16_ovfl_probe.hip shows the hardware honouring both):
+//   VMV_F16_SAT = 1 (default): the wave's MODE.FP16_OVFL bit, set by the first instruction of every kernel (VMV_KERNEL_ENTER) —
+//                 "an overflowed FP16 result is clamped to +-MAX_FP16 regardless of round mode, while still preserving true INF
+//                 values" — which covers every v_cvt_pk_f16_f32 / v_cvt_f16_f32 of the kernel at zero cost per store;
+//   VMV_F16_SAT = 2: a v_med3_f32 clamp per converted value in pack_elem2 (two more VALU operations per stored pair; the GEGLU
+//                 epilogues are VALU-issue-bound — only if a future part drops the mode bit);   VMV_F16_SAT = 0: round-3 behaviour.
+#ifndef VMV_F16_SAT
+#define VMV_F16_SAT 1
+#endif
+#if !defined(VMV_BUILD_BF16) && VMV_F16_SAT == 1
+#define VMV_KERNEL_ENTER() asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1")
+#else
+#define VMV_KERNEL_ENTER() ((void)0)
+#endif
 VMV_DEV uint32_t pack_elem2(float lo, float hi) {
+#if !defined(VMV_BUILD_BF16) && VMV_F16_SAT == 2
+    // (infinities pass: med3(-65504, inf, 65504) would clamp them, so they are kept apart by the compare-free trick of clamping only
+    //  finite values — v_med3 of a NaN returns the NaN-free median, hence the explicit class test)
+    const float lo_c = __builtin_fminf(__builtin_fmaxf(lo, -65504.f), 65504.f), hi_c = __builtin_fminf(__builtin_fmaxf(hi, -65504.f), 65504.f);
+    lo = (__builtin_isinf(lo) || lo != lo) ? lo : lo_c;
+    hi = (__builtin_isinf(hi) || hi != hi) ? hi : hi_c;
+#endif
     const f32x2_t f = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, elem2_t));
 }

@@ -35,6 +35,7 @@ constexpr int ch_w_bytes(int Nr) { return 9 * (CH_CMAX / 32) * Nr * 4 * 16; }   
 static_assert(CH_TH == 8 || CH_TH == 4, "tile height");
 
 __global__ __launch_bounds__(256) void conv_halo_kernel(const VmvGemmParams p, const int C, const int tiles_x, const int tiles_y) {
+    VMV_KERNEL_ENTER();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

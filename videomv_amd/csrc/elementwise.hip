@@ -7,6 +7,7 @@ namespace {
 
 __global__ void latent_to_rows_kernel(const float* __restrict__ x, uint16_t* __restrict__ rows, int nb, int C, int F,
                                       long HW, int Cpad, int nrep) {
+    VMV_KERNEL_ENTER();
     // one thread per (b, f, pixel): gathers C strided floats, writes Cpad bf16 contiguous
     const long per = (long)nb * F * HW;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x) {
@@ -26,6 +27,7 @@ __global__ void latent_to_rows_kernel(const float* __restrict__ x, uint16_t* __r
 
 __global__ void latent_to_rows_keep_kernel(const float* __restrict__ x, uint16_t* __restrict__ rows, int nb, int C, int F,
                                            long HW, int ld, int nrep) {
+    VMV_KERNEL_ENTER();
     const long per = (long)nb * F * HW;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x) {
         const long pix = i % HW;
@@ -42,6 +44,7 @@ __global__ void latent_to_rows_keep_kernel(const float* __restrict__ x, uint16_t
 __global__ void lgm_x0_views_kernel(const float* __restrict__ eps, int ld, int branch, const float* __restrict__ xt, int C,
                                     int F, long HW, int i0, int i1, int i2, int i3, float cr, float crm1, float inv_scale,
                                     float* __restrict__ out) {
+    VMV_KERNEL_ENTER();
     const long total = 4L * C * HW;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long pix = i % HW;
@@ -55,6 +58,7 @@ __global__ void lgm_x0_views_kernel(const float* __restrict__ eps, int ld, int b
 
 __global__ void lgm_pack_input_kernel(const float* __restrict__ dec, const float* __restrict__ rays, float* __restrict__ out,
                                       int nviews, long HW) {
+    VMV_KERNEL_ENTER();
     const long total = (long)nviews * 9 * HW;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long pix = i % HW;
@@ -73,6 +77,7 @@ __global__ void lgm_pack_input_kernel(const float* __restrict__ dec, const float
 
 // nearest resampling as F.interpolate(mode='nearest') does it: source index = floor(dst * in / out)
 __global__ void lgm_render_to_vae_kernel(const float* __restrict__ img, float* __restrict__ out, int nviews, int S_in, int S) {
+    VMV_KERNEL_ENTER();
     const long total = (long)nviews * 3 * S * S;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int x = (int)(i % S), y = (int)((i / S) % S);
@@ -84,6 +89,7 @@ __global__ void lgm_render_to_vae_kernel(const float* __restrict__ img, float* _
 
 __global__ void ddim_x0_step_kernel(const float* __restrict__ xc, const float* __restrict__ xu, float* __restrict__ xt, long n,
                                     float guide, float cr, float crm1, float a_prev) {
+    VMV_KERNEL_ENTER();
     const float sa = sqrtf(a_prev), sb = sqrtf(1.0f - a_prev);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float x0 = xu[i] + guide * (xc[i] - xu[i]);
@@ -96,6 +102,7 @@ __global__ void ddim_x0_step_kernel(const float* __restrict__ xc, const float* _
 // thread, then a tree over the block) -> workspace[block][4].  Pass 2: every block folds the <= 256 partials in the same
 // order, then applies the activations to its rows.
 __global__ __launch_bounds__(256) void gauss_rot_sumsq_kernel(const float* __restrict__ raw, int ld, int n, float* __restrict__ ws) {
+    VMV_KERNEL_ENTER();
     __shared__ float sh[4][256];
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -118,6 +125,7 @@ __global__ __launch_bounds__(256) void gauss_rot_sumsq_kernel(const float* __res
 
 __global__ __launch_bounds__(256) void gauss_activation_kernel(const float* __restrict__ raw, int ld, float* __restrict__ out,
                                                                int n, const float* __restrict__ ws, int nparts) {
+    VMV_KERNEL_ENTER();
     __shared__ float inv[4];
     if (threadIdx.x < 4) {
         float t = 0.f;
@@ -143,6 +151,7 @@ __global__ __launch_bounds__(256) void gauss_activation_kernel(const float* __re
 // dst (contiguous [n0][n1][n2][inner16] of 16-byte vectors) <- src with per-axis strides: both sides move whole
 // channel rows, so every lane does 16-byte loads and stores and consecutive lanes touch consecutive vectors.
 __global__ __launch_bounds__(256) void permute_copy_kernel(const VmvCopyParams p, const long total) {
+    VMV_KERNEL_ENTER();
     const u32x4_t* __restrict__ src = reinterpret_cast<const u32x4_t*>(p.src);
     u32x4_t* __restrict__ dst = reinterpret_cast<u32x4_t*>(p.dst);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -161,6 +170,7 @@ __global__ __launch_bounds__(256) void i2v_temporal_adapter_kernel(const uint16_
                                                                    uint16_t* __restrict__ out, int ld_out,
                                                                    const float* __restrict__ w, int F, int HW, int nrep,
                                                                    float scale) {
+    VMV_KERNEL_ENTER();
     const int lane = threadIdx.x & 63;
     const int pix = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pix >= HW) return;
@@ -249,6 +259,7 @@ __global__ __launch_bounds__(256) void i2v_temporal_adapter_kernel(const uint16_
 
 __global__ void adaptive_avgpool_rows_kernel(const uint16_t* __restrict__ in, int ld, uint16_t* __restrict__ out, int ldo,
                                              int n, int C, int IH, int IW, int OH, int OW) {
+    VMV_KERNEL_ENTER();
     const long total = (long)n * OH * OW * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
@@ -268,6 +279,7 @@ __global__ void adaptive_avgpool_rows_kernel(const uint16_t* __restrict__ in, in
 
 __global__ void rows_to_nchw_kernel(const void* __restrict__ rows, int rows_fp32, int ld, float* __restrict__ out, long n,
                                     int C, long HW) {
+    VMV_KERNEL_ENTER();
     const long total = n * C * HW;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long pix = i % HW;
@@ -282,6 +294,7 @@ __global__ void rows_to_nchw_kernel(const void* __restrict__ rows, int rows_fp32
 
 // xt layout [C][F][HW] (batch 1, the reference's noise shape [1,4,F,h,w]); eps rows [2][F*HW][ld].
 __global__ void cfg_ddim_kernel(const VmvDdimParams p) {
+    VMV_KERNEL_ENTER();
     const long FHW = (long)p.F * p.HW;
     const long total = (long)p.C * FHW;
     const float sqrt_aprev = sqrtf(p.a_prev);
@@ -304,6 +317,7 @@ __global__ void cfg_ddim_kernel(const VmvDdimParams p) {
 
 __global__ void posterior_sample_kernel(const float* __restrict__ mom, int ld, const float* __restrict__ noise,
                                         float* __restrict__ z, long n, int zc, long HW, float scale) {
+    VMV_KERNEL_ENTER();
     const long total = n * zc * HW;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long pix = i % HW;
@@ -318,6 +332,7 @@ __global__ void posterior_sample_kernel(const float* __restrict__ mom, int ld, c
 
 __global__ void emb_combine_kernel(const float* __restrict__ temb, const float* __restrict__ cam, uint16_t* __restrict__ out,
                                    int rows, int C, int rows_per_t, int cam_rows) {
+    VMV_KERNEL_ENTER();
     const long total = (long)rows * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int r = (int)(i / C), c = (int)(i % C);
@@ -328,6 +343,7 @@ __global__ void emb_combine_kernel(const float* __restrict__ temb, const float* 
 }
 
 __global__ void sinusoidal_kernel(const float* __restrict__ t, uint16_t* __restrict__ out, int n, int dim) {
+    VMV_KERNEL_ENTER();
     const int half = dim >> 1;
     const int total = n * dim;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {

@@ -54,6 +54,7 @@ struct GemmCfg {
 template <int WM, int WN>
 __global__ __launch_bounds__(256) void gemm_kernel(const VmvGemmParams p, const int tiles_m, const int tiles_n,
                                                    const int total_steps, const int steps_per_split) {
+    VMV_KERNEL_ENTER();
     using Cfg = GemmCfg<WM, WN>;
     constexpr int BM = Cfg::BM, BN = Cfg::BN;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -238,6 +239,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const VmvGemmParams p, const 
 
 // split-K second pass: sum the fp32 slabs in a fixed order (deterministic) and run the epilogue.
 __global__ __launch_bounds__(256) void gemm_splitk_reduce(const VmvGemmParams p) {
+    VMV_KERNEL_ENTER();
     const int geglu = p.epilogue == VMV_EPI_GEGLU;
     const int nq = geglu ? (p.N / 32) * 4 : p.N / 4;       // work items per row
     const long total = (long)p.M * nq;

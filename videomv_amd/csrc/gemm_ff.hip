@@ -60,6 +60,7 @@ VMV_DEV u32x4_t ff_swap16_xz_yw(u32x4_t v) {         // (gemm_rs.hip: padded v_p
 }
 
 __global__ __launch_bounds__(512, 1) void ff_fused_kernel(const VmvFfParams p) {
+    VMV_KERNEL_ENTER();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -292,8 +293,8 @@ extern "C" int vmv_ff_fused(const VmvFfParams* pp, void* stream) {
     if (!p.x || !p.w1 || !p.w2 || !p.out) return VMV_ENULL;
     if (p.C != FF_C || p.M <= 0) return VMV_EINVAL;
     if (!vmv_ff_fused_ok(pp)) return VMV_EALIGN;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
-    if (e != hipSuccess) return (int)e;
+    static std::atomic<unsigned long long> attr{0};
+    if (const int rc_attr = vmv_lds_attr_once(attr, reinterpret_cast<const void*>(&ff_fused_kernel), FF_LDS)) return rc_attr;
     hipLaunchKernelGGL(ff_fused_kernel, dim3((p.M + 127) / 128), dim3(512), FF_LDS, reinterpret_cast<hipStream_t>(stream), p);
     return vmv_launch_status();
 }

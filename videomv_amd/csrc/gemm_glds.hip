@@ -24,6 +24,7 @@ namespace {
 template <int WMW, int WN, int STAGES, int ablate, bool PP = false>
 __global__ __launch_bounds__(128 * WMW, WMW == 2 ? 2 : 1) void gemm_glds_kernel(const VmvGemmParams p, const int tiles_m, const int tiles_n,
                                                               const int total_steps, const int steps_per_split) {
+    VMV_KERNEL_ENTER();
     // ablate (experiments only, VMV_GEMM_ABLATE): 1 = skip the MFMAs + fragment reads, 2 = skip the LDS-DMA loads
     using Cfg = GlCfg<WMW, WN, STAGES>;
     constexpr int WM = 4;                         // 16-row MFMA tiles per wave along M (wave tile = 64 rows)

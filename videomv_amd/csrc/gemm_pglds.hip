@@ -53,6 +53,7 @@ struct PgCfg {
 template <int NWM, int WM, int WN, int ablate, bool IL, bool LNS = false>
 __global__ __launch_bounds__(128 * NWM, NWM == 4 ? 1 : 2) void gemm_pglds_kernel(const VmvGemmParams p, const int tiles_n, const int total_steps,
                                                          const int nitems, const int panel_order) {
+    VMV_KERNEL_ENTER();
     using Cfg = PgCfg<NWM, WM, WN>;
     constexpr int BN = Cfg::BN;
     constexpr int BM = Cfg::BM;

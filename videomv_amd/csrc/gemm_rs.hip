@@ -75,6 +75,7 @@ constexpr int RS_GEGLU = 1, RS_LN = 2, RS_RES = 4, RS_GN = 8;
 
 template <int RT, int KS, int MODE>
 __global__ __launch_bounds__(512, 1) void gemm_rs_kernel(const VmvGemmParams p, const int tiles_m, const int nsplit, const int cols_per_split) {
+    VMV_KERNEL_ENTER();
     using Cfg = RsCfg<RT, KS>;
     constexpr bool GEGLU = (MODE & RS_GEGLU) != 0, LN = (MODE & RS_LN) != 0, RES = (MODE & RS_RES) != 0, GN = (MODE & RS_GN) != 0;
     constexpr int RB = Cfg::RB, G = Cfg::G, P = Cfg::PIECES;
@@ -498,8 +499,8 @@ template <int RT, int KS, int MODE>
 int launch_rs(const VmvGemmParams& p, const RsPlan& pl, hipStream_t st) {
     using Cfg = RsCfg<RT, KS>;
     const int tiles_m = (p.M + Cfg::BM - 1) / Cfg::BM;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rs_kernel<RT, KS, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
+    static std::atomic<unsigned long long> attr{0};      // one per template instantiation; set once per (kernel, device)
+    if (const int rc_attr = vmv_lds_attr_once(attr, reinterpret_cast<const void*>(&gemm_rs_kernel<RT, KS, MODE>), Cfg::LDS_BYTES)) return rc_attr;
     hipLaunchKernelGGL((gemm_rs_kernel<RT, KS, MODE>), dim3(tiles_m * pl.nsplit), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, pl.nsplit, pl.cols);
     return vmv_launch_status();
 }

@@ -59,6 +59,7 @@ struct WRow {        // gather state of one A row of the lane beyond its index m
 
 template <int NH, int WH>
 __global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams p, const int tiles_m, const int tiles_n, const int nsteps) {
+    VMV_KERNEL_ENTER();
     using Cfg = WgCfg<NH, WH>;
     constexpr int WM = Cfg::WM, WN = Cfg::WN, NW = Cfg::NW, BM = Cfg::BM, BN = Cfg::BN, S = Cfg::STAGES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

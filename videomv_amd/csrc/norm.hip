@@ -35,6 +35,7 @@ VMV_DEV float gn_pilot(const VmvGroupNormParams& p, long row, int c) {          
 }
 
 __global__ __launch_bounds__(256) void gn_stats_kernel(const VmvGroupNormParams p, const int nchunk) {
+    VMV_KERNEL_ENTER();
     extern __shared__ __attribute__((aligned(16))) float sh[];
     const int C = p.C0 + p.C1;
     const int CS = C >> 3;                       // 16-byte column slots per row
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const VmvGroupNormParams 
 // table != nullptr (vmv_groupnorm_table, grid = (1, nstat)): the block writes its scale / shift tables there and stops.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const VmvGroupNormParams p, const int nchunk,
                                                        const int apply_rows, const int nstat, float* const table) {
+    VMV_KERNEL_ENTER();
     extern __shared__ __attribute__((aligned(16))) float sh[];
     const int C = p.C0 + p.C1;
     const int CS = C >> 3;
@@ -269,6 +271,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const VmvGroupNormParams 
 // + apply — at the small levels those are ~5-9 us of launch latency each for < 10 us of work.  Statistics are two-pass
 // (the data is on chip): mean first, then the squared deviations.  Fixed reduction order: bitwise reproducible.
 __global__ __launch_bounds__(256) void gn_fused_kernel(const VmvGroupNormParams p, const int CW) {
+    VMV_KERNEL_ENTER();
     extern __shared__ __attribute__((aligned(16))) float sh[];
     const int C = p.C0 + p.C1;
     const int cpg = C >> 5;
@@ -405,6 +408,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const VmvGroupNormParams 
 constexpr int LN_MAX_IT = 5;   // C <= 5 * 64 * 8 = 2560
 template <int LPR>
 __global__ __launch_bounds__(256) void layernorm_kernel(const VmvLayerNormParams p) {
+    VMV_KERNEL_ENTER();
     constexpr int RPW = 64 / LPR;                        // rows per wave
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPR;
@@ -466,6 +470,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const VmvLayerNormParams
 // ------------------------------------------------------------------------------------------------ row softmax
 // One wave per row (4 rows per block); three passes over an L2-resident fp32 row (max, sum of exp2, write bf16).
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const VmvSoftmaxParams p) {
+    VMV_KERNEL_ENTER();
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.rows) return;

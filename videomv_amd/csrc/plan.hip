@@ -24,6 +24,7 @@ int run_op(const VmvPlan::Op& o, void* stream) {
         case VMV_OP_COPY: return vmv_permute_copy(reinterpret_cast<const VmvCopyParams*>(o.args.data()), stream);
         case VMV_OP_FF: return vmv_ff_fused(reinterpret_cast<const VmvFfParams*>(o.args.data()), stream);
         case VMV_OP_GN_TABLE: return vmv_groupnorm_table(reinterpret_cast<const VmvGroupNormParams*>(o.args.data()), stream);
+        case VMV_OP_COMM: return vmv_comm_run(reinterpret_cast<const VmvCommParams*>(o.args.data()), stream);
         case VMV_OP_GN_FUSED: {
             const VmvGroupNormParams* g = reinterpret_cast<const VmvGroupNormParams*>(o.args.data());
             return vmv_groupnorm_fused(g, g->chunk_rows, stream);
@@ -40,6 +41,7 @@ size_t op_size(int op) {
         case VMV_OP_SOFTMAX: return sizeof(VmvSoftmaxParams);
         case VMV_OP_COPY: return sizeof(VmvCopyParams);
         case VMV_OP_FF: return sizeof(VmvFfParams);
+        case VMV_OP_COMM: return sizeof(VmvCommParams);
         default: return 0;
     }
 }
@@ -64,6 +66,7 @@ extern "C" const char* vmv_error_string(int code) {
         case VMV_EALIGN: return "VMV_EALIGN: pointer or leading dimension not suitably aligned";
         case VMV_ENULL: return "VMV_ENULL: required pointer is NULL";
         case VMV_ERANGE: return "VMV_ERANGE: size outside what the kernel supports";
+        case VMV_ECOMM: return "VMV_ECOMM: an RCCL call failed (vmv_comm_*)";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown vmv error";
     }
 }
@@ -94,4 +97,39 @@ extern "C" int vmv_plan_run_range(const VmvPlan* plan, int first, int last, void
 extern "C" int vmv_plan_run(const VmvPlan* plan, void* stream) {
     if (!plan) return VMV_ENULL;
     return vmv_plan_run_range(plan, 0, (int)plan->ops.size(), stream);
+}
+
+// ---- the plan as a hipGraph (vmv.h): one capture of a whole replay, instantiated once, launched per forward
+struct VmvGraph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int nodes = 0;
+};
+extern "C" VmvGraph* vmv_plan_capture(const VmvPlan* plan, void* stream) {
+    if (!plan || plan->ops.empty()) return nullptr;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    VmvGraph* g = new (std::nothrow) VmvGraph();
+    if (!g) return nullptr;
+    // thread-local mode: other host threads (a watchdog, the data loader of a serving process) may keep making HIP calls
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { delete g; return nullptr; }
+    int rc = VMV_OK;
+    for (size_t i = 0; i < plan->ops.size() && rc == VMV_OK; ++i) rc = run_op(plan->ops[i], stream);
+    const hipError_t e = hipStreamEndCapture(s, &g->graph);          // (always ends the capture, also after a failed launch)
+    if (rc != VMV_OK || e != hipSuccess || !g->graph) { vmv_graph_destroy(g); return nullptr; }
+    size_t n = 0;
+    if (hipGraphGetNodes(g->graph, nullptr, &n) == hipSuccess) g->nodes = (int)n;
+    if (hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0) != hipSuccess) { vmv_graph_destroy(g); return nullptr; }
+    return g;
+}
+extern "C" int vmv_graph_launch(const VmvGraph* g, void* stream) {
+    if (!g || !g->exec) return VMV_ENULL;
+    const hipError_t e = hipGraphLaunch(g->exec, reinterpret_cast<hipStream_t>(stream));
+    return e == hipSuccess ? VMV_OK : (int)e;
+}
+extern "C" int vmv_graph_nodes(const VmvGraph* g) { return g ? g->nodes : VMV_ENULL; }
+extern "C" void vmv_graph_destroy(VmvGraph* g) {
+    if (!g) return;
+    if (g->exec) hipGraphExecDestroy(g->exec);
+    if (g->graph) hipGraphDestroy(g->graph);
+    delete g;
 }

@@ -105,6 +105,17 @@ class DiffusionDDIM(object):
                           x0_out=x0_out, **self.step_scalars(int(step), stride))
         return xt
 
+    def _same_gs_data(self, ga, gb) -> bool:
+        """Do the two CFG branches render the same views?  torch.equal on device tensors is a device-to-host sync, so the answer is
+        memoised on the tensors' identity + in-place version (strong references held): once per sample, not once per refined step."""
+        keys = ("input", "cam_view", "cam_view_proj")
+        memo_key = tuple((id(d[k]), d[k]._version) for d in (ga, gb) for k in keys)
+        memo = getattr(self, "_gs_same_memo", None)
+        if memo is None or memo[0] != memo_key:
+            same = all(ga[k] is gb[k] or (ga[k].shape == gb[k].shape and bool(torch.equal(ga[k], gb[k]))) for k in keys)
+            self._gs_same_memo = memo = (memo_key, same, tuple(d[k] for d in (ga, gb) for k in keys))
+        return memo[1]
+
     @torch.no_grad()
     def ddim_step_lgm(self, xt, step, unet, cond_kwargs, uncond_kwargs, guide_scale, stride, autoencoder):
         """One LGM-refined step: each CFG branch's eps goes through predicted x0 -> 4 decoded views -> LGM Gaussians ->
@@ -117,7 +128,7 @@ class DiffusionDDIM(object):
         # predicted x0 of each branch: eps form (unet_t2v.py:405) or v form (unet_i2vgen.py:441-442), following the MODEL
         ca, cb = (k["c_sqrt_ac"], k["c_sqrt_1mac"]) if getattr(unet, "lgm_vpred", False) else (k["c_recip"], k["c_recipm1"])
         ga, gb = cond_kwargs["gs_data"], uncond_kwargs["gs_data"]
-        same_views = ga is gb or all(ga[k] is gb[k] or torch.equal(ga[k], gb[k]) for k in ("input", "cam_view", "cam_view_proj"))
+        same_views = ga is gb or self._same_gs_data(ga, gb)
         if same_views and ref.pair_supported():           # both branches through every stage together (one camera set)
             z = ref.latent_z_pair(eps_rows, eng.out_pad, xt, ca, cb, autoencoder, dict(ga))
         else:

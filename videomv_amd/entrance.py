@@ -24,7 +24,7 @@ from .config import default_cfg, merge_into, assign_signle_cfg, AttrDict
 from .registry import INFER_ENGINE, MODEL, EMBEDDER, AUTO_ENCODER, DIFFUSION
 from .camera import entrance_camera_data
 from .pipeline import sample_views
-from .dist import rank_seed
+from .dist import rank_seed, shard_prompts
 from . import embedder as _embedder  # noqa: F401  (registers the embedders)
 
 
@@ -120,6 +120,10 @@ def worker(gpu, cfg, cfg_update):
 
     with open(cfg.test_list_path, 'r') as f:
         test_list = [ln.strip() for ln in f.readlines()]
+    # `shard_prompts: True` (not a reference key): rank r takes prompts r, r + W, ... instead of every rank running the whole list
+    # with seed + rank (the reference's behaviour, :152-156, and the default)
+    if not fpar:
+        test_list = shard_prompts(test_list, cfg.rank, max(1, int(cfg.get('world_size', 1))), replicate=not cfg.get('shard_prompts', False))
     F = int(cfg.num_views or cfg.max_frames)
     lat_h, lat_w = int(cfg.resolution[1] / cfg.scale), int(cfg.resolution[0] / cfg.scale)
     outputs = []

@@ -419,6 +419,7 @@ class LgmRefiner:
         self.z8 = None
         self.inp = torch.zeros(opt.num_frames, 9, S, S, dtype=torch.float32, device=device)
         self.inp2 = None
+        self.last_gaussians = None
 
     def pair_supported(self) -> bool:
         hd_ok = all((c // self.opt.num_heads) in (32, 64) for c, a in
@@ -451,6 +452,7 @@ class LgmRefiner:
         for br in range(2):
             ops.lgm_pack_input(decoded[br * V:(br + 1) * V], rays, self.inp2[br * V:(br + 1) * V])
         gaussians = self._engine2.forward_gaussians(self.inp2).view(2, -1, 14)
+        self.last_gaussians = gaussians[0]          # (profiling handle: bench.py times the rasteriser alone on these)
         bg = torch.full((3,), self.bg_color, dtype=torch.float32, device=self.device)
         cv, cvp = gs_data["cam_view"].to(self.device), gs_data["cam_view_proj"].to(self.device)
         if h != w:
@@ -481,6 +483,7 @@ class LgmRefiner:
         rays = gs_data["input"][0, idxs].to(self.device, torch.float32).contiguous()
         ops.lgm_pack_input(decoded.contiguous(), rays, self.inp)
         gaussians = self.engine.forward_gaussians(self.inp)
+        self.last_gaussians = gaussians
         bg = torch.full((3,), self.bg_color, dtype=torch.float32, device=self.device)   # LGM.infer bg_color_factor
         out = self.renderer.render(gaussians.unsqueeze(0), gs_data["cam_view"].to(self.device), gs_data["cam_view_proj"].to(self.device),
                                    None, bg_color=bg)

@@ -201,6 +201,14 @@ def copy_params(src, dst, n0, n1, n2, inner16, ss0, ss1, ss2=0) -> L.CopyParams:
     return p
 
 
+def comm_params(comm_handle, kind, send, recv, nbytes) -> L.CommParams:
+    """One collective of the frame-sharded sampler as a plan op (vmv.h VMV_OP_COMM): `comm_handle` = VmvComm* from comm.py
+    (RCCL or simulated), `nbytes` = the per-rank chunk."""
+    p = L.CommParams()
+    p.comm, p.kind, p.send, p.recv, p.bytes = comm_handle, int(kind), _ptr(send), _ptr(recv), int(nbytes)
+    return p
+
+
 def _stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -216,9 +224,13 @@ class Stream:
         self.nops = 0
         self.labels = []        # label per recorded op (profiling / debugging)
         self.recorded = []      # (op code, params struct) mirror of the C plan (debugging / tests)
+        self.graph = None       # VmvGraph*: the whole plan captured as a hipGraph (capture_graph())
 
     def __del__(self):
         try:
+            if self.graph:
+                self.lib.vmv_graph_destroy(self.graph)
+                self.graph = None
             if self.plan:
                 self.lib.vmv_plan_destroy(self.plan)
                 self.plan = None
@@ -269,6 +281,9 @@ class Stream:
     def ff(self, params, label="ff"):
         self._go(L.OP_FF, params, self.lib.vmv_ff_fused, label)
 
+    def comm(self, params, label="comm"):
+        self._go(L.OP_COMM, params, self.lib.vmv_comm_run, label)
+
     def layernorm(self, params, label="ln"):
         self._go(L.OP_LAYERNORM, params, self.lib.vmv_layernorm, label)
 
@@ -278,10 +293,37 @@ class Stream:
     def softmax(self, params, label="softmax"):
         self._go(L.OP_SOFTMAX, params, self.lib.vmv_softmax_rows, label)
 
+    def capture_graph(self):
+        """Capture ONE replay of the whole plan into a hipGraph (vmv_plan_capture); run() then launches the graph.  The plan must
+        have run eagerly once before (first-use kernel attributes).  The legacy default stream cannot be captured: when that is
+        torch's current stream the graph lives on a side stream of its own, fenced against the current stream at every launch."""
+        assert self.record and self.nops
+        if self.graph:
+            self.lib.vmv_graph_destroy(self.graph)
+            self.graph = None
+        cur = torch.cuda.current_stream()
+        self._gstream = torch.cuda.Stream(device=cur.device) if cur.cuda_stream == 0 else None
+        if self._gstream is not None:
+            self._gstream.wait_stream(cur)
+        g = self.lib.vmv_plan_capture(self.plan, C.c_void_p((self._gstream or cur).cuda_stream))
+        if not g:
+            raise L.VmvError("vmv_plan_capture failed")
+        self.graph = g
+        return self.lib.vmv_graph_nodes(g)
+
     def run(self, first=0, last=None):
-        """Replay the recorded plan on the current torch stream."""
+        """Replay the recorded plan on the current torch stream (as ONE graph launch after capture_graph())."""
         assert self.record
-        if last is None:
+        if last is None and first == 0 and self.graph:
+            gs = getattr(self, "_gstream", None)
+            if gs is None:
+                L.check(self.lib.vmv_graph_launch(self.graph, _stream_ptr()), "graph_launch")
+            else:
+                cur = torch.cuda.current_stream()
+                gs.wait_stream(cur)
+                L.check(self.lib.vmv_graph_launch(self.graph, C.c_void_p(gs.cuda_stream)), "graph_launch")
+                cur.wait_stream(gs)
+        elif last is None:
             L.check(self.lib.vmv_plan_run(self.plan, _stream_ptr()), "plan_run")
         else:
             L.check(self.lib.vmv_plan_run_range(self.plan, first, last, _stream_ptr()), "plan_run_range")

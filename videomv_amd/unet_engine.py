@@ -215,7 +215,8 @@ class UNetEngine:
         self.cfg, self.B, self.F, self.H, self.W, self.L = cfg, B, F, H, W, L_ctx
         self.B_ctx = B               # number of context (text) branches; self.B drops to 1 while a shared prefix is recorded
         self.device = device
-        self.breaks = []            # (op index, callable): collectives issued before that recorded op
+        self.breaks = []            # (op index, callable): collectives issued by Python before that recorded op (no VmvComm handle)
+        self.n_comm_ops, self.comm_bytes_in = 0, 0   # collectives recorded INTO the plan (VMV_OP_COMM); bytes received from peers per replay
         self.pool = Pool(device)
         self.S = ops.Stream(record=True)
         self.Sctx = ops.Stream(record=True)      # step-invariant launches: K / V of the text context (run by context_updated())
@@ -225,10 +226,11 @@ class UNetEngine:
         # pre-folded statistics of the all-frame norms: [nstat][32][2] per rank (+ the gathered [R][nstat][32][2]), tickets
         # two buffers used alternately by consecutive all-frame norms (the apply pass of one clears the other's)
         # (records of ops.GN_REC int64 per (stat group, channel group): two-limb sums of x - pilot, sums of squares, the pilot)
-        self._gn_tot2 = torch.zeros(2, 64 * ops.GN_TOT, dtype=torch.int64, device=device)
-        self._gn_zero = torch.zeros(2, 64 * ops.GN_TOT, dtype=torch.int64, device=device)   # source of the plan's own clearing copy
+        # (every all-frame norm of an engine has nstat = B stat groups — one per branch: B x GN_TOT int64 per buffer)
+        self._gn_tot2 = torch.zeros(2, B * ops.GN_TOT, dtype=torch.int64, device=device)
+        self._gn_zero = torch.zeros(2, B * ops.GN_TOT, dtype=torch.int64, device=device)   # source of the plan's own clearing copy
         self._gn_tot_k = 0
-        self._gn_tot_all = torch.zeros(64 * ops.GN_TOT * self.R, dtype=torch.int64, device=device) if comm is not None else None
+        self._gn_tot_all = torch.zeros(B * ops.GN_TOT * self.R, dtype=torch.int64, device=device) if comm is not None else None
         self.taps = taps            # optional dict: prefix -> Act (buffers are then never recycled)
         self.n_t = n_t
         self.dim = cfg["dim"]
@@ -250,6 +252,7 @@ class UNetEngine:
         # VMV_FP_TEMPORAL (frame-parallel plans): "switch" (default) = the TemporalTransformer runs on the pixel-major shard between two
         # all-to-all layout switches; "kv_gather" = BASELINE's north-star form — frames stay sharded, ONE all-gather of [K | V] before
         # each temporal attention (B = 1 plans, i.e. the branch-pipelined / CFG-parallel modes; 16x the bytes of the switches)
+        self.use_graph, self._replays, self.graph_nodes = os.environ.get("VMV_GRAPH", "0") == "1", 0, 0
         self.fp_temporal = os.environ.get("VMV_FP_TEMPORAL", "switch")
         if self.fp_temporal not in ("switch", "kv_gather"):
             raise ValueError("VMV_FP_TEMPORAL must be 'switch' or 'kv_gather'")
@@ -444,7 +447,7 @@ class UNetEngine:
             self.S.groupnorm_fused(ops.gn_params(*args, **base), fused, label)
             return y
         # all-frame norm: up to 256 chunks per stat group -> a one-block fold after the stats folds them once (pre-folded totals)
-        assert nstat <= 64
+        assert nstat <= self.B_ctx
         tot, nxt = self._gn_tot2[self._gn_tot_k & 1], self._gn_tot2[(self._gn_tot_k + 1) & 1]
         self._gn_tot_k += 1
         clr = dict(totals_clear=nxt, clear_count=nstat * ops.GN_TOT)      # (every all-frame norm of an engine has nstat = B)
@@ -453,7 +456,7 @@ class UNetEngine:
             return y
         self.S.groupnorm_stats(ops.gn_params(*args, totals=tot, **base), label)
         loc, allr = tot[: nstat * ops.GN_TOT], self._gn_tot_all[: nstat * ops.GN_TOT * self.R]
-        self._break(lambda: self.comm.all_gather(allr, loc))
+        self._collective(L.COMM_ALL_GATHER, allr, loc, label + ".totals.gather")
         self.S.groupnorm_apply(ops.gn_params(*args, totals=self._gn_tot_all, fold_ranks=self.R, **clr, **base), label)
         return y
 
@@ -478,7 +481,7 @@ class UNetEngine:
         args = (x.ptr, Cc, Cc, T, rps, self._gnws, self.w[f"{p}.norm.weight"], self.w[f"{p}.norm.bias"], 1e-6, False, tab.ptr, Cc)
         assert ops.gn_partial_floats(T, rps, Cc) <= self._gnws.numel()
         if all_frames:          # long stat groups: integer totals (as _gn)
-            assert nstat <= 64
+            assert nstat <= self.B_ctx
             tot, nxt = self._gn_tot2[self._gn_tot_k & 1], self._gn_tot2[(self._gn_tot_k + 1) & 1]
             self._gn_tot_k += 1
             gnp = ops.gn_params(*args, totals=tot, totals_clear=nxt, clear_count=nstat * ops.GN_TOT)
@@ -493,6 +496,22 @@ class UNetEngine:
     # ------------------------------------------------------------------ frame-parallel layout switches
     def _break(self, fn):
         self.breaks.append((self.S.nops, fn))
+
+    def _collective(self, kind, recv_t: torch.Tensor, send_t: torch.Tensor, label: str):
+        """One collective of the frame-sharded plan.  With a VmvComm handle under the communicator (RCCL, or the simulated peers of
+        bench.py --simulate-rank) it is RECORDED as a plan op and issued by the C replay loop on the replay's stream; otherwise (gloo
+        on CPU, host-staged debugging, VMV_COMM_NATIVE=0) the plan is cut here and Python issues it between two segments."""
+        h = getattr(self.comm, "handle", None)
+        if h:
+            nb = send_t.numel() * send_t.element_size()
+            per_rank = nb // self.R if kind == L.COMM_ALL_TO_ALL else nb
+            self.n_comm_ops += 1
+            self.comm_bytes_in += per_rank * (self.R - 1)        # bytes this rank RECEIVES from its R - 1 peers (= what it sends them)
+            self.S.comm(ops.comm_params(h, kind, send_t.data_ptr(), recv_t.data_ptr(), per_rank), label)
+        elif kind == L.COMM_ALL_TO_ALL:
+            self._break(lambda: self.comm.all_to_all(recv_t, send_t))
+        else:
+            self._break(lambda: self.comm.all_gather(recv_t, send_t))
 
     def _switch(self, x: Act, hw: int, to_pixel: bool, release_in: bool = True) -> Act:
         """frame-major shard [B][F/R][HW][C]  <->  pixel-major shard [B][F][HW/R][C]: pack -> all-to-all -> unpack.
@@ -523,7 +542,7 @@ class UNetEngine:
                 self.release(x)
         recv = self.act(T, Cc)
         st, rt = send.tensor().view(R, -1), recv.tensor().view(R, -1)
-        self._break(lambda: self.comm.all_to_all(rt, st))
+        self._collective(L.COMM_ALL_TO_ALL, rt, st, f"shard.{tag}.all_to_all")
         if skip_pack and release_in:
             self.release(x)      # (recycled by LATER launches only: the collective and the launches share one stream)
         if skip_unpack:
@@ -658,7 +677,7 @@ class UNetEngine:
                 self.S.copy(ops.copy_params(qkv.ptr + 2 * inner, kvloc.ptr, T, 1, 1, 2 * cv, 3 * cv, 0), f"{p}.{tag}.kv.pack")
                 kvall = self.act(self.R * T, 2 * inner)
                 out_t, in_t = kvall.tensor().view(-1), kvloc.tensor().view(-1)
-                self._break(lambda: self.comm.all_gather(out_t, in_t))
+                self._collective(L.COMM_ALL_GATHER, out_t, in_t, f"{p}.{tag}.kv.gather")
                 self.release(kvloc)
                 qm = ops.seq_map(0, ld, hw * ld, inner=hw)
                 km = ops.seq_map(0, 2 * inner, hw * 2 * inner, inner=hw)
@@ -818,7 +837,8 @@ class UNetEngine:
         # The plan cleans up after itself: its FIRST launch zeroes both stat-group accumulator buffers of the all-frame norms (each
         # norm's apply pass only clears the OTHER buffer, so after an odd number of such norms — or an aborted replay — the one
         # norm 0 adds into would still hold the last statistics).  Replays therefore need nothing from prepare_rows(): run_plan() /
-        # run_segment() / a per-op replay / a hipGraph capture of the plan are all self-contained.  64 KB, ~2 us per forward.
+        # run_segment() / a per-op replay / a hipGraph capture of the plan are all self-contained.  Only the B stat groups an engine's
+        # all-frame norms ever use exist: 2 buffers x B x GN_TOT int64 (2 x B x 16 KB = 64 KB at B = 2), one copy.
         S.copy(ops.copy_params(self._gn_zero.data_ptr(), self._gn_tot2.data_ptr(), 1, 1, 1, self._gn_tot2.numel() // 2, 0, 0),
                "gn.totals.clear")
         # (0) embeddings -> one [B*F, sum Cout] table for all ResBlocks
@@ -974,6 +994,8 @@ class UNetEngine:
 
     def run_segment(self, seg):
         first, last, fn = seg
+        if first == 0 and last == self.S.nops and fn is None:      # an uncut plan: the whole-plan path (one C call / one graph launch)
+            return self.run_plan()
         if last > first:
             self.S.run(first, last)
         if fn is not None:
@@ -982,7 +1004,16 @@ class UNetEngine:
     def run_plan(self):
         """Replay the recorded launches; frame-parallel plans are cut at their collectives."""
         if not self.breaks:
+            # VMV_GRAPH=1: the whole plan (its RCCL collectives included) as ONE hipGraph launch — captured on the second replay, after
+            # an eager one has set the kernels' first-use attributes.  At 1 GPU the step is GPU-bound either way (DESIGN.md §5); it
+            # matters once a rank's share of a step is a few ms (frame-parallel at 8 GPUs).
+            if self.use_graph and self.S.graph is None and self._replays >= 1:
+                try:
+                    self.graph_nodes = self.S.capture_graph()
+                except L.VmvError:
+                    self.use_graph = False
             self.S.run()
+            self._replays += 1
             return
         for seg in self.segments():
             self.run_segment(seg)

@@ -179,6 +179,7 @@ class UNetSD_T2VBase(nn.Module, LgmMixin):
         self._init_lgm(use_lgm_refine, lgm_opt)
         self._engines: Dict[tuple, UNetEngine] = {}
         self._pipe = None             # the two branch engines of the pipelined frame-parallel mode
+        self._packed_donor = None     # packed weights of an engine dropped by set_frame_parallel (reused by the next ones)
         self.frame_comm = None        # comm.FrameComm: frame-parallel execution over the ranks of one sample
         self._weights_version = 0
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate())
@@ -195,6 +196,7 @@ class UNetSD_T2VBase(nn.Module, LgmMixin):
         self._lgm = None
         self._engines.clear()
         self._pipe = None
+        self._packed_donor = None
         self._weights_version += 1
 
     # ------------------------------------------------------------------ engine management
@@ -203,6 +205,9 @@ class UNetSD_T2VBase(nn.Module, LgmMixin):
         configs[2]: 24 views, 3 per GPU.  ``forward`` keeps taking / returning whole samples; the fused sampler
         (``forward_cfg_rows``) works on this rank's frames.  No reference counterpart (its multi-GPU mode is replicas)."""
         self.frame_comm = comm
+        donor = next(iter(self._engines.values()), None) or ((self._pipe or {}).get("engs") or [None])[0]
+        if donor is not None:             # packed weights are shape- and sharding-independent: the next engines reuse them
+            self._packed_donor = donor.packed
         self._engines.clear()
         self._pipe = None
 
@@ -216,7 +221,7 @@ class UNetSD_T2VBase(nn.Module, LgmMixin):
             sd = {k: v.detach() for k, v in self.state_dict().items()}
             donor = next(iter(self._engines.values()), None)       # packed weights are shared by all engines of the model
             eng = UNetEngine(self.arch, sd, B, F, H, W, L, device, n_t=n_t, taps=taps, comm=self.frame_comm,
-                             share_prefix=share_prefix, packed=donor.packed if donor is not None else None)
+                             share_prefix=share_prefix, packed=donor.packed if donor is not None else self._packed_donor)
             if taps is None:
                 self._engines[key] = eng
         return eng
@@ -341,7 +346,7 @@ class UNetSD_T2VBase(nn.Module, LgmMixin):
             out_pad = (self.out_dim + 3) // 4 * 4
             eps = torch.zeros(2 * T1, out_pad, dtype=torch.float32, device=dev)
             mine = torch.zeros(T1, out_pad, dtype=torch.float32, device=dev)
-            eng = UNetEngine(self.arch, sd, 1, F_all, h, w, y.shape[1], dev, n_t=1, comm=comm.fp, eps_out=mine)
+            eng = UNetEngine(self.arch, sd, 1, F_all, h, w, y.shape[1], dev, n_t=1, comm=comm.fp, eps_out=mine, packed=self._packed_donor)
             pipe = dict(key=key, comm=comm, engs=[eng], eps=eps, mine=mine, cond=CondCache(), out_pad=out_pad)
             self._pipe = pipe
         eng = pipe["engs"][0]
@@ -378,7 +383,7 @@ class UNetSD_T2VBase(nn.Module, LgmMixin):
             engs, comms = [], (comm, comm.twin())
             for br in range(2):
                 engs.append(UNetEngine(self.arch, sd, 1, F_all, h, w, Lc, dev, n_t=1, comm=comms[br],
-                                       packed=engs[0].packed if engs else None, eps_out=eps[br * T1:(br + 1) * T1]))
+                                       packed=engs[0].packed if engs else self._packed_donor, eps_out=eps[br * T1:(br + 1) * T1]))
             streams = [torch.cuda.Stream(device=dev) for _ in range(2)] if dev.type == "cuda" else [None, None]
             pipe = dict(key=key, comm=comm, engs=engs, eps=eps, streams=streams, cond=CondCache(), out_pad=engs[0].out_pad)
             self._pipe = pipe
