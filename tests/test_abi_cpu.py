@@ -73,7 +73,7 @@ def test_missing_library_fails_loudly(monkeypatch):
 def test_gemm_tile_policy(monkeypatch):
     """vmv_gemm_pick_tile (host logic): which kernel family the default policy gives the UNet's / VAE's characteristic GEMMs at
     latent 24x40x64 — pins DESIGN 4.1's table (pointers are never dereferenced: fake non-null addresses)."""
-    for k in ("VMV_GEMM_POLICY", "VMV_GEMM_XGLDS", "VMV_GEMM_ASTAT", "VMV_GEMM_RS", "VMV_GEMM_TILE_GEGLU", "VMV_GEMM_TILE_LIN160", "VMV_GEMM_TILE_LIN128"):
+    for k in ("VMV_GEMM_POLICY", "VMV_GEMM_XGLDS", "VMV_GEMM_XEPI", "VMV_GEMM_ASTAT", "VMV_GEMM_RS", "VMV_GEMM_TILE_GEGLU", "VMV_GEMM_TILE_LIN160", "VMV_GEMM_TILE_LIN128"):
         assert k not in os.environ, "policy overrides must be unset for this test"
     lib = L.load()
     X = 1 << 20          # any non-null, 16-byte aligned address
@@ -101,7 +101,12 @@ def test_gemm_tile_policy(monkeypatch):
     assert pick(M1, 5120, lin(640), epilogue=L.EPI_GEGLU, colsum=X, ln_eps=1e-5) == L.TILE_RS
     assert pick(M1, 640, lin(640), residual=X, ldr=640) == L.TILE_RS
     assert pick(M0, 320, lin(1280), residual=X, ldr=320) == L.TILE_P256x160
-    assert pick(M2, 10240, lin(1280), epilogue=L.EPI_GEGLU, rowstat=X, colsum=X) == L.TILE_P256x128
+    # round 4: the third level's LayerNorm-folded qkv / GEGLU on the wide tile's 256 x 256 form (fused epilogues in gemm_xglds.hip);
+    # grids that would leave the second round of the chip mostly empty (q, N = 1280: 150 tiles; the middle block) stay persistent
+    assert pick(M2, 10240, lin(1280), epilogue=L.EPI_GEGLU, rowstat=X, colsum=X) == L.TILE_X256x256
+    assert pick(M2, 3840, lin(1280), rowstat=X, colsum=X) == L.TILE_X256x256
+    assert pick(M2, 1280, lin(1280), rowstat=X, colsum=X) == L.TILE_P256x160
+    assert pick(M3, 10240, lin(1280), epilogue=L.EPI_GEGLU, rowstat=X, colsum=X) == L.TILE_P256x128
     assert lib.vmv_gemm_rs_ok(C.byref(ops.gemm_params(M0, 960, lin(320), X, X, 960, colsum=X, ln_eps=1e-5))) == 1
     assert lib.vmv_gemm_rs_ok(C.byref(ops.gemm_params(M2, 3840, lin(1280), X, X, 3840, colsum=X, ln_eps=1e-5))) == 0
     # VAE decoder at 24 frames of 320 x 512: 512- / 256-channel levels on 256 x 256 wide tiles, the 128-channel level on 256 x 128

@@ -122,7 +122,7 @@ def test_gemm_fp32_out_rowvec_act_residual(tile):
     check(dev["out"], cpu["out"], tol_l2=1e-3, tol_max=2e-3)
 
 
-@pytest.mark.parametrize("tile", [0, L.TILE_256x128, L.TILE_G128x128, L.TILE_P256x128, L.TILE_PP256x128, L.TILE_Q128x128, L.TILE_S256x128])
+@pytest.mark.parametrize("tile", [0, L.TILE_256x128, L.TILE_G128x128, L.TILE_P256x128, L.TILE_PP256x128, L.TILE_Q128x128, L.TILE_S256x128, L.TILE_X256x256])
 def test_gemm_geglu(tile):
     M, I2, K = 200, 512, 128        # 2*I = 512 rows -> 256 outputs
     w = rnd((I2, K), 2, K ** -0.5)
@@ -348,6 +348,22 @@ def test_gemm_geglu_many_tiles():
     def build(t):
         return ops.gemm_params(M, I2, ops.linear_segs([(t["a"], K, K)]), t["w"], t["out"], I2 // 2, bias=t["b"],
                                epilogue=L.EPI_GEGLU, tile=L.TILE_P256x128)
+    cpu, dev = run_gemm(build, c, cpu_ref=False)
+    h = cpu["a"].float() @ w.float().t() + b
+    x, gate = h.chunk(2, dim=-1)
+    check(dev["out"], x * torch.nn.functional.gelu(gate))
+
+
+@pytest.mark.parametrize("M,I2,K", [(7680, 10240, 1280), (1000, 1280, 320), (257, 512, 128)])
+def test_gemm_geglu_wide_tile(M, I2, K):
+    """GEGLU without a folded LayerNorm on the 256 x 256 wide tile (x | gate column tiles = adjacent accumulators of one lane)."""
+    w = rnd((I2, K), 2, K ** -0.5)
+    b = torch.randn(I2, generator=g(3))
+    c = Case(a=rnd((M, K), 1), w=P.geglu_interleave(w), b=P.geglu_interleave(b), out=torch.zeros(M, I2 // 2, dtype=BF))
+
+    def build(t):
+        return ops.gemm_params(M, I2, ops.linear_segs([(t["a"], K, K)]), t["w"], t["out"], I2 // 2, bias=t["b"],
+                               epilogue=L.EPI_GEGLU, tile=L.TILE_X256x256)
     cpu, dev = run_gemm(build, c, cpu_ref=False)
     h = cpu["a"].float() @ w.float().t() + b
     x, gate = h.chunk(2, dim=-1)
@@ -592,7 +608,13 @@ def test_layernorm_stats_out(rows, Cc):
                                                (70001, 960, 320, False, L.TILE_A128x160), (70001, 2560, 320, True, L.TILE_A128x128),
                                                (1000, 1000, 320, False, L.TILE_A128x160), (300, 640, 256, True, L.TILE_A128x128),
                                                (129, 320, 320, False, L.TILE_A128x128), (50000, 960, 320, False, 0),
-                                               (50000, 2560, 320, True, 0)])
+                                               (50000, 2560, 320, True, 0),
+                                               # round 4: the wide tile's 256 x 256 form with the folded LayerNorm and / or GEGLU in its epilogue
+                                               # (gemm_xglds.hip EPI): M / N tails, several tiles per block column, K = 128 .. 1280, the L2 shapes
+                                               (7680, 3840, 1280, False, L.TILE_X256x256), (7680, 10240, 1280, True, L.TILE_X256x256),
+                                               (300, 512, 128, False, L.TILE_X256x256), (513, 768, 192, True, L.TILE_X256x256),
+                                               (1000, 1000, 320, False, L.TILE_X256x256), (2001, 1280, 640, True, L.TILE_X256x256),
+                                               (7680, 3840, 1280, False, 0), (7680, 10240, 1280, True, 0)])
 def test_gemm_layernorm_folded(M, N, K, geglu, tile):
     """y = Linear(LayerNorm(x)) as ONE GEMM on the raw rows (packing.fold_layernorm + rowstat / colsum epilogue) against
     the unfused definition, x with a large per-row offset (mean / sigma ~ 3) to exercise the cancellation."""

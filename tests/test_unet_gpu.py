@@ -569,7 +569,7 @@ def test_full_size_i2vgen_properties():
     32 x 32 (i2vgen_xl_train.yaml resolution 256), 77 text + 64 local-image + 4 CLIP-image = 145 context tokens, v-prediction on the
     cosine / zero-terminal-SNR schedule, guide 6.  The fp32 oracle cannot run this shape in a test's time, so, as for configs[1]:
       * parameter count and context length are the reference's; every output is finite; two runs are bitwise identical;
-      * the batched [cond | uncond] plan agrees with two reference-structured B = 1 forwards (other plans / tiles): <= 2e-3;
+      * the batched [cond | uncond] plan agrees with two reference-structured B = 1 forwards (other plans / tiles): <= 4e-3;
       * the two branches differ (they saw different text / image tokens);
       * output statistics match the fp32 ORACLE (oracle/unet_i2v_ref.py, pinned to the reference golden) run with the same
         weights on a 24 x 8 x 8 crop of the same inputs: |std ratio - 1| <= 0.15, |mean difference| <= 0.35 std;
@@ -613,7 +613,9 @@ def test_full_size_i2vgen_properties():
     e_u = r1[T:, :4].reshape(F_, H * W, 4).permute(2, 0, 1).reshape(1, 4, F_, H, W)
     f_c = m(noise.cuda(), t, **kw[0])
     f_u = m(noise.cuda(), t, **kw[1])
-    lim = 2e-3 * (1 if FP16 else 8)
+    # (two plans with different tile / split-K choices round independently: sqrt(2) x the ~1.6e-3 a forward is from fp32 — measured
+    #  2.3e-3 at this shape; a wrong index map or a stale buffer gives O(1))
+    lim = 4e-3 * (1 if FP16 else 8)
     assert rel_l2(e_c, f_c) < lim and rel_l2(e_u, f_u) < lim, (rel_l2(e_c, f_c), rel_l2(e_u, f_u))
     assert rel_l2(e_c, e_u) > 1e-2
     # statistics vs the oracle on a crop (same weights, same tokens; the crop's local image is the crop of the local image)

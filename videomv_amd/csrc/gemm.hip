@@ -23,6 +23,7 @@ int vmv_gemm_glds_launch(const VmvGemmParams& p, int total_steps, int tile, hipS
 int vmv_gemm_pglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st);  // gemm_pglds.hip
 bool vmv_gemm_pglds_supported(const VmvGemmParams& p);
 int vmv_gemm_xglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st);  // gemm_xglds.hip
+int vmv_gemm_xglds_epi_ok(const VmvGemmParams& p, int tile);                                      // gemm_xglds.hip
 #if defined(VMV_EXPERIMENTS)
 int vmv_gemm_sglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st);  // gemm_sglds.hip
 int vmv_gemm_astat_launch(const VmvGemmParams& p, int tile, hipStream_t st);                   // gemm_astat.hip
@@ -348,6 +349,20 @@ int pick_tile(const VmvGemmParams& p, int total_steps) {
         // (plain rows too once the reduction is long: FF-down of the second level, K = 2560 — 937 -> 1008 TFLOP/s)
         if ((any_gather || total_steps >= 32) && 20 * rounds_x <= 11 * rounds_g) return bx == 320 ? VMV_TILE_X256x320 : VMV_TILE_X256x256;
     }
+    // Round 4: the transformer linears of the K = 1280 level that carry a folded LayerNorm (rowstat) and / or GEGLU — qkv, q, GEGLU of
+    // the third level and the middle block — on the wide tile's 256 x 256 form (gemm_xglds.hip EPI): 780-870 -> ~1000 TFLOP/s.  Taken
+    // when the tile grid makes at least ~1.7 rounds of the chip well filled (the same criterion as the persistent kernel's >= 2 tiles
+    // per CU, scaled to the twice-as-large tile); VMV_GEMM_XEPI=0 keeps the persistent kernel.
+    if (gemm_policy() >= 2 && xglds_policy() && (geglu || p.rowstat) && p.ksplit <= 1 && !vmv_gemm_ln_inline(p) && total_steps >= 20 &&
+        p.N % 256 == 0 && p.wgroup_rows == 0 && !p.out_fp32 && !p.rowvec && vmv_gemm_xglds_epi_ok(p, VMV_TILE_X256x256)) {
+        static int xepi = -1;
+        if (xepi < 0) { const char* e = getenv("VMV_GEMM_XEPI"); xepi = e ? atoi(e) : 1; }
+        bool lin = true;
+        for (int i = 0; i < p.nseg; ++i) lin = lin && p.seg[i].mode == VMV_SEG_LINEAR;
+        const long tiles = (long)((p.M + 255) / 256) * (p.N / 256);
+        const long rounds = (tiles + 255) / 256;
+        if (xepi && lin && tiles >= 400 && (double)tiles / (double)(rounds * 256) >= 0.85) return VMV_TILE_X256x256;
+    }
     {
         bool lin = p.ksplit <= 1 && total_steps <= 24 && p.M >= 16384;
         for (int i = 0; i < p.nseg; ++i) lin = lin && p.seg[i].mode == VMV_SEG_LINEAR;
@@ -438,7 +453,7 @@ int final_tile(const VmvGemmParams& p, int total_steps) {
         else if (picked == VMV_TILE_256x160) picked = VMV_TILE_256x128;
         else if (!ok) picked = VMV_TILE_G128x128;
     }
-    if (p.rowstat && picked != VMV_TILE_A128x160 && picked != VMV_TILE_A128x128 && picked != VMV_TILE_P256x128 && picked != VMV_TILE_P256x160 && picked != VMV_TILE_Q128x128 &&
+    if (p.rowstat && !(picked == VMV_TILE_X256x256 && vmv_gemm_xglds_epi_ok(p, picked)) && picked != VMV_TILE_A128x160 && picked != VMV_TILE_A128x128 && picked != VMV_TILE_P256x128 && picked != VMV_TILE_P256x160 && picked != VMV_TILE_Q128x128 &&
         picked != VMV_TILE_Q96x160 && picked != VMV_TILE_128x128 && picked != VMV_TILE_128x160 && picked != VMV_TILE_128x64 &&
         picked != VMV_TILE_64x64)
         picked = (p.epilogue != VMV_EPI_GEGLU && p.N % 160 == 0) ? VMV_TILE_P256x160 : VMV_TILE_P256x128;
@@ -558,6 +573,12 @@ extern "C" int vmv_gemm(const VmvGemmParams* pp, void* stream) {
         case VMV_TILE_X256x256:
         case VMV_TILE_X256x128:
             rc = vmv_gemm_xglds_launch(p, total_steps, picked, st);
+            if (rc == VMV_GLDS_UNSUPPORTED && (p.rowstat || p.epilogue == VMV_EPI_GEGLU)) {      // the fused epilogues' other home
+                if (p.tile != VMV_TILE_AUTO) return VMV_EINVAL;
+                rc = vmv_gemm_pglds_launch(p, total_steps, VMV_TILE_P256x128, st);
+                if (rc == VMV_GLDS_UNSUPPORTED) rc = launch_cfg<4, 4>(p, total_steps, st);
+                break;
+            }
             if (rc == VMV_GLDS_UNSUPPORTED) {
                 if (p.tile != VMV_TILE_AUTO) return VMV_EINVAL;
                 rc = vmv_gemm_glds_launch(p, total_steps, p.N % 160 == 0 ? VMV_TILE_256x160 : VMV_TILE_256x128, st);

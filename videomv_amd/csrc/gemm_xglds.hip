@@ -12,7 +12,11 @@
 // issued before the MFMAs of the current one; the second wave of the SIMD covers what latency remains.  A 72-KB stage per
 // 64-deep chunk would allow two stages only, hence 32-deep chunks (36 KB) and FOUR stages: chunk t + 4 goes out behind the
 // block barrier of step t.  LDS rows are 64 B with a 4-entry slot swizzle (see the loader).  Zero fill by
-// descriptor and the K-segment walk are those of gemm_glds.hip; no split-K, no GEGLU, no folded LayerNorm.
+// descriptor and the K-segment walk are those of gemm_glds.hip; no split-K.  Round 4: the 256 x 256 tile also carries the two
+// epilogues of the transformer linears (template EPI) — the folded LayerNorm (rowstat + colsum: rstd (acc - mean colsum) + b') and
+// GEGLU (x | gate column tiles are adjacent accumulators of one lane) — for the K = 1280 level, where the row-stationary kernel does
+// not apply (rows do not fit registers) and the 256 x 128 persistent tiles ran at 780-870 TFLOP/s against 1050-1100 for this one
+// (hipBLASLt on the same box: 1090-1130, profiles/r4_vendor_yardstick.tsv).
 // (tools/experiments/gemm_wglds.hip is the 4-wave / 512-register sibling that lost to LDS-DMA issue stalls.)
 #include "gemm_glds_common.h"
 #include <cstdlib>
@@ -49,7 +53,7 @@ struct WgCfg {
     static constexpr int LPT = NAI + NWI;                   // loads per lane per chunk (waves < NWX: LPT + 1)
     static constexpr int HALF_ROWS = 128;                   // epilogue staging: half a tile at a time
     static constexpr int XG_MAXG = 8;                       // row groups (rowvec rows) one tile's rows may span
-    static_assert(HALF_ROWS * (BN * 2 + 16) + XG_MAXG * BN * 4 <= LDS_BYTES && LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(HALF_ROWS * (BN * 2 + 16) + XG_MAXG * BN * 4 + BN * 4 <= LDS_BYTES && LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
 struct WRow {        // gather state of one A row of the lane beyond its index m (recomputed: it lives beside 160 accumulators)
@@ -57,7 +61,9 @@ struct WRow {        // gather state of one A row of the lane beyond its index m
     int yx;          // spatial: (oy << 16) | ox
 };
 
-template <int NH, int WH>
+constexpr int XE_GEGLU = 1, XE_LN = 2;       // EPI bits
+
+template <int NH, int WH, int EPI = 0>
 __global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams p, const int tiles_m, const int tiles_n, const int nsteps) {
     VMV_KERNEL_ENTER();
     using Cfg = WgCfg<NH, WH>;
@@ -271,8 +277,11 @@ __global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams 
     // (the launcher only sends GEMMs whose outputs can be staged: 16-bit, 16-byte aligned rows)
     // 16-bit outputs go through LDS (whole rows, 16-byte lanes, residual read the same way), half a tile (the two waves of
     // one wave row) at a time: the ring holds 128 rows of BN outputs
-    constexpr int row_bytes = BN * 2 + 16;          // +16 B: spreads the 8-byte writes over the banks
-    constexpr int U = BN >> 3;                      // 16-byte units per tile row
+    constexpr bool GEGLU = (EPI & XE_GEGLU) != 0, LNF = (EPI & XE_LN) != 0;
+    constexpr int BNO = GEGLU ? BN / 2 : BN;        // output columns of the tile (GEGLU: x | gate pairs -> one column)
+    constexpr int row_bytes = BNO * 2 + 16;         // +16 B: spreads the 8-byte writes over the banks
+    constexpr int U = BNO >> 3;                     // 16-byte units per tile row
+    const int n0o = GEGLU ? n0 / 2 : n0, No = GEGLU ? p.N / 2 : p.N;
     uint16_t* outp = reinterpret_cast<uint16_t*>(p.out);
     const uint16_t* resp = reinterpret_cast<const uint16_t*>(p.residual);
     const float rs = p.res_scale != 0.f ? p.res_scale : 1.f;
@@ -281,7 +290,8 @@ __global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams 
     // (Round 2 loaded them from global memory inside the (column tile, row tile) loops: exec-masked loads that the compiler
     //  follows with vmcnt(0) each — 40 dependent L2 round trips per wave — and whose hoisted 64-bit row pointers were the
     //  kernel's 10 spilled registers.)
-    float* cvec = reinterpret_cast<float*>(smem + Cfg::HALF_ROWS * row_bytes);
+    float* cvec = reinterpret_cast<float*>(smem + Cfg::HALF_ROWS * (BN * 2 + 16));
+    float* csum = cvec + Cfg::XG_MAXG * BN;         // folded LayerNorm: the column sums of W' (vmv.h)
     const int rv_div = p.rowvec ? p.rowvec_div : (1 << 30);
     const int g0 = m0 / rv_div;
     const int m_last = (m0 + BM < p.M ? m0 + BM : p.M) - 1;
@@ -296,23 +306,58 @@ __global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams 
         }
         cvec[idx] = v;
     }
+    if constexpr (LNF) {
+        for (int idx = tid; idx < BN; idx += Cfg::NT) csum[idx] = (n0 + idx) < p.N ? p.colsum[n0 + idx] : 0.f;
+    }
     int gi[WM];                                     // row group (relative to g0) of this lane's row in each row tile
 #pragma unroll
     for (int i = 0; i < WM; ++i) { const int m = mbase + 16 * i; gi[i] = ((m < p.M ? m : m_last) / rv_div - g0) * BN; }
+    float ln_mean[WM], ln_rstd[WM];                 // folded LayerNorm: (mean, rstd) of this lane's four rows
+    if constexpr (LNF) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const int m = mbase + 16 * i < p.M ? mbase + 16 * i : m_last;
+            const f32x2_t st2 = *reinterpret_cast<const f32x2_t*>(p.rowstat + 2 * (size_t)m);
+            ln_mean[i] = st2.x; ln_rstd[i] = st2.y;
+        }
+    }
+    auto finish = [&](const int j, const int i) -> f32x4_t {     // accumulator tile (j, i) after LN fold / column vector / activation
+        const int nl = wave_n * 16 * WN + 16 * j + 4 * fgrp;     // column inside the tile
+        f32x4_t v = acc[j][i];
+        if constexpr (LNF) {
+            const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(csum + nl);
+            v = (v - cs * ln_mean[i]) * ln_rstd[i];
+        }
+        v += *reinterpret_cast<const f32x4_t*>(cvec + gi[i] + nl);
+        act_apply(v, p.act);
+        return v;
+    };
 #pragma unroll 1
     for (int hh = 0; hh < 2; ++hh) {
         __syncthreads();                            // column vectors written / the previous half's slab no longer read by anyone
         if ((wave_m >> 1) == hh) {
+            if constexpr (GEGLU) {
 #pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                const int nl = wave_n * 16 * WN + 16 * j + 4 * fgrp;       // column inside the tile
+                for (int jj = 0; jj < WN / 2; ++jj) {
 #pragma unroll
-                for (int i = 0; i < WM; ++i) {
-                    f32x4_t v = acc[j][i] + *reinterpret_cast<const f32x4_t*>(cvec + gi[i] + nl);
-                    act_apply(v, p.act);
-                    u32x2_t o;
-                    o.x = pack_elem2(v.x, v.y); o.y = pack_elem2(v.z, v.w);
-                    *reinterpret_cast<u32x2_t*>(smem + ((wave_m & 1) * 16 * WM + 16 * i + frow) * row_bytes + (wave_n * 16 * WN + 16 * j + 4 * fgrp) * 2) = o;
+                    for (int i = 0; i < WM; ++i) {
+                        const f32x4_t x = finish(2 * jj, i), gt = finish(2 * jj + 1, i);
+                        u32x2_t o;
+                        o.x = pack_elem2(x.x * gelu_erf_f(gt.x), x.y * gelu_erf_f(gt.y));
+                        o.y = pack_elem2(x.z * gelu_erf_f(gt.z), x.w * gelu_erf_f(gt.w));
+                        *reinterpret_cast<u32x2_t*>(smem + ((wave_m & 1) * 16 * WM + 16 * i + frow) * row_bytes + (wave_n * 8 * WN + 16 * jj + 4 * fgrp) * 2) = o;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+#pragma unroll
+                    for (int i = 0; i < WM; ++i) {
+                        const f32x4_t v = finish(j, i);
+                        u32x2_t o;
+                        o.x = pack_elem2(v.x, v.y); o.y = pack_elem2(v.z, v.w);
+                        *reinterpret_cast<u32x2_t*>(smem + ((wave_m & 1) * 16 * WM + 16 * i + frow) * row_bytes + (wave_n * 16 * WN + 16 * j + 4 * fgrp) * 2) = o;
+                    }
                 }
             }
         }
@@ -323,8 +368,8 @@ __global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams 
 #pragma unroll 1
         for (int idx = tid; idx < Cfg::HALF_ROWS * U; idx += Cfg::NT) {
             const int r = idx / U, u = idx - r * U;
-            const int m = m0 + hh * Cfg::HALF_ROWS + r, n = n0 + u * 8;
-            if (m >= p.M || n >= p.N) continue;
+            const int m = m0 + hh * Cfg::HALF_ROWS + r, n = n0o + u * 8;
+            if (m >= p.M || n >= No) continue;
             u32x4_t v = *reinterpret_cast<const u32x4_t*>(smem + r * row_bytes + u * 16);
             if (resp) {
                 const u32x4_t rr = *reinterpret_cast<const u32x4_t*>(resp + (size_t)m * p.ldr + n);
@@ -346,35 +391,52 @@ __global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams 
     }
 }
 
-template <int NH, int WH>
+template <int NH, int WH, int EPI = 0>
 int launch_xglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
     using Cfg = WgCfg<NH, WH>;
     const int tiles_m = (p.M + Cfg::BM - 1) / Cfg::BM;
     const int tiles_n = (p.N + Cfg::BN - 1) / Cfg::BN;
     static std::atomic<unsigned long long> attr_set{0};
-    if (const int rc_attr = vmv_lds_attr_once(attr_set, reinterpret_cast<const void*>(&gemm_xglds_kernel<NH, WH>), Cfg::LDS_BYTES)) return rc_attr;
+    if (const int rc_attr = vmv_lds_attr_once(attr_set, reinterpret_cast<const void*>(&gemm_xglds_kernel<NH, WH, EPI>), Cfg::LDS_BYTES)) return rc_attr;
     int nsteps = 0;                                          // chunks of WBK = 32 (total_steps counts the other kernels' 64)
     for (int i = 0; i < p.nseg; ++i) nsteps += (p.seg[i].k + WBK - 1) / WBK;
     (void)total_steps;
     if (nsteps < Cfg::STAGES || (nsteps & 1)) return VMV_GLDS_UNSUPPORTED;
     if (p.rowvec && (Cfg::BM - 1) / p.rowvec_div + 2 > Cfg::XG_MAXG) return VMV_GLDS_UNSUPPORTED;      // column vectors staged per row group
-    hipLaunchKernelGGL((gemm_xglds_kernel<NH, WH>), dim3(tiles_m * tiles_n), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n, nsteps);
+    hipLaunchKernelGGL((gemm_xglds_kernel<NH, WH, EPI>), dim3(tiles_m * tiles_n), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n, nsteps);
     return vmv_launch_status();
 }
 
 }  // namespace
 
+// 1 if the wide-tile kernel has an instantiation for *p's epilogue on `tile` (host logic; used by the policy in gemm.hip)
+int vmv_gemm_xglds_epi_ok(const VmvGemmParams& p, int tile) {
+    const bool geglu = p.epilogue == VMV_EPI_GEGLU, lnf = p.rowstat != nullptr;
+    if (!geglu && !lnf) return 1;
+    if (tile != VMV_TILE_X256x256) return 0;                 // the fused epilogues exist for 64 x 128 wave tiles only
+    if (lnf && !p.colsum) return 0;
+    if (geglu && ((p.N & 31) || p.residual || p.act != VMV_ACT_NONE)) return 0;      // whole x | gate pairs; no residual (as the other kernels)
+    return 1;
+}
+
 // Called by vmv_gemm (gemm.hip) after argument validation.
 int vmv_gemm_xglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st) {
-    if (p.ksplit > 1 || p.epilogue == VMV_EPI_GEGLU || p.rowstat || vmv_gemm_ln_inline(p)) return VMV_GLDS_UNSUPPORTED;
+    if (p.ksplit > 1 || vmv_gemm_ln_inline(p) || !vmv_gemm_xglds_epi_ok(p, tile)) return VMV_GLDS_UNSUPPORTED;
+    const bool geglu = p.epilogue == VMV_EPI_GEGLU, lnf = p.rowstat != nullptr;
     long maxrows = p.M;
     if (p.OH > 0) { const long src_rows = (long)(p.M / (p.OH * p.OW) + 1) * p.IH * p.IW; if (src_rows > maxrows) maxrows = src_rows; }
     for (int i = 0; i < p.nseg; ++i)
         if (maxrows * (long)p.seg[i].ld * 2 >= (1L << 31) - 65536) return VMV_GLDS_UNSUPPORTED;
     if ((long)(p.N + 320) * p.ktot * 2 >= (1L << 31) - 65536) return VMV_GLDS_UNSUPPORTED;
     if (p.OH > 0 && (p.OH >= 32768 || p.OW >= 32768)) return VMV_GLDS_UNSUPPORTED;      // (oy, ox) packed in one register
-    if (p.out_fp32 || (p.ldo & 7) || (p.N & 7) || !vmv_aligned16(p.out) ||
+    const int No = geglu ? p.N / 2 : p.N;
+    if (p.out_fp32 || (p.ldo & 7) || (No & 7) || !vmv_aligned16(p.out) ||
         (p.residual && ((p.ldr & 7) || !vmv_aligned16(p.residual)))) return VMV_GLDS_UNSUPPORTED;   // staged epilogue only
+    if (geglu || lnf) {
+        if (geglu && lnf) return launch_xglds<2, 4, XE_GEGLU | XE_LN>(p, total_steps, st);
+        if (geglu) return launch_xglds<2, 4, XE_GEGLU>(p, total_steps, st);
+        return launch_xglds<2, 4, XE_LN>(p, total_steps, st);
+    }
     if (tile == VMV_TILE_X256x320) return launch_xglds<2, 5>(p, total_steps, st);
     if (tile == VMV_TILE_X256x256) return launch_xglds<2, 4>(p, total_steps, st);
     if (tile == VMV_TILE_X256x128) return launch_xglds<1, 4>(p, total_steps, st);

@@ -106,6 +106,41 @@ def gn_chunk_rows(rows_per_stat: int, C: int) -> int:
     return min(r, rows_per_stat)
 
 
+def gemm_signature(p: "L.GemmParams") -> str:
+    """Shape / feature key of an implicit-GEMM launch for the tuned (tile, split-K) table (videomv_amd/tuned_gemm.json): every
+    property the kernel choice can depend on and no pointer.  Runs of equal (mode, k) segments are run-length coded."""
+    runs, i = [], 0
+    while i < p.nseg:
+        j = i
+        while j < p.nseg and (p.seg[j].mode, p.seg[j].k) == (p.seg[i].mode, p.seg[i].k):
+            j += 1
+        runs.append(f"{p.seg[i].mode}:{p.seg[i].k}*{j - i}")
+        i = j
+    flags = (f"e{p.epilogue}a{p.act}f{p.out_fp32}r{int(bool(p.residual))}v{int(bool(p.rowvec))}:{p.rowvec_div if p.rowvec else 0}"
+             f"s{int(bool(p.rowstat))}c{int(bool(p.colsum))}l{int(p.ln_eps > 0)}g{int(bool(p.gn_table))}w{p.wgroup_rows}")
+    geo = f"{p.OH}x{p.OW}<{p.IH}x{p.IW}s{p.stride}u{p.ups}F{p.F}P{p.P}"
+    return f"{p.M}x{p.N}x{p.ktot};{','.join(runs)};{flags};{geo}"
+
+
+_TUNED = None
+
+
+def tuned_table() -> dict:
+    """signature -> {"tile": id, "ksplit": n}: per-shape kernel choices measured on an MI355X by tools/autotune_gemm.py (the policy in
+    csrc/gemm.hip was fitted to the 1-GPU shapes, M = 122 880 ...; the table carries what measurement found better — mostly the
+    small-M shapes of a frame-parallel rank).  VMV_TUNED=0 ignores it; VMV_TUNED_FILE points at another one."""
+    global _TUNED
+    if _TUNED is None:
+        _TUNED = {}
+        if os.environ.get("VMV_TUNED", "1") != "0":
+            import json
+            path = os.environ.get("VMV_TUNED_FILE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gemm.json")
+            if os.path.exists(path):
+                with open(path) as f:
+                    _TUNED = {k: v for k, v in json.load(f).get(L.elem_name(), {}).items()}
+    return _TUNED
+
+
 class SplitK:
     """Split-K policy + workspace for the small-M implicit GEMMs (a tile grid that cannot fill the 256 CUs with a long
     reduction): K is cut into `ks` slices (fp32 slabs in the workspace, deterministic reduce + epilogue pass, vmv.h).
@@ -129,6 +164,13 @@ class SplitK:
             self.ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=self.device)
             self.keep.append(self.ws)      # earlier recorded launches keep pointing at the old slab
         return ks, self.ws
+
+    def workspace(self, need_bytes: int):
+        """The shared fp32 slab, grown to `need_bytes` (a tuned split-K factor the heuristic did not pick)."""
+        if self.ws is None or self.ws.numel() < need_bytes:
+            self.ws = torch.empty(max(int(need_bytes), 1 << 20), dtype=torch.uint8, device=self.device)
+            self.keep.append(self.ws)
+        return self.ws
 
 
 def gn_fused_cols(rows_per_stat: int, C: int) -> int:
@@ -249,6 +291,8 @@ class Stream:
             L.check(fn(C.byref(params), _stream_ptr()), label)
 
     def gemm(self, params, label="gemm"):
+        if getattr(self, "tuner", None) is not None:
+            self.tuner(params)
         self._go(L.OP_GEMM, params, self.lib.vmv_gemm, label)
 
     def groupnorm(self, params, label="gn"):
