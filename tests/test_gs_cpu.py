@@ -105,3 +105,40 @@ def test_near_cull_saturation_stop_and_rotation_formula():
     p0 = preprocess(torch.tensor([[0.0, 0.0, 1.5]]), scs, torch.tensor([[1.0, 0, 0, 0]]), view, vp, 64, TAN)
     p1 = preprocess(torch.tensor([[0.0, 0.0, 1.5]]), scs, torch.tensor([[math.sqrt(0.5), 0.0, 0.0, math.sqrt(0.5)]]), view, vp, 64, TAN)
     assert torch.allclose(p0["conic"][0, 0], p1["conic"][0, 2], rtol=1e-4) and torch.allclose(p0["conic"][0, 2], p1["conic"][0, 0], rtol=1e-4)
+
+
+def test_oracle_closed_forms_rotated_anisotropic_and_tile_boundary_order():
+    """The two closed forms the GPU tier holds the HIP rasteriser to (tests/test_gs_gpu.py) hold for the oracle restatement too:
+    a rotated anisotropic Gaussian on the optical axis, and depth-ordered compositing of two off-axis Gaussians whose centres sit on
+    a 16-pixel tile boundary, in both memory orders."""
+    import math
+    import torch
+    from oracle.gs_ref import render_views
+    from videomv_amd.gs import GaussianRenderer
+    from tests.test_gs_gpu import _closed_form_cov2d, _alpha
+    S, d, o, th = 64, 1.5, 0.9, math.radians(35.0)
+    sx, sy, sz = 0.09, 0.03, 0.05
+    r = GaussianRenderer(output_size=S)
+    f = S / (2 * r.tan_half_fov)
+    c, s = math.cos(th), math.sin(th)
+    S3 = [[c * c * sx * sx + s * s * sy * sy, c * s * (sx * sx - sy * sy), 0.0],
+          [c * s * (sx * sx - sy * sy), s * s * sx * sx + c * c * sy * sy, 0.0], [0.0, 0.0, sz * sz]]
+    cov = _closed_form_cov2d(0.0, 0.0, d, S3, f)
+    one = torch.tensor([[0.0, 0.0, d, o, sx, sy, sz, math.cos(th / 2), 0.0, 0.0, math.sin(th / 2), 0.2, 0.7, 0.4]])
+    _, al = render_views(one, torch.eye(4).view(1, 4, 4), r.proj_matrix.view(1, 4, 4), S, 39.6, torch.zeros(3))
+    cx = cy = (S - 1) / 2.0
+    assert max(abs(float(al[0, 0, py, px]) - _alpha(px, py, cx, cy, cov, o)) for py in range(24, 41) for px in range(24, 41)) < 2e-6
+    tan = r.tan_half_fov
+    ndc_x, ndc_y = (2 * 15.5 + 1) / S - 1.0, (2 * 31.5 + 1) / S - 1.0
+    rows, info = [], []
+    for z, sg, og, col in ((1.2, 0.06, 0.7, (1.0, 0.1, 0.2)), (1.9, 0.10, 0.8, (0.1, 0.9, 0.3))):
+        x, y = ndc_x * tan * z, ndc_y * tan * z
+        rows.append([x, y, z, og, sg, sg, sg, 1.0, 0.0, 0.0, 0.0, *col])
+        info.append((_closed_form_cov2d(x, y, z, [[sg * sg, 0, 0], [0, sg * sg, 0], [0, 0, sg * sg]], f), og, col))
+    for order in (rows, rows[::-1]):
+        img, _ = render_views(torch.tensor(order), torch.eye(4).view(1, 4, 4), r.proj_matrix.view(1, 4, 4), S, 39.6, torch.zeros(3))
+        for py in range(28, 36):
+            for px in range(12, 20):
+                a0, a1 = _alpha(px, py, 15.5, 31.5, info[0][0], info[0][1]), _alpha(px, py, 15.5, 31.5, info[1][0], info[1][1])
+                for ch in range(3):
+                    assert abs(float(img[0, ch, py, px]) - (info[0][2][ch] * a0 + info[1][2][ch] * a1 * (1 - a0))) < 2e-6

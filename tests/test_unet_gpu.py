@@ -571,8 +571,8 @@ def test_full_size_i2vgen_properties():
       * parameter count and context length are the reference's; every output is finite; two runs are bitwise identical;
       * the batched [cond | uncond] plan agrees with two reference-structured B = 1 forwards (other plans / tiles): <= 4e-3;
       * the two branches differ (they saw different text / image tokens);
-      * output statistics match the fp32 ORACLE (oracle/unet_i2v_ref.py, pinned to the reference golden) run with the same
-        weights on a 24 x 8 x 8 crop of the same inputs: |std ratio - 1| <= 0.15, |mean difference| <= 0.35 std;
+      * (parity at this size: test_full_size_forwards_match_reference_goldens below — a crop cannot stand in for I2VGen, whose 64
+        local-image context tokens are pooled from the WHOLE conditioning image: measured 0.8 sigma of mean shift on a crop);
       * two fused v-prediction DDIM steps are finite and deterministic."""
     from videomv_amd.registry import MODEL, DIFFUSION
     import videomv_amd.unet_i2vgen  # noqa: F401
@@ -618,17 +618,51 @@ def test_full_size_i2vgen_properties():
     lim = 4e-3 * (1 if FP16 else 8)
     assert rel_l2(e_c, f_c) < lim and rel_l2(e_u, f_u) < lim, (rel_l2(e_c, f_c), rel_l2(e_u, f_u))
     assert rel_l2(e_c, e_u) > 1e-2
-    # statistics vs the oracle on a crop (same weights, same tokens; the crop's local image is the crop of the local image)
-    ys, xs_ = 12, 12
-    crop = noise[:, :, :, ys:ys + 8, xs_:xs_ + 8].contiguous()
-    ref = unet_i2v_forward(sd, cfg, crop, torch.tensor([741]), y, img, li[:, :, ys:ys + 8, xs_:xs_ + 8].contiguous(), fps, cam)
-    for ch in range(4):
-        a, b = e_c[0, ch].float().cpu(), ref[0, ch]
-        assert abs(float(a.std() / b.std()) - 1.0) < 0.15, (ch, float(a.std()), float(b.std()))
-        assert abs(float(a.mean() - b.mean())) < 0.35 * float(b.std()), (ch, float(a.mean()), float(b.mean()))
+    # (full-size parity itself: test_full_size_forwards_match_reference_goldens — the imported reference's own output at this shape)
     dif = DIFFUSION.build(dict(type="DiffusionDDIM", schedule="cosine",
                                schedule_param=dict(num_timesteps=1000, cosine_s=0.008, zero_terminal_snr=True),
                                mean_type="v", var_type="fixed_small"))
     xa = dif.ddim_sample_loop(noise=noise.cuda(), model=m, model_kwargs=kw, guide_scale=6.0, ddim_timesteps=4, eta=0.0)
     xb = dif.ddim_sample_loop(noise=noise.cuda(), model=m, model_kwargs=kw, guide_scale=6.0, ddim_timesteps=4, eta=0.0)
     assert xa.shape == noise.shape and torch.isfinite(xa).all() and torch.equal(xa, xb)
+
+
+@pytest.mark.parametrize("which", ["t2v", "i2v"])
+def test_full_size_forwards_match_reference_goldens(golden_dir, which):
+    """Direct full-size parity for BASELINE configs[1] / configs[3] (round 4): ONE forward of the full 1.413 B UNetSD_T2VBase /
+    1.422 B UNetSD_I2VGen at the reference's own 256-px shape (latent 24 x 32 x 32, 77 / 145 context tokens, real orbit cameras)
+    against the output of the IMPORTED REFERENCE on the same inputs and seeded weights (tests/golden/{t2v,i2v}_full_24x32x32,
+    written by oracle/make_golden_ddim50.py --only fwd; fp32 CPU eager).  SURVEY 8d: rel-L2 <= 1e-2 per forward."""
+    from videomv_amd.registry import MODEL
+    from oracle.weights import checksum
+    path = os.path.join(golden_dir, f"{which}_full_24x32x32.safetensors")
+    gld = load_file(path)
+    with safe_open(path, "pt") as f:
+        meta = f.metadata()
+    c = json.loads(meta["cfg"])
+    cfg = UNetCfg(**c)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    if which == "t2v":
+        sd = random_state_dict(unet_param_shapes(cfg), int(meta["seed"]))
+        m = build_model(c, sd).cuda()
+        kw = dict(y=gld["y"].cuda(), camera_data=gld["camera_data"])
+        key = "eps"
+    else:
+        import videomv_amd.unet_i2vgen  # noqa: F401
+        from oracle.unet_i2v_ref import i2v_param_shapes
+        shapes = dict(unet_param_shapes(UNetCfg(**dict(c, in_dim=8))))
+        shapes.update(i2v_param_shapes(cfg))
+        sd = random_state_dict({k: shapes[k] for k in sorted(shapes)}, int(meta["seed"]))
+        m = MODEL.build(dict(type="UNetSD_I2VGen", y_dim=1024, use_camera_condition=True, concat_dim=4, **c))
+        m.load_state_dict(sd, strict=True)
+        m = m.eval().cuda()
+        F_ = gld["x"].shape[2]
+        kw = dict(y=gld["y"].cuda(), image=gld["image"].cuda(), local_image=gld["local_image"].unsqueeze(2).repeat_interleave(F_, dim=2).cuda(),
+                  fps=gld["fps"].cuda(), camera_data=gld["camera_data"])
+        key = "out"
+    assert abs(checksum(sd) - float(gld["weights_checksum"][0])) < 1e-6 * abs(float(gld["weights_checksum"][0]))
+    out = m(gld["x"].cuda(), gld["t"].cuda(), **kw)
+    assert out.shape == gld[key].shape and torch.isfinite(out).all()
+    e = rel_l2(out, gld[key])
+    print(f"full-size {which} forward at 24x32x32 vs the imported reference: rel-L2 {e:.3e} ({_L.elem_name()})")
+    assert e < TOL_FWD, e
