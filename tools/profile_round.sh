@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
 RN=${RN:-r2}      # round tag of the output files; VMV_COMMIT (git hash of the submitted tree) is recorded in the traffic JSON
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py"
-P="--no-cpu-baseline --no-sample --no-op-profile"
+P="--no-cpu-baseline --no-sample --no-op-profile --simulate-rank 0"
 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_kt -- $B $P --steps 5 --warmup 1 > $O/prof_kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -f csv -d $O/prof_fetch -- $B $P --steps 2 --warmup 1 > $O/prof_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -f csv -d $O/prof_write -- $B $P --steps 2 --warmup 1 > $O/prof_write.log 2>&1
@@ -23,8 +23,10 @@ python tools/gemm_traffic.py $O/prof_fetch $O/prof_write $O/${RN}_gemm_traffic.j
 cp $O/${RN}_gemm_traffic.json $R/profiles/${RN}_gemm_traffic.json
 cd /tmp
 $B > $O/${RN}_bench_40x64.json 2> $O/bench_full.err
-$B --latent 32x32 --no-cpu-baseline > $O/${RN}_bench_32x32.json 2>> $O/bench_full.err
-$B --no-cpu-baseline --no-sample --dump-ops $O/${RN}_ops_40x64.tsv > /dev/null 2>> $O/bench_full.err
+$B --latent 32x32 --no-cpu-baseline --simulate-rank 0 > $O/${RN}_bench_32x32.json 2>> $O/bench_full.err
+$B --no-cpu-baseline --no-sample --simulate-rank 8 --dump-ops $O/${RN}_ops_40x64.tsv --dump-ops-sim $O/${RN}_ops_sim_rank0of8.tsv > $O/${RN}_bench_sim8.json 2>> $O/bench_full.err
+for w in 2 4; do $B --no-cpu-baseline --no-sample --no-op-profile --simulate-rank $w > $O/${RN}_bench_sim$w.json 2>> $O/bench_full.err; done
+python tools/kernel_resources.py > $O/${RN}_kernel_resources.txt 2>/dev/null || true
 cd $R
 rm -rf $O/prof_kt $O/prof_fetch $O/prof_write $O/prof_mfma $O/prof_lds
 tail -c 600 $O/${RN}_bench_40x64.json

@@ -67,22 +67,28 @@ class FrameComm:
         self._twin = None
         # handle (VmvComm*): with RCCL underneath the collectives are recorded INTO the plans (VMV_OP_COMM) and issued by the C
         # replay loop on the replay's stream — one host call per forward instead of one Python collective per plan segment
-        # (DESIGN.md §8).  VMV_COMM_NATIVE=0 keeps the torch.distributed calls (the gloo path always does).
-        self.handle = None
-        if self.backend == "nccl" and not self.local_only and os.environ.get("VMV_COMM_NATIVE", "1") != "0" and torch.cuda.is_available():
-            try:
-                self.handle = native_comm(group, torch.device("cuda", torch.cuda.current_device()))
-            except Exception as e:          # (the torch.distributed path below needs nothing from libvmv: keep going on it)
-                import warnings
-                warnings.warn(f"vmv_comm_* unavailable ({type(e).__name__}: {e}); collectives stay in Python")
-                self.handle = None
+        # (DESIGN.md §8).  Created on first use (collective: every rank of the group records its first plan at the same point);
+        # VMV_COMM_NATIVE=0 keeps the torch.distributed calls (the gloo path always does).
+        self._handle, self._handle_tried = None, False
+
+    @property
+    def handle(self):
+        if not self._handle_tried:
+            self._handle_tried = True
+            if self.backend == "nccl" and not self.local_only and os.environ.get("VMV_COMM_NATIVE", "1") != "0" and torch.cuda.is_available():
+                try:
+                    self._handle = native_comm(self.group, torch.device("cuda", torch.cuda.current_device()))
+                except Exception as e:      # (the torch.distributed path needs nothing from libvmv: keep going on it)
+                    import warnings
+                    warnings.warn(f"vmv_comm_* unavailable ({type(e).__name__}: {e}); collectives stay in Python")
+        return self._handle
 
     def __del__(self):
         try:
-            if self.handle:
+            if self._handle:
                 from . import _lib as L
-                L.load().vmv_comm_destroy(self.handle)
-                self.handle = None
+                L.load().vmv_comm_destroy(self._handle)
+                self._handle = None
         except Exception:
             pass
 
