@@ -198,10 +198,16 @@ def _rccl_world1_worker(port, q):
         except Exception as e:
             out["graph_error"] = f"{type(e).__name__}: {e}"
         q.put(out)
+        del eng
+        comm.close()
         dist.destroy_process_group()
     except Exception:
         import traceback
         q.put(dict(error=traceback.format_exc()))
+    finally:
+        q.close()
+        q.join_thread()      # (the queue's feeder thread has flushed the result)
+        os._exit(0)          # no interpreter teardown of HIP / RCCL state in the throw-away child
 
 
 def test_rccl_collectives_inside_the_plan_world1():
@@ -210,8 +216,12 @@ def test_rccl_collectives_inside_the_plan_world1():
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_world1_worker, args=(_free_port(), q))
     p.start()
-    r = q.get(timeout=420)
-    p.join(timeout=60)
+    try:
+        r = q.get(timeout=420)
+    finally:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
     assert "error" not in r, r["error"]
     assert r["handle"] and r["breaks"] == 0 and r["comm_ops"] > 30, r
     assert r["bitwise_vs_unsharded"], r                      # identity permutations + the rank's own totals: same bits (same GroupNorm form)

@@ -83,14 +83,16 @@ class FrameComm:
                     warnings.warn(f"vmv_comm_* unavailable ({type(e).__name__}: {e}); collectives stay in Python")
         return self._handle
 
-    def __del__(self):
-        try:
-            if self._handle:
-                from . import _lib as L
-                L.load().vmv_comm_destroy(self._handle)
-                self._handle = None
-        except Exception:
-            pass
+    def close(self):
+        """Destroy the RCCL communicator under this FrameComm (collective: every rank calls it; call it BEFORE
+        dist.destroy_process_group()).  Not done from __del__: a communicator torn down during interpreter shutdown, after the HIP
+        runtime / torch's own process group are gone, can block the exiting process."""
+        if self._handle:
+            from . import _lib as L
+            L.load().vmv_comm_destroy(self._handle)
+        self._handle, self._handle_tried = None, True
+        if self._twin is not None and self._twin._handle:
+            self._twin.close()
 
     def twin(self) -> "FrameComm":
         """A second communicator over the same ranks (its own process group, so that its collectives can be in flight on
