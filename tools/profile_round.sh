@@ -23,7 +23,7 @@ python tools/gemm_traffic.py $O/prof_fetch $O/prof_write $O/${RN}_gemm_traffic.j
 cp $O/${RN}_gemm_traffic.json $R/profiles/${RN}_gemm_traffic.json
 cd /tmp
 $B > $O/${RN}_bench_40x64.json 2> $O/bench_full.err
-$B --latent 32x32 --no-cpu-baseline --simulate-rank 0 > $O/${RN}_bench_32x32.json 2>> $O/bench_full.err
+$B --latent 32x32 --no-cpu-baseline --no-sample --simulate-rank 0 > $O/${RN}_bench_32x32.json 2>> $O/bench_full.err
 $B --no-cpu-baseline --no-sample --simulate-rank 8 --dump-ops $O/${RN}_ops_40x64.tsv --dump-ops-sim $O/${RN}_ops_sim_rank0of8.tsv > $O/${RN}_bench_sim8.json 2>> $O/bench_full.err
 for w in 2 4; do $B --no-cpu-baseline --no-sample --no-op-profile --simulate-rank $w > $O/${RN}_bench_sim$w.json 2>> $O/bench_full.err; done
 python tools/kernel_resources.py > $O/${RN}_kernel_resources.txt 2>/dev/null || true

@@ -40,9 +40,10 @@ def beta_schedule(schedule="cosine", num_timesteps=1000, zero_terminal_snr=False
 
 
 def _check_finite(t, what):
-    """the fp16 stores of the default build do not saturate (v_cvt_pk_f16_f32 gives inf above 65504), so a checkpoint whose
-    activations leave fp16's range would produce inf / NaN frames silently.  One reduction per SAMPLE (not per step) turns that into
-    an error that names the way out.  ``VMV_CHECK_FINITE=0`` disables."""
+    """One reduction per SAMPLE (not per step): a latent holding inf / NaN is an error that names the way out, not a video.  Since round
+    4 the fp16 stores saturate at +-65504 (MODE.FP16_OVFL, csrc/common.h), so a checkpoint whose activations merely leave fp16's range
+    clips instead of producing inf; what still reaches this check are true infinities / NaNs (the hardware mode preserves them) — bad
+    inputs, or an fp32 accumulator that overflowed.  ``VMV_CHECK_FINITE=0`` disables."""
     import os
     if os.environ.get("VMV_CHECK_FINITE", "1") == "0" or not t.is_cuda:
         return
