@@ -101,6 +101,7 @@ class _VaeEngine:
         else:
             self.wt = {}
             self._pack(sd)
+            P.check_finite_weights(self.wt, type(self).__name__)
         self._build()
 
     def _packers(self, sd):
@@ -465,8 +466,9 @@ class AutoencoderKL(nn.Module):
                   if k.startswith("decoder.") or k.startswith("post_quant_conv.")}
             eng = VaeDecoderEngine(self.ddconfig, sd, n, h, w, z.device, packed=self._packed_of(VaeDecoderEngine, z.device))
             self._engines[key] = eng
-        out = eng.decode(z.float())
         from .diffusion_ddim import _check_finite
+        _check_finite(z, "the latent handed to decode", is_input=True)
+        out = eng.decode(z.float())
         _check_finite(out, "the decoded frames")
         return out
 
@@ -482,6 +484,8 @@ class AutoencoderKL(nn.Module):
             sd = {k: v.detach() for k, v in self.state_dict().items() if k.startswith("encoder.") or k.startswith("quant_conv.")}
             eng = VaeEncoderEngine(self.ddconfig, sd, n, h, w, x.device, packed=self._packed_of(VaeEncoderEngine, x.device))
             self._engines[key] = eng
+        from .diffusion_ddim import _check_finite
+        _check_finite(x, "the image handed to encode", is_input=True)
         rows = eng.encode(x.float())
         return DiagonalGaussianDistribution(rows, n, self.ddconfig["z_channels"], eng.LH, eng.LW, x.device)
 

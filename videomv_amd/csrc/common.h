@@ -53,6 +53,12 @@ VMV_DEV float elem_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float1
 //   VMV_F16_SAT = 1 (default): the wave's MODE.FP16_OVFL bit, set by the first instruction of every kernel (VMV_KERNEL_ENTER) —
 //                 "an overflowed FP16 result is clamped to +-MAX_FP16 regardless of round mode, while still preserving true INF
 //                 values" — which covers every v_cvt_pk_f16_f32 / v_cvt_f16_f32 of the kernel at zero cost per store;
+//                 Measured side effect (tools/experiments/nan_probe.py, MI355X): with the bit set the fp16 MFMA no longer propagates
+//                 non-finite OPERANDS — a NaN element contributes 0, an inf element the largest finite value (fp32 results clamp at
+//                 FLT_MAX) — while the VALU paths (GroupNorm / LayerNorm statistics, softmax) still do.  Finite inputs and weights
+//                 therefore cannot produce inf / NaN inside a forward, and a NaN that ENTERS one would be swallowed by the first
+//                 GEMM: the host checks inputs and packed weights for finiteness at the door (diffusion_ddim._check_finite,
+//                 packing.check_finite_weights) instead of relying on the result alone.
 //   VMV_F16_SAT = 2: a v_med3_f32 clamp per converted value in pack_elem2 (two more VALU operations per stored pair; the GEGLU
 //                 epilogues are VALU-issue-bound — only if a future part drops the mode bit);   VMV_F16_SAT = 0: round-3 behaviour.
 #ifndef VMV_F16_SAT

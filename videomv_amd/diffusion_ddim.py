@@ -39,16 +39,21 @@ def beta_schedule(schedule="cosine", num_timesteps=1000, zero_terminal_snr=False
     return betas
 
 
-def _check_finite(t, what):
-    """One reduction per SAMPLE (not per step): a latent holding inf / NaN is an error that names the way out, not a video.  Since round
-    4 the fp16 stores saturate at +-65504 (MODE.FP16_OVFL, csrc/common.h), so a checkpoint whose activations merely leave fp16's range
-    clips instead of producing inf; what still reaches this check are true infinities / NaNs (the hardware mode preserves them) — bad
-    inputs, or an fp32 accumulator that overflowed.  ``VMV_CHECK_FINITE=0`` disables."""
+def _check_finite(t, what, is_input=False):
+    """A tensor holding inf / NaN is an error that names the way out, not a video; one reduction per SAMPLE (not per step).
+    Round 4: the fp16 kernels run with MODE.FP16_OVFL set (csrc/common.h) — 16-bit stores saturate at +-65504 instead of producing
+    inf, and (measured, tools/experiments/nan_probe.py) the fp16 MFMA then treats a NaN operand as 0 and an inf operand as the
+    largest finite value — so finite inputs and finite weights can no longer turn into inf / NaN inside the forward, and a NaN that
+    ENTERS it would be swallowed by the first GEMM.  The guard therefore stands at the door: the sampler checks the noise and the
+    conditioning tensors once per sample, ``decode`` / ``encode`` their input, the engines their weights once at pack time; the
+    check on the RESULT stays as the belt to those braces.  ``VMV_CHECK_FINITE=0`` disables all of them."""
     import os
-    if os.environ.get("VMV_CHECK_FINITE", "1") == "0" or not t.is_cuda:
+    if t is None or os.environ.get("VMV_CHECK_FINITE", "1") == "0" or not t.is_cuda or not t.is_floating_point():
         return
     if not bool(torch.isfinite(t).all()):
         from . import _lib as L
+        if is_input:
+            raise FloatingPointError(f"{what} holds inf / NaN: non-finite INPUT (the {L.elem_name()} kernels would silently drop it)")
         raise FloatingPointError(f"{what} holds inf / NaN after the {L.elem_name()} kernels: activations left the 16-bit range"
                                  + (" — rerun with hip_dtype: bf16 (VMV_DTYPE=bf16), the wide-range build" if L.elem_name() == "fp16" else ""))
 
@@ -164,6 +169,11 @@ class DiffusionDDIM(object):
             noise = noise[:, :, comm.rank * fl:(comm.rank + 1) * fl]
         xt = noise.detach().clone().float().contiguous()      # updated in place by the fused kernel
         kc, ku = model_kwargs
+        _check_finite(xt, "the initial noise", is_input=True)           # (once per sample: see _check_finite)
+        for kw in (kc, ku):
+            for name, v in kw.items():
+                if torch.is_tensor(v):
+                    _check_finite(v, f"model_kwargs[{name!r}]", is_input=True)
         if hasattr(unet, "begin_sample"):
             unet.begin_sample()                                # new sample: step-invariant conditioning is re-evaluated
         if autoencoder is not None and comm is not None:

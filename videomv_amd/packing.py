@@ -97,3 +97,20 @@ def pack_bias(b: torch.Tensor, device, n_pad_to=4) -> torch.Tensor:
 
 def f32(t: torch.Tensor, device) -> torch.Tensor:
     return t.detach().float().to(device).contiguous()
+
+
+def check_finite_weights(w: dict, what: str):
+    """One device-side reduction + ONE host sync over all packed tensors of an engine: a checkpoint holding inf / NaN (or values the
+    16-bit pack turned into inf) is refused at load time.  With MODE.FP16_OVFL set the fp16 MFMA silently treats a NaN operand as 0
+    (csrc/common.h, diffusion_ddim._check_finite), so this is where such a weight can still be seen.  VMV_CHECK_FINITE=0 disables."""
+    import os
+    if os.environ.get("VMV_CHECK_FINITE", "1") == "0":
+        return
+    ts = [t for t in w.values() if torch.is_tensor(t) and t.is_floating_point() and t.is_cuda]
+    if not ts:
+        return
+    ok = torch.stack([torch.isfinite(t).all() for t in ts])
+    if not bool(ok.all()):
+        names = [k for (k, t), good in zip([(k, t) for k, t in w.items() if torch.is_tensor(t) and t.is_floating_point() and t.is_cuda], ok.tolist()) if not good]
+        raise FloatingPointError(f"{what}: packed weights hold inf / NaN ({', '.join(names[:5])}{' ...' if len(names) > 5 else ''}) — "
+                                 f"values beyond the {L.elem_name()} range?" + (" Use hip_dtype: bf16 (VMV_DTYPE=bf16)." if L.elem_name() == "fp16" else ""))

@@ -378,6 +378,7 @@ class UNetEngine:
         w["out.2.weight"] = P.pack_conv3x3(sd["out.2.weight"], dev)
         w["out.2.bias"] = P.pack_bias(sd["out.2.bias"], dev)
         self.out_pad = w["out.2.weight"].shape[0]
+        P.check_finite_weights(w, "UNet")
 
     # ------------------------------------------------------------------ static I/O buffers
     def _static_inputs(self):
