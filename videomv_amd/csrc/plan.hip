@@ -129,7 +129,7 @@ extern "C" int vmv_graph_launch(const VmvGraph* g, void* stream) {
 extern "C" int vmv_graph_nodes(const VmvGraph* g) { return g ? g->nodes : VMV_ENULL; }
 extern "C" void vmv_graph_destroy(VmvGraph* g) {
     if (!g) return;
-    if (g->exec) hipGraphExecDestroy(g->exec);
-    if (g->graph) hipGraphDestroy(g->graph);
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
     delete g;
 }
