@@ -362,6 +362,18 @@ def main():
                 fpar["cfg_x_frame"] = dict(cfgp, parallelism=f"2 branch groups x {comm2.world} frame shards")
                 if cfgp["steps_per_s"] > fpar["steps_per_s"]:
                     fpar.update(cfgp, mode="cfg-parallel x frame-parallel")
+            # the branch-pipelined mode again with each branch plan replayed as ONE hipGraph (kernels + RCCL collectives captured
+            # together, VMV_GRAPH=1) — meaningful only when the collectives are plan ops; inside its own try
+            state["partial"] = dict(fpar)
+            if eng.n_comm_ops:
+                try:
+                    os.environ["VMV_GRAPH"], os.environ["VMV_FP_PIPELINE"] = "1", "1"
+                    model.set_frame_parallel(comm)
+                    fpar["branch_pipelined_graph"] = timed_leg("pipelined+graph")
+                except Exception as e:
+                    fpar["branch_pipelined_graph"] = dict(error=f"{type(e).__name__}: {e}")
+                finally:
+                    os.environ.pop("VMV_GRAPH", None)
             # BASELINE's north-star form of configs[2], measured beside the default: frames stay sharded through the temporal
             # transformers, one all-gather of [K | V] before each temporal attention (VMV_FP_TEMPORAL=kv_gather; branch-pipelined
             # B = 1 plans).  Last, inside its own try: nothing above depends on it.

@@ -120,3 +120,46 @@ def test_gemm_tile_policy(monkeypatch):
     assert pick(24 * 1024, 1024, lin(512), out_fp32=True, wgroup_rows=1024, wgroup_stride=1024 * 512) == L.TILE_P256x128
     assert pick(24 * 512, 1024, lin(512), wgroup_rows=512, wgroup_stride=1024 * 512) == L.TILE_G128x128
     assert pick(24 * 1024, 320, lin(512), wgroup_rows=1024, wgroup_stride=320 * 512, tile=L.TILE_P256x160) == -1
+
+
+def test_comm_api_host_logic():
+    """vmv_comm_* (ABI 8) without a GPU: the simulated communicator is pure host state; RCCL entry points refuse politely while the
+    library is not loaded (vmv_comm_load was never called in this process); argument validation of a collective op; plan recording."""
+    lib = L.load()
+    assert C.sizeof(L.CommParams) == lib.vmv_sizeof(L.OP_COMM)
+    assert lib.vmv_comm_loaded() == 0
+    idb = (C.c_uint8 * L.COMM_ID_BYTES)()
+    assert lib.vmv_comm_unique_id(idb) == -1 and not lib.vmv_comm_create(idb, 2, 0)
+    assert not lib.vmv_comm_create_sim(4, 4) and not lib.vmv_comm_create_sim(0, 0)
+    h = lib.vmv_comm_create_sim(8, 3)
+    assert h and lib.vmv_comm_world(h) == 8 and lib.vmv_comm_rank(h) == 3 and lib.vmv_comm_is_sim(h) == 1
+    X = 1 << 20
+    assert lib.vmv_comm_run(C.byref(ops.comm_params(h, L.COMM_ALL_TO_ALL, None, X, 64)), None) == -3         # VMV_ENULL
+    assert lib.vmv_comm_run(C.byref(ops.comm_params(h, L.COMM_ALL_TO_ALL, X, X, 0)), None) == -1            # VMV_EINVAL
+    assert lib.vmv_comm_run(C.byref(ops.comm_params(None, L.COMM_ALL_TO_ALL, X, X, 64)), None) == -3
+    plan = lib.vmv_plan_create()
+    p = ops.comm_params(h, L.COMM_ALL_GATHER, X, X, 4096)
+    assert lib.vmv_plan_add(plan, L.OP_COMM, C.byref(p), C.sizeof(p)) == 0 and lib.vmv_plan_size(plan) == 1
+    assert not lib.vmv_plan_capture(None, None) and lib.vmv_graph_launch(None, None) == -3 and lib.vmv_graph_nodes(None) == -3
+    lib.vmv_plan_destroy(plan)
+    lib.vmv_comm_destroy(h)
+    assert b"VMV_ECOMM" in lib.vmv_error_string(-5)
+
+
+def test_tuned_table_is_well_formed():
+    """videomv_amd/tuned_gemm.json (tools/autotune_gemm.py): every key parses as a GEMM signature, every entry names a tile id the header
+    declares and a sane split-K factor, and carries the measurement that justified it (>= 7 % faster than the policy)."""
+    import json
+    with open(os.path.join(ROOT, "videomv_amd", "tuned_gemm.json")) as f:
+        tab = json.load(f)
+    assert "meta" in tab and tab["meta"]["tool"] == "tools/autotune_gemm.py"
+    for elem in ("fp16", "bf16"):
+        assert tab[elem], elem
+        for sig, e in tab[elem].items():
+            assert re.fullmatch(r"\d+x\d+x\d+;[0-9:*,]+;e\da\df\dr\dv\d:\d+s\dc\dl\dg\dw\d+;\d+x\d+<\d+x\d+s\d+u\dF\d+P\d+", sig), sig
+            assert 1 <= e["tile"] <= 26 and e["ksplit"] in (0, 2, 3, 4, 6, 8, 12, 16)
+            assert e["us"] <= 0.93 * e["base_us"] + 1e-6, (sig, e)
+    # and the engine's hook finds an entry by the signature of the launch it is about to record
+    sig = next(iter(tab["fp16"]))
+    M, N, K = (int(v) for v in sig.split(";")[0].split("x"))
+    assert M > 0 and N % 4 == 0 and K % 8 == 0
