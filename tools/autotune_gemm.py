@@ -153,6 +153,7 @@ def main():
     ap.add_argument("--frames", type=int, default=24)
     ap.add_argument("--out", default=os.path.join(ROOT, "videomv_amd", "tuned_gemm.json"))
     ap.add_argument("--merge", action="store_true", help="keep the entries already in --out for signatures not measured now")
+    ap.add_argument("--lgm", action="store_true", help="also tune the VAE decoder / encoder and LGM U-Net plans (one LGM-refined step at 24x32x32 + the 24-frame decode)")
     a = ap.parse_args()
     H, W = (int(v) for v in a.latent.split("x"))
     dev = torch.device("cuda", 0)
@@ -197,7 +198,9 @@ def main():
         with open(a.out, "w") as f:
             json.dump(out, f, indent=1, sort_keys=True)
 
-    for w in [int(v) for v in a.worlds.split(",")]:
+    for w in [int(v) for v in a.worlds.split(",") if v.strip()]:
+        if w < 1:
+            continue
         if w == 1:
             model.set_frame_parallel(None)
             eng, _ = model.forward_cfg_rows(noise, t, kc, ku)
@@ -217,6 +220,38 @@ def main():
         os.environ.pop("VMV_FP_PIPELINE", None)
     model.set_frame_parallel(None)
     save()
+    if a.lgm:
+        # BASELINE configs[4] at its own shape: one LGM-refined step builds every other engine of the sampler — the VAE decoder (8 views
+        # at 256 px) and encoder (48 views), the LGM U-Net plans — and the 24-frame decode of the headline shape; their GEMMs get the same
+        # treatment (engines take the table through ops.make_tuner)
+        from videomv_amd.registry import AUTO_ENCODER, DIFFUSION
+        import videomv_amd.autoencoder  # noqa: F401
+        import videomv_amd.diffusion_ddim  # noqa: F401
+        from videomv_amd.lgm import prepare_gs_data
+        from videomv_amd.pipeline import decode_views
+        dd = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
+                  num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+        with torch.device(dev):
+            vae = AUTO_ENCODER.build(dict(type="AutoencoderKL", ddconfig=dd, embed_dim=4))
+            model_l = MODEL.build(dict(type="UNetSD_T2VBase", y_dim=1024, use_camera_condition=True, use_lgm_refine=True, **FULL))
+        bench.randomize_(vae, 4321)
+        bench.randomize_(model_l, 1234)
+        model_l.eval()
+        dif = DIFFUSION.build(dict(type="DiffusionDDIM", schedule="linear_sd",
+                                   schedule_param=dict(num_timesteps=1000, init_beta=0.00085, last_beta=0.012, zero_terminal_snr=False),
+                                   mean_type="eps", var_type="fixed_small"))
+        cam_l = entrance_camera_data(24, elevation=15, camera_distance=2.0)
+        gs_data = prepare_gs_data(cam_l, model_l.lgm_opt)
+        xl = torch.randn(1, 4, 24, 32, 32, generator=g, device=dev)
+        kl = [dict(y=y, camera_data=cam_l, gs_data=gs_data), dict(y=y0, camera_data=cam_l, gs_data=gs_data)]
+        dif.ddim_step_lgm(xl, 501, model_l, kl[0], kl[1], 9.0, 20, vae)
+        decode_views(vae, noise)
+        torch.cuda.synchronize()
+        ref = model_l.lgm_refiner(dev)
+        engines = [(f"vae {k}", e) for k, e in vae._engines.items()] + [("lgm b1", ref.engine)] + ([("lgm b2", ref._engine2)] if ref._engine2 is not None else [])
+        for tag, e in engines:
+            tune_plan(e, table, ws, tag if isinstance(tag, str) else str(tag))
+            save()
     gain = sum(e["base_us"] - e["us"] for e in table["entries"].values())
     print(f"{len(table['entries'])} of {len(table['done'])} signatures improved; sum of per-signature gains {gain:.0f} us; {time.time() - t0:.0f} s -> {a.out}")
 

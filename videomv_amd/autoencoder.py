@@ -94,6 +94,7 @@ class _VaeEngine:
         self.dd, self.n, self.h, self.w, self.device = dd, n, h, w, device
         self.pool = Pool(device)
         self.S = ops.Stream(record=True)
+        self.S.tuner = ops.make_tuner(self)      # measured per-shape (tile, split-K) choices: videomv_amd/tuned_gemm.json
         self._keep = []
         self._gnws = torch.empty(4 << 20, dtype=torch.float32, device=device)
         if packed is not None:

@@ -108,6 +108,7 @@ class LgmEngine:
         self.V = opt.num_frames * self.B             # images in the plan (rows are image-major)
         self.pool = Pool(device)
         self.S = ops.Stream(record=True)
+        self.S.tuner = ops.make_tuner(self)      # measured per-shape (tile, split-K) choices: videomv_amd/tuned_gemm.json
         self._gnws = torch.empty(4 << 20, dtype=torch.float32, device=device)
         self._keep = []
         self.taps = taps

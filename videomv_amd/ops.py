@@ -141,6 +141,27 @@ def tuned_table() -> dict:
     return _TUNED
 
 
+def make_tuner(owner):
+    """ops.Stream hook (Stream.tuner) of an engine: applies the measured (tile, split-K) choice of tuned_gemm.json to a GEMM about to be
+    recorded — auto tiles only; the library still validates the forced tile, so a stale entry fails loudly at record time.  `owner`
+    provides .device (or .dev) and keeps the split-K slab (._splitk) and the hit count (.n_tuned)."""
+    def tune(p):
+        if p.tile != L.TILE_AUTO or p.wgroup_rows:
+            return
+        ent = tuned_table().get(gemm_signature(p))
+        if not ent:
+            return
+        ks = int(ent.get("ksplit", 0))
+        if ks > 1:
+            if getattr(owner, "_splitk", None) is None:
+                owner._splitk = SplitK(owner.device if hasattr(owner, "device") else owner.dev, cap=8)
+            p.workspace = owner._splitk.workspace(ks * p.M * p.N * 4).data_ptr()
+        p.ksplit = ks if ks > 1 else 0
+        p.tile = int(ent.get("tile", 0))
+        owner.n_tuned = getattr(owner, "n_tuned", 0) + 1
+    return tune
+
+
 class SplitK:
     """Split-K policy + workspace for the small-M implicit GEMMs (a tile grid that cannot fill the 256 CUs with a long
     reduction): K is cut into `ks` slices (fp32 slabs in the workspace, deterministic reduce + epilogue pass, vmv.h).

@@ -268,7 +268,7 @@ class UNetEngine:
                            emb_off=self.emb_off, emb_total=self.emb_total, out_pad=self.out_pad)
         self._eps_out = eps_out
         self.n_tuned = 0
-        self.S.tuner = self._tune
+        self.S.tuner = ops.make_tuner(self)      # measured per-shape (tile, split-K) choices: videomv_amd/tuned_gemm.json
         self._static_inputs()
         self._build()
 
@@ -421,23 +421,6 @@ class UNetEngine:
         ks, ws = (0, None) if kw.get("rowstat") else self._ksplit(M, W.shape[0], segs)      # (folded-LN GEMMs: no split-K)
         p = ops.gemm_params(M, W.shape[0], segs, W, out.ptr, out.C, bias=bias, geom=geom, ksplit=ks, workspace=ws, **kw)
         (stream or self.S).gemm(p, label)
-
-    def _tune(self, p):
-        """ops.Stream hook: apply the measured (tile, split-K) choice of videomv_amd/tuned_gemm.json to a GEMM about to be recorded
-        (auto tiles only; the library still validates the forced tile, so a stale entry fails loudly at record time, not silently)."""
-        if p.tile != L.TILE_AUTO or p.wgroup_rows:
-            return
-        ent = ops.tuned_table().get(ops.gemm_signature(p))
-        if not ent:
-            return
-        ks = int(ent.get("ksplit", 0))
-        if ks > 1:
-            if self._splitk is None:
-                self._splitk = ops.SplitK(self.device, cap=8)
-            p.workspace = self._splitk.workspace(ks * p.M * p.N * 4).data_ptr()
-        p.ksplit = ks if ks > 1 else 0
-        p.tile = int(ent.get("tile", 0))
-        self.n_tuned += 1
 
     def _ksplit(self, M, N, segs):
         """Split K when the tile grid cannot fill 256 CUs and the reduction is long (small-spatial levels)."""
