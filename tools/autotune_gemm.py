@@ -76,7 +76,7 @@ def time_us(lib, p, stream, reps=10, warm=2):
     return 1000.0 * e0.elapsed_time(e1) / reps
 
 
-def tune_plan(eng, table, ws, tag):
+def tune_plan(eng, table, ws, tag, gains=(0.93, 0.90)):
     lib = eng.S.lib
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     eng.S.run()                                   # realistic (finite) contents in every buffer
@@ -112,7 +112,7 @@ def tune_plan(eng, table, ws, tag):
                     continue
                 cands.append((tile, ks))
         best = (t_base, base_tile, base.ksplit if base.ksplit > 1 else 0)
-        need = 0.90 if t_base >= 120.0 else 0.93
+        need = gains[1] if t_base >= 120.0 else gains[0]
         for tile, ks in cands:
             q = clone(p0)
             q.tile, q.ksplit = tile, ks
@@ -153,6 +153,8 @@ def main():
     ap.add_argument("--frames", type=int, default=24)
     ap.add_argument("--out", default=os.path.join(ROOT, "videomv_amd", "tuned_gemm.json"))
     ap.add_argument("--merge", action="store_true", help="keep the entries already in --out for signatures not measured now")
+    ap.add_argument("--min-gain", type=float, default=0.93, help="keep a candidate only if its time <= this fraction of the policy's (launches < 120 us)")
+    ap.add_argument("--min-gain-big", type=float, default=0.90, help="the same for launches >= 120 us (burst timings overstate dense kernels)")
     ap.add_argument("--lgm", action="store_true", help="also tune the VAE decoder / encoder and LGM U-Net plans (one LGM-refined step at 24x32x32 + the 24-frame decode)")
     a = ap.parse_args()
     H, W = (int(v) for v in a.latent.split("x"))
@@ -204,7 +206,7 @@ def main():
         if w == 1:
             model.set_frame_parallel(None)
             eng, _ = model.forward_cfg_rows(noise, t, kc, ku)
-            tune_plan(eng, table, ws, f"world1 {H}x{W}")
+            tune_plan(eng, table, ws, f"world1 {H}x{W}", (a.min_gain, a.min_gain_big))
             save()
             continue
         if a.frames % w:
@@ -215,7 +217,7 @@ def main():
             model.set_frame_parallel(SimComm(w, 0))
             eng, _ = model.forward_cfg_rows(xs, t, kc, ku)
             e = model._pipe["engs"][0] if pipe == "1" else eng
-            tune_plan(e, table, ws, f"world{w} rank0 B={'1' if pipe == '1' else '2'} {H}x{W}")
+            tune_plan(e, table, ws, f"world{w} rank0 B={'1' if pipe == '1' else '2'} {H}x{W}", (a.min_gain, a.min_gain_big))
             save()
         os.environ.pop("VMV_FP_PIPELINE", None)
     model.set_frame_parallel(None)
@@ -250,7 +252,7 @@ def main():
         ref = model_l.lgm_refiner(dev)
         engines = [(f"vae {k}", e) for k, e in vae._engines.items()] + [("lgm b1", ref.engine)] + ([("lgm b2", ref._engine2)] if ref._engine2 is not None else [])
         for tag, e in engines:
-            tune_plan(e, table, ws, tag if isinstance(tag, str) else str(tag))
+            tune_plan(e, table, ws, tag if isinstance(tag, str) else str(tag), (a.min_gain, a.min_gain_big))
             save()
     gain = sum(e["base_us"] - e["us"] for e in table["entries"].values())
     print(f"{len(table['entries'])} of {len(table['done'])} signatures improved; sum of per-signature gains {gain:.0f} us; {time.time() - t0:.0f} s -> {a.out}")

@@ -101,8 +101,9 @@ def gn_params(x, ld, C0, rows, rows_per_stat, partial, gamma, beta, eps, silu, y
 
 def gn_chunk_rows(rows_per_stat: int, C: int) -> int:
     """Rows per partial-sum block: ~64 KB of input per block, at most 256 chunks per stat group."""
-    r = max(1, 65536 // (C * 2))
-    r = max(r, (rows_per_stat + 255) // 256)
+    kb, cap = int(os.environ.get("VMV_GN_CHUNK_KB", "64")), int(os.environ.get("VMV_GN_MAXCHUNKS", "256"))     # (A/B experiments)
+    r = max(1, kb * 1024 // (C * 2))
+    r = max(r, (rows_per_stat + cap - 1) // cap)
     return min(r, rows_per_stat)
 
 
