@@ -492,3 +492,35 @@ def test_vae_attention_grouped_weights_matches_oracle(monkeypatch, batched):
     else:
         assert not grouped
     assert rel_l2(img, vae_decode(sd, z)) < 2e-2
+
+
+def test_tile_table_hook_and_rerecord(monkeypatch):
+    """ops.make_tuner / UNetEngine._rerecord (host logic of the measured tile table): an entry for a launch's signature
+    forces its tile and split-K factor (with a workspace) when the plan is recorded; launches without an entry stay on the policy;
+    recording the plan again after the table changed (what VMV_AUTOTUNE=1 does) gives the same result as a fresh engine."""
+    plan_interp.install(monkeypatch)
+    from videomv_amd import _lib as L, ops
+    from videomv_amd.unet_engine import UNetEngine
+    ocfg = UNetCfg(**{k: v for k, v in CFG.items() if k in {f.name for f in dataclasses.fields(UNetCfg)}})
+    sd = random_state_dict(unet_param_shapes(ocfg), 99)
+    B, F_, H, W, Lc = 2, 3, 8, 8, 5
+    x, t, y, cam = _inputs(B, F_, H, W, Lc)
+    monkeypatch.setattr(ops, "_TUNED", {})
+    eng = UNetEngine(CFG, sd, B, F_, H, W, Lc, torch.device("cpu"), n_t=B)
+    assert eng.n_tuned == 0
+    eng.set_context(y); eng.set_camera(cam); eng.forward_rows(x, t)
+    eps0 = eng.eps_ncfhw().clone()
+    gemms = [(lb, p) for lb, (op, p) in zip(eng.S.labels, eng.S.recorded) if op == L.OP_GEMM and p.tile == L.TILE_AUTO and not p.rowstat and p.ln_eps == 0]
+    lb, p = next((lb, p) for lb, p in gemms if lb.endswith(".conv1"))
+    sig = ops.gemm_signature(p)
+    n_same = sum(1 for _, q in gemms if ops.gemm_signature(q) == sig)
+    monkeypatch.setattr(ops, "_TUNED", {sig: dict(tile=L.TILE_G128x128, ksplit=2)})
+    eng._rerecord()                                    # what VMV_AUTOTUNE=1 does after measuring
+    assert eng.n_tuned == n_same >= 1
+    forced = [q for op, q in eng.S.recorded if op == L.OP_GEMM and ops.gemm_signature(q) == sig]
+    assert all(q.tile == L.TILE_G128x128 and q.ksplit == 2 and q.workspace for q in forced)
+    assert all(q.tile == L.TILE_AUTO for op, q in eng.S.recorded if op == L.OP_GEMM and ops.gemm_signature(q) != sig)
+    eng.set_context(y); eng.set_camera(cam); eng.forward_rows(x, t)
+    assert torch.equal(eng.eps_ncfhw(), eps0)          # (the interpreter ignores tile / split-K: same arithmetic, same bits)
+    fresh = UNetEngine(CFG, sd, B, F_, H, W, Lc, torch.device("cpu"), n_t=B)
+    assert fresh.n_tuned == n_same and fresh.S.nops == eng.S.nops

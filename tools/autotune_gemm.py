@@ -34,116 +34,7 @@ from videomv_amd import _lib as L, ops   # noqa: E402
 
 FULL = dict(in_dim=4, dim=320, context_dim=1024, out_dim=4, dim_mult=[1, 2, 4, 4], num_heads=8, head_dim=64,
             num_res_blocks=2, attn_scales=[1.0, 0.5, 0.25])
-TILES = [L.TILE_128x128, L.TILE_128x160, L.TILE_128x64, L.TILE_64x64, L.TILE_256x128, L.TILE_256x160, L.TILE_G128x128, L.TILE_G128x160,
-         L.TILE_P256x128, L.TILE_P256x160, L.TILE_Q128x128, L.TILE_Q96x160, L.TILE_X256x320, L.TILE_X256x256, L.TILE_X256x128,
-         L.TILE_RS, L.TILE_RS256, L.TILE_RS512]
-KSPLITS = [2, 3, 4, 6, 8, 12, 16]
-WS_CAP = 512 << 20
-
-
-def clone(p):
-    q = L.GemmParams()
-    C.memmove(C.byref(q), C.byref(p), C.sizeof(p))
-    return q
-
-
-class _DevView:
-    def __init__(self, ptr, n, typestr):
-        self.__cuda_array_interface__ = dict(shape=(n,), typestr=typestr, data=(int(ptr), False), version=2)
-
-
-def out_view(p):
-    """The [M, ldo] output of a recorded GEMM as a tensor view (no copy)."""
-    n_out = p.N // 2 if p.epilogue == L.EPI_GEGLU else p.N
-    if p.out_fp32:
-        t = torch.as_tensor(_DevView(p.out, p.M * p.ldo, "<f4"), device="cuda").view(p.M, p.ldo)
-    else:
-        t = torch.as_tensor(_DevView(p.out, p.M * p.ldo, "<i2"), device="cuda").view(L.elem()).view(p.M, p.ldo)
-    return t[:, :n_out]
-
-
-def time_us(lib, p, stream, reps=10, warm=2):
-    for _ in range(warm):
-        if lib.vmv_gemm(C.byref(p), stream) != 0:
-            return None
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(reps):
-        lib.vmv_gemm(C.byref(p), stream)
-    e1.record()
-    torch.cuda.synchronize()
-    return 1000.0 * e0.elapsed_time(e1) / reps
-
-
-def tune_plan(eng, table, ws, tag, gains=(0.93, 0.90)):
-    lib = eng.S.lib
-    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    eng.S.run()                                   # realistic (finite) contents in every buffer
-    torch.cuda.synchronize()
-    seen = {}
-    for (op, p), label in zip(eng.S.recorded, eng.S.labels):
-        if op != L.OP_GEMM or p.wgroup_rows:
-            continue
-        sig = ops.gemm_signature(p)
-        if sig in seen or sig in table["done"]:
-            continue
-        seen[sig] = label
-    print(f"[{tag}] {len(seen)} new GEMM signatures", flush=True)
-    for sig, label in seen.items():
-        p0 = next(p for (op, p) in eng.S.recorded if op == L.OP_GEMM and ops.gemm_signature(p) == sig)
-        base = clone(p0)
-        base_tile = lib.vmv_gemm_pick_tile(C.byref(base))
-        t_base = time_us(lib, base, stream)
-        if t_base is None:
-            continue
-        ref = out_view(base).float().clone()
-        ref = torch.nan_to_num(ref, nan=0.0, posinf=0.0, neginf=0.0)
-        refn = float(ref.norm()) + 1e-12
-        steps = sum((base.seg[i].k + 63) // 64 for i in range(base.nseg))
-        tiles128 = ((base.M + 127) // 128) * ((base.N + 127) // 128)
-        ks_ok = not (base.rowstat or base.ln_eps > 0 or base.gn_table) and tiles128 < 768
-        cands = []
-        for tile in TILES:
-            for ks in [0] + ([k for k in KSPLITS if steps >= 2 * k and k * base.M * base.N * 4 <= WS_CAP] if ks_ok else []):
-                if tile in (L.TILE_RS, L.TILE_RS256, L.TILE_RS512, L.TILE_X256x320, L.TILE_X256x256, L.TILE_X256x128) and ks:
-                    continue
-                if tile == base_tile and ks == (base.ksplit if base.ksplit > 1 else 0):
-                    continue
-                cands.append((tile, ks))
-        best = (t_base, base_tile, base.ksplit if base.ksplit > 1 else 0)
-        need = gains[1] if t_base >= 120.0 else gains[0]
-        for tile, ks in cands:
-            q = clone(p0)
-            q.tile, q.ksplit = tile, ks
-            q.workspace = ws.data_ptr() if ks > 1 else None
-            if lib.vmv_gemm_pick_tile(C.byref(q)) < 0:
-                continue
-            out_view(q).zero_()
-            if lib.vmv_gemm(C.byref(q), stream) != 0:
-                continue
-            torch.cuda.synchronize()
-            got = torch.nan_to_num(out_view(q).float(), nan=0.0, posinf=0.0, neginf=0.0)
-            err = float((got - ref).norm()) / refn
-            if not (err <= 2e-3):
-                continue
-            t = time_us(lib, q, stream)
-            if t is not None and t < best[0]:
-                best = (t, tile, ks)
-        entry = None
-        if (best[1], best[2]) != (base_tile, base.ksplit if base.ksplit > 1 else 0):
-            q = clone(p0)
-            q.tile, q.ksplit, q.workspace = best[1], best[2], (ws.data_ptr() if best[2] > 1 else None)
-            t2, tb2 = time_us(lib, q, stream, reps=20), time_us(lib, base, stream, reps=20)      # second, independent timing
-            if t2 is not None and tb2 is not None and t2 <= need * tb2 and best[0] <= need * t_base and tb2 - t2 >= 1.5:
-                entry = dict(tile=int(best[1]), ksplit=int(best[2]), us=round(t2, 1), base_us=round(tb2, 1), base_tile=int(base_tile),
-                             base_ksplit=int(base.ksplit), label=label, plan=tag)
-        lib.vmv_gemm(C.byref(base), stream)          # leave the policy's result in the buffer
-        table["done"].add(sig)
-        if entry:
-            table["entries"][sig] = entry
-            print(f"  {label:58s} {sig.split(';')[0]:22s} tile {base_tile:2d}/ks{base.ksplit} {entry['base_us']:7.1f} us -> tile {entry['tile']:2d}/ks{entry['ksplit']} "
-                  f"{entry['us']:7.1f} us ({entry['us'] / entry['base_us']:.2f})", flush=True)
+from videomv_amd.autotune import tune_plan, WS_CAP      # noqa: E402  (the measurement itself lives in the package)
 
 
 def main():

@@ -139,6 +139,15 @@ def tuned_table() -> dict:
             if os.path.exists(path):
                 with open(path) as f:
                     _TUNED = {k: v for k, v in json.load(f).get(L.elem_name(), {}).items()}
+            # the per-user cache VMV_AUTOTUNE=1 writes (autotune.py) goes over the packaged table; read only when autotuning is on or
+            # VMV_TUNED_CACHE names a file explicitly, so that a default run depends on nothing outside the package
+            if os.environ.get("VMV_AUTOTUNE", "0") == "1" or os.environ.get("VMV_TUNED_CACHE"):
+                from .autotune import cache_path
+                try:
+                    with open(cache_path()) as f:
+                        _TUNED.update(json.load(f).get(L.elem_name(), {}))
+                except (OSError, ValueError):
+                    pass
     return _TUNED
 
 

@@ -271,6 +271,28 @@ class UNetEngine:
         self.S.tuner = ops.make_tuner(self)      # measured per-shape (tile, split-K) choices: videomv_amd/tuned_gemm.json
         self._static_inputs()
         self._build()
+        # VMV_AUTOTUNE=1: a shape the tile table does not cover tunes itself once (autotune.py) and the plan is recorded again with
+        # the winners — from a clean slate: new streams, pool and accumulators (the packed weights are kept)
+        if os.environ.get("VMV_AUTOTUNE", "0") == "1" and taps is None and str(device).startswith("cuda"):
+            from . import autotune
+            if autotune.autotune_engine(self, tag=f"B{B} F{self.Fg} {H}x{W} world{self.R}") > 0:
+                self._rerecord()
+
+    def _rerecord(self):
+        """Record the plan again (the tile table changed): fresh streams / pool / accumulators, same packed weights and geometry."""
+        dev = self.device
+        self.B = self.B_ctx
+        self.breaks, self.n_comm_ops, self.comm_bytes_in = [], 0, 0
+        self.pool = Pool(dev)
+        self.S = ops.Stream(record=True)
+        self.Sctx = ops.Stream(record=True)
+        self._keepalive, self._splitk = [], None
+        self._gn_tot2.zero_()
+        self._gn_tot_k = 0
+        self._replays, self.graph_nodes, self.n_tuned = 0, 0, 0
+        self.S.tuner = ops.make_tuner(self)
+        self._static_inputs()
+        self._build()
 
     # ------------------------------------------------------------------ weights
     def _pack(self, sd):
