@@ -61,6 +61,17 @@ class _ClipTower:
         self._splitk = ops.SplitK(device, cap=8)
         self.wt: Dict[str, torch.Tensor] = {}
 
+    def _pack_or_share(self, sd, donor):
+        """Packed weights are immutable and batch-size independent: an engine for another B of the same tower takes its donor's copy
+        (one ~0.7 / 1.3 GB repack per batch size otherwise)."""
+        if donor is not None and type(donor) is type(self) and str(donor.device) == str(self.device) and \
+                getattr(donor, "layer_idx", None) == getattr(self, "layer_idx", None):
+            self.wt = donor.wt
+            for a in self._PACKED_ATTRS:
+                setattr(self, a, getattr(donor, a))
+        else:
+            self._pack(sd)
+
     def act(self, rows, C, dtype=None) -> Act:
         return Act(self.pool.get(rows * C * (4 if dtype == torch.float32 else 2)), rows, C, dtype)
 
@@ -131,14 +142,17 @@ class _ClipTower:
 class ClipTextEngine(_ClipTower):
     """Plan for ``B`` prompts: token ids [B, T] -> (xt fp32 [B, embed_dim], x fp32 [B, T, width])."""
 
-    def __init__(self, opt: ClipTextOptions, sd: Dict[str, torch.Tensor], B: int, device, layer_idx: int = 1, taps: Optional[dict] = None):
+    _PACKED_ATTRS = ("tok", "pos")          # what _pack leaves on the engine besides .wt (shared with a donor engine of another batch size)
+
+    def __init__(self, opt: ClipTextOptions, sd: Dict[str, torch.Tensor], B: int, device, layer_idx: int = 1, taps: Optional[dict] = None,
+                 donor=None):
         if opt.width % opt.heads or opt.width // opt.heads != 64:
             raise NotImplementedError("the flash kernel's causal path is head_dim 64 (ViT-H/14 text: 1024 / 16)")
         if not 0 <= layer_idx < opt.layers:
             raise ValueError("layer_idx")
         self.o, self.B, self.layer_idx = opt, int(B), int(layer_idx)
         self._init_common(device, taps)
-        self._pack(sd)
+        self._pack_or_share(sd, donor)
         self._build()
 
     # ------------------------------------------------------------------ weights

@@ -61,7 +61,9 @@ def _padded_head_dim(hd: int) -> int:
 class ClipVisionEngine(_ClipTower):
     """Plan for ``B`` images: normalised pixels [B, 3, S, S] -> image embedding fp32 [B, embed_dim]."""
 
-    def __init__(self, opt: ClipVisionOptions, sd: Dict[str, torch.Tensor], B: int, device, taps: Optional[dict] = None):
+    _PACKED_ATTRS = ("kpatch", "cls", "pos")
+
+    def __init__(self, opt: ClipVisionOptions, sd: Dict[str, torch.Tensor], B: int, device, taps: Optional[dict] = None, donor=None):
         if opt.width % opt.heads or (opt.width // opt.heads) % 8 or opt.image_size % opt.patch_size:
             raise ValueError("width / heads must be a multiple of 8 and the image a whole number of patches")
         self.o, self.B = opt, int(B)
@@ -70,7 +72,7 @@ class ClipVisionEngine(_ClipTower):
         self.grid = opt.image_size // opt.patch_size
         self.T = self.grid * self.grid + 1
         self._init_common(device, taps)
-        self._pack(sd)
+        self._pack_or_share(sd, donor)
         self._build()
 
     def _pack(self, sd):

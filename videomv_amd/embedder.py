@@ -92,7 +92,8 @@ class FrozenOpenCLIPTtxtVisualEmbedder(_TextFeatures):
                                 width=sd["positional_embedding"].shape[1], heads=sd["positional_embedding"].shape[1] // 64,
                                 layers=1 + max(int(k.split(".")[2]) for k in sd if k.startswith("transformer.resblocks.")),
                                 embed_dim=sd["text_projection"].shape[1])
-            self._towers[B] = ClipTextEngine(o, sd, B, torch.device(self.tower_device), layer_idx=self.layer_idx)
+            donor = next((e for k, e in self._towers.items() if not isinstance(k, tuple)), None)      # packed weights: one copy for all batch sizes
+            self._towers[B] = ClipTextEngine(o, sd, B, torch.device(self.tower_device), layer_idx=self.layer_idx, donor=donor)
         return self._towers[B]
 
     def _vision(self, B):
@@ -106,7 +107,8 @@ class FrozenOpenCLIPTtxtVisualEmbedder(_TextFeatures):
             o = ClipVisionOptions(image_size=g * ps, patch_size=ps, width=W, heads=W // hd,
                                   layers=1 + max(int(k.split(".")[3]) for k in sd if k.startswith("visual.transformer.resblocks.")),
                                   mlp_ratio=sd["visual.transformer.resblocks.0.mlp.c_fc.weight"].shape[0] / W, embed_dim=sd["visual.proj"].shape[1])
-            self._towers[("v", B)] = ClipVisionEngine(o, sd, B, torch.device(self.tower_device))
+            donor = next((e for k, e in self._towers.items() if isinstance(k, tuple)), None)
+            self._towers[("v", B)] = ClipVisionEngine(o, sd, B, torch.device(self.tower_device), donor=donor)
         return self._towers[("v", B)]
 
     def forward(self, text=None, image=None, tokens=None):
