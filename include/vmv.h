@@ -158,7 +158,9 @@ typedef struct {
 #define VMV_TILE_A128x160 18   /* A-stationary persistent kernel, deferred epilogue: K <= 320, wide N (gemm_astat.hip) */
 #define VMV_TILE_A128x128 19
 #define VMV_TILE_X256x320 20   /* 8 waves x 64 x {160,128,64} wave tiles, four-stage ring of 32-deep chunks (gemm_xglds.hip): the
-                                  long-K convolutions / temporal convolutions of the large levels */
+                                  long-K convolutions / temporal convolutions of the large levels; the 256 x 256 form also carries the folded
+                                  LayerNorm (rowstat) and GEGLU epilogues; all three accept ksplit > 1 (plain epilogue, even splits of >= 4
+                                  32-deep chunks: VMV_EINVAL otherwise) */
 #define VMV_TILE_X256x256 21
 #define VMV_TILE_X256x128 22
 #define VMV_TILE_RS       23   /* row-stationary kernel (gemm_rs.hip): the wave's rows of A live in registers for the whole K = 320 / 640

@@ -213,6 +213,37 @@ def test_gemm_splitk(ks, tile):
     check(dev["out"], cpu["out"])
 
 
+@pytest.mark.parametrize("tile,M,N,K,ks", [(L.TILE_X256x320, 1920, 1280, 11520, 8), (L.TILE_X256x320, 300, 640, 1280, 3), (L.TILE_X256x256, 960, 1280, 3840, 6),
+                                          (L.TILE_X256x256, 257, 256, 1152, 2), (L.TILE_X256x128, 513, 128, 2304, 4), (L.TILE_X256x320, 15360, 320, 2880, 2)])
+def test_gemm_splitk_wide_tile(tile, M, N, K, ks):
+    """Round 4: split-K on the wide-tile kernel (gemm_xglds.hip SK): every split an even number (>= 4) of 32-deep chunks starting in the
+    middle of the K walk, raw fp32 slabs, the shared reduce + epilogue pass (bias, residual) — linear rows and a 3 x 3 gather
+    (K = 9 C: the splits begin inside segments), M / N tails."""
+    ws = torch.zeros(ks * M * N)
+    if K % 9 == 0 and (K // 9) % 8 == 0 and M % 48 == 0:            # 3 x 3 convolution over [n, h, w] = M rows
+        Cc = K // 9
+        n_img, hh = 3, 16
+        ww = M // (n_img * hh)
+        wt = torch.randn(N, Cc, 3, 3, generator=g(2)) * (9 * Cc) ** -0.5
+        c = Case(x=rnd((M, Cc), 1), w=P.pack_conv3x3(wt, "cpu"), b=torch.randn(N, generator=g(3)), res=rnd((M, N), 5), out=torch.zeros(M, N, dtype=BF), ws=ws)
+
+        def build(t):
+            return ops.gemm_params(M, N, ops.conv3x3_segs([(t["x"], Cc, Cc)]), t["w"], t["out"], N, bias=t["b"], residual=t["res"], ldr=N,
+                                   geom=ops.Geom(OH=hh, OW=ww, IH=hh, IW=ww), ksplit=ks, workspace=t["ws"], tile=tile)
+        cpu, dev = run_gemm(build, c, cpu_ref=False)
+        x4 = cpu["x"].float().view(n_img, hh, ww, Cc).permute(0, 3, 1, 2)
+        ref = torch.nn.functional.conv2d(x4, wt.to(BF).float(), cpu["b"], padding=1).permute(0, 2, 3, 1).reshape(M, N) + cpu["res"].float()
+        check(dev["out"], ref)
+        return
+    c = Case(a=rnd((M, K), 1), w=rnd((N, K), 2, K ** -0.5), b=torch.randn(N, generator=g(3)), res=rnd((M, N), 5), out=torch.zeros(M, N, dtype=BF), ws=ws)
+
+    def build(t):
+        return ops.gemm_params(M, N, ops.linear_segs([(t["a"], K, K)]), t["w"], t["out"], N, bias=t["b"], residual=t["res"], ldr=N,
+                               ksplit=ks, workspace=t["ws"], tile=tile)
+    cpu, dev = run_gemm(build, c, cpu_ref=False)
+    check(dev["out"], cpu["a"].float() @ cpu["w"].float().t() + cpu["b"] + cpu["res"].float())
+
+
 @pytest.mark.parametrize("n,H,W,Cin,N,fp32,ldo", [(2, 20, 37, 128, 4, True, 4), (3, 9, 16, 320, 4, False, 8), (2, 8, 8, 512, 8, True, 8),
                                                    (1, 33, 50, 192, 4, True, 4), (2, 16, 17, 160, 4, True, 4), (1, 5, 3, 32, 8, False, 8),
                                                    (24, 40, 64, 320, 4, True, 4)])

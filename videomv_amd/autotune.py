@@ -95,7 +95,7 @@ def tune_plan(eng, table, ws, tag, gains=(0.93, 0.90), verbose=True):
         cands = []
         for tile in TILES:
             for ks in [0] + ([k for k in KSPLITS if steps >= 2 * k and k * base.M * base.N * 4 <= WS_CAP] if ks_ok else []):
-                if tile in (L.TILE_RS, L.TILE_RS256, L.TILE_RS512, L.TILE_X256x320, L.TILE_X256x256, L.TILE_X256x128) and ks:
+                if tile in (L.TILE_RS, L.TILE_RS256, L.TILE_RS512) and ks:
                     continue
                 if tile == base_tile and ks == (base.ksplit if base.ksplit > 1 else 0):
                     continue

@@ -63,8 +63,13 @@ struct WRow {        // gather state of one A row of the lane beyond its index m
 
 constexpr int XE_GEGLU = 1, XE_LN = 2;       // EPI bits
 
-template <int NH, int WH, int EPI = 0>
-__global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams p, const int tiles_m, const int tiles_n, const int nsteps) {
+// SK (round 4): split-K — blockIdx.y owns `nsteps_arg` chunks of the K walk starting at blockIdx.y * nsteps_arg (the last split takes
+// what is left; the launcher keeps every split even and >= STAGES) and writes its raw fp32 accumulators to slab blockIdx.y of
+// p.workspace; gemm_splitk_reduce (gemm.hip) sums the slabs and runs the epilogue.  For the grids that cannot fill the chip with
+// 256-row wide tiles on their own (the fourth UNet level, a frame-parallel rank's M / 8 rows) without falling back to 128-row tiles.
+template <int NH, int WH, int EPI = 0, bool SK = false>
+__global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams p, const int tiles_m, const int tiles_n, const int nsteps_arg,
+                                                            const int nsteps_total) {
     VMV_KERNEL_ENTER();
     using Cfg = WgCfg<NH, WH>;
     constexpr int WM = Cfg::WM, WN = Cfg::WN, NW = Cfg::NW, BM = Cfg::BM, BN = Cfg::BN, S = Cfg::STAGES;
@@ -133,6 +138,17 @@ __global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams 
     const uint32_t wstride = (uint32_t)(NW * 16 * p.ktot) * 2u;
 
     int s = 0, kc = 0, koff = 0;
+    int nsteps = nsteps_arg;
+    if constexpr (SK) {           // fast-forward the K walk to this split's first chunk
+        const int step_begin = (int)blockIdx.y * nsteps_arg;
+        nsteps = nsteps_total - step_begin < nsteps_arg ? nsteps_total - step_begin : nsteps_arg;
+        int skip = step_begin;
+        while (s < p.nseg) {
+            const int nch = (p.seg[s].k + WBK - 1) / WBK;
+            if (skip < nch) { kc = skip * WBK; break; }
+            skip -= nch; koff += p.seg[s].k; ++s;
+        }
+    }
     uint32_t avo[Cfg::NAI];
     auto enter_segment = [&]() {
 #pragma unroll
@@ -274,6 +290,17 @@ __global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams 
 
     // ---- epilogue
     const int mbase = m0 + wave_m * 16 * WM + frow;
+    if constexpr (SK) {           // raw partial sums -> this split's slab; the reduce pass owns bias / activation / residual / stores
+        float* ws = p.workspace + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                const int m = mbase + 16 * i, n = n0 + wave_n * 16 * WN + 16 * j + 4 * fgrp;
+                if (m < p.M && n < p.N) *reinterpret_cast<f32x4_t*>(ws + (size_t)m * p.N + n) = acc[j][i];
+            }
+        return;
+    }
     // (the launcher only sends GEMMs whose outputs can be staged: 16-bit, 16-byte aligned rows)
     // 16-bit outputs go through LDS (whole rows, 16-byte lanes, residual read the same way), half a tile (the two waves of
     // one wave row) at a time: the ring holds 128 rows of BN outputs
@@ -396,14 +423,29 @@ int launch_xglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
     using Cfg = WgCfg<NH, WH>;
     const int tiles_m = (p.M + Cfg::BM - 1) / Cfg::BM;
     const int tiles_n = (p.N + Cfg::BN - 1) / Cfg::BN;
-    static std::atomic<unsigned long long> attr_set{0};
-    if (const int rc_attr = vmv_lds_attr_once(attr_set, reinterpret_cast<const void*>(&gemm_xglds_kernel<NH, WH, EPI>), Cfg::LDS_BYTES)) return rc_attr;
     int nsteps = 0;                                          // chunks of WBK = 32 (total_steps counts the other kernels' 64)
     for (int i = 0; i < p.nseg; ++i) nsteps += (p.seg[i].k + WBK - 1) / WBK;
     (void)total_steps;
     if (nsteps < Cfg::STAGES || (nsteps & 1)) return VMV_GLDS_UNSUPPORTED;
     if (p.rowvec && (Cfg::BM - 1) / p.rowvec_div + 2 > Cfg::XG_MAXG) return VMV_GLDS_UNSUPPORTED;      // column vectors staged per row group
-    hipLaunchKernelGGL((gemm_xglds_kernel<NH, WH, EPI>), dim3(tiles_m * tiles_n), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n, nsteps);
+    if (p.ksplit > 1) {
+        if constexpr (EPI != 0) return VMV_GLDS_UNSUPPORTED;
+        else {
+            // even chunk counts per split (the loop body is two chunks), every split >= STAGES chunks, no empty split
+            int sps = (nsteps + p.ksplit - 1) / p.ksplit;
+            sps += sps & 1;
+            const int last = nsteps - (p.ksplit - 1) * sps;
+            if (sps < Cfg::STAGES || last < Cfg::STAGES || (last & 1)) return VMV_GLDS_UNSUPPORTED;
+            static std::atomic<unsigned long long> attr_sk{0};
+            if (const int rc_attr = vmv_lds_attr_once(attr_sk, reinterpret_cast<const void*>(&gemm_xglds_kernel<NH, WH, 0, true>), Cfg::LDS_BYTES)) return rc_attr;
+            hipLaunchKernelGGL((gemm_xglds_kernel<NH, WH, 0, true>), dim3(tiles_m * tiles_n, p.ksplit), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n,
+                               sps, nsteps);
+            return vmv_launch_status();
+        }
+    }
+    static std::atomic<unsigned long long> attr_set{0};
+    if (const int rc_attr = vmv_lds_attr_once(attr_set, reinterpret_cast<const void*>(&gemm_xglds_kernel<NH, WH, EPI>), Cfg::LDS_BYTES)) return rc_attr;
+    hipLaunchKernelGGL((gemm_xglds_kernel<NH, WH, EPI>), dim3(tiles_m * tiles_n), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n, nsteps, nsteps);
     return vmv_launch_status();
 }
 
@@ -421,8 +463,9 @@ int vmv_gemm_xglds_epi_ok(const VmvGemmParams& p, int tile) {
 
 // Called by vmv_gemm (gemm.hip) after argument validation.
 int vmv_gemm_xglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st) {
-    if (p.ksplit > 1 || vmv_gemm_ln_inline(p) || !vmv_gemm_xglds_epi_ok(p, tile)) return VMV_GLDS_UNSUPPORTED;
+    if (vmv_gemm_ln_inline(p) || !vmv_gemm_xglds_epi_ok(p, tile)) return VMV_GLDS_UNSUPPORTED;
     const bool geglu = p.epilogue == VMV_EPI_GEGLU, lnf = p.rowstat != nullptr;
+    if (p.ksplit > 1 && (geglu || lnf || !p.workspace)) return VMV_GLDS_UNSUPPORTED;      // split-K: plain epilogue only (the reduce pass runs it)
     long maxrows = p.M;
     if (p.OH > 0) { const long src_rows = (long)(p.M / (p.OH * p.OW) + 1) * p.IH * p.IW; if (src_rows > maxrows) maxrows = src_rows; }
     for (int i = 0; i < p.nseg; ++i)
@@ -430,8 +473,8 @@ int vmv_gemm_xglds_launch(const VmvGemmParams& p, int total_steps, int tile, hip
     if ((long)(p.N + 320) * p.ktot * 2 >= (1L << 31) - 65536) return VMV_GLDS_UNSUPPORTED;
     if (p.OH > 0 && (p.OH >= 32768 || p.OW >= 32768)) return VMV_GLDS_UNSUPPORTED;      // (oy, ox) packed in one register
     const int No = geglu ? p.N / 2 : p.N;
-    if (p.out_fp32 || (p.ldo & 7) || (No & 7) || !vmv_aligned16(p.out) ||
-        (p.residual && ((p.ldr & 7) || !vmv_aligned16(p.residual)))) return VMV_GLDS_UNSUPPORTED;   // staged epilogue only
+    if (p.ksplit <= 1 && (p.out_fp32 || (p.ldo & 7) || (No & 7) || !vmv_aligned16(p.out) ||
+                          (p.residual && ((p.ldr & 7) || !vmv_aligned16(p.residual))))) return VMV_GLDS_UNSUPPORTED;   // staged epilogue only
     if (geglu || lnf) {
         if (geglu && lnf) return launch_xglds<2, 4, XE_GEGLU | XE_LN>(p, total_steps, st);
         if (geglu) return launch_xglds<2, 4, XE_GEGLU>(p, total_steps, st);
