@@ -537,6 +537,13 @@ def test_full_size_config1_properties():
     xa = dif.ddim_sample_loop(noise=noise.cuda(), model=m, model_kwargs=kw, guide_scale=9.0, ddim_timesteps=2, eta=0.0)
     xb = dif.ddim_sample_loop(noise=noise.cuda(), model=m, model_kwargs=kw, guide_scale=9.0, ddim_timesteps=2, eta=0.0)
     assert xa.shape == noise.shape and torch.isfinite(xa).all() and torch.equal(xa, xb)
+    # (5) the WHOLE 50-step schedule at full size (it used to be timed by bench.py only): 100 batched forwards + 50
+    #     fused updates, finite, bitwise reproducible, and on the same scale as the reference's own 50-step result on this architecture
+    #     (tests/golden/ddim50_full_24x16x16: std 18.3 — CFG 9 on random weights inflates the latent; a lost or doubled update would not)
+    x50 = dif.ddim_sample_loop(noise=noise.cuda(), model=m, model_kwargs=kw, guide_scale=9.0, ddim_timesteps=50, eta=0.0)
+    x50b = dif.ddim_sample_loop(noise=noise.cuda(), model=m, model_kwargs=kw, guide_scale=9.0, ddim_timesteps=50, eta=0.0)
+    assert torch.isfinite(x50).all() and torch.equal(x50, x50b)
+    assert 5.0 < float(x50.std()) < 60.0, float(x50.std())
 
 
 def test_ddim50_full_arch_vs_reference_fixture(golden_dir):
