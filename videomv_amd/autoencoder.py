@@ -399,15 +399,25 @@ class DiagonalGaussianDistribution(object):
         ops.rows_to_nchw(self.moment_rows, 2 * self.zc, out)
         return out
 
-    def sample(self, scale=1.0, parts=1):
+    def sample(self, scale=1.0, parts=1, of=None):
         """parts > 1: the noise is drawn in that many consecutive host-RNG calls of n / parts images each — what the same number
-        of separate encode calls would have drawn (the batched LGM branch encodes both CFG branches at once)."""
-        if parts > 1 and self.n % parts == 0:
-            noise = torch.cat([torch.randn(self.n // parts, self.zc, self.h, self.w) for _ in range(parts)]).to(device=self.device)
+        of separate encode calls would have drawn (the batched LGM branch encodes both CFG branches at once).
+        of = (total, first): the n / parts images of every part are images [first, first + n / parts) of a batch of `total` — the
+        noise of the WHOLE batch is drawn (same host-RNG consumption and the same numbers as the unsharded call) and this slice of it
+        used: a frame-parallel rank that encodes only its own views of the LGM branch gets the unsharded run's noise for them."""
+        per = self.n // parts if (parts > 1 and self.n % parts == 0) else self.n
+        nparts = self.n // per
+        if of is not None:
+            total, first = int(of[0]), int(of[1])
+            if not (0 <= first and first + per <= total):
+                raise ValueError("posterior sample slice outside its batch")
+            noise = torch.cat([torch.randn(total, self.zc, self.h, self.w)[first:first + per] for _ in range(nparts)]).to(device=self.device)
+        elif nparts > 1:
+            noise = torch.cat([torch.randn(per, self.zc, self.h, self.w) for _ in range(nparts)]).to(device=self.device)
         else:
             noise = torch.randn(self.n, self.zc, self.h, self.w).to(device=self.device)
         z = torch.empty(self.n, self.zc, self.h, self.w, dtype=torch.float32, device=self.device)
-        ops.posterior_sample(self.moment_rows, 2 * self.zc, noise, z, scale)
+        ops.posterior_sample(self.moment_rows, 2 * self.zc, noise.contiguous(), z, scale)
         return z
 
 
@@ -491,9 +501,9 @@ class AutoencoderKL(nn.Module):
         return DiagonalGaussianDistribution(rows, n, self.ddconfig["z_channels"], eng.LH, eng.LW, x.device)
 
     @torch.no_grad()
-    def encode_firsr_stage(self, x, scale_factor=1.0, parts=1):
+    def encode_firsr_stage(self, x, scale_factor=1.0, parts=1, of=None):
         """scale_factor * posterior.sample()  (autoencoder.py:86-91; the typo is the reference's public name)."""
-        return self.encode(x).sample(scale=scale_factor, parts=parts)
+        return self.encode(x).sample(scale=scale_factor, parts=parts, of=of)
 
     def forward(self, input, sample_posterior=True):
         raise NotImplementedError("training-time autoencoding is out of scope (inference hot path only)")

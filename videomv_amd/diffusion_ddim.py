@@ -131,14 +131,30 @@ class DiffusionDDIM(object):
         eng, eps_rows = unet.forward_cfg_rows(xt, self._scale_timesteps(t), cond_kwargs, uncond_kwargs)
         k = self.step_scalars(int(step), stride)
         ref = unet.lgm_refiner(xt.device)
+        comm, views, xt_all, ld = getattr(unet, "frame_comm", None), None, xt, eng.out_pad
+        if comm is not None and comm.world > 1:
+            # Frame-parallel (no reference counterpart): the branch needs x0 of 4 KEY views (frames 0 / 6 / 12 / 18), which live on
+            # other ranks — one small all-gather of (x_t, eps rows) rebuilds the whole sample's on every rank (1.2 MB at 24 x 32 x 32);
+            # the 4-view decode and the LGM U-Net then run replicated, and every rank renders and re-encodes ONLY its own F / R views
+            # (the 24 renders + the 24-view encode are 2/3 of the branch), with the unsharded run's posterior noise for them.
+            from .unet_t2v import gather_frames
+            if hasattr(comm, "exchange_branches"):
+                raise NotImplementedError("LGM-refined steps with CFG-parallel x frame-parallel ranks")
+            fl = xt.shape[2]
+            xt_all = gather_frames(comm, xt)
+            loc = eps_rows.reshape(2, -1).contiguous()                                  # [branch][local rows x ld]
+            allr = torch.empty(comm.world, loc.numel(), dtype=loc.dtype, device=loc.device)
+            comm.all_gather(allr, loc)
+            eps_rows = allr.view(comm.world, 2, -1).permute(1, 0, 2).reshape(-1, ld).contiguous()      # [branch][frame-major rows][ld]
+            views = (comm.rank * fl, fl)
         # predicted x0 of each branch: eps form (unet_t2v.py:405) or v form (unet_i2vgen.py:441-442), following the MODEL
         ca, cb = (k["c_sqrt_ac"], k["c_sqrt_1mac"]) if getattr(unet, "lgm_vpred", False) else (k["c_recip"], k["c_recipm1"])
         ga, gb = cond_kwargs["gs_data"], uncond_kwargs["gs_data"]
         same_views = ga is gb or self._same_gs_data(ga, gb)
         if same_views and ref.pair_supported():           # both branches through every stage together (one camera set)
-            z = ref.latent_z_pair(eps_rows, eng.out_pad, xt, ca, cb, autoencoder, dict(ga))
+            z = ref.latent_z_pair(eps_rows, ld, xt_all, ca, cb, autoencoder, dict(ga), views=views)
         else:
-            z = [ref.latent_z(eps_rows, eng.out_pad, br, xt, ca, cb, autoencoder, dict(kw["gs_data"]))
+            z = [ref.latent_z(eps_rows, ld, br, xt_all, ca, cb, autoencoder, dict(kw["gs_data"]), views=views)
                  for br, kw in enumerate((cond_kwargs, uncond_kwargs))]
         ops.ddim_x0_step(z[0], z[1], xt, float(guide_scale), k["c_recip"], k["c_recipm1"], k["a_prev"])
         return xt
@@ -176,8 +192,6 @@ class DiffusionDDIM(object):
                     _check_finite(v, f"model_kwargs[{name!r}]", is_input=True)
         if hasattr(unet, "begin_sample"):
             unet.begin_sample()                                # new sample: step-invariant conditioning is re-evaluated
-        if autoencoder is not None and comm is not None:
-            raise NotImplementedError("LGM-refined sampling is not combined with frame-parallel execution")
         for idx, step in enumerate(steps):
             if autoencoder is not None and idx in (20, 30, 40):      # LGM-refined steps (diffusion_ddim.py:254-256)
                 self.ddim_step_lgm(xt, int(step), unet, kc, ku, guide_scale, stride, autoencoder)

@@ -9,7 +9,7 @@ reference hard-codes 50 at :264), VAE decode in ``decoder_bs`` chunks, output na
 Different by design: launches go to ``libvmv_hip_{f16,bf16}.so`` (``hip_dtype`` config key / ``VMV_DTYPE``); per sample the entrance
 writes the reference's frame PNGs (``<name>/{fid:05d}.png``) and ``<name>.mp4`` when an H.264 encoder exists (none ships here),
 plus a ``.pt`` tensor and a PNG contact sheet; the second, LGM-refined loop (:271-278)
-runs when ``UNet.use_lgm_refine`` is set (not combined with ``frame_parallel``).
+runs when ``UNet.use_lgm_refine`` is set (also under ``frame_parallel``; not under ``cfg_parallel``).
 """
 import logging
 import os
@@ -105,7 +105,8 @@ def worker(gpu, cfg, cfg_update):
                   prefix_filter='first_stage_model.')
     autoencoder.eval()
     unet_cfg = dict(cfg.UNet)
-    use_lgm = bool(unet_cfg.get('use_lgm_refine')) and not fpar
+    # (LGM-refined steps run frame-parallel too since round 4 — every rank renders / re-encodes its own views; not with cfg_parallel)
+    use_lgm = bool(unet_cfg.get('use_lgm_refine')) and not (fpar and bool(cfg.get('cfg_parallel', False)))
     unet_cfg['use_lgm_refine'] = use_lgm
     if use_lgm and cfg.get('lgm_opt'):              # (not a reference key: shrinks the LGM for CPU plumbing tests)
         unet_cfg['lgm_opt'] = _plain(dict(cfg.lgm_opt))

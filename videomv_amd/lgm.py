@@ -429,7 +429,7 @@ class LgmRefiner:
         return hd_ok and os.environ.get("VMV_LGM_BATCHED", "1") != "0"
 
     @torch.no_grad()
-    def latent_z_pair(self, eps_rows, ld, xt, c_recip, c_recipm1, autoencoder, gs_data, scale_factor=0.18215):
+    def latent_z_pair(self, eps_rows, ld, xt, c_recip, c_recipm1, autoencoder, gs_data, scale_factor=0.18215, views=None):
         """latent_z of BOTH CFG branches (rows blocks 0 and 1 of ``eps_rows``) with every stage batched over the two: one VAE
         decode of 8 views, one LGM plan of two samples, 2 x 24 renders, one VAE encode of 48 views.  Same arithmetic per image as
         two ``latent_z`` calls (the posterior noise is drawn in the same two host-RNG calls); the GEMMs see twice the rows, so
@@ -458,6 +458,10 @@ class LgmRefiner:
         cv, cvp = gs_data["cam_view"].to(self.device), gs_data["cam_view_proj"].to(self.device)
         if h != w:
             raise ValueError("the LGM branch renders square views")
+        of = None
+        if views is not None:      # frame-parallel: x0 / decode / LGM U-Net are the whole sample's (replicated on every rank), the renders
+            f0, cnt = int(views[0]), int(views[1])      # and the re-encode only this rank's views [f0, f0 + cnt)
+            cv, cvp, of = cv[:, f0:f0 + cnt].contiguous(), cvp[:, f0:f0 + cnt].contiguous(), (cv.shape[1], f0)
         small = None
         for br in range(2):
             images = self.renderer.render(gaussians[br].unsqueeze(0), cv, cvp, None, bg_color=bg)["image"][0].contiguous()
@@ -465,12 +469,12 @@ class LgmRefiner:
             if small is None:
                 small = torch.empty(2 * T, 3, 8 * h, 8 * w, dtype=torch.float32, device=self.device)
             ops.lgm_render_to_vae(images, small[br * T:(br + 1) * T])
-        z = autoencoder.encode_firsr_stage(small, scale_factor, parts=2)                # [2T, C, h, w]
+        z = autoencoder.encode_firsr_stage(small, scale_factor, parts=2, of=of)         # [2T, C, h, w]
         z = z.reshape(2, 1, T, z.shape[1], z.shape[2], z.shape[3]).permute(0, 1, 3, 2, 4, 5).contiguous()
         return z[0], z[1]
 
     @torch.no_grad()
-    def latent_z(self, eps_rows, ld, branch, xt, c_recip, c_recipm1, autoencoder, gs_data, scale_factor=0.18215):
+    def latent_z(self, eps_rows, ld, branch, xt, c_recip, c_recipm1, autoencoder, gs_data, scale_factor=0.18215, views=None):
         """x0 = c_recip * xt - c_recipm1 * pred  (eps-prediction: sqrt(1/a), sqrt(1/a - 1); v-prediction: sqrt(a), sqrt(1-a))."""
         _, Cc, F_, h, w = xt.shape
         idxs = [0, 6, 12, 18] if F_ == 24 else [i * F_ // 4 for i in range(4)]          # unet_t2v.py:409 (F = 24)
@@ -486,8 +490,11 @@ class LgmRefiner:
         gaussians = self.engine.forward_gaussians(self.inp)
         self.last_gaussians = gaussians
         bg = torch.full((3,), self.bg_color, dtype=torch.float32, device=self.device)   # LGM.infer bg_color_factor
-        out = self.renderer.render(gaussians.unsqueeze(0), gs_data["cam_view"].to(self.device), gs_data["cam_view_proj"].to(self.device),
-                                   None, bg_color=bg)
+        cv, cvp, of = gs_data["cam_view"].to(self.device), gs_data["cam_view_proj"].to(self.device), None
+        if views is not None:      # (frame-parallel: this rank's views only — see latent_z_pair)
+            f0, cnt = int(views[0]), int(views[1])
+            cv, cvp, of = cv[:, f0:f0 + cnt].contiguous(), cvp[:, f0:f0 + cnt].contiguous(), (cv.shape[1], f0)
+        out = self.renderer.render(gaussians.unsqueeze(0), cv, cvp, None, bg_color=bg)
         images = out["image"][0]                                                        # [T, 3, 2S, 2S]
         T = images.shape[0]
         # F.interpolate(images, (256, 256), mode='nearest') in the reference (unet_t2v.py:425-427) = 8 x the latent size here,
@@ -496,5 +503,5 @@ class LgmRefiner:
         if h != w:
             raise ValueError("the LGM branch renders square views")
         ops.lgm_render_to_vae(images.contiguous(), small)
-        z = autoencoder.encode_firsr_stage(small, scale_factor)                         # [T, C, h, w]
+        z = autoencoder.encode_firsr_stage(small, scale_factor, of=of)                  # [T, C, h, w]
         return z.reshape(1, T, z.shape[1], z.shape[2], z.shape[3]).permute(0, 2, 1, 3, 4).contiguous()
