@@ -86,7 +86,8 @@ def main():
                              worlds=a.worlds, latent=a.latent, signatures_measured=len(table["done"]), seconds=round(time.time() - t0, 1),
                              rule=">= 7 % (>= 10 % for >= 120-us launches) and >= 1.5 us faster than the policy in two timings; output within 2e-3 rel-L2"))
         out[L.elem_name()] = merged
-        out[other] = dict(old.get(other, {})) if old.get(other) else merged    # (same kernels, same shapes: one measurement serves both element types)
+        if old.get(other):                        # (a section measured with the other element type's library is kept; without one that
+            out[other] = dict(old[other])         #  library falls back to this table: same kernels, same shapes — ops.tuned_table)
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
         with open(a.out, "w") as f:
             json.dump(out, f, indent=1, sort_keys=True)

@@ -138,7 +138,10 @@ def tuned_table() -> dict:
             path = os.environ.get("VMV_TUNED_FILE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gemm.json")
             if os.path.exists(path):
                 with open(path) as f:
-                    _TUNED = {k: v for k, v in json.load(f).get(L.elem_name(), {}).items()}
+                    tab = json.load(f)
+                # (measured with the fp16 library; the bf16 build runs the same kernels on the same shapes: one table serves both
+                #  unless a "bf16" section says otherwise)
+                _TUNED = dict(tab.get(L.elem_name()) or tab.get("fp16") or {})
             # the per-user cache VMV_AUTOTUNE=1 writes (autotune.py) goes over the packaged table; read only when autotuning is on or
             # VMV_TUNED_CACHE names a file explicitly, so that a default run depends on nothing outside the package
             if os.environ.get("VMV_AUTOTUNE", "0") == "1" or os.environ.get("VMV_TUNED_CACHE"):
