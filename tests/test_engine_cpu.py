@@ -1,6 +1,7 @@
 """Host-logic parity without a GPU: the recorded UNet plan (segment lists, packed weights, index maps, pooled
 buffers) is executed by tests/plan_interp.py on host memory and compared with the oracle.  bf16 storage between
 ops => tolerance rel-L2 <= 2e-2 on eps (the HIP kernels themselves are tested with -m gpu)."""
+import ctypes
 import dataclasses
 import os
 
@@ -524,3 +525,36 @@ def test_tile_table_hook_and_rerecord(monkeypatch):
     assert torch.equal(eng.eps_ncfhw(), eps0)          # (the interpreter ignores tile / split-K: same arithmetic, same bits)
     fresh = UNetEngine(CFG, sd, B, F_, H, W, Lc, torch.device("cpu"), n_t=B)
     assert fresh.n_tuned == n_same and fresh.S.nops == eng.S.nops
+
+
+def test_tuned_table_matches_the_full_size_plans(monkeypatch):
+    """videomv_amd/tuned_gemm.json is keyed by launch signature: if the engine's recording changes (another segment order, a new flag)
+    the table silently stops applying.  The full-size plans are recorded here on the CPU (zero weights, seconds) and every entry tagged
+    with a world-1 / simulated-rank plan must still name a launch of that plan; the counts pin how much of each plan is tuned."""
+    import json
+    plan_interp.install(monkeypatch)
+    from videomv_amd import _lib as L, ops
+    from videomv_amd.comm import SimComm
+    from videomv_amd.unet_engine import UNetEngine, param_shapes
+    monkeypatch.setattr(ops, "_TUNED", None)
+    monkeypatch.delenv("VMV_TUNED", raising=False)
+    monkeypatch.delenv("VMV_TUNED_FILE", raising=False)
+    cfg = dict(in_dim=4, dim=320, context_dim=1024, out_dim=4, dim_mult=[1, 2, 4, 4], num_heads=8, head_dim=64, num_res_blocks=2,
+               attn_scales=[1.0, 0.5, 0.25], camera_dim=16, use_camera_condition=True, use_fps_condition=False)
+    sd = {k: torch.zeros(s) for k, s in param_shapes(cfg).items()}
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "videomv_amd", "tuned_gemm.json")) as f:
+        tab = json.load(f)["fp16"]
+    dev = torch.device("cpu")
+    e64 = UNetEngine(cfg, sd, 2, 24, 40, 64, 77, dev, n_t=1, share_prefix=True)
+    e32 = UNetEngine(cfg, sd, 2, 24, 32, 32, 77, dev, n_t=1, share_prefix=True, packed=e64.packed)
+    e8 = UNetEngine(cfg, sd, 2, 24, 40, 64, 77, dev, n_t=1, comm=SimComm(8, 0), packed=e64.packed)
+    sigs = lambda e: {ops.gemm_signature(p) for op, p in e.S.recorded if op == L.OP_GEMM}
+    assert e64.S.nops == 779 and e64.n_tuned >= 80 and e32.n_tuned >= 200 and e8.n_tuned >= 150, (e64.n_tuned, e32.n_tuned, e8.n_tuned)
+    for tag, eng in (("world1 40x64", e64), ("world1 32x32", e32), ("world8 rank0 B=2 40x64", e8)):
+        mine = {k for k, v in tab.items() if v["plan"] == tag}
+        assert mine and mine <= sigs(eng), (tag, sorted(mine - sigs(eng))[:3])
+    # every forced choice is one the library accepts for that launch (host-side validation: no launch)
+    for eng in (e64, e32, e8):
+        for op, p in eng.S.recorded:
+            if op == L.OP_GEMM and p.tile != L.TILE_AUTO:
+                assert eng.S.lib.vmv_gemm_pick_tile(ctypes.byref(p)) == p.tile
