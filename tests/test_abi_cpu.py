@@ -163,3 +163,30 @@ def test_tuned_table_is_well_formed():
     sig = next(iter(tab["fp16"]))
     M, N, K = (int(v) for v in sig.split(";")[0].split("x"))
     assert M > 0 and N % 4 == 0 and K % 8 == 0
+
+
+def test_autotune_cache_is_merged_only_on_request(monkeypatch, tmp_path):
+    """ops.tuned_table(): the packaged table always; the per-user cache VMV_AUTOTUNE=1 writes (autotune.py) only when autotuning is on
+    or VMV_TUNED_CACHE names it — a default run depends on nothing outside the package; VMV_TUNED=0 ignores both."""
+    import json
+    from videomv_amd import autotune
+    cache = tmp_path / "cache.json"
+    cache.write_text(json.dumps({"fp16": {"1x4x8;0:8*1;e0a0f0r0v0:0s0c0l0g0w0;0x0<0x0s1u0F0P0": {"tile": 4, "ksplit": 0}}, "bf16": {}}))
+    key = "1x4x8;0:8*1;e0a0f0r0v0:0s0c0l0g0w0;0x0<0x0s1u0F0P0"
+    for k in ("VMV_TUNED", "VMV_TUNED_FILE", "VMV_AUTOTUNE", "VMV_TUNED_CACHE"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(ops, "_TUNED", None)
+    base = dict(ops.tuned_table())
+    assert base and key not in base
+    monkeypatch.setattr(ops, "_TUNED", None)
+    monkeypatch.setenv("VMV_TUNED_CACHE", str(cache))
+    assert autotune.cache_path() == str(cache)
+    if L.elem_name() == "fp16":
+        assert key in ops.tuned_table() and len(ops.tuned_table()) == len(base) + 1
+    monkeypatch.setattr(ops, "_TUNED", None)
+    monkeypatch.setenv("VMV_TUNED", "0")
+    assert ops.tuned_table() == {}
+    # on a CPU engine the measurement is a no-op (nothing to time)
+    class _E:
+        device = "cpu"
+    assert autotune.autotune_engine(_E()) == 0
