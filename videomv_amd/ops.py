@@ -154,6 +154,42 @@ def tuned_table() -> dict:
     return _TUNED
 
 
+def fill_rule(p: "L.GemmParams", policy_tile: int):
+    """EXPERIMENT (VMV_TILE_RULES=1, off by default; tools/experiments/policy_vs_table.py): what the measured table suggests for launches it
+    does not cover — where the built-in policy falls back to 128-row tiles, 256-row tiles of 128 / 160 columns with the split-K factor
+    (<= 8, >= 8 chunks per split) that best fills ONE round of the 256 CUs; 64 x 64 register tiles for short-K linears on few rows.
+    -> (tile, ksplit) or None."""
+    import math
+    if policy_tile not in (L.TILE_G128x128, L.TILE_G128x160):
+        return None
+    M, N = p.M, p.N
+    steps = sum((p.seg[i].k + 63) // 64 for i in range(p.nseg))
+    geglu = p.epilogue == L.EPI_GEGLU
+    lin = all(p.seg[i].mode == L.SEG_LINEAR for i in range(p.nseg))
+    ks_ok = not (p.rowstat or p.ln_eps > 0 or p.gn_table)
+    best = None
+    for bn in (128, 160):
+        if bn == 160 and (N % 160 or geglu):
+            continue
+        tm, tn = math.ceil(M / 256), math.ceil(N / bn)
+        pad = (M * N) / (tm * 256 * tn * bn)
+        for ks in (1, 2, 3, 4, 6, 8):
+            if ks > 1 and (not ks_ok or steps // ks < 8):
+                continue
+            blocks = tm * tn * ks
+            score = blocks / (256 * math.ceil(blocks / 256)) * pad - 0.03 * (ks - 1) + (0.01 if bn == 128 else 0.0)
+            if best is None or score > best[0] + 1e-9:
+                best = (score, bn, ks)
+    if best and best[0] >= 0.70:
+        _, bn, ks = best
+        if ks == 1 and lin and steps <= 24:
+            return (L.TILE_P256x128 if bn == 128 else L.TILE_P256x160), 0
+        return (L.TILE_256x128 if bn == 128 else L.TILE_256x160), (ks if ks > 1 else 0)
+    if lin and steps <= 24 and M <= 4096 and not geglu and 200 <= math.ceil(M / 64) * math.ceil(N / 64) <= 1024:
+        return L.TILE_64x64, 0
+    return None
+
+
 def make_tuner(owner):
     """ops.Stream hook (Stream.tuner) of an engine: applies the measured (tile, split-K) choice of tuned_gemm.json to a GEMM about to be
     recorded — auto tiles only; the library still validates the forced tile, so a stale entry fails loudly at record time.  `owner`
@@ -162,6 +198,16 @@ def make_tuner(owner):
         if p.tile != L.TILE_AUTO or p.wgroup_rows:
             return
         ent = tuned_table().get(gemm_signature(p))
+        if not ent and os.environ.get("VMV_TILE_RULES", "0") == "1":
+            lib = L.load()
+            r = fill_rule(p, lib.vmv_gemm_pick_tile(C.byref(p)))
+            if r is not None:
+                keep = (p.tile, p.ksplit)
+                p.tile, p.ksplit = r[0], 0                   # (validity of the forced tile for this launch: host-side check, no launch)
+                ok = lib.vmv_gemm_pick_tile(C.byref(p)) == r[0]
+                p.tile, p.ksplit = keep
+                if ok:
+                    ent = dict(tile=r[0], ksplit=r[1])
         if not ent:
             return
         ks = int(ent.get("ksplit", 0))
