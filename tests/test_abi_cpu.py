@@ -190,3 +190,38 @@ def test_autotune_cache_is_merged_only_on_request(monkeypatch, tmp_path):
     class _E:
         device = "cpu"
     assert autotune.autotune_engine(_E()) == 0
+
+
+def test_fill_rule_host_logic():
+    """ops.fill_rule (opt-in, VMV_TILE_RULES=1): acts only where the built-in policy fell back to 128-row tiles; picks the 256-row tile
+    and split-K factor that fill one round of the 256 CUs; respects what a launch cannot do (no split-K under a folded LayerNorm, 128
+    columns for GEGLU); every choice is one the library accepts for that launch."""
+    lib = L.load()
+    X = 1 << 20
+    lin = lambda k: ops.linear_segs([(X, k, k)])
+    conv = lambda c: ops.conv3x3_segs([(X, c, c)])
+    g = ops.Geom(OH=8, OW=8, IH=8, IW=8)
+
+    def go(p):
+        pol = lib.vmv_gemm_pick_tile(C.byref(p))
+        r = ops.fill_rule(p, pol)
+        if r is not None:                                   # the forced choice passes the library's host-side validation
+            q = ops.gemm_params(p.M, p.N, [ops.Seg(p.seg[i].src, p.seg[i].ld, p.seg[i].k, p.seg[i].mode, p.seg[i].d0, p.seg[i].d1) for i in range(p.nseg)],
+                                X, X, p.ldo, tile=r[0], ksplit=r[1], workspace=X if r[1] > 1 else None, epilogue=p.epilogue,
+                                geom=ops.Geom(OH=p.OH, OW=p.OW, IH=p.IH, IW=p.IW, F=p.F, P=p.P))
+            assert lib.vmv_gemm_pick_tile(C.byref(q)) == r[0], (p.M, p.N, p.ktot, r)
+        return pol, r
+    # the third level at 24x32x32 (48 images of 8 x 8): 192 tiles of 128 x 160 -> 120 tiles of 256 x 128 split in two (measured 183 -> 96 us)
+    pol, r = go(ops.gemm_params(3072, 1280, conv(1280), X, X, 1280, geom=g))
+    assert pol == L.TILE_G128x160 and r == (L.TILE_256x128, 2)
+    # the second level there: 240 tiles of 256 x 128 fill the chip without a split
+    pol, r = go(ops.gemm_params(12288, 640, conv(640), X, X, 640, geom=ops.Geom(OH=16, OW=16, IH=16, IW=16)))
+    assert pol == L.TILE_G128x160 and r == (L.TILE_256x128, 0)
+    # where the policy already uses its large tiles the rule is silent
+    assert go(ops.gemm_params(122880, 320, conv(320), X, X, 320, geom=ops.Geom(OH=40, OW=64, IH=40, IW=64)))[1] is None
+    assert go(ops.gemm_params(122880, 960, lin(320), X, X, 960))[1] is None
+    # a folded LayerNorm cannot split K; GEGLU takes 128-column tiles
+    pol, r = go(ops.gemm_params(3072, 3840, lin(1280), X, X, 3840, rowstat=X, colsum=X))
+    assert r is None or r[1] == 0
+    pol, r = go(ops.gemm_params(3072, 10240, lin(1280), X, X, 5120, epilogue=L.EPI_GEGLU))
+    assert r is None or r[0] in (L.TILE_256x128, L.TILE_P256x128)
