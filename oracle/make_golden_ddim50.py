@@ -92,7 +92,9 @@ def full_forward_cases(ns):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--threads", type=int, default=max(1, (os.cpu_count() or 2) - 1))
+    # (fp32 reductions depend on the thread count: the committed fixtures were written with 8 threads and regenerate BIT-IDENTICALLY with
+    #  8 on the same CPU type; another count moves them by ~4e-6 absolute — far below the tests' tolerances, but not bitwise)
+    ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--steps", type=int, default=STEPS)
     ap.add_argument("--only", default="", help="ddim50 | fwd (default: both)")
     a = ap.parse_args()
