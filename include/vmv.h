@@ -30,7 +30,7 @@ extern "C" {
 #define VMV_ERANGE       -4   /* size outside what the kernel supports */
 #define VMV_ECOMM        -5   /* an RCCL call of vmv_comm_* failed */
 
-#define VMV_ABI_VERSION   8
+#define VMV_ABI_VERSION   9
 int vmv_abi_version(void);
 /* The 16-bit storage / MFMA operand type ("elem") this build of the library computes in.  The same sources are
  * compiled once per type: libvmv_hip_f16.so (VMV_ELEM_F16: IEEE fp16 — the default; the reference's own half mode,
@@ -180,6 +180,11 @@ int vmv_gemm_rs_ok(const VmvGemmParams* p);
 /* the VMV_TILE_* configuration vmv_gemm's policy picks for *p when p->tile == VMV_TILE_AUTO (p->tile otherwise); host logic only:
  * no launch, no device access (a launcher may still fall back when it cannot address the operands) */
 int vmv_gemm_pick_tile(const VmvGemmParams* p);
+/* Everything vmv_gemm(p, stream) does on the host — argument validation, the tile policy (or the forced p->tile / p->ksplit), the chosen
+ * launcher's own eligibility checks — without touching the device: VMV_OK iff the same call would launch a kernel, the VMV_E* code it
+ * would return otherwise.  Needs no GPU.  The Python host calls it when a measured (tile, split-K) entry of tuned_gemm.json is about
+ * to be forced on a recorded launch: a stale entry is dropped there, with a warning, instead of aborting the first replay. */
+int vmv_gemm_validate(const VmvGemmParams* p);
 
 /* ------------------------------------------------------------------------------------------------------
  * FeedForward of a BasicTransformerBlock in one launch (util.py:536-540 `x = ff(norm3(x)) + x`, FeedForward :553-578,
@@ -343,6 +348,13 @@ typedef struct {
     int32_t v_pred;                /* 0: eps-prediction, 1: v-prediction                               */
     float* xt;                     /* fp32 [C][F][HW] updated in place to x_{t-1}                      */
     float* x0_out;                 /* optional fp32 [C][F][HW] predicted x0                            */
+    /* Sampler options of the reference signature (diffusion_ddim.py:201-205, 233-243).  clamp > 0: x0 is restricted to
+     * [-clamp, clamp] before eps is re-derived from it; sigma > 0 (stochastic DDIM, eta > 0; the host computes
+     * sigma = eta * sqrt((1 - a_prev) / (1 - a_t) * (1 - a_t / a_prev)) in fp32 as the reference does): the update becomes
+     * sqrt(a_prev) x0 + sqrt(1 - a_prev - sigma^2) eps + sigma * noise with noise = fp32 [C][F][HW] standard normal (required then). */
+    float clamp;
+    float sigma;
+    const float* noise;
 } VmvDdimParams;
 int vmv_cfg_ddim_step(const VmvDdimParams* p, void* stream);
 

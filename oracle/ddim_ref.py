@@ -7,7 +7,8 @@ Follows:
   * ``p_mean_variance`` (CFG + eps/v/x0 -> x0)          tools/modules/diffusions/diffusion_ddim.py:138-208
   * ``ddim_sample`` / ``ddim_sample_loop``              tools/modules/diffusions/diffusion_ddim.py:210-260
 Parity is pinned by ``tests/golden/schedules.safetensors`` and ``tests/golden/ddim_tiny.safetensors``
-(generated from the imported reference by ``oracle/make_golden.py``).
+(generated from the imported reference by ``oracle/make_golden.py``) and, for the sampler options (eta > 0, clamp,
+percentile, condition_fn), by ``tests/golden/ddim_options.safetensors`` (``oracle/make_golden_sampler_opts.py``).
 """
 import math
 
@@ -52,10 +53,10 @@ def ddim_steps(T, ddim_timesteps):
 
 @torch.no_grad()
 def ddim_sample_loop(noise, model, tables: DDIMTables, model_kwargs, guide_scale, ddim_timesteps=50,
-                     mean_type="eps", eta=0.0, trace=None):
-    """``model(xt, t, **kw)`` -> eps (or v).  ``model_kwargs`` = [cond, uncond].  eta must be 0 (the reference
-    path; sigma = 0 so no noise is injected)."""
-    assert eta == 0.0
+                     mean_type="eps", eta=0.0, trace=None, clamp=None, percentile=None, condition_fn=None, step_noise=None):
+    """``model(xt, t, **kw)`` -> eps (or v).  ``model_kwargs`` = [cond, uncond].  The sampler options follow
+    diffusion_ddim.py:200-205 (percentile / clamp on x0), :218-226 (condition_fn) and :233-243 (eta: sigma, direction, noise).
+    ``step_noise(i, xt)`` supplies the noise of step i (default: ``torch.randn_like`` — one draw per step, as the reference)."""
     xt = noise
     b = noise.shape[0]
     T = tables.T
@@ -76,9 +77,22 @@ def ddim_sample_loop(noise, model, tables: DDIMTables, model_kwargs, guide_scale
             x0 = c(tables.sqrt_ac) * xt - c(tables.sqrt_1mac) * out
         else:
             raise ValueError(mean_type)
+        if percentile is not None:
+            sq = torch.quantile(x0.flatten(1).abs(), percentile, dim=1).clamp_(1.0).view(-1, *((1,) * (x0.ndim - 1)))
+            x0 = torch.min(sq, torch.max(-sq, x0)) / sq
+        elif clamp is not None:
+            x0 = x0.clamp(-clamp, clamp)
+        if condition_fn is not None:
+            alpha = c(tables.ac)
+            eps = (c(tables.sqrt_recip) * xt - x0) / c(tables.sqrt_recipm1)
+            eps = eps - (1 - alpha).sqrt() * condition_fn(xt, t)
+            x0 = c(tables.sqrt_recip) * xt - c(tables.sqrt_recipm1) * eps
         eps = (c(tables.sqrt_recip) * xt - x0) / c(tables.sqrt_recipm1)
+        a_t = c(tables.ac)
         a_prev = tables.ac[max(ti - stride, 0)].to(xt.dtype)
-        xt = torch.sqrt(a_prev) * x0 + torch.sqrt(1 - a_prev) * eps
+        sigma = eta * torch.sqrt((1 - a_prev) / (1 - a_t) * (1 - a_t / a_prev))
+        nz = step_noise(len(trace) if trace is not None else None, xt) if step_noise is not None else torch.randn_like(xt)
+        xt = torch.sqrt(a_prev) * x0 + torch.sqrt(1 - a_prev - sigma ** 2) * eps + sigma * nz
         if trace is not None:
             trace.append(xt.clone())
     return xt

@@ -418,7 +418,7 @@ def sinusoidal(t, out, n, dim):
 
 
 def cfg_ddim_step(eps_rows, ld, xt, guide_scale, c_recip, c_recipm1, c_sqrt_ac, c_sqrt_1mac, a_prev, v_pred=False,
-                  x0_out=None):
+                  x0_out=None, clamp=0.0, sigma=0.0, noise=None):
     _, Cc, F_, H, W = xt.shape
     FHW = F_ * H * W
     e = eps_rows.view(2, FHW, ld)[:, :, :Cc]
@@ -427,9 +427,14 @@ def cfg_ddim_step(eps_rows, ld, xt, guide_scale, c_recip, c_recipm1, c_sqrt_ac, 
     f = torch.float32
     x0 = (torch.tensor(c_sqrt_ac, dtype=f) * xt - torch.tensor(c_sqrt_1mac, dtype=f) * out) if v_pred else \
         (torch.tensor(c_recip, dtype=f) * xt - torch.tensor(c_recipm1, dtype=f) * out)
+    if clamp:
+        x0 = x0.clamp(-clamp, clamp)
     eps = (torch.tensor(c_recip, dtype=f) * xt - x0) / torch.tensor(c_recipm1, dtype=f)
-    ap = torch.tensor(a_prev, dtype=f)
-    xt.copy_(torch.sqrt(ap) * x0 + torch.sqrt(1 - ap) * eps)
+    ap, sg = torch.tensor(a_prev, dtype=f), torch.tensor(float(sigma), dtype=f)
+    nx = torch.sqrt(ap) * x0 + torch.sqrt(1 - ap - sg * sg) * eps
+    if sigma:
+        nx = nx + sg * noise
+    xt.copy_(nx)
     if x0_out is not None:
         x0_out.copy_(x0)
 

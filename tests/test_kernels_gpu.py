@@ -1158,6 +1158,21 @@ def test_layout_and_ddim_kernels():
     I.cfg_ddim_step(eps, 4, xt2_ref, v_pred=True, **args)
     ops.cfg_ddim_step(eps.cuda(), 4, xt2, v_pred=True, **args)
     assert torch.allclose(xt2.cpu(), xt2_ref, rtol=1e-5, atol=1e-5)
+    # the sampler options that ride in the fused update (diffusion_ddim.py:204-205 clamp, :233-243 eta > 0): x0 clamped BEFORE eps is
+    # re-derived, direction sqrt(1 - a_prev - sigma^2), + sigma * noise
+    nz = torch.randn(x.shape, generator=g(5))
+    for v_pred in (False, True):
+        for kw in (dict(clamp=0.6), dict(sigma=0.31, noise=nz), dict(clamp=1.1, sigma=0.2, noise=nz)):
+            a_ref, x0r = x.clone(), torch.zeros_like(x)
+            I.cfg_ddim_step(eps, 4, a_ref, v_pred=v_pred, x0_out=x0r, **args, **kw)
+            a_dev, x0d = x.clone().cuda(), torch.zeros_like(x).cuda()
+            kd = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in kw.items()}
+            ops.cfg_ddim_step(eps.cuda(), 4, a_dev, v_pred=v_pred, x0_out=x0d, **args, **kd)
+            assert torch.allclose(a_dev.cpu(), a_ref, rtol=1e-5, atol=1e-5) and torch.allclose(x0d.cpu(), x0r, rtol=1e-5, atol=1e-5)
+            if "clamp" in kw:
+                assert float(x0d.abs().max()) <= kw["clamp"] + 1e-6 and float(x0r.abs().max()) > 0.5 * kw["clamp"]
+    with pytest.raises(Exception):      # sigma without noise is refused, not read through a null pointer
+        ops.cfg_ddim_step(eps.cuda(), 4, x.clone().cuda(), sigma=0.3, **args)
     out = torch.zeros(3, 4, H, W, device="cuda")
     r = torch.randn(3 * H * W, 4, generator=g(3))
     ops.rows_to_nchw(r.cuda(), 4, out)

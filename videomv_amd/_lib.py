@@ -53,7 +53,7 @@ TILE_X256x320, TILE_X256x256, TILE_X256x128 = 20, 21, 22
 TILE_RS, TILE_RS512, TILE_RS256, TILE_HALO = 23, 24, 25, 26
 OP_GEMM, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTENTION, OP_SOFTMAX, OP_COPY, OP_GN_FUSED, OP_FF, OP_GN_TABLE, OP_COMM = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 COMM_ALL_TO_ALL, COMM_ALL_GATHER, COMM_ID_BYTES = 0, 1, 128
-ABI_VERSION = 8
+ABI_VERSION = 9
 GN_FUSED_BYTES = 131072
 
 
@@ -141,7 +141,8 @@ class DdimParams(C.Structure):
     _fields_ = [("eps_rows", C.c_void_p), ("ld", C.c_int32), ("C", C.c_int32), ("F", C.c_int32), ("HW", C.c_int32),
                 ("guide_scale", C.c_float), ("c_recip", C.c_float), ("c_recipm1", C.c_float),
                 ("c_sqrt_ac", C.c_float), ("c_sqrt_1mac", C.c_float), ("a_prev", C.c_float),
-                ("v_pred", C.c_int32), ("xt", C.c_void_p), ("x0_out", C.c_void_p)]
+                ("v_pred", C.c_int32), ("xt", C.c_void_p), ("x0_out", C.c_void_p),
+                ("clamp", C.c_float), ("sigma", C.c_float), ("noise", C.c_void_p)]
 
 
 # every symbol include/vmv.h declares: name -> (restype, argtypes)
@@ -158,6 +159,7 @@ SYMBOLS = {
     "vmv_ff_fused": (C.c_int, [C.POINTER(FfParams), _P]),
     "vmv_ff_fused_ok": (C.c_int, [C.POINTER(FfParams)]),
     "vmv_gemm_pick_tile": (C.c_int, [C.POINTER(GemmParams)]),
+    "vmv_gemm_validate": (C.c_int, [C.POINTER(GemmParams)]),
     "vmv_groupnorm_stats": (C.c_int, [C.POINTER(GroupNormParams), _P]),
     "vmv_groupnorm_apply": (C.c_int, [C.POINTER(GroupNormParams), _P]),
     "vmv_groupnorm_table": (C.c_int, [C.POINTER(GroupNormParams), _P]),

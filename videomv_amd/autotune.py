@@ -12,7 +12,12 @@ faster by the stated margin in two independent timings, and returns the winners 
 
 The built-in policy of csrc/gemm.hip was fitted by hand to M = 122 880 / 30 720 / 7 680 / 1 920 (latent 24x40x64); on the reference's
 own 24x32x32 it left 16 % of the step on the table.  Measurement is the general answer; the table is data, and a stale
-entry is refused by ``vmv_gemm`` when the plan is recorded (forced tiles are validated)."""
+entry is dropped with a warning when the plan is recorded (``ops.make_tuner`` validates every forced choice with ``vmv_gemm_validate``).
+
+Multi-rank plans: the tuning replay skips the plan's collectives (``Stream.run_local``), so a rank with nothing left to
+tune never leaves its peers inside one; rank 0's winners are broadcast and every rank records the same choices (the replicated VAE /
+LGM plans then round identically on every rank); signatures that were tested without a gain are remembered in the cache (``"done"``)
+so a later engine build does not re-tune them; the cache file is merged under an ``flock``."""
 import ctypes as C
 import json
 import os
@@ -67,7 +72,7 @@ def time_us(lib, p, stream, reps=10, warm=2):
 def tune_plan(eng, table, ws, tag, gains=(0.93, 0.90), verbose=True):
     lib = eng.S.lib
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    eng.S.run()                                   # realistic (finite) contents in every buffer
+    eng.S.run_local()                             # realistic (finite) contents in every buffer; no collectives (see the header)
     torch.cuda.synchronize()
     seen = {}
     for (op, p), label in zip(eng.S.recorded, eng.S.labels):
@@ -140,38 +145,85 @@ def cache_path() -> str:
     return os.environ.get("VMV_TUNED_CACHE") or os.path.join(os.path.expanduser("~"), ".cache", "videomv_amd", "tuned_gemm.json")
 
 
+def _real_world(eng) -> int:
+    c = getattr(eng, "comm", None)
+    if c is None or getattr(c, "backend", "") == "sim" or getattr(c, "local_only", False):
+        return 1
+    return int(getattr(c, "world", 1))
+
+
+def _merge_cache(entries: dict, tested: set):
+    """Merge winners and tested-without-gain signatures into the per-user cache under an exclusive lock (several ranks / processes
+    may finish tuning at the same time: read-modify-write of one file)."""
+    path = cache_path()
+    try:
+        import fcntl
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path + ".lock", "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            old = {}
+            if os.path.exists(path):
+                try:
+                    with open(path) as f:
+                        old = json.load(f)
+                except ValueError:
+                    old = {}
+            old.setdefault(L.elem_name(), {}).update(entries)
+            done = set(old.get("done", {}).get(L.elem_name(), [])) | set(tested)
+            old.setdefault("done", {})[L.elem_name()] = sorted(done - set(old[L.elem_name()]))
+            tmp = path + f".{os.getpid()}.tmp"
+            with open(tmp, "w") as f:
+                json.dump(old, f, indent=1, sort_keys=True)
+            os.replace(tmp, path)
+    except OSError:
+        pass            # (a read-only home: the choices still hold for this process)
+
+
+def cached_done() -> set:
+    """Signatures an earlier run tested and found no better choice for (not re-tuned)."""
+    try:
+        with open(cache_path()) as f:
+            return set(json.load(f).get("done", {}).get(L.elem_name(), []))
+    except (OSError, ValueError):
+        return set()
+
+
 def autotune_engine(eng, tag="autotune") -> int:
     """VMV_AUTOTUNE=1: tune the GEMM signatures of `eng`'s freshly recorded plan that no table covers yet; returns the number of
-    improved signatures (the caller re-records the plan when it is > 0).  Winners go into the in-memory table and the per-user cache."""
+    improved signatures (the caller re-records the plan when it is > 0).  Winners go into the in-memory table and the per-user cache.
+    Collective when the engine is frame-parallel over real peers: every rank calls it at the same point (engine construction is
+    already collective), rank 0 measures, everyone adopts rank 0's table."""
     if not torch.cuda.is_available() or str(eng.device).startswith("cpu"):
         return 0
+    import torch.distributed as dist
+    world = _real_world(eng)
+    group = getattr(getattr(eng, "comm", None), "group", None) if world > 1 else None
     known = ops.tuned_table()
-    table = dict(done=set(known.keys()), entries={})
+    table = dict(done=set(known.keys()) | cached_done(), entries={})
     need = 0
     for (op, p) in eng.S.recorded:
         if op == L.OP_GEMM and not p.wgroup_rows and p.tile == L.TILE_AUTO and ops.gemm_signature(p) not in table["done"]:
             need += 1
+    if world > 1:           # the ranks record the same plan, but agree explicitly: one decision for the group
+        flag = torch.tensor([need], device=eng.device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        need = int(flag.item())
     if not need:
         return 0
-    ws = torch.empty(WS_CAP, dtype=torch.uint8, device=eng.device)
-    with torch.cuda.device(eng.device):
-        tune_plan(eng, table, ws, tag, verbose=os.environ.get("VMV_AUTOTUNE_VERBOSE", "0") == "1")
-    del ws
-    if not table["entries"]:
-        return 0
+    before = set(table["done"])
+    measuring = world == 1 or dist.get_rank(group) == 0
+    if measuring:
+        ws = torch.empty(WS_CAP, dtype=torch.uint8, device=eng.device)
+        with torch.cuda.device(eng.device):
+            tune_plan(eng, table, ws, tag, verbose=os.environ.get("VMV_AUTOTUNE_VERBOSE", "0") == "1")
+        del ws
+    if world > 1:
+        box = [(table["entries"], sorted(table["done"] - before)) if measuring else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        table["entries"], tested = dict(box[0][0]), set(box[0][1])
+    else:
+        tested = table["done"] - before
     known.update(table["entries"])
-    path = cache_path()
-    try:
-        old = {}
-        if os.path.exists(path):
-            with open(path) as f:
-                old = json.load(f)
-        old.setdefault(L.elem_name(), {}).update(table["entries"])
-        os.makedirs(os.path.dirname(path), exist_ok=True)
-        tmp = path + f".{os.getpid()}.tmp"
-        with open(tmp, "w") as f:
-            json.dump(old, f, indent=1, sort_keys=True)
-        os.replace(tmp, path)
-    except OSError:
-        pass            # (a read-only home: the choices still hold for this process)
+    if measuring:
+        _merge_cache(table["entries"], tested)
     return len(table["entries"])

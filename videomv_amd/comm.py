@@ -31,24 +31,42 @@ def _rccl_path() -> str:
     return cand if os.path.exists(cand) else ""
 
 
+def _all_ok(ok: bool, group, device) -> bool:
+    """Did EVERY rank of the group succeed?  (one small all-reduce: the ranks must take the same branch afterwards)"""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()))
+
+
 def native_comm(group, device):
     """A VmvComm* over the ranks of `group` (include/vmv.h vmv_comm_*): rank 0 draws the RCCL id, torch.distributed carries its 128
-    bytes to the others, every rank joins.  Collective: all ranks of the group call it at the same point."""
+    bytes to the others, every rank joins.  Collective: all ranks of the group call it at the same point, and all of them get the
+    same answer — a handle everywhere or ``None`` everywhere (a rank that failed alone used to fall back to the Python
+    collectives while its peers blocked in the id broadcast, or later recorded a different plan): every local step that can fail is
+    followed by an agreement all-reduce before the next collective step."""
     from . import _lib as L
     lib = L.load()
-    L.check(lib.vmv_comm_load(_rccl_path().encode()), "vmv_comm_load")
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     idb = (C.c_uint8 * L.COMM_ID_BYTES)()
-    if rank == 0:
-        L.check(lib.vmv_comm_unique_id(idb), "vmv_comm_unique_id")
+    err = None
+    try:
+        L.check(lib.vmv_comm_load(_rccl_path().encode()), "vmv_comm_load")
+        if rank == 0:
+            L.check(lib.vmv_comm_unique_id(idb), "vmv_comm_unique_id")
+    except Exception as e:
+        err = e
+    if not _all_ok(err is None, group, device):
+        raise L.VmvError(f"vmv_comm_load / unique_id failed on {'this' if err else 'another'} rank" + (f": {err}" if err else ""))
     t = torch.tensor(list(idb), dtype=torch.uint8, device=device)
     src = dist.get_global_rank(group, 0) if group is not None else 0
     dist.broadcast(t, src=src, group=group)
     idb = (C.c_uint8 * L.COMM_ID_BYTES)(*[int(v) for v in t.cpu()])
     with torch.cuda.device(device):
         h = lib.vmv_comm_create(idb, world, rank)
-    if not h:
-        raise L.VmvError("vmv_comm_create failed (ncclCommInitRank)")
+    if not _all_ok(bool(h), group, device):
+        if h:
+            lib.vmv_comm_destroy(h)
+        raise L.VmvError("vmv_comm_create failed (ncclCommInitRank) on " + ("another rank" if h else "this rank"))
     return h
 
 
@@ -204,6 +222,11 @@ class CfgFrameComm:
 
     def all_to_all(self, out, inp):
         self.fp.all_to_all(out, inp)
+
+    def close(self):
+        """Destroy the RCCL communicators of both sub-groups (collective; before dist.destroy_process_group())."""
+        self.fp.close()
+        self.pair.close()
 
     def exchange_branches(self, out, mine):
         """out [2, n] <- (cond rows, uncond rows) of this rank's frames: slot b comes from the rank of branch b."""

@@ -6,7 +6,13 @@
 #include <atomic>
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: set it once per (kernel, device), thread-safely
 // (a function-local `static bool` skipped the second GPU of a process and raced between host threads).
+// vmv_gemm_validate(): the whole host side of a launch — argument checks, tile policy, every launcher's own eligibility tests —
+// with the device left alone.  A thread-local flag makes VMV_LAUNCH / vmv_lds_attr_once / vmv_launch_status no-ops, so the answer
+// needs no GPU (the CPU test tier validates the packaged tile table with it).
+extern thread_local int vmv_dry_run;
+#define VMV_LAUNCH(kernel, grid, block, lds, st, ...) do { if (!vmv_dry_run) hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__); } while (0)
 inline int vmv_lds_attr_once(std::atomic<unsigned long long>& done, const void* fn, int bytes) {
+    if (vmv_dry_run) return 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     const unsigned long long bit = 1ull << (dev & 63);
@@ -181,6 +187,7 @@ VMV_DEV float wave_sum(float v) {
 VMV_DEV bool vmv_ptr_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int vmv_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 static inline int vmv_launch_status() {
+    if (vmv_dry_run) return VMV_OK;
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? VMV_OK : (int)e;
 }

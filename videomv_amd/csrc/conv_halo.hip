@@ -172,6 +172,6 @@ int vmv_conv_halo_launch(const VmvGemmParams& p, hipStream_t st) {
     static std::atomic<unsigned long long> attr{0};
     if (const int rc_attr = vmv_lds_attr_once(attr, reinterpret_cast<const void*>(&conv_halo_kernel), CH_HALO_BYTES + ch_w_bytes(8))) return rc_attr;
     const int lds = CH_HALO_BYTES + ch_w_bytes(p.N <= 4 ? 4 : 8);          // 36 / 45 KB (TH = 4), 55 / 64 KB (TH = 8)
-    hipLaunchKernelGGL(conv_halo_kernel, dim3((unsigned)blocks), dim3(256), lds, st, p, p.seg[0].k, tiles_x, tiles_y);
+    VMV_LAUNCH(conv_halo_kernel, dim3((unsigned)blocks), dim3(256), lds, st, p, p.seg[0].k, tiles_x, tiles_y);
     return vmv_launch_status();
 }

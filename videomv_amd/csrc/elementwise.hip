@@ -298,7 +298,7 @@ __global__ void cfg_ddim_kernel(const VmvDdimParams p) {
     const long FHW = (long)p.F * p.HW;
     const long total = (long)p.C * FHW;
     const float sqrt_aprev = sqrtf(p.a_prev);
-    const float sqrt_1m = sqrtf(1.0f - p.a_prev);
+    const float sqrt_1m = sqrtf(1.0f - p.a_prev - p.sigma * p.sigma);     // :241 (sigma = 0 unless eta > 0)
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i / FHW);
         const long r = i - (long)c * FHW;
@@ -309,8 +309,11 @@ __global__ void cfg_ddim_kernel(const VmvDdimParams p) {
         float x0;
         if (p.v_pred) x0 = p.c_sqrt_ac * xt - p.c_sqrt_1mac * out;   // :196-199
         else x0 = p.c_recip * xt - p.c_recipm1 * out;                // :192-195
+        if (p.clamp > 0.f) x0 = fminf(fmaxf(x0, -p.clamp), p.clamp); // :204-205
         const float eps = (p.c_recip * xt - x0) / p.c_recipm1;       // :233-234
-        p.xt[i] = sqrt_aprev * x0 + sqrt_1m * eps;                   // :240-243 (eta = 0 -> sigma = 0)
+        float nx = sqrt_aprev * x0 + sqrt_1m * eps;                  // :240-243
+        if (p.sigma > 0.f) nx += p.sigma * p.noise[i];               // (mask = t != 0 is always 1: the DDIM steps start at 1)
+        p.xt[i] = nx;
         if (p.x0_out) p.x0_out[i] = x0;
     }
 }
@@ -481,6 +484,8 @@ extern "C" int vmv_cfg_ddim_step(const VmvDdimParams* pp, void* stream) {
     const VmvDdimParams& p = *pp;
     if (!p.eps_rows || !p.xt) return VMV_ENULL;
     if (p.C <= 0 || p.F <= 0 || p.HW <= 0 || p.ld < p.C) return VMV_EINVAL;
+    if (p.sigma < 0.f || p.clamp < 0.f || p.sigma * p.sigma > 1.0f - p.a_prev) return VMV_EINVAL;
+    if (p.sigma > 0.f && !p.noise) return VMV_ENULL;
     hipLaunchKernelGGL(cfg_ddim_kernel, dim3(grid_for((long)p.C * p.F * p.HW)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), p);
     return vmv_launch_status();

@@ -268,7 +268,7 @@ int launch_cfg(const VmvGemmParams& p, int total_steps, hipStream_t st) {
     static std::atomic<unsigned long long> attr_set{0};
     if (const int rc_attr = vmv_lds_attr_once(attr_set, reinterpret_cast<const void*>(&gemm_kernel<WM, WN>), Cfg::LDS_BYTES)) return rc_attr;
     dim3 grid(tiles_m * tiles_n, ks, 1);
-    hipLaunchKernelGGL((gemm_kernel<WM, WN>), grid, dim3(256), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n, total_steps, sps);
+    VMV_LAUNCH((gemm_kernel<WM, WN>), grid, dim3(256), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n, total_steps, sps);
     return vmv_launch_status();
 }
 
@@ -495,6 +495,17 @@ extern "C" int vmv_gemm_pick_tile(const VmvGemmParams* pp) {
     return final_tile(*pp, total_steps);
 }
 
+thread_local int vmv_dry_run = 0;
+// everything vmv_gemm(p, stream) does on the host — argument validation, the tile policy (or the forced p->tile), the chosen launcher's
+// own eligibility checks — without touching the device: VMV_OK iff the same call would launch.  Used at RECORD time for forced tiles
+// (a stale tuned-table entry is ignored there instead of failing on the first replay) and by the CPU tests.
+extern "C" int vmv_gemm_validate(const VmvGemmParams* pp) {
+    vmv_dry_run = 1;
+    const int rc = vmv_gemm(pp, nullptr);
+    vmv_dry_run = 0;
+    return rc;
+}
+
 extern "C" int vmv_gemm(const VmvGemmParams* pp, void* stream) {
     if (!pp) return VMV_ENULL;
     const VmvGemmParams& p = *pp;
@@ -645,7 +656,7 @@ extern "C" int vmv_gemm(const VmvGemmParams* pp, void* stream) {
         const long items = (long)p.M * (p.N / 4);
         int blocks = (int)((items + 255) / 256);
         if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(gemm_splitk_reduce, dim3(blocks), dim3(256), 0, st, p);
+        VMV_LAUNCH(gemm_splitk_reduce, dim3(blocks), dim3(256), 0, st, p);
         rc = vmv_launch_status();
     }
     return rc;

@@ -453,7 +453,7 @@ int launch_glds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
         constexpr int AB = decltype(tag)::value;
         static std::atomic<unsigned long long> attr_set{0};
         if (const int rc_attr = vmv_lds_attr_once(attr_set, reinterpret_cast<const void*>(&gemm_glds_kernel<WMW, WN, STAGES, AB, PP>), Cfg::LDS_BYTES)) return rc_attr;
-        hipLaunchKernelGGL((gemm_glds_kernel<WMW, WN, STAGES, AB, PP>), grid, dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n,
+        VMV_LAUNCH((gemm_glds_kernel<WMW, WN, STAGES, AB, PP>), grid, dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n,
                            total_steps, sps);
         return VMV_OK;
     };

@@ -652,19 +652,24 @@ int launch_pglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
     const int tiles_n = (p.N + Cfg::BN - 1) / Cfg::BN;
     const int nitems = tiles_m * tiles_n;
     static int ncu = 0;
+    int ncu_eff = ncu;
     if (ncu == 0) {
         int dev = 0, n = 0;
         hipError_t e = hipGetDevice(&dev);
         if (e == hipSuccess) e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e != hipSuccess) return (int)e;
+        if (e != hipSuccess) {
+            if (!vmv_dry_run) return (int)e;
+            n = 256;                                 // (vmv_gemm_validate without a device: the MI355X count, not cached)
+        }
         if (n < 8) n = 8;
-        ncu = n & ~7;                                // whole XCD groups: item & 7 == block & 7 in every round
+        ncu_eff = n & ~7;                            // whole XCD groups: item & 7 == block & 7 in every round
+        if (e == hipSuccess) ncu = ncu_eff;
     }
     static int ablate = -1;
     if (ablate < 0) { const char* e = getenv("VMV_GEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
     static int order_env = -1;
     if (order_env < 0) { const char* e = getenv("VMV_GEMM_ORDER"); order_env = e ? atoi(e) : 0; }
-    const int slots = ncu * (NWM == 4 ? 1 : 2);
+    const int slots = ncu_eff * (NWM == 4 ? 1 : 2);
     const int G = nitems < slots ? nitems : slots;
     dim3 grid(G, 1, 1);
     const int order = (order_env == 1 && G == 256 && NWM == 4) ? 1 : 0;       // (the panel map assumes 32 single-block CUs per XCD)
@@ -675,7 +680,7 @@ int launch_pglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
         constexpr bool IL = decltype(il_tag)::value;
         static std::atomic<unsigned long long> attr_set{0};
         if (const int rc_attr = vmv_lds_attr_once(attr_set, reinterpret_cast<const void*>(&gemm_pglds_kernel<NWM, WM, WN, AB, IL>), Cfg::LDS_TOTAL)) return rc_attr;
-        hipLaunchKernelGGL((gemm_pglds_kernel<NWM, WM, WN, AB, IL>), grid, dim3(Cfg::NT), Cfg::LDS_TOTAL, st, p, tiles_n, total_steps,
+        VMV_LAUNCH((gemm_pglds_kernel<NWM, WM, WN, AB, IL>), grid, dim3(Cfg::NT), Cfg::LDS_TOTAL, st, p, tiles_n, total_steps,
                            nitems, order);
         return VMV_OK;
     };
@@ -690,7 +695,7 @@ int launch_pglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
         if constexpr (NWM == 4) {
             static std::atomic<unsigned long long> attr_set_lns{0};
             if (const int rc_attr = vmv_lds_attr_once(attr_set_lns, reinterpret_cast<const void*>(&gemm_pglds_kernel<NWM, WM, WN, 0, false, true>), Cfg::LDS_TOTAL)) return rc_attr;
-            hipLaunchKernelGGL((gemm_pglds_kernel<NWM, WM, WN, 0, false, true>), grid, dim3(Cfg::NT), Cfg::LDS_TOTAL, st, p, tiles_n,
+            VMV_LAUNCH((gemm_pglds_kernel<NWM, WM, WN, 0, false, true>), grid, dim3(Cfg::NT), Cfg::LDS_TOTAL, st, p, tiles_n,
                                total_steps, nitems, order);
             return vmv_launch_status();
         } else {

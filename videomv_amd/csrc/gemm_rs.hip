@@ -501,7 +501,7 @@ int launch_rs(const VmvGemmParams& p, const RsPlan& pl, hipStream_t st) {
     const int tiles_m = (p.M + Cfg::BM - 1) / Cfg::BM;
     static std::atomic<unsigned long long> attr{0};      // one per template instantiation; set once per (kernel, device)
     if (const int rc_attr = vmv_lds_attr_once(attr, reinterpret_cast<const void*>(&gemm_rs_kernel<RT, KS, MODE>), Cfg::LDS_BYTES)) return rc_attr;
-    hipLaunchKernelGGL((gemm_rs_kernel<RT, KS, MODE>), dim3(tiles_m * pl.nsplit), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, pl.nsplit, pl.cols);
+    VMV_LAUNCH((gemm_rs_kernel<RT, KS, MODE>), dim3(tiles_m * pl.nsplit), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, pl.nsplit, pl.cols);
     return vmv_launch_status();
 }
 

@@ -438,14 +438,14 @@ int launch_xglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
             if (sps < Cfg::STAGES || last < Cfg::STAGES || (last & 1)) return VMV_GLDS_UNSUPPORTED;
             static std::atomic<unsigned long long> attr_sk{0};
             if (const int rc_attr = vmv_lds_attr_once(attr_sk, reinterpret_cast<const void*>(&gemm_xglds_kernel<NH, WH, 0, true>), Cfg::LDS_BYTES)) return rc_attr;
-            hipLaunchKernelGGL((gemm_xglds_kernel<NH, WH, 0, true>), dim3(tiles_m * tiles_n, p.ksplit), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n,
+            VMV_LAUNCH((gemm_xglds_kernel<NH, WH, 0, true>), dim3(tiles_m * tiles_n, p.ksplit), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n,
                                sps, nsteps);
             return vmv_launch_status();
         }
     }
     static std::atomic<unsigned long long> attr_set{0};
     if (const int rc_attr = vmv_lds_attr_once(attr_set, reinterpret_cast<const void*>(&gemm_xglds_kernel<NH, WH, EPI>), Cfg::LDS_BYTES)) return rc_attr;
-    hipLaunchKernelGGL((gemm_xglds_kernel<NH, WH, EPI>), dim3(tiles_m * tiles_n), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n, nsteps, nsteps);
+    VMV_LAUNCH((gemm_xglds_kernel<NH, WH, EPI>), dim3(tiles_m * tiles_n), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n, nsteps, nsteps);
     return vmv_launch_status();
 }
 

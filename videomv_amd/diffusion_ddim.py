@@ -104,11 +104,22 @@ class DiffusionDDIM(object):
 
     # ------------------------------------------------------------------ fused HIP path
     @torch.no_grad()
-    def ddim_step_hip(self, xt, step, unet, cond_kwargs, uncond_kwargs, guide_scale, stride, x0_out=None):
+    def ddim_sigma(self, step: int, stride: int, eta: float) -> float:
+        """sigma_t of stochastic DDIM (diffusion_ddim.py:233-236), evaluated in fp32 like the reference's ``_i`` lookups."""
+        if not eta:
+            return 0.0
+        a = self.alphas_cumprod[step].to(torch.float32)
+        ap = self.alphas_cumprod[max(step - stride, 0)].to(torch.float32)
+        return float(eta * torch.sqrt((1 - ap) / (1 - a) * (1 - a / ap)))
+
+    def ddim_step_hip(self, xt, step, unet, cond_kwargs, uncond_kwargs, guide_scale, stride, x0_out=None, clamp=None, eta=0.0):
         t = torch.full((xt.shape[0],), int(step), dtype=torch.long, device=xt.device)
         eng, eps_rows = unet.forward_cfg_rows(xt, self._scale_timesteps(t), cond_kwargs, uncond_kwargs)
+        sigma = self.ddim_sigma(int(step), stride, eta)
+        # (the reference draws randn_like(xt) every step, eta = 0 included; only a stochastic step needs it here)
+        noise = torch.randn_like(xt) if sigma > 0.0 else None
         ops.cfg_ddim_step(eps_rows, eng.out_pad, xt, float(guide_scale), v_pred=(self.mean_type == 'v'),
-                          x0_out=x0_out, **self.step_scalars(int(step), stride))
+                          x0_out=x0_out, clamp=clamp, sigma=sigma, noise=noise, **self.step_scalars(int(step), stride))
         return xt
 
     def _same_gs_data(self, ga, gb) -> bool:
@@ -167,9 +178,11 @@ class DiffusionDDIM(object):
         stride = self.num_timesteps // ddim_timesteps
         unet = _unwrap(model)
         fused = (hasattr(unet, "forward_cfg_rows") and guide_scale is not None and isinstance(model_kwargs, list)
-                 and len(model_kwargs) == 2 and clamp is None and percentile is None
-                 and condition_fn is None and eta == 0.0 and b == 1 and self.mean_type in ('eps', 'v')
+                 and len(model_kwargs) == 2 and percentile is None
+                 and condition_fn is None and b == 1 and self.mean_type in ('eps', 'v')
                  and noise.is_cuda)
+        # (clamp and eta > 0 ride in the fused update kernel; percentile clipping needs a quantile of the whole x0 and classifier
+        #  guidance a foreign callable — both take the generic two-forward path below, as does any foreign model)
         if not fused:
             xt = noise
             for idx, step in enumerate(steps):
@@ -196,7 +209,7 @@ class DiffusionDDIM(object):
             if autoencoder is not None and idx in (20, 30, 40):      # LGM-refined steps (diffusion_ddim.py:254-256)
                 self.ddim_step_lgm(xt, int(step), unet, kc, ku, guide_scale, stride, autoencoder)
             else:
-                self.ddim_step_hip(xt, int(step), unet, kc, ku, guide_scale, stride)
+                self.ddim_step_hip(xt, int(step), unet, kc, ku, guide_scale, stride, clamp=clamp, eta=eta)
         if comm is not None:
             from .unet_t2v import gather_frames
             xt = gather_frames(comm, xt)
@@ -209,10 +222,6 @@ class DiffusionDDIM(object):
                     guide_scale=None, ddim_timesteps=20, eta=0.0):
         """One DDIM step for an arbitrary callable ``model`` (API compatibility; the HIP UNet never takes this
         route inside ``ddim_sample_loop``).  All samples of a call share one timestep, as in the reference loop."""
-        if condition_fn is not None or percentile is not None:
-            raise NotImplementedError("classifier guidance / percentile clipping are not on the built path")
-        if eta != 0.0:
-            raise NotImplementedError("stochastic DDIM (eta > 0) is not used by VideoMV")
         step = int(t.reshape(-1)[0])
         ts = self._scale_timesteps(t)
         tabs = dict(autoencoder=autoencoder, sqrt_alphas_cumprod=self.sqrt_alphas_cumprod,
@@ -237,7 +246,21 @@ class DiffusionDDIM(object):
             x0 = pred
         else:
             raise NotImplementedError(self.mean_type)
-        if clamp is not None:
+        if percentile is not None:          # diffusion_ddim.py:200-203
+            assert percentile > 0 and percentile <= 1
+            sq = torch.quantile(x0.flatten(1).abs(), percentile, dim=1).clamp_(1.0).view(-1, *((1,) * (x0.ndim - 1)))
+            x0 = torch.min(sq, torch.max(-sq, x0)) / sq
+        elif clamp is not None:
             x0 = x0.clamp(-clamp, clamp)
+        if condition_fn is not None:        # classifier guidance (:218-226): x0 -> eps, shift by the classifier's gradient, eps -> x0
+            alpha = self.alphas_cumprod[step].to(xt.dtype).to(xt.device)
+            eps = (k["c_recip"] * xt - x0) / k["c_recipm1"]
+            kw = model_kwargs if isinstance(model_kwargs, dict) else {}
+            eps = eps - (1 - alpha).sqrt() * condition_fn(xt, ts, **kw)
+            x0 = k["c_recip"] * xt - k["c_recipm1"] * eps
         eps = (k["c_recip"] * xt - x0) / k["c_recipm1"]
-        return torch.sqrt(k["a_prev"]) * x0 + torch.sqrt(1 - k["a_prev"]) * eps, x0
+        sigma = self.ddim_sigma(step, self.num_timesteps // ddim_timesteps, eta)
+        noise = torch.randn_like(xt)        # drawn every step, as the reference does (:239), so the RNG stream matches
+        mask = t.ne(0).to(xt.dtype).view(-1, *((1,) * (xt.ndim - 1)))
+        direction = torch.sqrt(1 - k["a_prev"] - sigma ** 2) * eps
+        return torch.sqrt(k["a_prev"]) * x0 + direction + mask * sigma * noise, x0

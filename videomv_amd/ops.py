@@ -124,6 +124,7 @@ def gemm_signature(p: "L.GemmParams") -> str:
 
 
 _TUNED = None
+_STALE_WARNED = False
 
 
 def tuned_table() -> dict:
@@ -192,7 +193,9 @@ def fill_rule(p: "L.GemmParams", policy_tile: int):
 
 def make_tuner(owner):
     """ops.Stream hook (Stream.tuner) of an engine: applies the measured (tile, split-K) choice of tuned_gemm.json to a GEMM about to be
-    recorded — auto tiles only; the library still validates the forced tile, so a stale entry fails loudly at record time.  `owner`
+    recorded — auto tiles only.  The forced choice is VALIDATED here (vmv_gemm_validate: the launch's whole host side without the
+    device); an entry the library would refuse — a stale VMV_TUNED_CACHE / VMV_TUNED_FILE, a tile whose eligibility changed — is
+    dropped with one warning and the built-in policy stands, instead of VMV_EINVAL on the first replay.  `owner`
     provides .device (or .dev) and keeps the split-K slab (._splitk) and the hit count (.n_tuned)."""
     def tune(p):
         if p.tile != L.TILE_AUTO or p.wgroup_rows:
@@ -211,12 +214,24 @@ def make_tuner(owner):
         if not ent:
             return
         ks = int(ent.get("ksplit", 0))
+        keep = (p.tile, p.ksplit, p.workspace)
         if ks > 1:
             if getattr(owner, "_splitk", None) is None:
                 owner._splitk = SplitK(owner.device if hasattr(owner, "device") else owner.dev, cap=8)
             p.workspace = owner._splitk.workspace(ks * p.M * p.N * 4).data_ptr()
         p.ksplit = ks if ks > 1 else 0
         p.tile = int(ent.get("tile", 0))
+        rc = L.load().vmv_gemm_validate(C.byref(p))
+        if rc != 0:
+            p.tile, p.ksplit, p.workspace = keep
+            global _STALE_WARNED
+            if not _STALE_WARNED:
+                _STALE_WARNED = True
+                import warnings
+                warnings.warn(f"tuned GEMM entry {ent} for {gemm_signature(p)} is refused by the library (rc {rc}): stale tile table / "
+                              f"cache — ignored, the built-in policy is used (further stale entries are dropped silently)")
+            owner.n_stale = getattr(owner, "n_stale", 0) + 1
+            return
         owner.n_tuned = getattr(owner, "n_tuned", 0) + 1
     return tune
 
@@ -435,6 +450,22 @@ class Stream:
         self.graph = g
         return self.lib.vmv_graph_nodes(g)
 
+    def run_local(self):
+        """Replay every recorded op EXCEPT the collectives (VMV_OP_COMM): fills the buffers with finite, realistic contents without
+        needing the peers (autotune.tune_plan on a multi-rank plan: a per-rank replay with collectives would hang the ranks that
+        have nothing left to tune)."""
+        assert self.record
+        i, n = 0, len(self.recorded)
+        while i < n:
+            if self.recorded[i][0] == L.OP_COMM:
+                i += 1
+                continue
+            j = i
+            while j < n and self.recorded[j][0] != L.OP_COMM:
+                j += 1
+            L.check(self.lib.vmv_plan_run_range(self.plan, i, j, _stream_ptr()), "plan_run_range")
+            i = j
+
     def run(self, first=0, last=None):
         """Replay the recorded plan on the current torch stream (as ONE graph launch after capture_graph())."""
         assert self.record
@@ -486,13 +517,16 @@ def rows_to_nchw(rows: torch.Tensor, ld: int, out: torch.Tensor):
 
 
 def cfg_ddim_step(eps_rows, ld, xt, guide_scale, c_recip, c_recipm1, c_sqrt_ac, c_sqrt_1mac, a_prev, v_pred=False,
-                  x0_out=None):
+                  x0_out=None, clamp=0.0, sigma=0.0, noise=None):
     _, Cc, F_, H, W = xt.shape
     p = L.DdimParams()
     p.eps_rows, p.ld, p.C, p.F, p.HW = eps_rows.data_ptr(), ld, Cc, F_, H * W
     p.guide_scale, p.c_recip, p.c_recipm1 = guide_scale, c_recip, c_recipm1
     p.c_sqrt_ac, p.c_sqrt_1mac, p.a_prev, p.v_pred = c_sqrt_ac, c_sqrt_1mac, a_prev, 1 if v_pred else 0
     p.xt, p.x0_out = xt.data_ptr(), _ptr(x0_out)
+    p.clamp, p.sigma, p.noise = float(clamp or 0.0), float(sigma), _ptr(noise)
+    if noise is not None:
+        assert noise.dtype == torch.float32 and noise.is_contiguous() and noise.numel() == xt.numel()
     L.check(L.load().vmv_cfg_ddim_step(C.byref(p), _stream_ptr()), "cfg_ddim_step")
 
 

@@ -9,7 +9,8 @@ therefore run ONCE per sample, not on each of the 100 forwards as the reference 
   * ``local_image_embedding`` (conv, adaptive-avg-pool 32x32, two stride-2 convs) -> 64 context tokens;
   * ``context_embedding`` (CLIP image feature -> ``num_tokens`` tokens); ``fps_embedding`` added to the time embedding.
 Everything runs on libvmv_hip.so (implicit-GEMM convs, ``vmv_i2v_temporal_adapter``, ``vmv_adaptive_avgpool_rows``).
-The LGM branch raises ``NotImplementedError`` as in ``unet_t2v.py``.
+The LGM refinement branch (``autoencoder=`` + ``gs_data``, unet_i2vgen.py:438-468) is the shared ``LgmMixin`` of ``unet_t2v.py`` with the
+v-prediction x0 (``lgm_vpred``); only its training-time form (``x0 is not None``) raises.
 """
 import math
 from typing import Dict
