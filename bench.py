@@ -269,7 +269,7 @@ def main():
         # HBM bytes per launch of the same family from the committed PMC passes of this command (tools/gemm_traffic.py;
         # FETCH_SIZE doubled as the microarch guide prescribes for gfx950) — counters cannot be read from inside the run
         traffic, traffic_src = None, None
-        tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_gemm_traffic.json") for r in (4, 3)) if os.path.exists(q)), None)
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_gemm_traffic.json") for r in (5, 4, 3)) if os.path.exists(q)), None)
         if (H, W) == (40, 64) and args.frames == 24 and tpath:
             with open(tpath) as f:
                 tj = json.load(f)
@@ -287,6 +287,49 @@ def main():
             roof["whole_step"] = dict(algorithmic_tflop=step_tflop, achieved=round(step_tflop * steps_per_s / world, 1),
                                       frac=round(step_tflop * steps_per_s / world / PEAK_MFMA16_TFLOPS, 4))
 
+    # ---- the reference's OWN shape (256 px = latent 24 x 32 x 32): the same timed loop on that latent, with the
+    #      default tile policy + rule and whatever the packaged table adds; `no_table_ms_per_step` is the same with VMV_TUNED=0 semantics
+    #      (a fresh engine recorded while the table is hidden), i.e. what an UNTABLED shape gets
+    ref_shape = None
+    if rank == 0 and world == 1 and (H, W) == (40, 64) and not args.no_op_profile:
+        from videomv_amd import ops as _ops
+
+        def time_shape(h, w, n=10):
+            x = torch.randn(1, 4, args.frames, h, w, generator=g, device=dev)
+            for i in range(3):
+                dif.ddim_step_hip(x, steps[i], model, kw_c, kw_u, 9.0, stride)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n):
+                dif.ddim_step_hip(x, steps[(3 + i) % len(steps)], model, kw_c, kw_u, 9.0, stride)
+            torch.cuda.synchronize()
+            return 1000.0 * (time.perf_counter() - t0) / n, bool(torch.isfinite(x).all())
+        try:
+            ms32, fin32 = time_shape(32, 32)
+            e32 = model.engine_for(2, args.frames, 32, 32, 77, dev, n_t=1, share_prefix=True)
+            ref_shape = dict(latent=f"{args.frames}x32x32", ms_per_step=round(ms32, 3), steps_per_s=round(1000.0 / ms32, 3), finite=fin32,
+                             whole_step=dict(algorithmic_tflop=STEP_TFLOP[(32, 32)], achieved=round(STEP_TFLOP[(32, 32)] / (ms32 * 1e-3), 1),
+                                             frac=round(STEP_TFLOP[(32, 32)] / (ms32 * 1e-3) / PEAK_MFMA16_TFLOPS, 4)),
+                             launches_from_table=e32.n_tuned, launches_from_rule=e32.n_ruled)
+            # the same shape with the table hidden (rule + built-in policy only) and with neither (built-in policy only): fresh engines
+            keep_tab, keep_eng = _ops._TUNED, dict(model._engines) if hasattr(model, "_engines") else None
+            for tag, env in (("no_table", {}), ("policy_only", {"VMV_TILE_RULES": "0"})):
+                _ops._TUNED = {}
+                os.environ.update(env)
+                try:
+                    if keep_eng is not None:
+                        model._engines.pop(next((k for k in model._engines if k[2:4] == (32, 32)), None), None)
+                    ms_x, _ = time_shape(32, 32)
+                    ref_shape[tag + "_ms_per_step"] = round(ms_x, 3)
+                finally:
+                    for k in env:
+                        os.environ.pop(k, None)
+                    _ops._TUNED = keep_tab
+            if keep_eng is not None:
+                model._engines.pop(next((k for k in model._engines if k[2:4] == (32, 32)), None), None)
+        except Exception as e:
+            ref_shape = dict(ref_shape or {}, error=f"{type(e).__name__}: {e}")
+
     def headline():
         return {"metric": "denoise-steps/sec, t2v %dx%dx%d (latent %dx%dx%d), CFG 9.0, 50-step DDIM schedule" % (8 * H, 8 * W, args.frames, args.frames, H, W),
                "value": round(steps_per_s, 4), "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps,
@@ -295,7 +338,7 @@ def main():
                "weights, zero-inits re-randomised)",
                "config": {"workload": f"t2v_infer.yaml UNetSD_T2VBase 1.413B, 24 views, latent {H}x{W}, 77 ctx tokens, "
                                       f"1 sample per GPU (cond+uncond batched)", "parallelism": f"replicas x{world}"},
-               "finite": finite, "roofline": roof}
+               "finite": finite, "roofline": roof, "reference_shape": ref_shape}
 
     # ---- frame-parallel leg: ONE sample over all ranks (strong scaling of a sample's latency)
     fpar = None

@@ -157,7 +157,7 @@ def test_tuned_table_is_well_formed():
         assert tab[elem], elem
         for sig, e in tab[elem].items():
             assert re.fullmatch(r"\d+x\d+x\d+;[0-9:*,]+;e\da\df\dr\dv\d:\d+s\dc\dl\dg\dw\d+;\d+x\d+<\d+x\d+s\d+u\dF\d+P\d+", sig), sig
-            assert 1 <= e["tile"] <= 26 and e["ksplit"] in (0, 2, 3, 4, 6, 8, 12, 16)
+            assert 1 <= e["tile"] <= 27 and e["ksplit"] in (0, 2, 3, 4, 6, 8, 12, 16)
             assert e["us"] <= 0.97 * e["base_us"] + 1e-6, (sig, e)       # (>= 7 % per launch, or >= 3 % and confirmed by a whole-step A/B)
     # and the engine's hook finds an entry by the signature of the launch it is about to record
     sig = next(iter(tab["fp16"]))
@@ -193,9 +193,10 @@ def test_autotune_cache_is_merged_only_on_request(monkeypatch, tmp_path):
 
 
 def test_fill_rule_host_logic():
-    """ops.fill_rule (opt-in, VMV_TILE_RULES=1): acts only where the built-in policy fell back to 128-row tiles; picks the 256-row tile
-    and split-K factor that fill one round of the 256 CUs; respects what a launch cannot do (no split-K under a folded LayerNorm, 128
-    columns for GEGLU); every choice is one the library accepts for that launch."""
+    """ops.fill_rule (the default since round 5; VMV_TILE_RULES=0 turns it off): where the built-in policy fell back to 128-row tiles it
+    picks the 256-row tile and split-K factor that fill one round of the 256 CUs; few-row GEMMs go to 64 x 64 register tiles with more
+    K splits; respects what a launch cannot do (no split-K under a folded LayerNorm, 128 columns for GEGLU); every choice is one the
+    library accepts for that launch (vmv_gemm_validate: the launch's whole host side, no device)."""
     lib = L.load()
     X = 1 << 20
     lin = lambda k: ops.linear_segs([(X, k, k)])
@@ -210,6 +211,7 @@ def test_fill_rule_host_logic():
                                 X, X, p.ldo, tile=r[0], ksplit=r[1], workspace=X if r[1] > 1 else None, epilogue=p.epilogue,
                                 geom=ops.Geom(OH=p.OH, OW=p.OW, IH=p.IH, IW=p.IW, F=p.F, P=p.P))
             assert lib.vmv_gemm_pick_tile(C.byref(q)) == r[0], (p.M, p.N, p.ktot, r)
+            assert lib.vmv_gemm_validate(C.byref(q)) == 0, (p.M, p.N, p.ktot, r)
         return pol, r
     # the third level at 24x32x32 (48 images of 8 x 8): 192 tiles of 128 x 160 -> 120 tiles of 256 x 128 split in two (measured 183 -> 96 us)
     pol, r = go(ops.gemm_params(3072, 1280, conv(1280), X, X, 1280, geom=g))
@@ -225,3 +227,45 @@ def test_fill_rule_host_logic():
     assert r is None or r[1] == 0
     pol, r = go(ops.gemm_params(3072, 10240, lin(1280), X, X, 5120, epilogue=L.EPI_GEGLU))
     assert r is None or r[0] in (L.TILE_256x128, L.TILE_P256x128)
+    # few rows (a frame-parallel rank's fourth level, 120 rows): 64 x 64 register tiles; the long reduction split 12 ways (measured
+    # 34.7 -> 23.9 us), the short-K linear unsplit (20.8 -> 15.0 us)
+    pol, r = go(ops.gemm_params(120, 1280, conv(1280), X, X, 1280, geom=ops.Geom(OH=3, OW=5, IH=3, IW=5), ksplit=8, workspace=X))
+    assert r == (L.TILE_64x64, 12)
+    pol, r = go(ops.gemm_params(120, 1280, lin(1280), X, X, 1280, rowstat=X, colsum=X))
+    assert r == (L.TILE_64x64, 0)
+
+
+def test_gemm_validate_is_the_launch_without_the_device():
+    """vmv_gemm_validate: VMV_OK iff vmv_gemm would launch — argument checks, policy, the forced tile's own launcher checks; no GPU
+    needed.  A stale tuned entry (a tile that cannot serve the launch) is dropped by the tuner hook with ONE warning and the policy
+    stands (it used to surface as VMV_EINVAL on the first replay)."""
+    import warnings
+    lib = L.load()
+    X = 1 << 20
+    p = ops.gemm_params(4096, 1280, ops.linear_segs([(X, 1280, 1280)]), X, X, 1280)
+    assert lib.vmv_gemm_validate(C.byref(p)) == 0
+    p.tile = L.TILE_RS                       # the row-stationary kernel serves K = 320 / 640 only
+    assert lib.vmv_gemm_validate(C.byref(p)) == -1
+    p.tile, p.N = L.TILE_AUTO, 1281
+    assert lib.vmv_gemm_validate(C.byref(p)) == -1
+    p.N = 1280
+    p.tile, p.ksplit, p.workspace = L.TILE_X256x320, 64, X       # an impossible split of the wide tile
+    assert lib.vmv_gemm_validate(C.byref(p)) != 0
+
+    class Owner:
+        device = "cpu"
+    q = ops.gemm_params(4096, 1280, ops.linear_segs([(X, 1280, 1280)]), X, X, 1280)
+    sig = ops.gemm_signature(q)
+    old, ops._TUNED = ops._TUNED, {sig: dict(tile=L.TILE_RS, ksplit=0)}
+    old_w, ops._STALE_WARNED = ops._STALE_WARNED, False
+    try:
+        o = Owner()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            ops.make_tuner(o)(q)
+            q2 = ops.gemm_params(4096, 1280, ops.linear_segs([(X, 1280, 1280)]), X, X, 1280)
+            ops.make_tuner(o)(q2)
+        assert q.tile == L.TILE_AUTO and q2.tile == L.TILE_AUTO and o.n_stale == 2 and getattr(o, "n_tuned", 0) == 0
+        assert len([x for x in w if "stale" in str(x.message)]) == 1
+    finally:
+        ops._TUNED, ops._STALE_WARNED = old, old_w

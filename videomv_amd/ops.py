@@ -156,18 +156,41 @@ def tuned_table() -> dict:
 
 
 def fill_rule(p: "L.GemmParams", policy_tile: int):
-    """EXPERIMENT (VMV_TILE_RULES=1, off by default; tools/experiments/policy_vs_table.py): what the measured table suggests for launches it
-    does not cover — where the built-in policy falls back to 128-row tiles, 256-row tiles of 128 / 160 columns with the split-K factor
-    (<= 8, >= 8 chunks per split) that best fills ONE round of the 256 CUs; 64 x 64 register tiles for short-K linears on few rows.
-    -> (tile, ksplit) or None."""
+    """The default tile RULE on top of csrc/gemm.hip's built-in policy (round 5; VMV_TILE_RULES=0 turns it off).  The built-in policy was
+    fitted to the 24x40x64 plan (M = 122 880 / 30 720 / 7 680 / 1 920); this is what the MEASURED table (tools/autotune_gemm.py, round 4)
+    says about every other grid, written as rules instead of 255 shape-specific entries (tools/experiments/rule_eval.py scores it against
+    that table; tools/prune_tuned_table.py removes the entries it reproduces):
+      * where the policy falls back to 128-row tiles (ids 7 / 8) because 256-row tiles alone do not reach 240 blocks: 256-row tiles of
+        128 / 160 columns with the split-K factor (<= 8, >= 8 chunks per split) that best fills ONE round of the 256 CUs —
+        score = fill x padding efficiency - 0.03 per extra split; persistent tiles for short-K linears that need no split;
+      * few rows (M <= 512: the fourth level of a frame-parallel rank, the embedding GEMMs): 64 x 64 register tiles — a 256- or 128-row
+        tile wastes most of its rows — with more K splits than the policy's cap of 8 on the long reductions (12 / 16), 256 x 128 tiles
+        from 240 rows on when the reduction is >= 100 chunks;
+      * short-K linears on a few thousand rows (200-1024 tiles of 64 x 64): 64 x 64 register tiles.
+    -> (tile, ksplit) or None (keep the policy's choice).  The caller validates the choice with vmv_gemm_validate before forcing it."""
     import math
-    if policy_tile not in (L.TILE_G128x128, L.TILE_G128x160):
-        return None
     M, N = p.M, p.N
     steps = sum((p.seg[i].k + 63) // 64 for i in range(p.nseg))
     geglu = p.epilogue == L.EPI_GEGLU
     lin = all(p.seg[i].mode == L.SEG_LINEAR for i in range(p.nseg))
-    ks_ok = not (p.rowstat or p.ln_eps > 0 or p.gn_table)
+    ks_ok = not (p.rowstat or p.ln_eps > 0 or p.gn_table or p.colsum)
+    small_pol = policy_tile in (L.TILE_G128x128, L.TILE_G128x160, L.TILE_P256x128, L.TILE_P256x160, L.TILE_128x160, L.TILE_128x128)
+    if M <= 512 and small_pol and not geglu and not p.out_fp32 and N >= 256:
+        if lin and steps <= 24:
+            if M > 256 and N > 1280:        # (measured: the persistent tile is within 7 % there)
+                return None
+            ks = 0
+            if ks_ok and p.ksplit > 1:
+                ks = 4 if M <= 256 else 3
+            return L.TILE_64x64, ks
+        if ks_ok and steps >= 56 and (M <= 256 or steps >= 100):
+            ks = 6 if steps < 70 else (12 if steps < 210 or M > 256 else 16)
+            if M > 128 and steps < 100:
+                ks = min(ks, 8)
+            tile = L.TILE_64x64 if (M <= 128 or steps < 100) else L.TILE_256x128
+            return tile, ks
+    if policy_tile not in (L.TILE_G128x128, L.TILE_G128x160):
+        return None
     best = None
     for bn in (128, 160):
         if bn == 160 and (N % 160 or geglu):
@@ -201,16 +224,12 @@ def make_tuner(owner):
         if p.tile != L.TILE_AUTO or p.wgroup_rows:
             return
         ent = tuned_table().get(gemm_signature(p))
-        if not ent and os.environ.get("VMV_TILE_RULES", "0") == "1":
-            lib = L.load()
-            r = fill_rule(p, lib.vmv_gemm_pick_tile(C.byref(p)))
-            if r is not None:
-                keep = (p.tile, p.ksplit)
-                p.tile, p.ksplit = r[0], 0                   # (validity of the forced tile for this launch: host-side check, no launch)
-                ok = lib.vmv_gemm_pick_tile(C.byref(p)) == r[0]
-                p.tile, p.ksplit = keep
-                if ok:
-                    ent = dict(tile=r[0], ksplit=r[1])
+        from_rule = False
+        if not ent and os.environ.get("VMV_TILE_RULES", "1") != "0":
+            pol = L.load().vmv_gemm_pick_tile(C.byref(p))
+            r = fill_rule(p, pol)
+            if r is not None and (int(r[0]), int(r[1])) != (pol, p.ksplit if p.ksplit > 1 else 0):
+                ent, from_rule = dict(tile=r[0], ksplit=r[1]), True
         if not ent:
             return
         ks = int(ent.get("ksplit", 0))
@@ -224,6 +243,8 @@ def make_tuner(owner):
         rc = L.load().vmv_gemm_validate(C.byref(p))
         if rc != 0:
             p.tile, p.ksplit, p.workspace = keep
+            if from_rule:           # (a rule's suggestion the library cannot serve for this launch: the policy stands, silently)
+                return
             global _STALE_WARNED
             if not _STALE_WARNED:
                 _STALE_WARNED = True
@@ -232,7 +253,10 @@ def make_tuner(owner):
                               f"cache — ignored, the built-in policy is used (further stale entries are dropped silently)")
             owner.n_stale = getattr(owner, "n_stale", 0) + 1
             return
-        owner.n_tuned = getattr(owner, "n_tuned", 0) + 1
+        if from_rule:
+            owner.n_ruled = getattr(owner, "n_ruled", 0) + 1
+        else:
+            owner.n_tuned = getattr(owner, "n_tuned", 0) + 1
     return tune
 
 

@@ -267,7 +267,7 @@ class UNetEngine:
         self.packed = dict(fold_ln=self.fold_ln, device=str(device), w=self.w, has_cam=self.has_cam, has_fps=self.has_fps,
                            emb_off=self.emb_off, emb_total=self.emb_total, out_pad=self.out_pad)
         self._eps_out = eps_out
-        self.n_tuned = 0
+        self.n_tuned, self.n_ruled, self.n_stale = 0, 0, 0      # launches forced by the table / by ops.fill_rule / table entries the library refused
         self.S.tuner = ops.make_tuner(self)      # measured per-shape (tile, split-K) choices: videomv_amd/tuned_gemm.json
         self._static_inputs()
         self._build()
@@ -289,7 +289,7 @@ class UNetEngine:
         self._keepalive, self._splitk = [], None
         self._gn_tot2.zero_()
         self._gn_tot_k = 0
-        self._replays, self.graph_nodes, self.n_tuned = 0, 0, 0
+        self._replays, self.graph_nodes, self.n_tuned, self.n_ruled, self.n_stale = 0, 0, 0, 0, 0
         self.S.tuner = ops.make_tuner(self)
         self._static_inputs()
         self._build()
