@@ -568,7 +568,7 @@ def main():
                    lgm_refined_step_min_ms=round(1000 * t_lgm_min, 2), lgm_refined_step_calls=6,
                    plain_step_ms=round(1000 * t_plain, 2),
                    lgm_refined_step_in_loop_ms=round(1000 * (t_loop - 47 * t_plain) / 3, 2),
-                   instances_per_view=int(sum(ref_l.renderer.last_num_rendered) / max(1, len(ref_l.renderer.last_num_rendered))),
+                   instances_per_view=int(sum(ref_l.renderer.last_num_rendered) / max(1, getattr(ref_l.renderer, "last_views", 0) or len(ref_l.renderer.last_num_rendered))),
                    finite=bool(torch.isfinite(x0_l).all()))
         del model_l
 
@@ -590,11 +590,25 @@ def main():
             nview, S_out = cv.shape[1], ref_l.renderer.size
             inst = sum(ref_l.renderer.last_num_rendered)
             by = nview * (gsn.shape[1] * 48 + S_out * S_out * 16) + inst * 12
+            # same-run A/B: the per-view loop of round 4 (one host round trip per view)
+            os.environ["VMV_GS_BATCH"] = "0"
+            try:
+                ref_l.renderer.render(gsn, cv, cvp, None)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    ref_l.renderer.render(gsn, cv, cvp, None)
+                torch.cuda.synchronize()
+                t_pv = (time.perf_counter() - t1) / 3
+            finally:
+                os.environ.pop("VMV_GS_BATCH", None)
             lgm["rasteriser"] = dict(views=nview, gaussians=int(gsn.shape[1]), instances=int(inst), ms_per_24_views=round(1000 * t_r, 3),
                                      ms_per_view=round(1000 * t_r / nview, 4), algorithmic_bytes=int(by),
                                      achieved_gb_s=round(by / t_r / 1e9, 1), peak_gb_s=8000.0, frac=round(by / t_r / 8e12, 4),
-                                     note="wall time of GaussianRenderer.render incl. its one host round trip per view (the instance count); "
-                                          "rocprim radix sort passes are traffic on top of the algorithmic bytes")
+                                     per_view_loop_ms_per_24_views=round(1000 * t_pv, 3), host_syncs_per_call=1,
+                                     note="wall time of GaussianRenderer.render: ONE batched pass over all views (one preprocess / scan / radix sort / "
+                                          "ranges / blend launch, one host read of the instance total); per_view_loop = round 4's loop with a host "
+                                          "round trip per view, same run; rocprim radix sort passes are traffic on top of the algorithmic bytes")
         except Exception as e:
             lgm["rasteriser"] = {"error": f"{type(e).__name__}: {e}"}
     if lgm is not None:

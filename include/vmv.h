@@ -44,7 +44,7 @@ int vmv_elem_type(void);
 int vmv_has_experiments(void);
 /* sizeof() of the argument blocks, so a foreign-language binding can verify its struct layout:
  * which = VMV_OP_* (GN_STATS/GN_APPLY share a block), 100 = VmvDdimParams, 101 = VmvGemmSeg, 102 = VmvSeqMap,
- * 103 = VmvGsParams */
+ * 103 = VmvGsParams, 104 = VmvGsBatchParams */
 int vmv_sizeof(int which);
 /* human-readable text for a code returned by any launcher (VMV_E* or hipError_t) */
 const char* vmv_error_string(int code);
@@ -439,6 +439,43 @@ typedef struct {
 int vmv_gs_workspace_bytes(int n_gaussians, int n_instances, size_t* scan_bytes, size_t* sort_bytes);
 int vmv_gs_preprocess(const VmvGsParams* p, void* stream);
 int vmv_gs_render(const VmvGsParams* p, void* stream);
+
+/* The same rasteriser for ALL views of a call in one pass (the LGM branch renders 24 views of each CFG branch's Gaussians per refined
+ * step, core/gs.py:41-83 loops `for b in range(B): for v in range(V):` around the extension): "view" vv = b * V + v uses sample b's
+ * Gaussians and the vv-th camera.  ONE preprocess launch over (view, Gaussian), ONE inclusive scan over the B * V * N tile counts, ONE
+ * 64-bit radix sort of every instance with key = (vv * tiles + tile) << 32 | depth bits, one ranges and one blend launch (grid =
+ * tiles x views; a tile without instances writes the background) — 6 launches and ONE host read of the instance total per call instead
+ * of 6 launches and one host round trip per view.  Per-(view, Gaussian) arrays hold B * V * N entries; keys / vals num_rendered.
+ * Same arithmetic as the per-view entry points (shared device code): the images are bit-identical.
+ *   vmv_gs_batch_key_bits(n_views, size)       -> significant key bits (32 depth + ceil(log2(n_views * tiles)))
+ *   vmv_gs_batch_workspace_bytes(n_view_gaussians, n_instances, key_bits, &scan, &sort)
+ *   vmv_gs_batch_preprocess -> offsets[B*V*N - 1] = num_rendered (host reads it, sizes keys / vals / sort_temp), vmv_gs_batch_render. */
+typedef struct {
+    const float* gaussians;      /* [B][N][14] (layout of VmvGsParams.gaussians per sample)                     */
+    int32_t B, N, V, size;
+    const float* views;          /* [B * V][16] cam_view, row-major, row-vector convention                     */
+    const float* view_projs;     /* [B * V][16] cam_view_proj                                                  */
+    float tan_half_fov;
+    float bg[3];
+    float* depth;                /* [B * V * N]   preprocess outputs, view-major */
+    float* xy;                   /* [B * V * N][2] */
+    float* conic_opacity;        /* [B * V * N][4] */
+    int32_t* rect;               /* [B * V * N][4] */
+    uint32_t* tiles_touched;     /* [B * V * N] */
+    uint32_t* offsets;           /* [B * V * N] inclusive scan over all views */
+    void* scan_temp; size_t scan_temp_bytes;
+    uint64_t* keys; uint64_t* keys_sorted;      /* [num_rendered] */
+    uint32_t* vals; uint32_t* vals_sorted;      /* [num_rendered] Gaussian index inside its sample */
+    int32_t num_rendered; int32_t _pad;
+    void* sort_temp; size_t sort_temp_bytes;
+    uint32_t* ranges;            /* [B * V * tiles][2] */
+    float* out_color;            /* [B * V][3][size][size], clamped to [0, 1] */
+    float* out_alpha;            /* [B * V][size][size] or NULL */
+} VmvGsBatchParams;
+int vmv_gs_batch_key_bits(int n_views, int size);
+int vmv_gs_batch_workspace_bytes(int n_view_gaussians, int n_instances, int key_bits, size_t* scan_bytes, size_t* sort_bytes);
+int vmv_gs_batch_preprocess(const VmvGsBatchParams* p, void* stream);
+int vmv_gs_batch_render(const VmvGsBatchParams* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Block permute-copy (frame-sharded sampling, DESIGN.md §8: packs / unpacks the all-to-all buffers that switch an

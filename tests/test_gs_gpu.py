@@ -179,3 +179,38 @@ def test_rasteriser_depth_order_across_a_tile_boundary(swap):
                 worst = max(worst, abs(float(img[ch, py, px]) - e))
             worst = max(worst, abs(float(al[py, px]) - (a0 + a1 * (1.0 - a0))))
     assert worst < 3e-5, worst
+
+
+def test_batched_pass_equals_the_per_view_loop(monkeypatch):
+    """vmv_gs_batch_* (all B x V views in one preprocess / scan / sort / blend pass, one host read) against the per-view entry points
+    it shares its device code with: same bits, for two samples with different Gaussians, views that see nothing (every Gaussian
+    behind the near plane -> background), and a call whose instance total is zero."""
+    from videomv_amd.gs import GaussianRenderer
+    size = 96
+    ga, gb = _scene(2500, 11), _scene(2500, 12, big=True)
+    gauss = torch.stack([ga, gb]).cuda()
+    cv, cvp = _cams(5)
+    cv2, cvp2 = torch.stack([cv, cv.flip(0)]).cuda(), torch.stack([cvp, cvp.flip(0)]).cuda()
+    # view 2 of sample 0 looks AWAY from the scene: nothing in front of the near plane
+    away = cv2[0, 2].clone()
+    away[:, 2] = -away[:, 2]
+    cv2[0, 2] = away
+    cvp2[0, 2] = away @ GaussianRenderer(output_size=size).proj_matrix.cuda()
+    bg = torch.tensor([0.2, 0.5, 0.9]).cuda()
+    r = GaussianRenderer(output_size=size)
+    monkeypatch.setenv("VMV_GS_BATCH", "1")
+    out_b = r.render(gauss, cv2, cvp2, None, bg_color=bg)
+    n_batch = sum(r.last_num_rendered)
+    assert r.last_views == 10 and len(r.last_num_rendered) == 1
+    monkeypatch.setenv("VMV_GS_BATCH", "0")
+    out_v = r.render(gauss, cv2, cvp2, None, bg_color=bg)
+    torch.cuda.synchronize()
+    assert len(r.last_num_rendered) == 10 and sum(r.last_num_rendered) == n_batch and r.last_num_rendered[2] == 0
+    assert torch.equal(out_b["image"], out_v["image"]) and torch.equal(out_b["alpha"], out_v["alpha"])
+    assert torch.equal(out_b["image"][0, 2], bg.view(3, 1, 1).expand(3, size, size)) and float(out_b["alpha"][0, 2].abs().max()) == 0.0
+    assert float(out_b["alpha"][1].max()) > 0.5
+    # a call with no instance at all: every view is the background
+    monkeypatch.setenv("VMV_GS_BATCH", "1")
+    out0 = r.render(ga.cuda().unsqueeze(0), cv2[:1, 2:3].contiguous(), cvp2[:1, 2:3].contiguous(), None, bg_color=bg)
+    torch.cuda.synchronize()
+    assert r.last_num_rendered == [0] and torch.equal(out0["image"][0, 0], bg.view(3, 1, 1).expand(3, size, size))

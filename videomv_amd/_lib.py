@@ -104,6 +104,16 @@ class GsParams(C.Structure):
                 ("sort_temp_bytes", C.c_size_t), ("ranges", C.c_void_p), ("out_color", C.c_void_p), ("out_alpha", C.c_void_p)]
 
 
+class GsBatchParams(C.Structure):
+    _fields_ = [("gaussians", C.c_void_p), ("B", C.c_int32), ("N", C.c_int32), ("V", C.c_int32), ("size", C.c_int32),
+                ("views", C.c_void_p), ("view_projs", C.c_void_p), ("tan_half_fov", C.c_float), ("bg", C.c_float * 3),
+                ("depth", C.c_void_p), ("xy", C.c_void_p), ("conic_opacity", C.c_void_p), ("rect", C.c_void_p),
+                ("tiles_touched", C.c_void_p), ("offsets", C.c_void_p), ("scan_temp", C.c_void_p),
+                ("scan_temp_bytes", C.c_size_t), ("keys", C.c_void_p), ("keys_sorted", C.c_void_p), ("vals", C.c_void_p),
+                ("vals_sorted", C.c_void_p), ("num_rendered", C.c_int32), ("_pad", C.c_int32), ("sort_temp", C.c_void_p),
+                ("sort_temp_bytes", C.c_size_t), ("ranges", C.c_void_p), ("out_color", C.c_void_p), ("out_alpha", C.c_void_p)]
+
+
 class CopyParams(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("n0", C.c_int32), ("n1", C.c_int32), ("n2", C.c_int32),
                 ("inner16", C.c_int32), ("ss0", C.c_int64), ("ss1", C.c_int64), ("ss2", C.c_int64)]
@@ -176,6 +186,10 @@ SYMBOLS = {
     "vmv_gs_workspace_bytes": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "vmv_gs_preprocess": (C.c_int, [C.POINTER(GsParams), _P]),
     "vmv_gs_render": (C.c_int, [C.POINTER(GsParams), _P]),
+    "vmv_gs_batch_key_bits": (C.c_int, [C.c_int, C.c_int]),
+    "vmv_gs_batch_workspace_bytes": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "vmv_gs_batch_preprocess": (C.c_int, [C.POINTER(GsBatchParams), _P]),
+    "vmv_gs_batch_render": (C.c_int, [C.POINTER(GsBatchParams), _P]),
     "vmv_latent_to_rows": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "vmv_latent_to_rows_keep": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "vmv_i2v_temporal_adapter": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
@@ -230,7 +244,7 @@ def load():
     if lib.vmv_elem_type() != (ELEM_F16 if _elem == "f16" else ELEM_BF16):
         raise RuntimeError(f"{LIB_PATH} was built for another element type")
     for which, st in ((OP_GEMM, GemmParams), (OP_GN_STATS, GroupNormParams), (OP_LAYERNORM, LayerNormParams),
-                      (OP_ATTENTION, AttnParams), (OP_SOFTMAX, SoftmaxParams), (OP_COPY, CopyParams), (OP_FF, FfParams), (OP_COMM, CommParams), (103, GsParams), (100, DdimParams), (101, GemmSeg), (102, SeqMap)):
+                      (OP_ATTENTION, AttnParams), (OP_SOFTMAX, SoftmaxParams), (OP_COPY, CopyParams), (OP_FF, FfParams), (OP_COMM, CommParams), (103, GsParams), (104, GsBatchParams), (100, DdimParams), (101, GemmSeg), (102, SeqMap)):
         if lib.vmv_sizeof(which) != C.sizeof(st):
             raise RuntimeError(f"struct layout drift for {st.__name__}: C {lib.vmv_sizeof(which)} vs ctypes "
                                f"{C.sizeof(st)}")

@@ -55,6 +55,7 @@ extern "C" int vmv_sizeof(int which) {
         case 101: return (int)sizeof(VmvGemmSeg);
         case 102: return (int)sizeof(VmvSeqMap);
         case 103: return (int)sizeof(VmvGsParams);
+        case 104: return (int)sizeof(VmvGsBatchParams);
         default: return (int)op_size(which);
     }
 }

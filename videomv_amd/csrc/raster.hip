@@ -26,14 +26,14 @@ namespace {
 
 constexpr int GS_TILE = 16;
 
-__global__ __launch_bounds__(256) void gs_preprocess_kernel(const VmvGsParams p) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.N) return;
-    p.tiles_touched[i] = 0;
-    const float* g = p.gaussians + (long)i * 14;
+// One Gaussian against one view: everything gs_preprocess writes for it.  `V` / `M` = the view's cam_view / cam_view_proj (row-major,
+// row-vector convention), outputs at index `o` of the per-(view, Gaussian) arrays.  Shared by the per-view and the batched kernels, so
+// the two paths produce the same bits.
+struct GsOut { float* depth; float* xy; float* conic_opacity; int32_t* rect; uint32_t* tiles_touched; };
+VMV_DEV void gs_project(const float* __restrict__ g, const float* __restrict__ V, const float* __restrict__ M, const int size,
+                        const float tan_half_fov, const GsOut& out, const long o) {
+    out.tiles_touched[o] = 0;
     const float mx = g[0], my = g[1], mz = g[2];
-    const float* V = p.view;
-    const float* M = p.view_proj;
     // row-vector convention: [m, 1] @ matrix
     const float vx = mx * V[0] + my * V[4] + mz * V[8] + V[12];
     const float vy = mx * V[1] + my * V[5] + mz * V[9] + V[13];
@@ -58,8 +58,8 @@ __global__ __launch_bounds__(256) void gs_preprocess_kernel(const VmvGsParams p)
         for (int b = 0; b < 3; ++b)
             S3[a * 3 + b] = R[a * 3 + 0] * s2[0] * R[b * 3 + 0] + R[a * 3 + 1] * s2[1] * R[b * 3 + 1] + R[a * 3 + 2] * s2[2] * R[b * 3 + 2];
     // EWA projection: T = J W3, W3 = V[:3,:3]^T
-    const float focal = (float)p.size / (2.0f * p.tan_half_fov);
-    const float lim = 1.3f * p.tan_half_fov;
+    const float focal = (float)size / (2.0f * tan_half_fov);
+    const float lim = 1.3f * tan_half_fov;
     const float tx = fminf(lim, fmaxf(-lim, vx / vz)) * vz;
     const float ty = fminf(lim, fmaxf(-lim, vy / vz)) * vz;
     const float j00 = focal / vz, j02 = -focal * tx / (vz * vz), j11 = focal / vz, j12 = -focal * ty / (vz * vz);
@@ -84,21 +84,74 @@ __global__ __launch_bounds__(256) void gs_preprocess_kernel(const VmvGsParams p)
     const float mid = 0.5f * (ca + cc);
     const float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
     const float radius = ceilf(3.0f * sqrtf(lam));
-    const float px = ((nx + 1.0f) * (float)p.size - 1.0f) * 0.5f;
-    const float py = ((ny + 1.0f) * (float)p.size - 1.0f) * 0.5f;
-    const int grid = (p.size + GS_TILE - 1) / GS_TILE;
+    const float px = ((nx + 1.0f) * (float)size - 1.0f) * 0.5f;
+    const float py = ((ny + 1.0f) * (float)size - 1.0f) * 0.5f;
+    const int grid = (size + GS_TILE - 1) / GS_TILE;
     auto clampi = [&](float v) { const int t = (int)v; return t < 0 ? 0 : (t > grid ? grid : t); };
     const int x0 = clampi((px - radius) / GS_TILE), y0 = clampi((py - radius) / GS_TILE);
     const int x1 = clampi((px + radius + GS_TILE - 1) / GS_TILE), y1 = clampi((py + radius + GS_TILE - 1) / GS_TILE);
     const int touched = (x1 - x0) * (y1 - y0);
     if (touched <= 0) return;
-    p.depth[i] = vz;
-    p.xy[2 * i] = px; p.xy[2 * i + 1] = py;
-    float* co = p.conic_opacity + 4L * i;
+    out.depth[o] = vz;
+    out.xy[2 * o] = px; out.xy[2 * o + 1] = py;
+    float* co = out.conic_opacity + 4L * o;
     co[0] = cc * idet; co[1] = -cb * idet; co[2] = ca * idet; co[3] = g[3];
-    int* rc = p.rect + 4L * i;
+    int* rc = out.rect + 4L * o;
     rc[0] = x0; rc[1] = y0; rc[2] = x1; rc[3] = y1;
-    p.tiles_touched[i] = (uint32_t)touched;
+    out.tiles_touched[o] = (uint32_t)touched;
+}
+
+__global__ __launch_bounds__(256) void gs_preprocess_kernel(const VmvGsParams p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.N) return;
+    const GsOut out{p.depth, p.xy, p.conic_opacity, p.rect, p.tiles_touched};
+    gs_project(p.gaussians + (long)i * 14, p.view, p.view_proj, p.size, p.tan_half_fov, out, i);
+}
+
+// ---- batched form (vmv.h VmvGsBatchParams): all B * V views of B samples in ONE pass — one preprocess launch, one scan, one
+//      radix sort over every (view, tile, depth) instance, one ranges launch, one blend launch; "view" vv = b * V + v everywhere.
+__global__ __launch_bounds__(256) void gs_preprocess_batch_kernel(const VmvGsBatchParams p) {
+    __shared__ float s_m[32];
+    const int vv = blockIdx.y;
+    if (threadIdx.x < 16) s_m[threadIdx.x] = p.views[16 * vv + threadIdx.x];
+    else if (threadIdx.x < 32) s_m[threadIdx.x] = p.view_projs[16 * vv + threadIdx.x - 16];
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.N) return;
+    const GsOut out{p.depth, p.xy, p.conic_opacity, p.rect, p.tiles_touched};
+    gs_project(p.gaussians + ((long)(vv / p.V) * p.N + i) * 14, s_m, s_m + 16, p.size, p.tan_half_fov, out, (long)vv * p.N + i);
+}
+
+__global__ __launch_bounds__(256) void gs_duplicate_batch_kernel(const VmvGsBatchParams p) {
+    const int vv = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.N) return;
+    const long o = (long)vv * p.N + i;
+    if (p.tiles_touched[o] == 0) return;
+    uint32_t off = o == 0 ? 0u : p.offsets[o - 1];
+    const int* rc = p.rect + 4L * o;
+    const int grid = (p.size + GS_TILE - 1) / GS_TILE;
+    const uint32_t tile0 = (uint32_t)vv * (uint32_t)(grid * grid);
+    const uint32_t dbits = __float_as_uint(p.depth[o]);           // depth > 0.2: the bit pattern orders like the float
+    for (int y = rc[1]; y < rc[3]; ++y)
+        for (int x = rc[0]; x < rc[2]; ++x) {
+            if (off >= (uint32_t)p.num_rendered) return;
+            p.keys[off] = ((uint64_t)(tile0 + (uint32_t)(y * grid + x)) << 32) | dbits;      // (view, tile) major, depth minor
+            p.vals[off] = (uint32_t)i;                                                       // Gaussian index inside its sample
+            ++off;
+        }
+}
+
+__global__ __launch_bounds__(256) void gs_ranges_batch_kernel(const VmvGsBatchParams p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.num_rendered) return;
+    const uint32_t t = (uint32_t)(p.keys_sorted[i] >> 32);
+    if (i == 0) p.ranges[2 * t] = 0;
+    else {
+        const uint32_t tp = (uint32_t)(p.keys_sorted[i - 1] >> 32);
+        if (tp != t) { p.ranges[2 * tp + 1] = (uint32_t)i; p.ranges[2 * t] = (uint32_t)i; }
+    }
+    if (i == p.num_rendered - 1) p.ranges[2 * t + 1] = (uint32_t)p.num_rendered;
 }
 
 __global__ __launch_bounds__(256) void gs_duplicate_kernel(const VmvGsParams p) {
@@ -129,16 +182,16 @@ __global__ __launch_bounds__(256) void gs_ranges_kernel(const VmvGsParams p) {
     if (i == p.num_rendered - 1) p.ranges[2 * t + 1] = (uint32_t)p.num_rendered;
 }
 
-__global__ __launch_bounds__(256) void gs_render_kernel(const VmvGsParams p) {
+// One 16 x 16 tile of one view: blend the tile's sorted instances [lo, hi) front to back.  Arrays are the view's own (already offset).
+VMV_DEV void gs_blend_tile(const int size, const float* __restrict__ bg, const uint32_t lo, const uint32_t hi,
+                           const uint32_t* __restrict__ vals_sorted, const float* __restrict__ xy, const float* __restrict__ conic_opacity,
+                           const float* __restrict__ gaussians, float* __restrict__ out_color, float* __restrict__ out_alpha) {
     __shared__ float s_xy[256][2];
     __shared__ float s_co[256][4];
     __shared__ float s_rgb[256][3];
     __shared__ int s_done;
-    const int grid = (p.size + GS_TILE - 1) / GS_TILE;
-    const int tile = blockIdx.y * grid + blockIdx.x;
     const int px = blockIdx.x * GS_TILE + (threadIdx.x & 15), py = blockIdx.y * GS_TILE + (threadIdx.x >> 4);
-    const bool inside = px < p.size && py < p.size;
-    const uint32_t lo = p.ranges[2 * tile], hi = p.ranges[2 * tile + 1];
+    const bool inside = px < size && py < size;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Wt = 0.f;
     bool done = !inside;
     for (uint32_t base = lo; base < hi; base += 256) {
@@ -146,11 +199,11 @@ __global__ __launch_bounds__(256) void gs_render_kernel(const VmvGsParams p) {
         __syncthreads();
         const uint32_t j = base + threadIdx.x;
         if (j < hi) {
-            const uint32_t gi = p.vals_sorted[j];
-            s_xy[threadIdx.x][0] = p.xy[2 * gi]; s_xy[threadIdx.x][1] = p.xy[2 * gi + 1];
-            const float* co = p.conic_opacity + 4L * gi;
+            const uint32_t gi = vals_sorted[j];
+            s_xy[threadIdx.x][0] = xy[2 * gi]; s_xy[threadIdx.x][1] = xy[2 * gi + 1];
+            const float* co = conic_opacity + 4L * gi;
             s_co[threadIdx.x][0] = co[0]; s_co[threadIdx.x][1] = co[1]; s_co[threadIdx.x][2] = co[2]; s_co[threadIdx.x][3] = co[3];
-            const float* g = p.gaussians + 14L * gi + 11;
+            const float* g = gaussians + 14L * gi + 11;
             s_rgb[threadIdx.x][0] = g[0]; s_rgb[threadIdx.x][1] = g[1]; s_rgb[threadIdx.x][2] = g[2];
         }
         __syncthreads();
@@ -173,13 +226,30 @@ __global__ __launch_bounds__(256) void gs_render_kernel(const VmvGsParams p) {
         __syncthreads();
     }
     if (inside) {
-        const long hw = (long)p.size * p.size, o = (long)py * p.size + px;
-        const float r = C0 + T * p.bg[0], g = C1 + T * p.bg[1], b = C2 + T * p.bg[2];
-        p.out_color[o] = fminf(1.f, fmaxf(0.f, r));              // core/gs.py:84  rendered_image.clamp(0, 1)
-        p.out_color[hw + o] = fminf(1.f, fmaxf(0.f, g));
-        p.out_color[2 * hw + o] = fminf(1.f, fmaxf(0.f, b));
-        if (p.out_alpha) p.out_alpha[o] = Wt;
+        const long hw = (long)size * size, o = (long)py * size + px;
+        const float r = C0 + T * bg[0], g = C1 + T * bg[1], b = C2 + T * bg[2];
+        out_color[o] = fminf(1.f, fmaxf(0.f, r));              // core/gs.py:84  rendered_image.clamp(0, 1)
+        out_color[hw + o] = fminf(1.f, fmaxf(0.f, g));
+        out_color[2 * hw + o] = fminf(1.f, fmaxf(0.f, b));
+        if (out_alpha) out_alpha[o] = Wt;
     }
+}
+
+__global__ __launch_bounds__(256) void gs_render_kernel(const VmvGsParams p) {
+    const int grid = (p.size + GS_TILE - 1) / GS_TILE;
+    const int tile = blockIdx.y * grid + blockIdx.x;
+    gs_blend_tile(p.size, p.bg, p.ranges[2 * tile], p.ranges[2 * tile + 1], p.vals_sorted, p.xy, p.conic_opacity, p.gaussians,
+                  p.out_color, p.out_alpha);
+}
+
+__global__ __launch_bounds__(256) void gs_render_batch_kernel(const VmvGsBatchParams p) {
+    const int grid = (p.size + GS_TILE - 1) / GS_TILE;
+    const int vv = blockIdx.z;
+    const long tile = (long)vv * grid * grid + blockIdx.y * grid + blockIdx.x;
+    const long hw = (long)p.size * p.size, vo = (long)vv * p.N;
+    // (a view without instances has ranges 0 / 0 from the memset: the tile writes the background)
+    gs_blend_tile(p.size, p.bg, p.ranges[2 * tile], p.ranges[2 * tile + 1], p.vals_sorted, p.xy + 2 * vo, p.conic_opacity + 4 * vo,
+                  p.gaussians + (long)(vv / p.V) * p.N * 14, p.out_color + 3 * hw * vv, p.out_alpha ? p.out_alpha + hw * vv : nullptr);
 }
 
 int gs_check(const VmvGsParams& p) {
@@ -239,5 +309,75 @@ extern "C" int vmv_gs_render(const VmvGsParams* pp, void* stream) {
         hipLaunchKernelGGL(gs_ranges_kernel, dim3((p.num_rendered + 255) / 256), dim3(256), 0, st, p);
     }
     hipLaunchKernelGGL(gs_render_kernel, dim3(grid, grid), dim3(256), 0, st, p);
+    return vmv_launch_status();
+}
+
+// ---- batched entry points (vmv.h VmvGsBatchParams)
+namespace {
+int gs_batch_check(const VmvGsBatchParams& p) {
+    if (!p.gaussians || !p.views || !p.view_projs || !p.depth || !p.xy || !p.conic_opacity || !p.rect || !p.tiles_touched || !p.offsets)
+        return VMV_ENULL;
+    if (p.B <= 0 || p.V <= 0 || p.N <= 0 || p.size <= 0 || !(p.tan_half_fov > 0.f)) return VMV_EINVAL;
+    const long grid = (p.size + GS_TILE - 1) / GS_TILE;
+    if ((long)p.B * p.V > 65535 || (long)p.B * p.V * p.N >= (1L << 31) || (long)p.B * p.V * grid * grid >= (1L << 31)) return VMV_ERANGE;
+    return VMV_OK;
+}
+}  // namespace
+
+extern "C" int vmv_gs_batch_workspace_bytes(int n_view_gaussians, int n_instances, int key_bits, size_t* scan_bytes, size_t* sort_bytes) {
+    if (!scan_bytes || !sort_bytes || n_view_gaussians <= 0 || n_instances < 0 || key_bits < 1 || key_bits > 64) return VMV_EINVAL;
+    uint32_t* a = nullptr;
+    uint64_t* k = nullptr;
+    hipError_t e = rocprim::inclusive_scan(nullptr, *scan_bytes, a, a, (size_t)n_view_gaussians, rocprim::plus<uint32_t>(), (hipStream_t)0);
+    if (e != hipSuccess) return (int)e;
+    e = rocprim::radix_sort_pairs(nullptr, *sort_bytes, k, k, a, a, (size_t)(n_instances > 0 ? n_instances : 1), 0u, (unsigned)key_bits,
+                                  (hipStream_t)0);
+    return e == hipSuccess ? VMV_OK : (int)e;
+}
+
+extern "C" int vmv_gs_batch_key_bits(int n_views, int size) {
+    if (n_views <= 0 || size <= 0) return VMV_EINVAL;
+    const long grid = (size + GS_TILE - 1) / GS_TILE;
+    int bits = 1;
+    while ((1L << bits) < (long)n_views * grid * grid) ++bits;
+    return 32 + bits;
+}
+
+extern "C" int vmv_gs_batch_preprocess(const VmvGsBatchParams* pp, void* stream) {
+    if (!pp) return VMV_ENULL;
+    const VmvGsBatchParams& p = *pp;
+    int rc = gs_batch_check(p);
+    if (rc != VMV_OK) return rc;
+    if (!p.scan_temp) return VMV_ENULL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(gs_preprocess_batch_kernel, dim3((p.N + 255) / 256, p.B * p.V), dim3(256), 0, st, p);
+    size_t bytes = p.scan_temp_bytes;
+    hipError_t e = rocprim::inclusive_scan(p.scan_temp, bytes, p.tiles_touched, p.offsets, (size_t)p.B * p.V * p.N, rocprim::plus<uint32_t>(), st);
+    if (e != hipSuccess) return (int)e;
+    return vmv_launch_status();
+}
+
+extern "C" int vmv_gs_batch_render(const VmvGsBatchParams* pp, void* stream) {
+    if (!pp) return VMV_ENULL;
+    const VmvGsBatchParams& p = *pp;
+    int rc = gs_batch_check(p);
+    if (rc != VMV_OK) return rc;
+    if (!p.ranges || !p.out_color) return VMV_ENULL;
+    if (p.num_rendered < 0) return VMV_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int grid = (p.size + GS_TILE - 1) / GS_TILE;
+    const int VV = p.B * p.V;
+    hipError_t e = hipMemsetAsync(p.ranges, 0, sizeof(uint32_t) * 2 * (size_t)VV * grid * grid, st);
+    if (e != hipSuccess) return (int)e;
+    if (p.num_rendered > 0) {
+        if (!p.keys || !p.keys_sorted || !p.vals || !p.vals_sorted || !p.sort_temp) return VMV_ENULL;
+        hipLaunchKernelGGL(gs_duplicate_batch_kernel, dim3((p.N + 255) / 256, VV), dim3(256), 0, st, p);
+        size_t bytes = p.sort_temp_bytes;
+        e = rocprim::radix_sort_pairs(p.sort_temp, bytes, p.keys, p.keys_sorted, p.vals, p.vals_sorted, (size_t)p.num_rendered,
+                                      0u, (unsigned)vmv_gs_batch_key_bits(VV, p.size), st);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(gs_ranges_batch_kernel, dim3((p.num_rendered + 255) / 256), dim3(256), 0, st, p);
+    }
+    hipLaunchKernelGGL(gs_render_batch_kernel, dim3(grid, grid, VV), dim3(256), 0, st, p);
     return vmv_launch_status();
 }

@@ -1,8 +1,11 @@
 """``GaussianRenderer`` — the LGM branch's splatting renderer on the gfx950 rasteriser (``csrc/raster.hip``).
 
 Mirrors ``core/gs.py:16-94`` of the reference: ``render(gaussians [B,N,14], cam_view, cam_view_proj, cam_pos, bg_color)``
--> ``{"image": [B,V,3,S,S] (clamped to [0,1]), "alpha": [B,V,1,S,S]}``, one rasterisation per (sample, view).  The
-reference delegates to the third-party ``diff_gaussian_rasterization`` extension, which is absent and unpinned; the
+-> ``{"image": [B,V,3,S,S] (clamped to [0,1]), "alpha": [B,V,1,S,S]}``.  The reference rasterises one (sample, view) at a time;
+here ALL B * V views of a call go through ONE batched pass (``vmv_gs_batch_*``: one preprocess launch, one scan, one radix sort with
+the view in the key, one blend launch over tiles x views) and the host reads the instance total ONCE per call — 48 host round trips
+per LGM-refined step in round 4, one now (``VMV_GS_BATCH=0`` restores the per-view loop; both share their device code and give the
+same bits).  The reference delegates to the third-party ``diff_gaussian_rasterization`` extension, which is absent and unpinned; the
 kernels follow the published forward algorithm (oracle/gs_ref.py, parity unpinned — DESIGN.md §2).
 """
 import ctypes as C
@@ -25,7 +28,7 @@ class GaussianRenderer:
         self.proj_matrix[3, 2] = -(zfar * znear) / (zfar - znear)
         self.proj_matrix[2, 3] = 1
         self._buf = {}
-        self.last_num_rendered = []
+        self.last_num_rendered, self.last_views = [], 0
 
     def _buffers(self, N, device):
         key = (N, str(device))
@@ -53,10 +56,70 @@ class GaussianRenderer:
         b.update(keys=i64(), keys_s=i64(), vals=i32(), vals_s=i32(), cap=cap,
                  sort=torch.zeros(max(int(so.value), 16), dtype=torch.uint8, device=device))
 
+    def _batch_buffers(self, B, V, N, device):
+        key = ("batch", B, V, N, str(device))
+        b = self._buf.get(key)
+        if b is None:
+            lib = L.load()
+            VN = B * V * N
+            bits = lib.vmv_gs_batch_key_bits(B * V, self.size)
+            sb, so = C.c_size_t(0), C.c_size_t(0)
+            L.check(lib.vmv_gs_batch_workspace_bytes(VN, 1, bits, C.byref(sb), C.byref(so)), "gs_batch_workspace_bytes")
+            grid = (self.size + 15) // 16
+            f = lambda *shape, dt=torch.float32: torch.zeros(*shape, dtype=dt, device=device)
+            b = dict(depth=f(VN), xy=f(VN, 2), co=f(VN, 4), rect=f(VN, 4, dt=torch.int32), touched=f(VN, dt=torch.int32),
+                     offsets=f(VN, dt=torch.int32), scan=torch.zeros(max(int(sb.value), 16), dtype=torch.uint8, device=device),
+                     ranges=f(B * V * grid * grid, 2, dt=torch.int32), cap=0, bits=bits,
+                     total=torch.zeros(1, dtype=torch.int32).pin_memory() if str(device).startswith("cuda") else torch.zeros(1, dtype=torch.int32))
+            self._buf[key] = b
+        return b
+
+    def _render_batch(self, gaussians, cam_view, cam_view_proj, bg, images, alphas):
+        """All B * V views in one pass (vmv.h VmvGsBatchParams)."""
+        device = gaussians.device
+        B, V = cam_view.shape[:2]
+        N, S = gaussians.shape[1], self.size
+        lib = L.load()
+        buf = self._batch_buffers(B, V, N, device)
+        g = gaussians.float().contiguous()
+        views = cam_view.to(device, torch.float32).reshape(B * V, 16).contiguous()
+        vps = cam_view_proj.to(device, torch.float32).reshape(B * V, 16).contiguous()
+        p = L.GsBatchParams()
+        p.gaussians, p.B, p.N, p.V, p.size = g.data_ptr(), B, N, V, S
+        p.views, p.view_projs, p.tan_half_fov = views.data_ptr(), vps.data_ptr(), self.tan_half_fov
+        p.bg[0], p.bg[1], p.bg[2] = bg
+        p.depth, p.xy, p.conic_opacity, p.rect = buf["depth"].data_ptr(), buf["xy"].data_ptr(), buf["co"].data_ptr(), buf["rect"].data_ptr()
+        p.tiles_touched, p.offsets = buf["touched"].data_ptr(), buf["offsets"].data_ptr()
+        p.scan_temp, p.scan_temp_bytes = buf["scan"].data_ptr(), buf["scan"].numel()
+        L.check(lib.vmv_gs_batch_preprocess(C.byref(p), _stream_ptr()), "gs_batch_preprocess")
+        # the ONE host round trip of the call: the instance total sizes the sort (pinned destination: a 4-byte copy + stream sync)
+        buf["total"].copy_(buf["offsets"][B * V * N - 1:], non_blocking=True)
+        torch.cuda.current_stream(device).synchronize()
+        n = int(buf["total"][0])
+        self.last_num_rendered, self.last_views = [n], B * V
+        if n > buf["cap"]:
+            cap = max(int(n * 1.25), 1 << 16)
+            sb, so = C.c_size_t(0), C.c_size_t(0)
+            L.check(lib.vmv_gs_batch_workspace_bytes(B * V * N, cap, buf["bits"], C.byref(sb), C.byref(so)), "gs_batch_workspace_bytes")
+            i64 = lambda: torch.zeros(cap, dtype=torch.int64, device=device)
+            i32 = lambda: torch.zeros(cap, dtype=torch.int32, device=device)
+            buf.update(keys=i64(), keys_s=i64(), vals=i32(), vals_s=i32(), cap=cap,
+                       sort=torch.zeros(max(int(so.value), 16), dtype=torch.uint8, device=device))
+        p.num_rendered = n
+        if n > 0:
+            p.keys, p.keys_sorted, p.vals, p.vals_sorted = (buf["keys"].data_ptr(), buf["keys_s"].data_ptr(), buf["vals"].data_ptr(),
+                                                            buf["vals_s"].data_ptr())
+            p.sort_temp, p.sort_temp_bytes = buf["sort"].data_ptr(), buf["sort"].numel()
+        p.ranges = buf["ranges"].data_ptr()
+        p.out_color, p.out_alpha = images.data_ptr(), alphas.data_ptr()
+        L.check(lib.vmv_gs_batch_render(C.byref(p), _stream_ptr()), "gs_batch_render")
+        self._keep = (g, views, vps)          # (referenced by the enqueued launches)
+
     @torch.no_grad()
     def render(self, gaussians, cam_view, cam_view_proj, cam_pos=None, bg_color=None, scale_modifier=1):
         if scale_modifier != 1:
             raise NotImplementedError("scale_modifier != 1 is not a VideoMV configuration")
+        import os
         device = gaussians.device
         B, V = cam_view.shape[:2]
         N, S = gaussians.shape[1], self.size
@@ -64,8 +127,11 @@ class GaussianRenderer:
         bg = [1.0, 1.0, 1.0] if bg_color is None else [float(v) for v in bg_color.reshape(-1)[:3]]
         images = torch.empty(B, V, 3, S, S, dtype=torch.float32, device=device)
         alphas = torch.empty(B, V, 1, S, S, dtype=torch.float32, device=device)
+        if os.environ.get("VMV_GS_BATCH", "1") != "0" and B * V * N < (1 << 31) and B * V <= 65535:
+            self._render_batch(gaussians, cam_view, cam_view_proj, bg, images, alphas)
+            return {"image": images, "alpha": alphas}
         buf = self._buffers(N, device)
-        self.last_num_rendered = []
+        self.last_num_rendered, self.last_views = [], B * V
         for b in range(B):
             g = gaussians[b].float().contiguous()
             for v in range(V):

@@ -462,13 +462,11 @@ class LgmRefiner:
         if views is not None:      # frame-parallel: x0 / decode / LGM U-Net are the whole sample's (replicated on every rank), the renders
             f0, cnt = int(views[0]), int(views[1])      # and the re-encode only this rank's views [f0, f0 + cnt)
             cv, cvp, of = cv[:, f0:f0 + cnt].contiguous(), cvp[:, f0:f0 + cnt].contiguous(), (cv.shape[1], f0)
-        small = None
-        for br in range(2):
-            images = self.renderer.render(gaussians[br].unsqueeze(0), cv, cvp, None, bg_color=bg)["image"][0].contiguous()
-            T = images.shape[0]
-            if small is None:
-                small = torch.empty(2 * T, 3, 8 * h, 8 * w, dtype=torch.float32, device=self.device)
-            ops.lgm_render_to_vae(images, small[br * T:(br + 1) * T])
+        # both branches' views in ONE rasteriser pass (gs.py: B = 2 samples x T views; one host read of the instance total per step)
+        T = cv.shape[1]
+        both = self.renderer.render(gaussians, cv.expand(2, -1, -1, -1), cvp.expand(2, -1, -1, -1), None, bg_color=bg)["image"]
+        small = torch.empty(2 * T, 3, 8 * h, 8 * w, dtype=torch.float32, device=self.device)
+        ops.lgm_render_to_vae(both.reshape(2 * T, *both.shape[2:]), small)
         z = autoencoder.encode_firsr_stage(small, scale_factor, parts=2, of=of)         # [2T, C, h, w]
         z = z.reshape(2, 1, T, z.shape[1], z.shape[2], z.shape[3]).permute(0, 1, 3, 2, 4, 5).contiguous()
         return z[0], z[1]
