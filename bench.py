@@ -675,10 +675,15 @@ def main():
                         note="peers simulated on one GPU: kernels, tiles, local copies and host time are the real rank's; wire time is not included "
                              "and the output is not a sample", modes={})
 
-            def sim_leg(pipeline, graph):
+            def sim_leg(pipeline, graph, cfgpar=False):
                 os.environ["VMV_FP_PIPELINE"], os.environ["VMV_GRAPH"] = ("1" if pipeline else "0"), ("1" if graph else "0")
-                model.set_frame_parallel(SimComm(Wn, 0))
-                xs = xs0.clone()
+                if cfgpar:       # 2 branch groups of Wn / 2 ranks: this rank runs ONE B = 1 plan on 2 * frames / Wn views
+                    from videomv_amd.comm import SimCfgFrameComm
+                    model.set_frame_parallel(SimCfgFrameComm(Wn))
+                    xs = noise[:, :, :2 * fl].clone().contiguous()
+                else:
+                    model.set_frame_parallel(SimComm(Wn, 0))
+                    xs = xs0.clone()
                 for i in range(3):                                   # eager, capture, first graph launch
                     dif.ddim_step_hip(xs, steps[i % len(steps)], model, kw_c, kw_u, 9.0, stride)
                 torch.cuda.synchronize()
@@ -695,7 +700,7 @@ def main():
                     dif.ddim_step_hip(xs, steps[(7 + i) % len(steps)], model, kw_c, kw_u, 9.0, stride)
                     hs.append(time.perf_counter() - t1)
                 torch.cuda.synchronize()
-                engs = model._pipe["engs"] if (pipeline and model._pipe) else [model.engine_for(2, args.frames, H, W, 77, dev, n_t=1, share_prefix=True)]
+                engs = model._pipe["engs"] if ((pipeline or cfgpar) and model._pipe) else [model.engine_for(2, args.frames, H, W, 77, dev, n_t=1, share_prefix=True)]
                 e0 = engs[0]
                 ncoll = sum(e.n_comm_ops for e in engs)
                 bytes_in = sum(e.comm_bytes_in for e in engs)
@@ -710,9 +715,12 @@ def main():
                     r["frac_of_peak_if_all_ranks_equal"] = round(step_tflop / Wn / (t_all / args.steps) / PEAK_MFMA16_TFLOPS, 4)
                 return r, e0
 
-            for tag, pl, gr in (("single-plan", 0, 0), ("single-plan+graph", 0, 1), ("branch-pipelined", 1, 0), ("branch-pipelined+graph", 1, 1)):
+            legs = [("single-plan", 0, 0, False), ("branch-pipelined", 1, 0, False)]
+            if Wn % 2 == 0 and args.frames % (Wn // 2) == 0:
+                legs.append((f"cfg x frame (2 x {Wn // 2})", 0, 0, True))         # half the launches per rank
+            for tag, pl, gr, cp in legs:
                 try:
-                    simr["modes"][tag], e0 = sim_leg(pl, gr)
+                    simr["modes"][tag], e0 = sim_leg(pl, gr, cp)
                     if tag == "single-plan":          # per-family table of the rank-local B = 2 plan (tile policy at M / W)
                         fam_s, _ = profile_plan(e0, dump=args.dump_ops_sim)
                         simr["families_single_plan"], simr["serial_forward_ms"] = fam_table(fam_s)

@@ -516,6 +516,20 @@ def test_simulated_rank_plan_records_its_collectives(monkeypatch):
     pe = m._pipe["engs"]
     assert len(pe) == 2 and all(not e.breaks and e.n_comm_ops == n_a2a + n_ag for e in pe)
     assert pe[0].comm.handle != pe[1].comm.handle                            # a communicator per branch stream
+    # CFG-parallel x frame-parallel on a simulated rank (comm.SimCfgFrameComm: 2 branch groups of R / 2 ranks): ONE B = 1 plan over
+    # 2 * F / R frames — half the launches of the pipelined pair — and the partner's eps rows are this rank's own
+    from videomv_amd.comm import SimCfgFrameComm
+    sc2 = SimCfgFrameComm(R)
+    assert (sc2.branch, sc2.rank, sc2.world) == (0, 0, R // 2)
+    m.set_frame_parallel(sc2)
+    xt2 = x[:, :, :2].clone().contiguous()
+    dif.ddim_step_hip(xt2, 501, m, dict(y=y[:1], camera_data=cam), dict(y=y[1:], camera_data=cam), 9.0, 500)
+    assert torch.isfinite(xt2).all()
+    pc = m._pipe["engs"]
+    assert len(pc) == 1 and pc[0].B == 1 and pc[0].F == 2 and not pc[0].breaks and pc[0].n_comm_ops == n_a2a + n_ag
+    assert pc[0].S.nops < sum(e.S.nops for e in pe)
+    eps2 = m._pipe["eps"].view(2, -1)
+    assert torch.equal(eps2[0], eps2[1])                                     # (sim: both branch slots hold this rank's rows)
 
 
 LGM_TINY = dict(down_channels=(32, 64), down_attention=(False, True), mid_attention=True, up_channels=(64, 32),
@@ -622,3 +636,58 @@ def test_lgm_refined_step_frame_parallel_two_ranks():
     for r in res:
         assert "error" not in r, r["error"]
         assert r["finite"] and r["rel"] < 0.25 and r["cos"] > 0.97, r
+
+
+def _lgm_cfgpar_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        torch.set_num_threads(2)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from tests import plan_interp as pi
+        pi.install(_Patch)
+        from videomv_amd.comm import CfgFrameComm
+        from videomv_amd.unet_t2v import gather_frames
+        m, vae, dif, xt, kw = _lgm_setup()
+        torch.manual_seed(9)
+        x_single = xt.clone()
+        dif.ddim_step_lgm(x_single, 581, m, kw[0], kw[1], 9.0, 20, vae)
+        comm = CfgFrameComm()
+        m.set_frame_parallel(comm)
+        fl = xt.shape[2] // comm.world
+        x_loc = xt[:, :, comm.rank * fl:(comm.rank + 1) * fl].clone().contiguous()
+        torch.manual_seed(9)
+        dif.ddim_step_lgm(x_loc, 581, m, kw[0], kw[1], 9.0, 20, vae)
+        x_all = gather_frames(comm, x_loc)
+        d = (x_all - x_single).flatten()
+        cos = float(torch.nn.functional.cosine_similarity(x_all.flatten(), x_single.flatten(), dim=0))
+        # the partner ranks (same frames, other branch) must hold IDENTICAL x_{t-1}: they applied the same update to the same pair of latent_z
+        both = torch.empty(2 * x_all.numel())
+        dist.all_gather_into_tensor(both, x_all.reshape(-1).contiguous())
+        both = both.view(2, -1)
+        q.put(dict(rank=rank, finite=bool(torch.isfinite(x_all).all()), rel=float(d.norm() / x_single.norm()), cos=cos,
+                   pair_equal=bool(torch.equal(both[0], both[1]))))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put(dict(rank=rank, error=traceback.format_exc()))
+
+
+def test_lgm_refined_step_cfg_parallel_two_ranks():
+    """Round 5 (it raised NotImplementedError): one LGM-refined DDIM step with CFG-parallel ranks — rank 0 runs the
+    conditional branch (UNet + decode + LGM U-Net + renders + re-encode), rank 1 the unconditional one; they swap their latent_z and apply
+    the CFG-on-latent_z update identically.  Statistical agreement with the single-rank step (each branch draws its own posterior
+    noise here, the unsharded pair draws both in one call: SURVEY 8d asks only for statistics on the LGM steps) and bitwise agreement
+    between the two ranks of the pair."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_lgm_cfgpar_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert "error" not in r, r["error"]
+        assert r["finite"] and r["pair_equal"] and r["rel"] < 0.6 and r["cos"] > 0.85, r

@@ -191,6 +191,32 @@ class SimComm:
         out.view(self.world, -1).copy_(inp.view(1, -1).expand(self.world, -1))
 
 
+class SimCfgFrameComm:
+    """Rank 0 of a W-GPU CFG-parallel x frame-parallel run (2 branch groups of W / 2 ranks) with every peer ABSENT — the ``SimComm``
+    idea for ``CfgFrameComm``: the branch group's layout switches / totals gathers are device-local copies recorded into the B = 1
+    plan, and the once-per-step eps exchange with the partner rank delivers this rank's own rows in both slots.  Same launch sequence,
+    tiles, local traffic and host time as the real rank; not a sample (bench.py --simulate-rank reports it as mode "cfg x frame")."""
+
+    def __init__(self, world: int):
+        if world % 2:
+            raise ValueError("CFG-parallel needs an even number of ranks")
+        self.branch, self.rank, self.world = 0, 0, world // 2
+        self.fp = SimComm(self.world, 0)
+        self.local_only, self.backend, self.group = False, "sim", None
+
+    def all_gather(self, out, inp):
+        self.fp.all_gather(out, inp)
+
+    def all_to_all(self, out, inp):
+        self.fp.all_to_all(out, inp)
+
+    def exchange_branches(self, out, mine):
+        out.view(2, -1).copy_(mine.view(1, -1).expand(2, -1))
+
+    def close(self):
+        pass
+
+
 class CfgFrameComm:
     """CFG-parallel x frame-parallel (SURVEY §8e "other cheap axis"): W ranks = 2 branch groups of W/2.  Group b runs ONLY the
     b-th classifier-free-guidance branch (0 = cond, 1 = uncond), its frames sharded W/2 ways with the same layout-switch

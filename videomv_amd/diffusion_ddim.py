@@ -143,16 +143,32 @@ class DiffusionDDIM(object):
         k = self.step_scalars(int(step), stride)
         ref = unet.lgm_refiner(xt.device)
         comm, views, xt_all, ld = getattr(unet, "frame_comm", None), None, xt, eng.out_pad
-        if comm is not None and comm.world > 1:
+        cfgpar = comm is not None and hasattr(comm, "exchange_branches")
+        if comm is not None and (comm.world > 1 or cfgpar):
             # Frame-parallel (no reference counterpart): the branch needs x0 of 4 KEY views (frames 0 / 6 / 12 / 18), which live on
             # other ranks — one small all-gather of (x_t, eps rows) rebuilds the whole sample's on every rank (1.2 MB at 24 x 32 x 32);
             # the 4-view decode and the LGM U-Net then run replicated, and every rank renders and re-encodes ONLY its own F / R views
             # (the 24 renders + the 24-view encode are 2/3 of the branch), with the unsharded run's posterior noise for them.
             from .unet_t2v import gather_frames
-            if hasattr(comm, "exchange_branches"):
-                raise NotImplementedError("LGM-refined steps with CFG-parallel x frame-parallel ranks")
             fl = xt.shape[2]
-            xt_all = gather_frames(comm, xt)
+            xt_all = gather_frames(comm, xt)                                            # (CfgFrameComm: inside my branch group)
+            if cfgpar:
+                # CFG-parallel x frame-parallel (round 5: no longer NotImplementedError): this rank's group runs ONE branch, so it
+                # runs that branch's LGM pass only — gather my branch's eps rows over the group, latent_z of my views, then the
+                # partner ranks (same frames, other branch) swap their latent_z and both apply the CFG-on-latent_z update identically.
+                mine = eps_rows.view(2, -1)[comm.branch].contiguous()
+                allr = torch.empty(comm.world, mine.numel(), dtype=mine.dtype, device=mine.device)
+                comm.all_gather(allr, mine)
+                both = torch.zeros(2, allr.numel(), dtype=mine.dtype, device=mine.device)
+                both[comm.branch] = allr.view(-1)
+                kw_b = (cond_kwargs, uncond_kwargs)[comm.branch]
+                ca, cb = (k["c_sqrt_ac"], k["c_sqrt_1mac"]) if getattr(unet, "lgm_vpred", False) else (k["c_recip"], k["c_recipm1"])
+                zb = ref.latent_z(both.view(-1, ld), ld, comm.branch, xt_all, ca, cb, autoencoder, dict(kw_b["gs_data"]),
+                                  views=(comm.rank * fl, fl)).contiguous()
+                pair = torch.empty(2, zb.numel(), dtype=zb.dtype, device=zb.device)
+                comm.exchange_branches(pair, zb.view(-1))
+                ops.ddim_x0_step(pair[0].view_as(zb), pair[1].view_as(zb), xt, float(guide_scale), k["c_recip"], k["c_recipm1"], k["a_prev"])
+                return xt
             loc = eps_rows.reshape(2, -1).contiguous()                                  # [branch][local rows x ld]
             allr = torch.empty(comm.world, loc.numel(), dtype=loc.dtype, device=loc.device)
             comm.all_gather(allr, loc)
