@@ -134,7 +134,13 @@ typedef struct {
      * >= 512; vmv_gemm returns VMV_EINVAL otherwise.  NULL = off.                                                       */
     const float* gn_table;
     int32_t gn_rows_per_stat;
-    int32_t _pad_gn;
+    /* Frame-resident temporal convolution (VMV_TILE_TFR; TemporalConvBlock_v2, util.py:1357-1392: GroupNorm over all frames -> SiLU ->
+     * Conv3d (3,1,1)): with three TEMPORAL segments (dt = -1, 0, +1 of ONE source) gn_table folds that norm into the convolution's A
+     * path — gn_table = [samples][2][C] with C = the segment width (not ktot), gn_rows_per_stat = F * P (one stat group per sample) —
+     * and gn_silu != 0 applies SiLU after the affine: the GEMM multiplies elem(silu(x * scale + shift)), the values
+     * vmv_groupnorm_apply(silu = 1) would have stored, with the zero padding of frames -1 / F applied AFTER the norm (as Conv3d pads
+     * the normalised tensor).  Ask vmv_gemm_tfr_ok() first.  gn_silu is ignored by the row-stationary kernel (must be 0 there).    */
+    int32_t gn_silu;
 } VmvGemmParams;
 
 #define VMV_TILE_AUTO     0
@@ -170,6 +176,9 @@ typedef struct {
 #define VMV_TILE_RS256    25   /* the same, forced to 32 rows per wave (256-row blocks) */
 #define VMV_TILE_HALO     26   /* halo-resident 3 x 3 convolution for N <= 8 output channels (conv_halo.hip): 4 x 16 pixel tiles, the 6 x 18 halo and
                                   the weights in LDS — the VAE / UNet output heads */
+#define VMV_TILE_TFR      27   /* frame-resident temporal convolution (gemm_tfr.hip): a block owns all F frames (12 <= F <= 24) of 192 / F pixels x 320
+                                  output channels, A staged once through registers (optional GroupNorm + SiLU on the way, gn_table / gn_silu), the
+                                  three taps as row-shifted views of one LDS tile; N % 320 == 0, C % 64 == 0 */
 
 int vmv_gemm(const VmvGemmParams* p, void* stream);
 /* 1 if vmv_gemm accepts *p (rowstat ignored) with in-loop LayerNorm statistics (VmvGemmParams.ln_eps), else 0 */
@@ -177,6 +186,9 @@ int vmv_gemm_ln_inline_ok(const VmvGemmParams* p);
 /* 1 if vmv_gemm would run *p (tile = VMV_TILE_AUTO) on the row-stationary kernel, which takes the statistics of a folded
  * LayerNorm from its resident rows: the host then passes colsum + ln_eps and no rowstat (no statistics launch at all) */
 int vmv_gemm_rs_ok(const VmvGemmParams* p);
+/* 1 if vmv_gemm would run *p (tile = VMV_TILE_AUTO, a temporal convolution, with or without gn_table) on the frame-resident kernel
+ * (VMV_TILE_TFR): the host then records statistics + vmv_groupnorm_table + this GEMM instead of statistics + apply + GEMM */
+int vmv_gemm_tfr_ok(const VmvGemmParams* p);
 /* the VMV_TILE_* configuration vmv_gemm's policy picks for *p when p->tile == VMV_TILE_AUTO (p->tile otherwise); host logic only:
  * no launch, no device access (a launcher may still fall back when it cannot address the operands) */
 int vmv_gemm_pick_tile(const VmvGemmParams* p);

@@ -50,7 +50,7 @@ TILE_Q128x128, TILE_Q96x160 = 13, 14
 TILE_S256x128, TILE_S192x160, TILE_S256x160 = 15, 16, 17
 TILE_A128x160, TILE_A128x128 = 18, 19
 TILE_X256x320, TILE_X256x256, TILE_X256x128 = 20, 21, 22
-TILE_RS, TILE_RS512, TILE_RS256, TILE_HALO = 23, 24, 25, 26
+TILE_RS, TILE_RS512, TILE_RS256, TILE_HALO, TILE_TFR = 23, 24, 25, 26, 27
 OP_GEMM, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTENTION, OP_SOFTMAX, OP_COPY, OP_GN_FUSED, OP_FF, OP_GN_TABLE, OP_COMM = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 COMM_ALL_TO_ALL, COMM_ALL_GATHER, COMM_ID_BYTES = 0, 1, 128
 ABI_VERSION = 9
@@ -76,7 +76,7 @@ class GemmParams(C.Structure):
                 ("ksplit", C.c_int32), ("workspace", C.c_void_p),
                 ("tile", C.c_int32), ("res_scale", C.c_float), ("rowstat", C.c_void_p), ("colsum", C.c_void_p),
                 ("ln_eps", C.c_float), ("wgroup_rows", C.c_int32), ("wgroup_stride", C.c_int64),
-                ("gn_table", C.c_void_p), ("gn_rows_per_stat", C.c_int32), ("_pad_gn", C.c_int32)]
+                ("gn_table", C.c_void_p), ("gn_rows_per_stat", C.c_int32), ("gn_silu", C.c_int32)]
 
 
 class GroupNormParams(C.Structure):
@@ -165,6 +165,7 @@ SYMBOLS = {
     "vmv_gemm": (C.c_int, [C.POINTER(GemmParams), _P]),
     "vmv_gemm_ln_inline_ok": (C.c_int, [C.POINTER(GemmParams)]),
     "vmv_gemm_rs_ok": (C.c_int, [C.POINTER(GemmParams)]),
+    "vmv_gemm_tfr_ok": (C.c_int, [C.POINTER(GemmParams)]),
     "vmv_has_experiments": (C.c_int, []),
     "vmv_ff_fused": (C.c_int, [C.POINTER(FfParams), _P]),
     "vmv_ff_fused_ok": (C.c_int, [C.POINTER(FfParams)]),

@@ -37,6 +37,9 @@ bool vmv_gemm_rs_supported(const VmvGemmParams& p);
 int vmv_conv_halo_launch(const VmvGemmParams& p, hipStream_t st);                             // conv_halo.hip
 bool vmv_conv_halo_supported(const VmvGemmParams& p);
 bool vmv_gemm_rs_preferred(const VmvGemmParams& p);
+int vmv_gemm_tfr_launch(const VmvGemmParams& p, hipStream_t st);                              // gemm_tfr.hip
+bool vmv_gemm_tfr_supported(const VmvGemmParams& p);
+bool vmv_gemm_tfr_preferred(const VmvGemmParams& p);
 #if defined(VMV_EXPERIMENTS)
 bool vmv_gemm_astat_eligible(const VmvGemmParams& p);
 #else
@@ -335,6 +338,10 @@ int pick_tile(const VmvGemmParams& p, int total_steps) {
     if (gemm_policy() >= 2 && vmv_gemm_rs_preferred(p)) return VMV_TILE_RS;
     // 3 x 3 convolutions with N <= 8 output channels (the VAE / UNet heads): halo tile + weights in LDS (conv_halo.hip)
     if (gemm_policy() >= 2 && conv_halo_policy() && vmv_conv_halo_supported(p)) return VMV_TILE_HALO;
+    // temporal convolutions whose frame-resident tiles fill the chip (gemm_tfr.hip); a GroupNorm folded into a temporal convolution
+    // lives in that kernel only
+    if (gemm_policy() >= 2 && vmv_gemm_tfr_preferred(p)) return VMV_TILE_TFR;
+    if (p.gn_table && p.nseg == 3 && p.seg[0].mode == VMV_SEG_TEMPORAL) return VMV_TILE_TFR;
     if (p.gn_table) return VMV_TILE_RS;             // a folded GroupNorm lives in that kernel's prologue only (vmv_gemm checks eligibility)
     if (gemm_policy() >= 2 && xglds_policy() && !geglu && p.ksplit <= 1 && !p.rowstat && !vmv_gemm_ln_inline(p) && total_steps >= 12 &&
         (p.N % 320 == 0 || p.N % 256 == 0)) {
@@ -437,6 +444,7 @@ int final_tile(const VmvGemmParams& p, int total_steps) {
         picked == VMV_TILE_A128x128) return VMV_EINVAL;
 #endif
     if (picked == VMV_TILE_HALO) return vmv_conv_halo_supported(p) ? picked : VMV_EINVAL;
+    if (picked == VMV_TILE_TFR) return vmv_gemm_tfr_supported(p) ? picked : VMV_EINVAL;
     const bool rs_tile = picked == VMV_TILE_RS || picked == VMV_TILE_RS512 || picked == VMV_TILE_RS256;
     if (rs_tile) return vmv_gemm_rs_supported(p) ? picked : VMV_EINVAL;      // (handles rowstat / colsum / grouped weights itself)
     if (p.gn_table) return VMV_EINVAL;                                       // (a forced tile that cannot fold the GroupNorm)
@@ -486,6 +494,11 @@ extern "C" int vmv_gemm_ln_inline_ok(const VmvGemmParams* pp) { return pp && ln_
 extern "C" int vmv_gemm_rs_ok(const VmvGemmParams* pp) {
     if (!pp || pp->tile != VMV_TILE_AUTO || pp->nseg <= 0 || pp->nseg > VMV_MAX_SEGS) return 0;
     return gemm_policy() >= 2 && vmv_gemm_rs_preferred(*pp) ? 1 : 0;
+}
+
+extern "C" int vmv_gemm_tfr_ok(const VmvGemmParams* pp) {
+    if (!pp || pp->tile != VMV_TILE_AUTO || pp->nseg <= 0 || pp->nseg > VMV_MAX_SEGS) return 0;
+    return gemm_policy() >= 2 && vmv_gemm_tfr_preferred(*pp) ? 1 : 0;
 }
 
 extern "C" int vmv_gemm_pick_tile(const VmvGemmParams* pp) {
@@ -546,7 +559,8 @@ extern "C" int vmv_gemm(const VmvGemmParams* pp, void* stream) {
         const long groups = ((long)p.M + p.wgroup_rows - 1) / p.wgroup_rows;
         if (((groups - 1) * p.wgroup_stride + (long)p.N * p.ktot) * 2 >= (1L << 31) - 65536) return VMV_ERANGE;
     }
-    if (p.gn_table && !vmv_gemm_rs_supported(p)) return VMV_EINVAL;      // folded GroupNorm: the row-stationary kernel's prologue only
+    if (p.gn_table && !vmv_gemm_rs_supported(p) && !vmv_gemm_tfr_supported(p)) return VMV_EINVAL;      // folded GroupNorm: gemm_rs / gemm_tfr only
+    if (p.gn_silu && !(p.gn_table && vmv_gemm_tfr_supported(p))) return VMV_EINVAL;
     const bool ln_inline = vmv_gemm_ln_inline(p);
     if (ln_inline) {       // statistics in the main loop: the persistent one-block-per-CU kernel, staged 16-bit output
         if (!ln_inline_ok(p)) return VMV_EINVAL;
@@ -595,6 +609,10 @@ extern "C" int vmv_gemm(const VmvGemmParams* pp, void* stream) {
                 rc = vmv_gemm_glds_launch(p, total_steps, p.N % 160 == 0 ? VMV_TILE_256x160 : VMV_TILE_256x128, st);
                 if (rc == VMV_GLDS_UNSUPPORTED) rc = p.N % 160 == 0 ? launch_cfg<4, 5>(p, total_steps, st) : launch_cfg<4, 4>(p, total_steps, st);
             }
+            break;
+        case VMV_TILE_TFR:
+            rc = vmv_gemm_tfr_launch(p, st);
+            if (rc == VMV_GLDS_UNSUPPORTED) return VMV_EINVAL;
             break;
         case VMV_TILE_HALO:
             rc = vmv_conv_halo_launch(p, st);

@@ -59,7 +59,7 @@ class Geom:
 def gemm_params(M, N, segs: Sequence[Seg], W, out, ldo, bias=None, rowvec=None, rowvec_div=1, rowvec_ld=0,
                 residual=None, ldr=0, epilogue=L.EPI_NONE, act=L.ACT_NONE, out_fp32=False, geom: Optional[Geom] = None,
                 ksplit=0, workspace=None, tile=L.TILE_AUTO, res_scale=0.0, rowstat=None, colsum=None, ln_eps=0.0, wgroup_rows=0, wgroup_stride=0,
-                gn_table=None, gn_rows_per_stat=0) -> L.GemmParams:
+                gn_table=None, gn_rows_per_stat=0, gn_silu=False) -> L.GemmParams:
     p = L.GemmParams()
     p.M, p.N, p.nseg = int(M), int(N), len(segs)
     if len(segs) > L.VMV_MAX_SEGS:
@@ -80,7 +80,8 @@ def gemm_params(M, N, segs: Sequence[Seg], W, out, ldo, bias=None, rowvec=None, 
     p.ksplit, p.workspace, p.tile, p.res_scale = int(ksplit), _ptr(workspace), tile, float(res_scale)
     p.rowstat, p.colsum, p.ln_eps = _ptr(rowstat), _ptr(colsum), float(ln_eps)
     p.wgroup_rows, p.wgroup_stride = int(wgroup_rows), int(wgroup_stride)
-    p.gn_table, p.gn_rows_per_stat = _ptr(gn_table), int(gn_rows_per_stat)       # GroupNorm folded into the A rows (vmv.h; gemm_rs only)
+    p.gn_table, p.gn_rows_per_stat = _ptr(gn_table), int(gn_rows_per_stat)       # GroupNorm folded into the A rows (vmv.h; gemm_rs / gemm_tfr)
+    p.gn_silu = 1 if gn_silu else 0
     return p
 
 
@@ -118,7 +119,7 @@ def gemm_signature(p: "L.GemmParams") -> str:
         runs.append(f"{p.seg[i].mode}:{p.seg[i].k}*{j - i}")
         i = j
     flags = (f"e{p.epilogue}a{p.act}f{p.out_fp32}r{int(bool(p.residual))}v{int(bool(p.rowvec))}:{p.rowvec_div if p.rowvec else 0}"
-             f"s{int(bool(p.rowstat))}c{int(bool(p.colsum))}l{int(p.ln_eps > 0)}g{int(bool(p.gn_table))}w{p.wgroup_rows}")
+             f"s{int(bool(p.rowstat))}c{int(bool(p.colsum))}l{int(p.ln_eps > 0)}g{int(bool(p.gn_table)) + 2 * int(bool(p.gn_silu))}w{p.wgroup_rows}")
     geo = f"{p.OH}x{p.OW}<{p.IH}x{p.IW}s{p.stride}u{p.ups}F{p.F}P{p.P}"
     return f"{p.M}x{p.N}x{p.ktot};{','.join(runs)};{flags};{geo}"
 
