@@ -32,6 +32,7 @@ def gemm(p: L.GemmParams):
     M, N = p.M, p.N
     m = torch.arange(M)
     cols = []
+    tfr_gn = bool(p.gn_table) and p.nseg == 3 and p.seg[0].mode == L.SEG_TEMPORAL      # GroupNorm (+ SiLU) folded into a temporal conv (vmv.h gn_silu)
     for s in range(p.nseg):
         sg = p.seg[s]
         if sg.mode == L.SEG_LINEAR:
@@ -54,10 +55,18 @@ def gemm(p: L.GemmParams):
         nsrc = int(src_row.max()) + 1
         src = _rows(sg.src, nsrc, sg.ld)[:, : sg.k].float()
         a = src[src_row]
+        if tfr_gn:            # the norm is applied to the SOURCE rows; the frame-axis zero padding comes after it (Conv3d pads the normalised tensor)
+            nstat = (M + p.gn_rows_per_stat - 1) // p.gn_rows_per_stat
+            tab = _view(p.gn_table, nstat * 2 * sg.k, "f32").view(nstat, 2, sg.k)
+            st = src_row // p.gn_rows_per_stat
+            a = a * tab[st, 0] + tab[st, 1]
+            if p.gn_silu:
+                a = torch.nn.functional.silu(a)
+            a = a.to(L.elem()).float()
         a[~valid] = 0
         cols.append(a)
     A = torch.cat(cols, dim=1)
-    if p.gn_table:            # GroupNorm folded into the A rows: elem(x * scale + shift) per (stat group, channel)
+    if p.gn_table and not tfr_gn:            # GroupNorm folded into the A rows: elem(x * scale + shift) per (stat group, channel)
         nstat = (M + p.gn_rows_per_stat - 1) // p.gn_rows_per_stat
         tab = _view(p.gn_table, nstat * 2 * p.ktot, "f32").view(nstat, 2, p.ktot)
         st = m // p.gn_rows_per_stat

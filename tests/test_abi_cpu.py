@@ -87,6 +87,9 @@ def test_gemm_tile_policy(monkeypatch):
     assert pick(M0, 320, ops.conv3x3_segs([(X, 320, 320)]), g0) == L.TILE_X256x320
     assert pick(M0 // 2, 320, ops.conv3x3_segs([(X, 320, 320)]), g0) == L.TILE_X256x320          # shared CFG prefix: one branch
     assert pick(M0, 320, ops.temporal_segs(X, 320, 320), ops.Geom(F=24, P=M0 // 48)) == L.TILE_X256x320
+    # (round 5: where its tiles fill whole rounds of the chip the temporal convolution goes to the frame-resident kernel: the first
+    #  level at the reference's own 24 x 32 x 32 — 256 tiles of 24 frames x 8 pixels x 320 channels; 640 tiles at 24 x 40 x 64 do not)
+    assert pick(2 * 24 * 1024, 320, ops.temporal_segs(X, 320, 320), ops.Geom(F=24, P=1024)) == L.TILE_TFR
     assert pick(M1, 640, ops.conv3x3_segs([(X, 640, 640)]), g1) == L.TILE_X256x320
     assert pick(M2, 1280, ops.conv3x3_segs([(X, 1280, 1280)]), g2) == L.TILE_256x160
     # transformer linears of the two large levels with K = C (qkv / q, out-projections, proj_in / proj_out, GEGLU): the

@@ -159,3 +159,30 @@ def test_groupnorm_fold_argument_block_equals_apply_then_gemm():
     ref = torch.nn.functional.group_norm(x.float().view(nstat, rps, K).permute(0, 2, 1), 32, gamma, beta, 1e-6).permute(0, 2, 1).reshape(M, K)
     close(y, ref, 1e-2)
     assert float((o_new.float() - o_ref.float()).abs().max()) <= 2 ** -6 * float(o_ref.float().abs().max())      # (one rounding of x_hat apart at most)
+
+
+def test_temporal_conv_groupnorm_fold_argument_block():
+    """VmvGemmParams.gn_table + gn_silu on three TEMPORAL segments (the frame-resident kernel, csrc/gemm_tfr.hip): the interpreter's
+    reading — norm + SiLU applied to the SOURCE rows, the zero frames -1 / F padded afterwards — equals statistics + apply(silu) + the
+    plain temporal convolution, and F.group_norm + F.silu + Conv3d; the table is per (sample, segment channel), not per ktot."""
+    Bn, F_, Pp, Cc, N = 2, 4, 6, 64, 32
+    M, rps = Bn * F_ * Pp, F_ * Pp
+    x = (torch.randn(M, Cc, generator=g(1)) * 1.5 + 0.7).to(BF)
+    gamma, beta = 1 + 0.2 * torch.randn(Cc, generator=g(2)), 0.3 * torch.randn(Cc, generator=g(3))
+    wt = torch.randn(N, Cc, 3, 1, 1, generator=g(4)) * (3 * Cc) ** -0.5
+    w, b = P.pack_tconv(wt, "cpu"), torch.randn(N, generator=g(5))
+    part = torch.zeros(ops.gn_partial_floats(M, rps, Cc) + 64)
+    y, tab = torch.zeros(M, Cc, dtype=BF), torch.zeros(Bn, 2, Cc)
+    o_ref, o_new = torch.zeros(M, N, dtype=BF), torch.zeros(M, N, dtype=BF)
+    gp = ops.gn_params(x, Cc, Cc, M, rps, part, gamma, beta, 1e-5, True, y, Cc)
+    I.groupnorm_stats(gp); I.groupnorm(gp)
+    I.gemm(ops.gemm_params(M, N, ops.temporal_segs(y, Cc, Cc), w, o_ref, N, bias=b, geom=ops.Geom(F=F_, P=Pp)))
+    gt = ops.gn_params(x, Cc, Cc, M, rps, part, gamma, beta, 1e-5, False, tab, Cc)
+    I.groupnorm_stats(gt); I.groupnorm_table(gt)
+    I.gemm(ops.gemm_params(M, N, ops.temporal_segs(x, Cc, Cc), w, o_new, N, bias=b, geom=ops.Geom(F=F_, P=Pp), gn_table=tab,
+                           gn_rows_per_stat=rps, gn_silu=True))
+    assert float((o_new.float() - o_ref.float()).abs().max()) <= 2 ** -6 * float(o_ref.float().abs().max())
+    xn = torch.nn.functional.silu(torch.nn.functional.group_norm(x.float().view(Bn, rps, Cc).permute(0, 2, 1), 32, gamma, beta, 1e-5))
+    x5 = xn.permute(0, 2, 1).reshape(Bn, F_, Pp, Cc).permute(0, 3, 1, 2)[..., None]
+    ref = torch.nn.functional.conv3d(x5, wt.to(BF).float(), b, padding=(1, 0, 0))[..., 0].permute(0, 2, 3, 1).reshape(M, N)
+    close(o_new, ref, 2e-2)

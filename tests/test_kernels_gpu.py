@@ -6,6 +6,7 @@ tests/test_interp_cpu.py).  Tolerances (stated per test): outputs are bf16 (8 ma
 0.2 %) of fp32-accumulated results, so max-abs error <= 1 % of the output scale and rel-L2 <= 4e-3; fp32 outputs
 rel-L2 <= 1e-3 (bf16 operands, fp32 accumulate in a different order).
 """
+import ctypes as C
 import math
 
 import pytest
@@ -321,6 +322,106 @@ def test_gemm_temporal_conv_many_tiles(tile):
     ref = torch.nn.functional.conv3d(x5, wt.to(BF).float(), cpu["b"], padding=(1, 0, 0))
     ref = ref[..., 0].permute(0, 2, 3, 1).reshape(M, Cc) + cpu["res"].float()
     check(dev["out"], ref)
+
+
+def _tconv_ref(x, wt, bias, Bn, F_, Pp, Cc, N):
+    x5 = x.float().view(Bn, F_, Pp, Cc).permute(0, 3, 1, 2)[..., None]      # b c f p 1
+    ref = torch.nn.functional.conv3d(x5, wt.to(BF).float(), bias, padding=(1, 0, 0))
+    return ref[..., 0].permute(0, 2, 3, 1).reshape(Bn * F_ * Pp, N)
+
+
+@pytest.mark.parametrize("Bn,F_,Pp,Cc,N,res", [(2, 24, 40, 320, 320, True), (1, 24, 21, 128, 640, False), (2, 12, 40, 64, 320, True),
+                                                (1, 16, 30, 192, 320, False), (1, 20, 23, 128, 320, True), (3, 24, 8, 640, 640, False)])
+def test_gemm_tfr_plain(Bn, F_, Pp, Cc, N, res):
+    """Frame-resident temporal convolution (csrc/gemm_tfr.hip, VMV_TILE_TFR) WITHOUT the norm fold: a block owns all F frames of
+    192 // F pixels, the three taps are row-shifted views of one LDS tile.  F = 24 / 20 / 16 / 12 (8 / 9 / 12 / 16 pixels per tile;
+    F = 20 leaves 12 rows of the tile unused), pixel counts that are not a multiple of the tile (ragged last tile), one to four
+    A stages of 64 channels... ten at C = 640, two column tiles at N = 640, several samples, residual — against Conv3d and the interpreter."""
+    M = Bn * F_ * Pp
+    wt = torch.randn(N, Cc, 3, 1, 1, generator=g(2)) * (3 * Cc) ** -0.5
+    c = Case(x=rnd((M, Cc), 1), w=P.pack_tconv(wt, "cpu"), b=torch.randn(N, generator=g(3)), res=rnd((M, N), 5), out=torch.zeros(M, N, dtype=BF))
+
+    def build(t):
+        return ops.gemm_params(M, N, ops.temporal_segs(t["x"], Cc, Cc), t["w"], t["out"], N, bias=t["b"], geom=ops.Geom(F=F_, P=Pp),
+                               residual=t["res"] if res else None, ldr=N if res else 0, tile=L.TILE_TFR)
+    cpu, dev = run_gemm(build, c, cpu_ref=M * N * Cc < 4e8)
+    ref = _tconv_ref(cpu["x"], wt, cpu["b"], Bn, F_, Pp, Cc, N) + (cpu["res"].float() if res else 0)
+    check(dev["out"], ref)
+    if M * N * Cc < 4e8:
+        check(dev["out"], cpu["out"])
+    # the same launch on the tile kernels agrees (other accumulation order only)
+    dev2 = c.on("cuda")
+    q = build(dev2)
+    q.tile = L.TILE_AUTO if not ops.Stream(record=False).lib.vmv_gemm_tfr_ok(C.byref(q)) else L.TILE_G128x128
+    ops.Stream(record=False).gemm(q, "tile")
+    torch.cuda.synchronize()
+    check(dev["out"], dev2["out"].cpu(), tol_l2=2e-3, tol_max=6e-3)
+
+
+@pytest.mark.parametrize("Bn,F_,Pp,Cc,N,silu,res", [(2, 24, 40, 320, 320, True, True), (1, 24, 21, 128, 640, True, False), (2, 12, 19, 64, 320, False, True),
+                                                     (1, 20, 23, 128, 320, True, False), (2, 24, 16, 640, 640, True, True)])
+def test_gemm_tfr_groupnorm_fold(Bn, F_, Pp, Cc, N, silu, res):
+    """GroupNorm over all frames -> SiLU -> Conv3d (3,1,1) (TemporalConvBlock_v2, util.py:1357-1392) as statistics + table + ONE GEMM:
+    the frame-resident kernel applies elem(silu(x * scale + shift)) to its A tile in LDS.  Against (a) the two-kernel form — statistics
+    + vmv_groupnorm_apply(silu) + the same kernel without the fold — which multiplies the very same rounded values (same kernel, same
+    accumulation order: bitwise), (b) the interpreter, (c) F.group_norm + F.silu + Conv3d in fp32.  The zero padding of frames -1 / F
+    must stay zero AFTER the norm (silu(shift) != 0), and rows of a ragged last tile must not leak into valid pixels."""
+    M = Bn * F_ * Pp
+    rps = F_ * Pp
+    wt = torch.randn(N, Cc, 3, 1, 1, generator=g(2)) * (3 * Cc) ** -0.5
+    x = (torch.randn(M, Cc, generator=g(1)) * 1.5 + 0.7).to(BF)
+    gamma, beta = 1 + 0.2 * torch.randn(Cc, generator=g(6)), 0.3 * torch.randn(Cc, generator=g(7))
+    c = Case(x=x, w=P.pack_tconv(wt, "cpu"), b=torch.randn(N, generator=g(3)), res=rnd((M, N), 5), out=torch.zeros(M, N, dtype=BF),
+             out2=torch.zeros(M, N, dtype=BF), y=torch.zeros(M, Cc, dtype=BF), tab=torch.zeros(Bn * 2 * Cc), gamma=gamma, beta=beta,
+             ws=torch.zeros(ops.gn_partial_floats(M, rps, Cc)))
+
+    def gnp(t, y, silu_flag):
+        return ops.gn_params(t["x"], Cc, Cc, M, rps, t["ws"], t["gamma"], t["beta"], 1e-5, silu_flag, y, Cc)
+
+    def build(t, fold):
+        kw = dict(gn_table=t["tab"], gn_rows_per_stat=rps, gn_silu=silu) if fold else {}
+        return ops.gemm_params(M, N, ops.temporal_segs(t["x"] if fold else t["y"], Cc, Cc), t["w"], t["out"] if fold else t["out2"], N, bias=t["b"],
+                               geom=ops.Geom(F=F_, P=Pp), residual=t["res"] if res else None, ldr=N if res else 0, tile=L.TILE_TFR, **kw)
+    dev = c.on("cuda")
+    S = ops.Stream(record=False)
+    S.groupnorm_stats(gnp(dev, dev["tab"], False), "stats")
+    S.groupnorm_table(gnp(dev, dev["tab"], False), "table")
+    S.gemm(build(dev, True), "folded")
+    S.groupnorm_apply(gnp(dev, dev["y"], silu), "apply")
+    S.gemm(build(dev, False), "two-kernel")
+    torch.cuda.synchronize()
+    assert torch.equal(dev["out"], dev["out2"])
+    cpu = c.on("cpu")
+    I.groupnorm_stats(gnp(cpu, cpu["tab"], False)); I.groupnorm_table(gnp(cpu, cpu["tab"], False))
+    if M * N * Cc < 4e8:
+        I.gemm(build(cpu, True))
+        check(dev["out"], cpu["out"])
+    xn = torch.nn.functional.group_norm(x.float().view(Bn, rps, Cc).permute(0, 2, 1), 32, gamma, beta, 1e-5)
+    xn = (torch.nn.functional.silu(xn) if silu else xn).permute(0, 2, 1).reshape(M, Cc).to(BF)
+    ref = _tconv_ref(xn, wt, cpu["b"], Bn, F_, Pp, Cc, N) + (cpu["res"].float() if res else 0)
+    check(dev["out"], ref, tol_l2=6e-3, tol_max=2.5e-2)
+    # refused where it cannot run: a stat group that is not the sample, SiLU without a table, F outside 12 .. 24
+    bad = build(dev, True); bad.gn_rows_per_stat = rps // 2
+    assert S.lib.vmv_gemm(C.byref(bad), None) == -1
+    bad = build(dev, True); bad.gn_table = None; bad.gn_silu = 1
+    assert S.lib.vmv_gemm(C.byref(bad), None) == -1
+
+
+def test_gemm_tfr_policy():
+    """vmv_gemm_tfr_ok: the frame-resident kernel is chosen where its tiles (samples x ceil(P / (192 // F)) x N / 320) fill whole rounds
+    of the 256 CUs — the first UNet level at 24 x 32 x 32 (256 tiles; 512 at 24 x 32 x 64) — and not at 24 x 40 x 64 (640 tiles = 2.5
+    rounds: measured slower than the 256 x 320 tile there), at the second level (320 / 128 tiles) or on tiny nets; F < 12 and
+    N % 320 != 0 are unsupported."""
+    lib = ops.Stream(record=False).lib
+    X = 1 << 20
+
+    def ok(Bn, F_, Pp, Cc, N):
+        p = ops.gemm_params(Bn * F_ * Pp, N, ops.temporal_segs(X, Cc, Cc), X, X, N, geom=ops.Geom(F=F_, P=Pp))
+        return lib.vmv_gemm_tfr_ok(C.byref(p)), lib.vmv_gemm_pick_tile(C.byref(p))
+    assert ok(2, 24, 1024, 320, 320) == (1, L.TILE_TFR) and ok(2, 24, 2048, 320, 320) == (1, L.TILE_TFR)
+    assert ok(2, 24, 2560, 320, 320) == (0, L.TILE_X256x320)
+    assert ok(2, 24, 640, 640, 640)[0] == 0 and ok(2, 24, 256, 640, 640)[0] == 0
+    assert ok(2, 4, 64, 64, 320)[0] == 0 and ok(2, 24, 2560, 320, 256)[0] == 0
 
 
 @pytest.mark.parametrize("tile", [L.TILE_X256x320, L.TILE_X256x128])

@@ -49,6 +49,10 @@ static_assert(TF_ROWS * TF_ROWB <= TF_OFF_TAB && TF_LDS <= 160 * 1024, "LDS budg
 constexpr int TF_WM = 3, TF_WN = 10, TF_WH = 5;  // accumulator tiles per wave: 3 row fragments x 10 column tiles, in two halves of 5
 constexpr int TF_NWI = 2, TF_NWX = 4;            // W wave-instructions per wave per stage: 2, + 1 for waves < 4 (20 groups of 16 rows)
 
+#ifndef VMV_TFR_SGB
+#define VMV_TFR_SGB 0      // experiments: 1 = pin "1 MFMA : 2 VALU" with sched_group_barrier in the half-phases that carry an A half-unit
+#endif
+
 template <bool GN>
 __global__ __launch_bounds__(512, 1) void gemm_tfr_kernel(const VmvGemmParams p, const int tiles_g, const int tiles_n, const int PT) {
     VMV_KERNEL_ENTER();
@@ -100,27 +104,28 @@ __global__ __launch_bounds__(512, 1) void gemm_tfr_kernel(const VmvGemmParams p,
 #pragma unroll
         for (int q = 0; q < 3; ++q) VMV_BLDS16(a_rsrc, dst + q * 8192, avo[q], (uint32_t)a * 128u);
     };
-    auto a_commit = [&](const int a, const int q) {       // unit q of stage a, in place: elem(silu(x * scale + shift)); zero rows stay zero
+    // half-unit hu = 2 q + h (4 channels = 8 bytes) of stage a, in place: elem(silu(x * scale + shift)); zero rows stay zero.  Six of
+    // them per A stage, one per MFMA half-phase (below), so that each is ~30 VALU operations beside 15 MFMAs.
+    auto a_commit_half = [&](const int a, const int hu) {
         if constexpr (GN) {
-            u32x4_t* up = reinterpret_cast<u32x4_t*>(abuf + (a & 1) * TF_ABYTES + ado + q * 8192);
-            u32x4_t v = *up;
-            // four channels at a time (8 table registers live, not 16: the kernel sits at the register limit)
-            const float* ts = tab + a * 64 + aslot * 8;
-            const bool silu = p.gn_silu != 0;
-            auto half = [&](uint32_t w0, uint32_t w1, const float* t4) -> u32x2_t {
-                const f32x4_t sc = *reinterpret_cast<const f32x4_t*>(t4), sh = *reinterpret_cast<const f32x4_t*>(t4 + C);
-                float x0 = fmaf(elem_lo(w0), sc.x, sh.x), x1 = fmaf(elem_hi(w0), sc.y, sh.y);
-                float x2 = fmaf(elem_lo(w1), sc.z, sh.z), x3 = fmaf(elem_hi(w1), sc.w, sh.w);
-                if (silu) { x0 = silu_f(x0); x1 = silu_f(x1); x2 = silu_f(x2); x3 = silu_f(x3); }
-                return u32x2_t{pack_elem2(x0, x1), pack_elem2(x2, x3)};
-            };
-            const u32x2_t h0 = half(v.x, v.y, ts);
-            const u32x2_t h1 = half(v.z, v.w, ts + 4);
-            v = u32x4_t{h0.x, h0.y, h1.x, h1.y};
-            if (avo[q] == OOB) v = u32x4_t{0u, 0u, 0u, 0u};         // rows outside the tile stay the zero padding of the frame axis
-            *up = v;
+            const int q = hu >> 1, h = hu & 1;
+            // (the two lane-dependent bases are made opaque per use: left visible, the six half-units of the unrolled block each get
+            //  their own pre-added address registers hoisted out of the loop — 12 registers the kernel does not have)
+            uint32_t ad = ado, ts8 = (uint32_t)aslot * 32u;
+            asm volatile("" : "+v"(ad), "+v"(ts8));
+            u32x2_t* up = reinterpret_cast<u32x2_t*>(abuf + (a & 1) * TF_ABYTES + ad + q * 8192 + h * 8);
+            const u32x2_t v = *up;
+            const float* t4 = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(tab) + a * 256 + ts8 + h * 16);
+            const f32x4_t sc = *reinterpret_cast<const f32x4_t*>(t4), sh = *reinterpret_cast<const f32x4_t*>(t4 + C);
+            float x0 = fmaf(elem_lo(v.x), sc.x, sh.x), x1 = fmaf(elem_hi(v.x), sc.y, sh.y);
+            float x2 = fmaf(elem_lo(v.y), sc.z, sh.z), x3 = fmaf(elem_hi(v.y), sc.w, sh.w);
+            if (p.gn_silu) { x0 = silu_f(x0); x1 = silu_f(x1); x2 = silu_f(x2); x3 = silu_f(x3); }
+            u32x2_t o = u32x2_t{pack_elem2(x0, x1), pack_elem2(x2, x3)};
+            if (avo[q] == OOB) o = u32x2_t{0u, 0u};               // rows outside the tile stay the zero padding of the frame axis
+            *up = o;
         }
     };
+    auto a_commit = [&](const int a, const int q) { a_commit_half(a, 2 * q); a_commit_half(a, 2 * q + 1); };
 
     // ---- W loader (gemm_xglds.hip): a wave instruction covers 16 rows x 64 B; lane -> (row lane >> 2, physical slot lane & 3),
     //      logical k-slot (lane & 3) ^ T[(row >> 2) & 3], T = {0, 2, 3, 1}
@@ -173,20 +178,18 @@ __global__ __launch_bounds__(512, 1) void gemm_tfr_kernel(const VmvGemmParams p,
     const int fslot = fgrp ^ ((0x78 >> (2 * ((frow >> 2) & 3))) & 3);        // W fragments: physical slot of this lane's k-slice
     // B fragments of tap index tp (dt = tp - 1): lane row rr = wave_m * 48 + 16 i + frow + TF_PAD + dt * PT; (rr >> 1) & 7 is the
     // same for every i (16-row steps), so per tap: a lane-constant byte offset + a 64-byte half select
-    uint32_t boff[3];
-    uint32_t bsel = 0;                                           // bit tp: the 64-byte half select of tap tp
+    uint32_t boff[3];                                            // (bit 6 = the 64-byte half that holds k-slots 0-3 of an even k-step for this lane's rows)
 #pragma unroll
     for (int tp = 0; tp < 3; ++tp) {
         const int rr0 = wave_m * 16 * TF_WM + frow + TF_PAD + (tp - 1) * PT;
         const int sw = (rr0 >> 1) & 7;
-        boff[tp] = (uint32_t)(rr0 * 128 + ((fgrp ^ (sw & 3)) << 4));
-        bsel |= (uint32_t)(sw >> 2) << tp;
+        boff[tp] = (uint32_t)(rr0 * 128 + ((fgrp ^ (sw & 3)) << 4)) | ((uint32_t)(sw >> 2) << 6);
     }
     elem8_t bfr[2][TF_WM], wfr[2][TF_WH];
     auto read_b = [&](const int t, auto par_tag) {              // the 3 row-shifted B fragments of stage t
         constexpr int par = decltype(par_tag)::value;
         const int ks = t / 3, tap = t - 3 * ks;
-        const unsigned char* ap = abuf + ((ks >> 1) & 1) * TF_ABYTES + boff[tap] + ((((uint32_t)ks ^ (bsel >> tap)) & 1u) << 6);
+        const unsigned char* ap = abuf + ((ks >> 1) & 1) * TF_ABYTES + (boff[tap] ^ ((uint32_t)(ks & 1) << 6));
 #pragma unroll
         for (int i = 0; i < TF_WM; ++i) bfr[par][i] = __builtin_bit_cast(elem8_t, *reinterpret_cast<const u32x4_t*>(ap + i * 2048));
     };
@@ -212,20 +215,17 @@ __global__ __launch_bounds__(512, 1) void gemm_tfr_kernel(const VmvGemmParams p,
     read_b(0, std::integral_constant<int, 0>{});
     read_w(0, std::integral_constant<int, 0>{});
 
-    // One phase = one W stage.  The loop body is a block of six phases (two k-steps x three taps = one A stage) with every decision a
-    // compile-time value — which phases commit / request A units, which still issue W — so that the compiler's own vmcnt bookkeeping
-    // for the register-returning A loads sees a fixed instruction sequence (a run-time condition around a VMEM issue makes it fall
-    // back to vmcnt(0) in front of every use, which would drain the W ring each phase).
-    //   KIND 0 (blocks 0 .. NA - 3): commit stage a + 1, request stage a + 2, issue W(t + S)
-    //   KIND 1 (block NA - 2)      : commit stage a + 1, issue W(t + S)
-    //   KIND 2 (block NA - 1, last): issue W(t + S) in its first two phases only; the waits shrink with the ring
-    auto wait_landed = [&](auto n2_tag, auto n3_tag) {         // vmcnt literal for waves with 2 / 3 W loads per stage
-        constexpr int N2 = decltype(n2_tag)::value, N3 = decltype(n3_tag)::value;
-        if (xw) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N3) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N2) : "memory");
-    };
-    auto phase = [&](const int t, auto t6_tag, auto kind_tag) {
-        constexpr int t6 = decltype(t6_tag)::value, KIND = decltype(kind_tag)::value, par = t6 & 1;
+    // One phase = one W stage = two half-phases of 15 MFMAs.  The loop body is TWO phases (the fragment-buffer parity is a compile-time
+    // value; a body of the six phases of an A stage, with every decision static, costs ~50 more registers and spills), everything else
+    // is wave-uniform run-time state (the A path is LDS-DMA: no register-returning load whose compiler-managed vmcnt a branch degrades).
+    // The norm of stage a + 1 (GN): one UNIT (8 channels of one row) per slot, after the wait of phase 6 a + 2 that covers its DMA and
+    // before the barrier of phase 6 a + 5 that publishes it — and STAGGERED between the two waves of a SIMD (w, w + 4): waves 0-3 use
+    // the H0 half-phases of phases 3, 4, 5, waves 4-7 the H1 half-phases of phases 2, 3, 4, so that while one wave of a SIMD runs its
+    // ~100 VALU operations the other is in its 15 MFMAs (both at once leave the matrix pipe idle: measured +22 us per launch).
+    const int T = 6 * NA;
+    const bool early = wave >= TF_NW / 2;                        // this wave's norm slots are the H1 halves of phases 2..4
+    auto phase = [&](const int t, const int t6, auto par_tag) {
+        constexpr int par = decltype(par_tag)::value;
         using P0 = std::integral_constant<int, par>;
         using P1 = std::integral_constant<int, par ^ 1>;
         using H0 = std::integral_constant<int, 0>;
@@ -233,14 +233,23 @@ __global__ __launch_bounds__(512, 1) void gemm_tfr_kernel(const VmvGemmParams p,
         const int a_next = t / 6 + 1;
         read_w(t, H1{});
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (GN) { if (!early && t6 >= 3 && a_next < NA) a_commit(a_next, t6 - 3); }
         mma(P0{}, H0{});
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (KIND != 2 || t6 != 5) {
+        if (t + 1 < T) {
             // stage t + 1 landed for every wave, every wave done with ring slot t % S and with its A-buffer reads of phase t;
             // in flight behind W(t + 1): the later W stages already issued and, in phases 0 / 1, the A units of the next stage
-            constexpr int w_out = KIND != 2 ? TF_S - 2 : (t6 <= 2 ? 2 : 4 - t6);
-            constexpr int a_out = (KIND != 2 && t6 <= 1) ? 3 : 0;
-            wait_landed(std::integral_constant<int, w_out * TF_NWI + a_out>{}, std::integral_constant<int, w_out * (TF_NWI + 1) + a_out>{});
+            const int issued = t + TF_S < T ? t + TF_S : T;
+            int allow = (issued - t - 2) * LW;
+            if (t6 <= 1 && a_next < NA) allow += 3;
+            // (allow = {0, 1, 2} x LW (+ 3), LW = 2 / 3: seven literals; a smaller literal only waits for more)
+            if (allow >= 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else if (allow >= 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else if (allow >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (allow >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (allow >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (allow >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -248,24 +257,19 @@ __global__ __launch_bounds__(512, 1) void gemm_tfr_kernel(const VmvGemmParams p,
             read_w(t + 1, H0{});
             __builtin_amdgcn_sched_barrier(0);
         }
-        // the A unit of this phase rides among the MFMAs (VALU / LDS of one wave under the matrix pipe of both)
-        if constexpr (KIND != 2 && t6 >= 2 && t6 <= 4) a_commit(a_next, t6 - 2);
+        if constexpr (GN) { if (early && t6 >= 2 && t6 <= 4 && a_next < NA) a_commit(a_next, t6 - 2); }
         mma(P0{}, H1{});
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (KIND == 0 && t6 == 5) a_request(a_next + 1);     // stage a + 2's units: in front of W(t + S) in the queue
-        if constexpr (KIND != 2 || t6 <= 1) w_issue(t + TF_S);         // into the slot this phase's barrier freed
+        if (t6 == 5 && a_next + 1 < NA) a_request(a_next + 1);     // stage a + 2's units: in front of W(t + S) in the queue
+        if (t + TF_S < T) w_issue(t + TF_S);                       // into the slot this phase's barrier freed
         __builtin_amdgcn_s_waitcnt(0xc07f);
     };
-    auto block6 = [&](const int t0, auto kind_tag) {
-        phase(t0 + 0, std::integral_constant<int, 0>{}, kind_tag); phase(t0 + 1, std::integral_constant<int, 1>{}, kind_tag);
-        phase(t0 + 2, std::integral_constant<int, 2>{}, kind_tag); phase(t0 + 3, std::integral_constant<int, 3>{}, kind_tag);
-        phase(t0 + 4, std::integral_constant<int, 4>{}, kind_tag); phase(t0 + 5, std::integral_constant<int, 5>{}, kind_tag);
-    };
-    int t0 = 0;
-#pragma unroll 1
-    for (int a = 0; a + 2 < NA; ++a, t0 += 6) block6(t0, std::integral_constant<int, 0>{});
-    if (NA >= 2) { block6(t0, std::integral_constant<int, 1>{}); t0 += 6; }
-    block6(t0, std::integral_constant<int, 2>{});
+    int t6 = 0;
+    for (int t = 0; t < T; t += 2) {
+        phase(t, t6, std::integral_constant<int, 0>{});
+        phase(t + 1, t6 + 1, std::integral_constant<int, 1>{});
+        t6 = t6 == 4 ? 0 : t6 + 2;
+    }
 
     // ---- epilogue: bias, activation -> LDS staging of whole rows -> 16-byte row stores (+ residual), as gemm_xglds.hip
     __syncthreads();                                            // ring / A buffers no longer read by anyone
@@ -344,13 +348,19 @@ bool vmv_gemm_tfr_supported(const VmvGemmParams& p) {
     return true;
 }
 
-// policy: taken when its grid fills the chip — tiles = samples x pixel groups x (N / 320), >= 200 of them and >= 80 % of the last round
+// policy: taken when its tiles (samples x pixel groups x N / 320) fill WHOLE rounds of the 256 CUs — >= 200 tiles and >= 95 % of the
+// last round.  Measured (tools/experiments/tfr_bench.py, profiles/r5_tfr_bench.log): a tile runs at the same ~3.4 TFLOP/s per CU as the
+// 256 x 320 tile of gemm_xglds.hip, so the frame-resident form wins where its grid quantises better — the first level at 24 x 32 x 32:
+// 256 tiles = one round, 36-39 us against 43 us, folded norm 62-67 us against 74 us for statistics + apply + convolution — and loses
+// where it does not: 24 x 40 x 64 has 640 tiles = 2.5 rounds (100-111 us against 90-94 us).
 bool vmv_gemm_tfr_preferred(const VmvGemmParams& p) {
     if (!tfr_policy() || !vmv_gemm_tfr_supported(p)) return false;
     const int PT = TF_ROWS / p.F;
     const long tiles = (long)(p.M / ((long)p.F * p.P)) * ((p.P + PT - 1) / PT) * (p.N / TF_BN);
     const long rounds = (tiles + 255) / 256;
-    return tiles >= 200 && (double)tiles / (double)(rounds * 256) >= 0.8;
+    static double fill_min = -1.0;
+    if (fill_min < 0.0) { const char* e = getenv("VMV_TFR_FILL"); fill_min = e ? atof(e) : 0.95; }      // (A/B experiments)
+    return tiles >= 200 && (double)tiles / (double)(rounds * 256) >= fill_min;
 }
 
 int vmv_gemm_tfr_launch(const VmvGemmParams& p, hipStream_t st) {

@@ -249,6 +249,9 @@ class UNetEngine:
         self.ff_fused = os.environ.get("VMV_FF_FUSED", "0") == "1" and self.fold_ln
         # VMV_GN_FOLD (default 1): the transformers' GroupNorm -> proj_in with the apply pass folded into the GEMM (_gn_folded_proj_in)
         self.gn_fold = os.environ.get("VMV_GN_FOLD", "1") != "0"
+        # VMV_TCONV_FOLD (default 1): the temporal conv block's GroupNorm -> SiLU -> (3,1,1) conv with the apply pass folded into the
+        # frame-resident kernel's A path (_tconv_folded, csrc/gemm_tfr.hip) wherever that kernel's tiles fill the chip
+        self.tconv_fold = os.environ.get("VMV_TCONV_FOLD", "1") != "0"
         # VMV_FP_TEMPORAL (frame-parallel plans): "switch" (default) = the TemporalTransformer runs on the pixel-major shard between two
         # all-to-all layout switches; "kv_gather" = BASELINE's north-star form — frames stay sharded, ONE all-gather of [K | V] before
         # each temporal attention (B = 1 plans, i.e. the branch-pipelined / CFG-parallel modes; 16x the bytes of the switches)
@@ -518,6 +521,43 @@ class UNetEngine:
         self.release(tab)
         return True
 
+    def _tconv_folded(self, q, cur: Act, T, rps, out: Act, tg, residual=None, ldr=0) -> bool:
+        """One step of TemporalConvBlock_v2 (util.py:1357-1392: GroupNorm over all frames -> SiLU -> Conv3d (3,1,1)) with the norm's
+        apply pass folded into the convolution: statistics (integer totals, as _gn) + a one-block table launch + the frame-resident
+        kernel (csrc/gemm_tfr.hip), which applies elem(silu(x * scale + shift)) to its A tile on the way through LDS — the values
+        vmv_groupnorm_apply would have stored.  The normalised tensor is never written or re-read.  Taken where the library's policy
+        runs the convolution on that kernel (vmv_gemm_tfr_ok: its tiles fill the chip — the first level at 24 x 40 x 64 and
+        24 x 32 x 32); frame-parallel plans gather their totals between the statistics and the table launch as before."""
+        if not self.tconv_fold:
+            return False
+        Cc = cur.C
+        nstat = T // rps
+        W = self.w[f"{q}.weight"]
+        tab = self.act(nstat * 2, Cc, dtype=torch.float32)
+        gp = ops.gemm_params(T, W.shape[0], ops.temporal_segs(cur.ptr, Cc, Cc), W, out.ptr, out.C, bias=self.w[f"{q}.bias"], geom=tg,
+                             residual=residual, ldr=ldr, gn_table=tab.ptr, gn_rows_per_stat=rps, gn_silu=True)
+        if not self.S.lib.vmv_gemm_tfr_ok(C.byref(gp)):
+            self.release(tab)
+            return False
+        label = q + ".gn"
+        assert nstat <= self.B_ctx and ops.gn_partial_floats(T, rps, Cc) <= self._gnws.numel()
+        args = (cur.ptr, Cc, Cc, T, rps, self._gnws, self.w[f"{q}.0.weight"], self.w[f"{q}.0.bias"], 1e-5, False, tab.ptr, Cc)
+        tot, nxt = self._gn_tot2[self._gn_tot_k & 1], self._gn_tot2[(self._gn_tot_k + 1) & 1]
+        self._gn_tot_k += 1
+        clr = dict(totals_clear=nxt, clear_count=nstat * ops.GN_TOT)
+        if self.comm is None:
+            gnp = ops.gn_params(*args, totals=tot, **clr)
+            self.S.groupnorm_stats(gnp, label)
+            self.S.groupnorm_table(gnp, label)
+        else:
+            self.S.groupnorm_stats(ops.gn_params(*args, totals=tot), label)
+            loc, allr = tot[: nstat * ops.GN_TOT], self._gn_tot_all[: nstat * ops.GN_TOT * self.R]
+            self._collective(L.COMM_ALL_GATHER, allr, loc, label + ".totals.gather")
+            self.S.groupnorm_table(ops.gn_params(*args, totals=self._gn_tot_all, fold_ranks=self.R, **clr), label)
+        self.S.gemm(gp, q)
+        self.release(tab)
+        return True
+
     # ------------------------------------------------------------------ frame-parallel layout switches
     def _break(self, fn):
         self.breaks.append((self.S.nops, fn))
@@ -654,12 +694,13 @@ class UNetEngine:
         cur = h3
         for i, name in enumerate(("conv1", "conv2", "conv3", "conv4")):
             q = f"{p}.temopral_conv.{name}"
-            g = self._gn(q + ".gn", [cur], T, F * h * w, f"{q}.0", 1e-5, True, all_frames=True)
             nxt = self.act(T, cout)
             last = i == 3
-            self._gemm(q, T, cout, ops.temporal_segs(g.ptr, g.C, g.C), f"{q}.weight", nxt, bias=self.w[f"{q}.bias"],
-                       geom=tg, residual=h3.ptr if last else None, ldr=h3.C if last else 0)
-            self.release(g)
+            if not self._tconv_folded(q, cur, T, F * h * w, nxt, tg, residual=h3.ptr if last else None, ldr=h3.C if last else 0):
+                g = self._gn(q + ".gn", [cur], T, F * h * w, f"{q}.0", 1e-5, True, all_frames=True)
+                self._gemm(q, T, cout, ops.temporal_segs(g.ptr, g.C, g.C), f"{q}.weight", nxt, bias=self.w[f"{q}.bias"],
+                           geom=tg, residual=h3.ptr if last else None, ldr=h3.C if last else 0)
+                self.release(g)
             if cur is not h3:
                 self.release(cur)
             cur = nxt
