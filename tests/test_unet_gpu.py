@@ -684,3 +684,34 @@ def test_full_size_forwards_match_reference_goldens(golden_dir, which):
     e = rel_l2(out, gld[key])
     print(f"full-size {which} forward at 24x32x32 vs the imported reference: rel-L2 {e:.3e} ({_L.elem_name()})")
     assert e < TOL_FWD, e
+
+
+def test_fp16_saturation_probe():
+    """UNetEngine.saturation_report (opt-in validation pass): with saturating fp16 stores a checkpoint whose activations leave
+    fp16's range gives a finite but wrong result — the probe names the launches whose outputs sit on the +-65504 clamp.  A healthy net
+    reports nothing; the same net with one conv's weights scaled by 3e4 reports that conv (and what it feeds)."""
+    if not FP16:
+        pytest.skip("bf16 has fp32's exponent range: nothing saturates")
+    from videomv_amd.unet_engine import UNetEngine
+    cfg = dict(in_dim=4, dim=64, context_dim=1024, out_dim=4, dim_mult=[1, 2], num_heads=2, head_dim=64, num_res_blocks=1,
+               attn_scales=[1.0, 0.5], camera_dim=16, use_camera_condition=True, use_fps_condition=False)
+    ocfg = UNetCfg(**{k: v for k, v in cfg.items() if k in {f.name for f in dataclasses.fields(UNetCfg)}})
+    sd = random_state_dict(unet_param_shapes(ocfg), 99)
+    B, F_, H, W, Lc = 2, 4, 8, 8, 7
+    gen = torch.Generator().manual_seed(5)
+    x, t = torch.randn(B, 4, F_, H, W, generator=gen).cuda(), torch.tensor([501, 21]).cuda()
+    y, cam = torch.randn(B, Lc, 1024, generator=gen).cuda(), torch.randn(B, F_, 16, generator=gen).cuda()
+
+    def run(state):
+        eng = UNetEngine(cfg, state, B, F_, H, W, Lc, torch.device("cuda"), n_t=B)
+        eng.set_context(y); eng.set_camera(cam); eng.forward_rows(x, t)
+        torch.cuda.synchronize()
+        return eng, eng.saturation_report()
+    eng, hits = run(sd)
+    assert hits == [] and torch.isfinite(eng.eps_ncfhw()).all()
+    bad = dict(sd)
+    key = "input_blocks.1.0.in_layers.2.weight"
+    bad[key] = sd[key] * 3e4
+    eng, hits = run(bad)
+    assert hits and hits[0][0].endswith("input_blocks.1.0.conv1") and hits[0][1] > 0, hits[:3]
+    assert torch.isfinite(eng.eps_ncfhw()).all()          # finite — which is exactly why the probe exists

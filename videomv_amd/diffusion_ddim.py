@@ -62,6 +62,10 @@ def _unwrap(model):
     return getattr(model, "module", model)      # DistributedDataParallel / DataParallel
 
 
+def comm_of(unet):
+    return getattr(unet, "frame_comm", None)
+
+
 @DIFFUSION.register_class()
 class DiffusionDDIM(object):
     def __init__(self, schedule='linear_sd', schedule_param={}, mean_type='eps', var_type='learned_range',
@@ -186,6 +190,21 @@ class DiffusionDDIM(object):
         ops.ddim_x0_step(z[0], z[1], xt, float(guide_scale), k["c_recip"], k["c_recipm1"], k["a_prev"])
         return xt
 
+    def _saturation_probe(self, unet, xt):
+        """VMV_F16_SAT_PROBE=1 (debug, off by default): after the first step of a sample, replay the step's UNet plan launch by launch
+        and warn when 16-bit GEMM outputs sit on the fp16 clamp (+-65504) — the silent failure the saturating stores make possible."""
+        import os
+        if os.environ.get("VMV_F16_SAT_PROBE", "0") != "1" or comm_of(unet) is not None:
+            return
+        engs = [e for e in getattr(unet, "_engines", {}).values() if e.B == 2 and e.F == xt.shape[2] and (e.H, e.W) == tuple(xt.shape[-2:])]
+        for e in engs[:1]:
+            hits = e.saturation_report()
+            if hits:
+                import warnings
+                tot = sum(h[1] for h in hits)
+                warnings.warn(f"fp16 saturation: {tot} activation values clamped at +-65504 in {len(hits)} launches (first: {hits[0][0]}, "
+                              f"{hits[0][1]} of {hits[0][2]}) — this checkpoint leaves fp16's range; rerun with hip_dtype: bf16 (VMV_DTYPE=bf16)")
+
     @torch.no_grad()
     def ddim_sample_loop(self, noise, model, autoencoder=None, model_kwargs={}, clamp=None, percentile=None,
                          condition_fn=None, guide_scale=None, ddim_timesteps=20, eta=0.0):
@@ -226,6 +245,8 @@ class DiffusionDDIM(object):
                 self.ddim_step_lgm(xt, int(step), unet, kc, ku, guide_scale, stride, autoencoder)
             else:
                 self.ddim_step_hip(xt, int(step), unet, kc, ku, guide_scale, stride, clamp=clamp, eta=eta)
+            if idx == 0:
+                self._saturation_probe(unet, xt)
         if comm is not None:
             from .unet_t2v import gather_frames
             xt = gather_frames(comm, xt)

@@ -1084,6 +1084,29 @@ class UNetEngine:
         for seg in self.segments():
             self.run_segment(seg)
 
+    def saturation_report(self, limit: int = 20):
+        """Opt-in fp16 saturation probe: with MODE.FP16_OVFL every 16-bit store clamps at +-65504 instead of producing inf,
+        so a checkpoint whose activations leave fp16's range yields a plausible but WRONG video with no non-finite value anywhere.
+        This replays the recorded plan launch by launch (slow: one sync per GEMM; a validation pass, not a production path — no
+        collectives are replayed, so unsharded plans only) and counts, per 16-bit GEMM output, the elements sitting exactly on the
+        clamp.  -> [(label, count, elements)] of the launches that saturate.  ``VMV_F16_SAT_PROBE=1`` makes the sampler run it once per
+        sample after the first step and warn (diffusion_ddim.ddim_sample_loop); nothing to report on the bf16 build."""
+        if L.elem_name() != "fp16" or not str(self.device).startswith("cuda") or self.breaks or self.n_comm_ops:
+            return []
+        from .autotune import out_view
+        hits = []
+        for i, ((op, p), label) in enumerate(zip(self.S.recorded, self.S.labels)):
+            self.S.run(i, i + 1)
+            if op != L.OP_GEMM or p.out_fp32:
+                continue
+            o = out_view(p)
+            n = int((o.abs() >= 65504.0).sum())
+            if n:
+                hits.append((label, n, o.numel()))
+                if len(hits) >= limit:
+                    break
+        return hits
+
     def eps_ncfhw(self) -> torch.Tensor:
         """eps rows -> [B, out_dim, F, H, W] fp32 (reference output layout)."""
         out = torch.empty(self.B * self.F, self.out_pad, self.H, self.W, dtype=torch.float32, device=self.device)
