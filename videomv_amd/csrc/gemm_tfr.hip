@@ -218,12 +218,13 @@ __global__ __launch_bounds__(512, 1) void gemm_tfr_kernel(const VmvGemmParams p,
     // One phase = one W stage = two half-phases of 15 MFMAs.  The loop body is TWO phases (the fragment-buffer parity is a compile-time
     // value; a body of the six phases of an A stage, with every decision static, costs ~50 more registers and spills), everything else
     // is wave-uniform run-time state (the A path is LDS-DMA: no register-returning load whose compiler-managed vmcnt a branch degrades).
-    // The norm of stage a + 1 (GN): one UNIT (8 channels of one row) per slot, after the wait of phase 6 a + 2 that covers its DMA and
-    // before the barrier of phase 6 a + 5 that publishes it — and STAGGERED between the two waves of a SIMD (w, w + 4): waves 0-3 use
-    // the H0 half-phases of phases 3, 4, 5, waves 4-7 the H1 half-phases of phases 2, 3, 4, so that while one wave of a SIMD runs its
-    // ~100 VALU operations the other is in its 15 MFMAs (both at once leave the matrix pipe idle: measured +22 us per launch).
+    // The norm of stage a + 1 (GN): its six half-units (4 channels of one row each, ~30 VALU operations) ride in the six half-phases
+    // between the wait of phase 6 a + 2 that covers their DMA and the barrier of phase 6 a + 5 that publishes them — (2, H1) -> 0,
+    // (3, H0) -> 1, (3, H1) -> 2, (4, H0) -> 3, (4, H1) -> 4, (5, H0) -> 5 — and the two waves of a SIMD (w, w + 4) take them on
+    // OPPOSITE sides of the half-phase's 15 MFMAs: waves 0-3 normalise first and multiply second, waves 4-7 multiply first, so one
+    // wave's VALU work runs under the other's MFMAs (both normalising at once leaves the matrix pipe idle: +22-30 us per launch).
     const int T = 6 * NA;
-    const bool early = wave >= TF_NW / 2;                        // this wave's norm slots are the H1 halves of phases 2..4
+    const bool late = wave >= TF_NW / 2;                         // this wave normalises AFTER the MFMAs of a half-phase
     auto phase = [&](const int t, const int t6, auto par_tag) {
         constexpr int par = decltype(par_tag)::value;
         using P0 = std::integral_constant<int, par>;
@@ -233,8 +234,12 @@ __global__ __launch_bounds__(512, 1) void gemm_tfr_kernel(const VmvGemmParams p,
         const int a_next = t / 6 + 1;
         read_w(t, H1{});
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (GN) { if (!early && t6 >= 3 && a_next < NA) a_commit(a_next, t6 - 3); }
+        const bool c0 = GN && t6 >= 3 && a_next < NA, c1 = GN && t6 >= 2 && t6 <= 4 && a_next < NA;
+        if constexpr (GN) { if (c0 && !late) a_commit_half(a_next, 2 * (t6 - 3) + 1); }
+        __builtin_amdgcn_sched_barrier(0);
         mma(P0{}, H0{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (GN) { if (c0 && late) a_commit_half(a_next, 2 * (t6 - 3) + 1); }
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < T) {
             // stage t + 1 landed for every wave, every wave done with ring slot t % S and with its A-buffer reads of phase t;
@@ -257,8 +262,11 @@ __global__ __launch_bounds__(512, 1) void gemm_tfr_kernel(const VmvGemmParams p,
             read_w(t + 1, H0{});
             __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (GN) { if (early && t6 >= 2 && t6 <= 4 && a_next < NA) a_commit(a_next, t6 - 2); }
+        if constexpr (GN) { if (c1 && !late) a_commit_half(a_next, 2 * (t6 - 2)); }
+        __builtin_amdgcn_sched_barrier(0);
         mma(P0{}, H1{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (GN) { if (c1 && late) a_commit_half(a_next, 2 * (t6 - 2)); }
         __builtin_amdgcn_sched_barrier(0);
         if (t6 == 5 && a_next + 1 < NA) a_request(a_next + 1);     // stage a + 2's units: in front of W(t + S) in the queue
         if (t + TF_S < T) w_issue(t + TF_S);                       // into the slot this phase's barrier freed
