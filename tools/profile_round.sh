@@ -3,7 +3,7 @@
 # separate PMC passes; summaries land in gpurun_out/ and are copied to profiles/ by hand.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
-RN=${RN:-r2}      # round tag of the output files; VMV_COMMIT (git hash of the submitted tree) is recorded in the traffic JSON
+RN=${RN:-r5}      # round tag of the output files; VMV_COMMIT (git hash of the submitted tree) is recorded in the traffic JSON
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py"
 P="--no-cpu-baseline --no-sample --no-op-profile --simulate-rank 0"
