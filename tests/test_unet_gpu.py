@@ -126,6 +126,50 @@ def test_fused_cfg_ddim_loop_matches_oracle():
     print("fused-vs-oracle", e, "generic-vs-oracle", e_gen_ref, "generic-vs-fused", e_gen)
 
 
+def test_fused_loop_with_clamp_and_eta_matches_oracle(monkeypatch):
+    """The sampler options that ride in the fused update (round 5: they used to raise): `clamp` on x0 and stochastic DDIM (`eta > 0`:
+    sigma_t, the shortened direction term, + sigma * noise) through `ddim_sample_loop` on the HIP path against the oracle loop, which is
+    itself pinned to the imported reference for these options (tests/golden/ddim_options.safetensors).  The noise of every step is the
+    SAME tensor on both sides (torch.randn_like is intercepted on the product side, `step_noise` on the oracle side)."""
+    from videomv_amd.registry import DIFFUSION
+    cfg = dict(in_dim=4, dim=64, context_dim=1024, out_dim=4, dim_mult=[1, 2], num_heads=2, head_dim=64,
+               num_res_blocks=1, attn_scales=[1.0, 0.5])
+    ocfg = UNetCfg(**cfg)
+    sd = random_state_dict(unet_param_shapes(ocfg), 31)
+    m = build_model(cfg, sd).cuda()
+    dif = DIFFUSION.build(dict(type="DiffusionDDIM", schedule="linear_sd",
+                               schedule_param=dict(num_timesteps=1000, init_beta=0.00085, last_beta=0.012, zero_terminal_snr=False),
+                               mean_type="eps", var_type="fixed_small"))
+    gen = torch.Generator().manual_seed(12)
+    noise = torch.randn(1, 4, 4, 8, 8, generator=gen)
+    y, y0 = torch.randn(1, 7, 1024, generator=gen), torch.randn(1, 7, 1024, generator=gen)
+    cam = torch.randn(1, 4, 16, generator=gen)
+    step_nz = [torch.randn(1, 4, 4, 8, 8, generator=gen) for _ in range(3)]
+    kw = [dict(y=y.cuda(), camera_data=cam), dict(y=y0.cuda(), camera_data=cam)]
+    calls = []
+    real_randn_like = torch.randn_like
+
+    def fake_randn_like(t, *a, **k):
+        if tuple(t.shape) == (1, 4, 4, 8, 8):
+            calls.append(1)
+            return step_nz[len(calls) - 1].to(t.device)
+        return real_randn_like(t, *a, **k)
+    monkeypatch.setattr(torch, "randn_like", fake_randn_like)
+    x_hip = dif.ddim_sample_loop(noise=noise.cuda(), model=m, model_kwargs=kw, guide_scale=9.0, ddim_timesteps=3, eta=0.6, clamp=2.5)
+    monkeypatch.setattr(torch, "randn_like", real_randn_like)
+    assert len(calls) == 3 and hasattr(m, "forward_cfg_rows")        # the FUSED path ran (one noise draw per stochastic step)
+    tb = DDIMTables(betas_for("linear_sd"))
+    trace = []
+    x_ref = ddim_sample_loop(noise.clone(), lambda xt, t, y, camera_data: unet_forward(sd, ocfg, xt, t, y, camera_data),
+                             tb, [dict(y=y, camera_data=cam), dict(y=y0, camera_data=cam)], 9.0, ddim_timesteps=3, eta=0.6, clamp=2.5,
+                             trace=trace, step_noise=lambda i, xt: step_nz[i])
+    e = rel_l2(x_hip, x_ref)
+    assert e < TOL_X0, e
+    # and the options are not no-ops: the plain loop from the same start lands elsewhere
+    x_plain = dif.ddim_sample_loop(noise=noise.cuda(), model=m, model_kwargs=kw, guide_scale=9.0, ddim_timesteps=3, eta=0.0)
+    assert rel_l2(x_plain, x_ref) > 10 * e
+
+
 def test_ddim50_psnr_vs_fp32_oracle():
     """SURVEY 8d's reported number (not a gate there): 50 DDIM steps with CFG 9 — 100 forwards — on the HIP path against the fp32
     oracle's loop from the same noise, compared on the final latent and on the image the VAE decoder makes of it.  Random
