@@ -12,7 +12,12 @@ lib = S.lib
 stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def timeit(fn, reps=20, warm=3):
+REPS = int(os.environ.get("TFR_BENCH_REPS", "20"))
+ONLY = os.environ.get("TFR_BENCH_ONLY", "")          # substring filter on the shape tag (profiling runs)
+
+
+def timeit(fn, reps=None, warm=3):
+    reps = reps or REPS
     for _ in range(warm):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -26,6 +31,8 @@ def timeit(fn, reps=20, warm=3):
 print(f"{'shape':28s} {'tile':>5s} {'plain us':>9s} {'TFLOP/s':>8s} | {'tfr us':>8s} {'TFLOP/s':>8s} | {'3-launch us':>11s} {'folded us':>10s} {'eff TFLOP/s':>11s}")
 for tag, Bn, F_, Pp, Cc in (("L0 40x64", 2, 24, 2560, 320), ("L0 40x64 B=1", 1, 24, 2560, 320), ("L0 32x32", 2, 24, 1024, 320), ("L1 40x64", 2, 24, 640, 640),
                             ("L1 32x32", 2, 24, 256, 640), ("L2 40x64", 2, 24, 160, 1280), ("rank0of8 L0", 1, 24, 320, 320)):
+    if ONLY and ONLY not in tag:
+        continue
     M, N, rps = Bn * F_ * Pp, Cc, F_ * Pp
     g = torch.Generator(device="cuda").manual_seed(1)
     x = (torch.randn(M, Cc, generator=g, device="cuda") * 1.3 + 0.4).to(BF)
