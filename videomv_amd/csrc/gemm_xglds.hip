@@ -359,8 +359,29 @@ __global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams 
         act_apply(v, p.act);
         return v;
     };
+    // Residual rows run RD store-loop iterations AHEAD of their use (round 5), the first RD of a half tile requested BEFORE that half is
+    // staged: instead of one dependent global-memory round trip per iteration (the temporal convolution block's last conv adds a
+    // tensor written four launches earlier — out of L2 and, at the first level, out of the Infinity Cache: +28 us on a 95-us launch)
+    // RD 16-byte loads per lane are in flight.  (All ITER at once would need 40 registers beside the 160 accumulators the other half's
+    // waves still hold: 30 spilled.)  Buffer loads with out-of-range offsets for the tile tails.
+    constexpr int ITER = Cfg::HALF_ROWS * U / Cfg::NT;
+    constexpr int RD = EPI != 0 ? 1 : (ITER < 4 ? ITER : 4);      // (the folded-LayerNorm / GEGLU instantiations never carry a residual in the
+                                                                   //  plans and have no registers to spare: one load ahead, as before)
+    static_assert(ITER * Cfg::NT == Cfg::HALF_ROWS * U, "store loop trip count");
+    const __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(resp), 0, resp ? SRD_RECORDS : 0u, SRD_FLAGS);
+    auto res_request = [&](const int hh, const int it) -> u32x4_t {
+        const int idx = tid + it * Cfg::NT;
+        const int r = idx / U, u = idx - r * U;
+        const int m = m0 + hh * Cfg::HALF_ROWS + r, n = n0o + u * 8;
+        return __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, (m < p.M && n < No) ? (uint32_t)(m * p.ldr + n) * 2u : OOB, 0, 0);
+    };
 #pragma unroll 1
     for (int hh = 0; hh < 2; ++hh) {
+        u32x4_t rr[RD];
+        if (resp) {
+#pragma unroll
+            for (int it = 0; it < RD; ++it) rr[it] = res_request(hh, it);
+        }
         __syncthreads();                            // column vectors written / the previous half's slab no longer read by anyone
         if ((wave_m >> 1) == hh) {
             if constexpr (GEGLU) {
@@ -392,19 +413,20 @@ __global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams 
         // Store-data discipline (see gemm_pglds.hip): the stored registers are a VALU-written copy, never the destination of an
         // LDS read, and the previous iteration's copy stays alive until this iteration's LDS read has returned.
         u32x4_t sd_prev = u32x4_t{0u, 0u, 0u, 0u};
-#pragma unroll 1
-        for (int idx = tid; idx < Cfg::HALF_ROWS * U; idx += Cfg::NT) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int idx = tid + it * Cfg::NT;
             const int r = idx / U, u = idx - r * U;
             const int m = m0 + hh * Cfg::HALF_ROWS + r, n = n0o + u * 8;
             if (m >= p.M || n >= No) continue;
             u32x4_t v = *reinterpret_cast<const u32x4_t*>(smem + r * row_bytes + u * 16);
             if (resp) {
-                const u32x4_t rr = *reinterpret_cast<const u32x4_t*>(resp + (size_t)m * p.ldr + n);
                 float a[8], b[8];
-                unpack8(v, a); unpack8(rr, b);
+                unpack8(v, a); unpack8(rr[it % RD], b);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) a[e] += rs * b[e];
                 v = pack8(a);
+                if (it + RD < ITER) rr[it % RD] = res_request(hh, it + RD);
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             asm volatile("" ::"v"(sd_prev));
@@ -472,6 +494,7 @@ int vmv_gemm_xglds_launch(const VmvGemmParams& p, int total_steps, int tile, hip
         if (maxrows * (long)p.seg[i].ld * 2 >= (1L << 31) - 65536) return VMV_GLDS_UNSUPPORTED;
     if ((long)(p.N + 320) * p.ktot * 2 >= (1L << 31) - 65536) return VMV_GLDS_UNSUPPORTED;
     if (p.OH > 0 && (p.OH >= 32768 || p.OW >= 32768)) return VMV_GLDS_UNSUPPORTED;      // (oy, ox) packed in one register
+    if (p.residual && (long)p.M * p.ldr * 2 >= (1L << 31) - 65536) return VMV_GLDS_UNSUPPORTED;      // residual rows by 32-bit buffer offsets
     const int No = geglu ? p.N / 2 : p.N;
     if (p.ksplit <= 1 && (p.out_fp32 || (p.ldo & 7) || (No & 7) || !vmv_aligned16(p.out) ||
                           (p.residual && ((p.ldr & 7) || !vmv_aligned16(p.residual))))) return VMV_GLDS_UNSUPPORTED;   // staged epilogue only
