@@ -144,7 +144,8 @@ def test_fused_loop_with_clamp_and_eta_matches_oracle(monkeypatch):
     noise = torch.randn(1, 4, 4, 8, 8, generator=gen)
     y, y0 = torch.randn(1, 7, 1024, generator=gen), torch.randn(1, 7, 1024, generator=gen)
     cam = torch.randn(1, 4, 16, generator=gen)
-    step_nz = [torch.randn(1, 4, 4, 8, 8, generator=gen) for _ in range(3)]
+    n_steps = len(dif.ddim_steps(3))            # (1 + arange(0, 1000, 333) = 4 steps: the reference's stride rule)
+    step_nz = [torch.randn(1, 4, 4, 8, 8, generator=gen) for _ in range(n_steps)]
     kw = [dict(y=y.cuda(), camera_data=cam), dict(y=y0.cuda(), camera_data=cam)]
     calls = []
     real_randn_like = torch.randn_like
@@ -157,7 +158,7 @@ def test_fused_loop_with_clamp_and_eta_matches_oracle(monkeypatch):
     monkeypatch.setattr(torch, "randn_like", fake_randn_like)
     x_hip = dif.ddim_sample_loop(noise=noise.cuda(), model=m, model_kwargs=kw, guide_scale=9.0, ddim_timesteps=3, eta=0.6, clamp=2.5)
     monkeypatch.setattr(torch, "randn_like", real_randn_like)
-    assert len(calls) == 3 and hasattr(m, "forward_cfg_rows")        # the FUSED path ran (one noise draw per stochastic step)
+    assert len(calls) == n_steps and hasattr(m, "forward_cfg_rows")        # the FUSED path ran (one noise draw per stochastic step)
     tb = DDIMTables(betas_for("linear_sd"))
     trace = []
     x_ref = ddim_sample_loop(noise.clone(), lambda xt, t, y, camera_data: unet_forward(sd, ocfg, xt, t, y, camera_data),
