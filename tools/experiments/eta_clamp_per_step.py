@@ -1,3 +1,8 @@
+#!/usr/bin/env python
+"""GPU: per-step (teacher-forced) error of the fused CFG + DDIM update with the sampler options eta / clamp against the oracle loop.
+Why it exists: the free-running 4-step CFG-9 loop with a hard clamp amplifies the per-step 16-bit error to ~4e-2, which first looked like a
+formula mismatch; fed the oracle's x_t at every step the HIP step agrees to 3e-4 .. 7e-3 (tests/test_unet_gpu.py::
+test_fused_step_with_clamp_and_eta_matches_oracle asserts exactly this)."""
 import sys, os, torch, dataclasses
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle.unet_ref import UNetCfg, unet_forward
