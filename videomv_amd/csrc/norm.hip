@@ -270,6 +270,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const VmvGroupNormParams 
 // they stream in, and normalises from the stage: one launch and one read of x where the general path needs stats (+ fold)
 // + apply — at the small levels those are ~5-9 us of launch latency each for < 10 us of work.  Statistics are two-pass
 // (the data is on chip): mean first, then the squared deviations.  Fixed reduction order: bitwise reproducible.
+#ifndef VMV_GNF_UNROLL
+#define VMV_GNF_UNROLL 4      // (A/B, round 5: 8 / 16 loads in flight per lane measured 1.29 / 1.31 ms per step against 1.28: not the bound)
+#endif
 __global__ __launch_bounds__(256) void gn_fused_kernel(const VmvGroupNormParams p, const int CW) {
     VMV_KERNEL_ENTER();
     extern __shared__ __attribute__((aligned(16))) float sh[];
@@ -304,12 +307,14 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const VmvGroupNormParams 
             const uint16_t* base = first ? (x0 + c) : (x1 + (c - p.C0));
             const long ld = first ? p.ld : p.ld1;
             int r = rl;
-            for (; r + 3 * RPP < rows; r += 4 * RPP) {
-                u32x4_t v[4];
+            // GNF_UNR loads in flight per lane (more were tried: profiles/r5_gnf_unroll_ab.log)
+            constexpr int GNF_UNR = VMV_GNF_UNROLL;
+            for (; r + (GNF_UNR - 1) * RPP < rows; r += GNF_UNR * RPP) {
+                u32x4_t v[GNF_UNR];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const u32x4_t*>(base + (row0 + r + k * RPP) * ld);
+                for (int k = 0; k < GNF_UNR; ++k) v[k] = *reinterpret_cast<const u32x4_t*>(base + (row0 + r + k * RPP) * ld);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < GNF_UNR; ++k) {
                     stage[(size_t)(r + k * RPP) * SW + cs] = v[k];
                     float f[8];
                     unpack8(v[k], f);
