@@ -129,7 +129,61 @@ def cpu_baseline(frames, cores, shape, threads=None, budget=None):
     return best if best else (None, threads, None)
 
 
-def main():
+def _device_count():
+    """GPUs this process may use (VMV_BENCH_FAKE_DEVICES: the CPU test of the launcher pretends to have some)."""
+    fake = os.environ.get("VMV_BENCH_FAKE_DEVICES")
+    return int(fake) if fake else torch.cuda.device_count()
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """``python bench.py --gpus N`` with no launcher around it (WORLD_SIZE unset): start the N ranks HERE, one process per GPU, the way
+    the reference's entrance starts its workers (mp.spawn over the visible devices, inference_text2video_entrance.py:55-61) and with the
+    environment torch.distributed.run would have set (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR = 127.0.0.1 / MASTER_PORT).  Rank 0
+    prints the one JSON line on the inherited stdout.  A rank that dies takes the others down (exact PIDs, never by pattern); the exit
+    code is the first non-zero one."""
+    import subprocess
+    have = _device_count()
+    if have < n:
+        raise SystemExit(f"--gpus {n} but only {have} GPU(s) are visible to this process")
+    port = int(os.environ.get("MASTER_PORT") or _free_port())
+    script = os.path.abspath(__file__)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), VMV_BENCH_LAUNCHER="self-spawned")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # (dmabuf IPC: RCCL between processes needs it on this pool)
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env, cwd=os.getcwd(),
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        alive = list(procs)
+        while alive:
+            for p_ in list(alive):
+                code = p_.poll()
+                if code is None:
+                    continue
+                alive.remove(p_)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in alive:                       # one rank failed: the others would wait in a collective for ever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.kill()
+    return rc
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -151,20 +205,51 @@ def main():
     ap.add_argument("--no-alt-dtype", action="store_true", help="(default since round 3; kept for old command lines)")
     ap.add_argument("--alt-dtype", action="store_true", help="also time the other 16-bit element type's library in a child process "
                     "(bf16 is the range fallback — DESIGN.md §6 — and not part of the headline line)")
-    args = ap.parse_args()
+    ap.add_argument("--pg-dry-run", action="store_true", help="(launcher test) join the process group, count the ranks, print the line's "
+                    "launch fields and exit before any GPU work; VMV_BENCH_PG_BACKEND=gloo lets it run without GPUs")
+    args = ap.parse_args(argv)
     H, W = (int(v) for v in args.latent.split("x"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: be the launcher (VERDICT r5 #1 — `python bench.py --gpus 8` used to time ONE GPU and say n_gpus: 1)
+        rc = launch_ranks(args.gpus, argv)
+        if rc:
+            raise SystemExit(rc)
+        return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local)
+    backend = os.environ.get("VMV_BENCH_PG_BACKEND", "nccl")          # nccl IS RCCL on ROCm; gloo only for the launcher's CPU test
+    if backend == "nccl":
+        if _device_count() <= local:
+            raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {_device_count()} GPU(s) visible")
+        torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = None
+    dist, rccl_ranks = None, None
     if world > 1 or os.environ.get("VMV_BENCH_FORCE_PG") == "1":     # (forced at world 1 only to smoke-test the RCCL path)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        # the ranks that actually JOINED the communicator, counted by the communicator itself: one all-reduce of a 1 per rank
+        one = torch.ones(1, dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(one)
+        rccl_ranks = int(one[0])
+        if rccl_ranks != world:
+            raise SystemExit(f"process group of {world} ranks counted {rccl_ranks}")
+    launcher = os.environ.get("VMV_BENCH_LAUNCHER") or ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
+                                                        ("none (single process)" if world == 1 else "external"))
+    if args.pg_dry_run:
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "rccl_ranks": rccl_ranks, "pg_backend": backend if dist is not None else None,
+                              "launcher": launcher, "steps": args.steps, "warmup": args.warmup}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from videomv_amd import _lib
     _lib.load()      # the product path fails loudly without the HIP extension
@@ -339,6 +424,7 @@ def main():
                "weights, zero-inits re-randomised)",
                "config": {"workload": f"t2v_infer.yaml UNetSD_T2VBase 1.413B, 24 views, latent {H}x{W}, 77 ctx tokens, "
                                       f"1 sample per GPU (cond+uncond batched)", "parallelism": f"replicas x{world}"},
+               "rccl_ranks": rccl_ranks, "launcher": launcher,
                "finite": finite, "roofline": roof, "reference_shape": ref_shape}
 
     # ---- frame-parallel leg: ONE sample over all ranks (strong scaling of a sample's latency)
@@ -402,6 +488,8 @@ def main():
                           collectives_issued_by=("C plan replay (VMV_OP_COMM, RCCL)" if eng.n_comm_ops else "Python (torch.distributed) between plan segments"),
                           all_to_all_per_step=sum(1 for lb in eng.S.labels if lb.endswith(".all_to_all")) + sum(1 for i, _ in eng.breaks if eng.S.labels[i].endswith(".unpack")),
                           parallelism=f"frames x{world} (frame-major <-> pixel-major all-to-all, DESIGN.md §8)")
+            if comm._handle:         # the plan-recorded collectives' own RCCL communicator (csrc/comm.hip): ncclCommCount of it
+                common["native_rccl_ranks"] = int(L.load().vmv_comm_world(comm._handle))
             state["partial"] = dict(common, mode="single-plan", **single)
             os.environ["VMV_FP_PIPELINE"] = "1"
             piped = timed_leg("branch-pipelined")

@@ -30,7 +30,7 @@ extern "C" {
 #define VMV_ERANGE       -4   /* size outside what the kernel supports */
 #define VMV_ECOMM        -5   /* an RCCL call of vmv_comm_* failed */
 
-#define VMV_ABI_VERSION   9
+#define VMV_ABI_VERSION   10
 int vmv_abi_version(void);
 /* The 16-bit storage / MFMA operand type ("elem") this build of the library computes in.  The same sources are
  * compiled once per type: libvmv_hip_f16.so (VMV_ELEM_F16: IEEE fp16 — the default; the reference's own half mode,
@@ -403,13 +403,14 @@ int vmv_adaptive_avgpool_rows(const void* in, int ld, void* out, int ldo, int n,
  *   (S, S), mode='nearest'): source index floor(dst * S_in / S), unet_t2v.py:425-427) and
  *   (x - 0.5) / 0.5; out [V][3][S][S].
  * vmv_ddim_x0_step: x0 = u + guide * (c - u) (CFG on the two branches' latent_z), eps = (c_recip*xt - x0)/c_recipm1,
- *   xt <- sqrt(a_prev) * x0 + sqrt(1 - a_prev) * eps, in place; all [n] floats. */
+ *   x0 clamped to +-clamp when clamp > 0 (diffusion_ddim.py:204-205), xt <- sqrt(a_prev) * x0 + sqrt(1 - a_prev - sigma^2) * eps
+ *   + sigma * noise (:233-243; noise may be NULL when sigma == 0), in place; all [n] floats.  (ABI 10: clamp / sigma / noise) */
 int vmv_lgm_x0_views(const float* eps_rows, int ld, int branch, const float* xt, int C, int F, int HW, const int32_t* idx4,
                      float c_recip, float c_recipm1, float inv_scale, float* out, void* stream);
 int vmv_lgm_pack_input(const float* decoded, const float* rays, float* out, int nviews, int HW, void* stream);
 int vmv_lgm_render_to_vae(const float* images, float* out, int nviews, int S_in, int S, void* stream);
 int vmv_ddim_x0_step(const float* x0_cond, const float* x0_uncond, float* xt, long n, float guide, float c_recip,
-                     float c_recipm1, float a_prev, void* stream);
+                     float c_recipm1, float a_prev, float clamp, float sigma, const float* noise, void* stream);
 
 /* LGM Gaussian activations (core/models.py:37-43,102-112): raw fp32 rows [n][ld >= 14] -> out [n][14] =
  * (pos.clamp(-1,1) x3, sigmoid(opacity), 0.1*softplus(scale) x3, rotation x4, 0.5*tanh(rgb)+0.5 x3).  The reference applies

@@ -388,10 +388,15 @@ def lgm_render_to_vae(images, out):
     out.copy_((torch.nn.functional.interpolate(images, size=out.shape[-2:], mode="nearest") - 0.5) / 0.5)
 
 
-def ddim_x0_step(x0_cond, x0_uncond, xt, guide, c_recip, c_recipm1, a_prev):
+def ddim_x0_step(x0_cond, x0_uncond, xt, guide, c_recip, c_recipm1, a_prev, clamp=None, sigma=0.0, noise=None):
     x0 = x0_uncond + guide * (x0_cond - x0_uncond)
+    if clamp:
+        x0 = x0.clamp(-clamp, clamp)
     eps = (c_recip * xt - x0) / c_recipm1
-    xt.copy_(math.sqrt(a_prev) * x0 + math.sqrt(1 - a_prev) * eps)
+    nx = math.sqrt(a_prev) * x0 + math.sqrt(1 - a_prev - sigma * sigma) * eps
+    if sigma:
+        nx = nx + sigma * noise
+    xt.copy_(nx)
 
 
 def gaussian_activation(raw, ld, out, n, workspace):

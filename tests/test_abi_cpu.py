@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
-    assert lib.vmv_abi_version() == L.ABI_VERSION == 9
+    assert lib.vmv_abi_version() == L.ABI_VERSION == 10
 
 
 def test_struct_layouts_match_c():

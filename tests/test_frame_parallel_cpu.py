@@ -587,6 +587,55 @@ def test_lgm_branch_on_a_view_slice_equals_the_slice_of_the_whole(monkeypatch):
             assert torch.allclose(part[br], full[br][:, :, f0:f0 + n], atol=1e-5, rtol=1e-5), (f0, n, br)
 
 
+def test_lgm_refined_step_honours_clamp_and_eta(monkeypatch):
+    """``ddim_step_lgm`` dropped the x0 clamp and the stochastic term that the reference applies on EVERY step, refined ones
+    included (diffusion_ddim.py:200-205, 233-243).  The fused refined step with clamp + eta against the generic two-forward
+    ``ddim_sample`` (the reference's own structure: model(..., autoencoder=...) twice -> CFG on latent_z -> clamp -> update + sigma *
+    noise) from the same seeds: same posterior draws (cond, then uncond), then the same sigma-noise draw."""
+    from tests import plan_interp
+    plan_interp.install(monkeypatch)
+    m, vae, dif, xt, kw = _lgm_setup()
+    t = torch.full((1,), 581, dtype=torch.long)
+    outs = {}
+    for clamp, eta in ((0.35, 0.8), (None, 0.0)):
+        torch.manual_seed(21)
+        got = xt.clone()
+        dif.ddim_step_lgm(got, 581, m, kw[0], kw[1], 9.0, 20, vae, clamp=clamp, eta=eta)
+        assert torch.isfinite(got).all()
+        outs[(clamp, eta)] = got
+    torch.manual_seed(21)
+    want, _ = dif.ddim_sample(xt.clone(), t, m, vae, kw, 0.35, None, None, 9.0, 50, 0.8)
+    rel = float((outs[(0.35, 0.8)] - want).norm() / want.norm())
+    assert rel < 2e-2, rel
+    # and the options are not no-ops
+    assert float((outs[(0.35, 0.8)] - outs[(None, 0.0)]).abs().max()) > 1e-2
+
+
+def test_frame_parallel_sigma_noise_is_the_unsharded_runs_slice():
+    """frame-parallel ranks share the seed, so ``randn_like(local xt)`` gave every shard the SAME noise block.  Each rank now
+    draws the whole sample's noise and keeps its frames."""
+    from videomv_amd.diffusion_ddim import DiffusionDDIM
+
+    class _C:
+        def __init__(self, rank, world):
+            self.rank, self.world = rank, world
+
+    class _U:
+        frame_comm = None
+    xt = torch.zeros(1, 4, 2, 8, 8)
+    torch.manual_seed(4)
+    full = torch.randn(1, 4, 6, 8, 8)
+    parts = []
+    for r in range(3):
+        u = _U(); u.frame_comm = _C(r, 3)
+        torch.manual_seed(4)
+        parts.append(DiffusionDDIM._step_noise(xt, u))
+    assert torch.equal(torch.cat(parts, dim=2), full)
+    assert not torch.equal(parts[0], parts[1])
+    torch.manual_seed(4)
+    assert torch.equal(DiffusionDDIM._step_noise(full, _U()), full)
+
+
 def _lgm_fp_worker(rank, world, port, q):
     try:
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -676,9 +725,10 @@ def _lgm_cfgpar_worker(rank, world, port, q):
 def test_lgm_refined_step_cfg_parallel_two_ranks():
     """Round 5 (it raised NotImplementedError): one LGM-refined DDIM step with CFG-parallel ranks — rank 0 runs the
     conditional branch (UNet + decode + LGM U-Net + renders + re-encode), rank 1 the unconditional one; they swap their latent_z and apply
-    the CFG-on-latent_z update identically.  Statistical agreement with the single-rank step (each branch draws its own posterior
-    noise here, the unsharded pair draws both in one call: SURVEY 8d asks only for statistics on the LGM steps) and bitwise agreement
-    between the two ranks of the pair."""
+    the CFG-on-latent_z update identically.  Round 6: every rank consumes BOTH posterior draws of the unsharded run (cond,
+    then uncond) and uses its branch's, so the two groups' noises are independent and equal to the single-rank run's; what is left is the
+    16-bit rounding of a B = 1 plan against the B = 2 plan through the random-weight decode -> LGM -> render -> encode chain (the same
+    bound as the frame-parallel test above), and bitwise agreement between the two ranks of the pair."""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -690,4 +740,4 @@ def test_lgm_refined_step_cfg_parallel_two_ranks():
         p.join(timeout=60)
     for r in res:
         assert "error" not in r, r["error"]
-        assert r["finite"] and r["pair_equal"] and r["rel"] < 0.6 and r["cos"] > 0.85, r
+        assert r["finite"] and r["pair_equal"] and r["rel"] < 0.25 and r["cos"] > 0.97, r

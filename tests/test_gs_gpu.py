@@ -209,8 +209,20 @@ def test_batched_pass_equals_the_per_view_loop(monkeypatch):
     assert torch.equal(out_b["image"], out_v["image"]) and torch.equal(out_b["alpha"], out_v["alpha"])
     assert torch.equal(out_b["image"][0, 2], bg.view(3, 1, 1).expand(3, size, size)) and float(out_b["alpha"][0, 2].abs().max()) == 0.0
     assert float(out_b["alpha"][1].max()) > 0.5
-    # a call with no instance at all: every view is the background
+    # an instance total past the budget (or past int32) is refused and the views are split — per sample, then halves of a
+    # sample's views; the chunks are independent renders, so the images are the one-pass call's, bit for bit
     monkeypatch.setenv("VMV_GS_BATCH", "1")
+    monkeypatch.setenv("VMV_GS_BATCH_MAX_INSTANCES", str(max(1, n_batch // 5)))
+    out_c = r.render(gauss, cv2, cvp2, None, bg_color=bg)
+    torch.cuda.synchronize()
+    assert len(r.last_num_rendered) > 2 and sum(r.last_num_rendered) == n_batch
+    assert torch.equal(out_c["image"], out_b["image"]) and torch.equal(out_c["alpha"], out_b["alpha"])
+    monkeypatch.setenv("VMV_GS_BATCH_MAX_INSTANCES", "1")          # nothing fits, not even one view: the per-view entry points
+    out_c = r.render(gauss, cv2, cvp2, None, bg_color=bg)
+    torch.cuda.synchronize()
+    assert len(r.last_num_rendered) == 10 and torch.equal(out_c["image"], out_b["image"])
+    monkeypatch.delenv("VMV_GS_BATCH_MAX_INSTANCES")
+    # a call with no instance at all: every view is the background
     out0 = r.render(ga.cuda().unsqueeze(0), cv2[:1, 2:3].contiguous(), cvp2[:1, 2:3].contiguous(), None, bg_color=bg)
     torch.cuda.synchronize()
     assert r.last_num_rendered == [0] and torch.equal(out0["image"][0, 0], bg.view(3, 1, 1).expand(3, size, size))

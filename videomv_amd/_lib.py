@@ -53,7 +53,7 @@ TILE_X256x320, TILE_X256x256, TILE_X256x128 = 20, 21, 22
 TILE_RS, TILE_RS512, TILE_RS256, TILE_HALO, TILE_TFR = 23, 24, 25, 26, 27
 OP_GEMM, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTENTION, OP_SOFTMAX, OP_COPY, OP_GN_FUSED, OP_FF, OP_GN_TABLE, OP_COMM = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 COMM_ALL_TO_ALL, COMM_ALL_GATHER, COMM_ID_BYTES = 0, 1, 128
-ABI_VERSION = 9
+ABI_VERSION = 10
 GN_FUSED_BYTES = 131072
 
 
@@ -183,7 +183,7 @@ SYMBOLS = {
     "vmv_lgm_x0_views": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, C.c_float, C.c_float, C.c_float, _P, _P]),
     "vmv_lgm_pack_input": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
     "vmv_lgm_render_to_vae": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
-    "vmv_ddim_x0_step": (C.c_int, [_P, _P, _P, C.c_long, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
+    "vmv_ddim_x0_step": (C.c_int, [_P, _P, _P, C.c_long, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]),
     "vmv_gs_workspace_bytes": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "vmv_gs_preprocess": (C.c_int, [C.POINTER(GsParams), _P]),
     "vmv_gs_render": (C.c_int, [C.POINTER(GsParams), _P]),

@@ -399,15 +399,28 @@ class DiagonalGaussianDistribution(object):
         ops.rows_to_nchw(self.moment_rows, 2 * self.zc, out)
         return out
 
-    def sample(self, scale=1.0, parts=1, of=None):
+    def sample(self, scale=1.0, parts=1, of=None, rng_part=None):
         """parts > 1: the noise is drawn in that many consecutive host-RNG calls of n / parts images each — what the same number
         of separate encode calls would have drawn (the batched LGM branch encodes both CFG branches at once).
         of = (total, first): the n / parts images of every part are images [first, first + n / parts) of a batch of `total` — the
         noise of the WHOLE batch is drawn (same host-RNG consumption and the same numbers as the unsharded call) and this slice of it
-        used: a frame-parallel rank that encodes only its own views of the LGM branch gets the unsharded run's noise for them."""
+        used: a frame-parallel rank that encodes only its own views of the LGM branch gets the unsharded run's noise for them.
+        rng_part = (i, k): this call stands for the i-th of k consecutive encode calls of the unsharded run (CFG-parallel: a branch
+        group encodes ONE branch where the unsharded run encodes cond, then uncond): all k draws are consumed, the i-th is used."""
         per = self.n // parts if (parts > 1 and self.n % parts == 0) else self.n
         nparts = self.n // per
-        if of is not None:
+        if rng_part is not None:
+            if nparts != 1:
+                raise ValueError("rng_part stands for whole encode calls: parts must be 1")
+            i, k = int(rng_part[0]), int(rng_part[1])
+            if not 0 <= i < k:
+                raise ValueError("rng_part index outside its count")
+            total, first = (int(of[0]), int(of[1])) if of is not None else (self.n, 0)
+            if not (0 <= first and first + self.n <= total):
+                raise ValueError("posterior sample slice outside its batch")
+            draws = [torch.randn(total, self.zc, self.h, self.w) for _ in range(k)]
+            noise = draws[i][first:first + self.n].to(device=self.device)
+        elif of is not None:
             total, first = int(of[0]), int(of[1])
             if not (0 <= first and first + per <= total):
                 raise ValueError("posterior sample slice outside its batch")
@@ -501,9 +514,9 @@ class AutoencoderKL(nn.Module):
         return DiagonalGaussianDistribution(rows, n, self.ddconfig["z_channels"], eng.LH, eng.LW, x.device)
 
     @torch.no_grad()
-    def encode_firsr_stage(self, x, scale_factor=1.0, parts=1, of=None):
+    def encode_firsr_stage(self, x, scale_factor=1.0, parts=1, of=None, rng_part=None):
         """scale_factor * posterior.sample()  (autoencoder.py:86-91; the typo is the reference's public name)."""
-        return self.encode(x).sample(scale=scale_factor, parts=parts, of=of)
+        return self.encode(x).sample(scale=scale_factor, parts=parts, of=of, rng_part=rng_part)
 
     def forward(self, input, sample_posterior=True):
         raise NotImplementedError("training-time autoencoding is out of scope (inference hot path only)")

@@ -88,13 +88,17 @@ __global__ void lgm_render_to_vae_kernel(const float* __restrict__ img, float* _
 }
 
 __global__ void ddim_x0_step_kernel(const float* __restrict__ xc, const float* __restrict__ xu, float* __restrict__ xt, long n,
-                                    float guide, float cr, float crm1, float a_prev) {
+                                    float guide, float cr, float crm1, float a_prev, float clamp, float sigma,
+                                    const float* __restrict__ noise) {
     VMV_KERNEL_ENTER();
-    const float sa = sqrtf(a_prev), sb = sqrtf(1.0f - a_prev);
+    const float sa = sqrtf(a_prev), sb = sqrtf(1.0f - a_prev - sigma * sigma);   // diffusion_ddim.py:241
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const float x0 = xu[i] + guide * (xc[i] - xu[i]);
+        float x0 = xu[i] + guide * (xc[i] - xu[i]);                              // :157-160 on latent_z, x0 = out (:179-182)
+        if (clamp > 0.f) x0 = fminf(fmaxf(x0, -clamp), clamp);                   // :204-205 (applied on refined steps too)
         const float eps = (cr * xt[i] - x0) / crm1;
-        xt[i] = sa * x0 + sb * eps;
+        float nx = sa * x0 + sb * eps;
+        if (sigma > 0.f) nx += sigma * noise[i];                                 // :240-243
+        xt[i] = nx;
     }
 }
 
@@ -399,11 +403,12 @@ extern "C" int vmv_lgm_render_to_vae(const float* images, float* out, int nviews
 }
 
 extern "C" int vmv_ddim_x0_step(const float* x0_cond, const float* x0_uncond, float* xt, long n, float guide, float c_recip,
-                                float c_recipm1, float a_prev, void* stream) {
+                                float c_recipm1, float a_prev, float clamp, float sigma, const float* noise, void* stream) {
     if (!x0_cond || !x0_uncond || !xt) return VMV_ENULL;
-    if (n <= 0 || c_recipm1 == 0.0f) return VMV_EINVAL;
+    if (sigma > 0.0f && !noise) return VMV_ENULL;
+    if (n <= 0 || c_recipm1 == 0.0f || clamp < 0.0f || sigma < 0.0f || 1.0f - a_prev - sigma * sigma < 0.0f) return VMV_EINVAL;
     hipLaunchKernelGGL(ddim_x0_step_kernel, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x0_cond,
-                       x0_uncond, xt, n, guide, c_recip, c_recipm1, a_prev);
+                       x0_uncond, xt, n, guide, c_recip, c_recipm1, a_prev, clamp, sigma, noise);
     return vmv_launch_status();
 }
 

@@ -107,7 +107,6 @@ class DiffusionDDIM(object):
                     a_prev=f(self.alphas_cumprod, max(step - stride, 0)))
 
     # ------------------------------------------------------------------ fused HIP path
-    @torch.no_grad()
     def ddim_sigma(self, step: int, stride: int, eta: float) -> float:
         """sigma_t of stochastic DDIM (diffusion_ddim.py:233-236), evaluated in fp32 like the reference's ``_i`` lookups."""
         if not eta:
@@ -116,12 +115,25 @@ class DiffusionDDIM(object):
         ap = self.alphas_cumprod[max(step - stride, 0)].to(torch.float32)
         return float(eta * torch.sqrt((1 - ap) / (1 - a) * (1 - a / ap)))
 
+    @staticmethod
+    def _step_noise(xt, unet):
+        """sigma-noise of a stochastic step (diffusion_ddim.py:239).  Frame-parallel ranks share the seed: each draws the noise of the
+        WHOLE sample and keeps its own frames — independent across shards and the numbers the unsharded run draws — instead of every
+        rank drawing the same local-shape block (which would repeat one noise block in every shard)."""
+        comm = getattr(unet, "frame_comm", None)
+        if comm is None or comm.world <= 1:
+            return torch.randn_like(xt)
+        b, c, fl, h, w = xt.shape
+        full = torch.randn(b, c, fl * comm.world, h, w, dtype=xt.dtype, device=xt.device)
+        return full[:, :, comm.rank * fl:(comm.rank + 1) * fl].contiguous()
+
+    @torch.no_grad()
     def ddim_step_hip(self, xt, step, unet, cond_kwargs, uncond_kwargs, guide_scale, stride, x0_out=None, clamp=None, eta=0.0):
         t = torch.full((xt.shape[0],), int(step), dtype=torch.long, device=xt.device)
         eng, eps_rows = unet.forward_cfg_rows(xt, self._scale_timesteps(t), cond_kwargs, uncond_kwargs)
         sigma = self.ddim_sigma(int(step), stride, eta)
         # (the reference draws randn_like(xt) every step, eta = 0 included; only a stochastic step needs it here)
-        noise = torch.randn_like(xt) if sigma > 0.0 else None
+        noise = self._step_noise(xt, unet) if sigma > 0.0 else None
         ops.cfg_ddim_step(eps_rows, eng.out_pad, xt, float(guide_scale), v_pred=(self.mean_type == 'v'),
                           x0_out=x0_out, clamp=clamp, sigma=sigma, noise=noise, **self.step_scalars(int(step), stride))
         return xt
@@ -138,13 +150,18 @@ class DiffusionDDIM(object):
         return memo[1]
 
     @torch.no_grad()
-    def ddim_step_lgm(self, xt, step, unet, cond_kwargs, uncond_kwargs, guide_scale, stride, autoencoder):
+    def ddim_step_lgm(self, xt, step, unet, cond_kwargs, uncond_kwargs, guide_scale, stride, autoencoder, clamp=None, eta=0.0):
         """One LGM-refined step: each CFG branch's eps goes through predicted x0 -> 4 decoded views -> LGM Gaussians ->
         24 renders -> VAE-encoded latent_z (unet_t2v.py:404-433); CFG is applied to the two latent_z, the result is taken
-        as x0 (diffusion_ddim.py:157-160,179-182) and the DDIM update follows from it (:233-243)."""
+        as x0 (diffusion_ddim.py:157-160,179-182), clamped like any other step's x0 (:204-205), and the DDIM update with its
+        stochastic term follows from it (:233-243).  RNG order as the reference: the posterior draws of the two branches'
+        encodes (inside the model calls) come BEFORE the step's sigma-noise."""
         t = torch.full((xt.shape[0],), int(step), dtype=torch.long, device=xt.device)
         eng, eps_rows = unet.forward_cfg_rows(xt, self._scale_timesteps(t), cond_kwargs, uncond_kwargs)
         k = self.step_scalars(int(step), stride)
+        sigma = self.ddim_sigma(int(step), stride, eta)
+        upd = lambda zc, zu: ops.ddim_x0_step(zc, zu, xt, float(guide_scale), k["c_recip"], k["c_recipm1"], k["a_prev"], clamp=clamp,
+                                              sigma=sigma, noise=self._step_noise(xt, unet) if sigma > 0.0 else None)
         ref = unet.lgm_refiner(xt.device)
         comm, views, xt_all, ld = getattr(unet, "frame_comm", None), None, xt, eng.out_pad
         cfgpar = comm is not None and hasattr(comm, "exchange_branches")
@@ -167,11 +184,14 @@ class DiffusionDDIM(object):
                 both[comm.branch] = allr.view(-1)
                 kw_b = (cond_kwargs, uncond_kwargs)[comm.branch]
                 ca, cb = (k["c_sqrt_ac"], k["c_sqrt_1mac"]) if getattr(unet, "lgm_vpred", False) else (k["c_recip"], k["c_recipm1"])
+                # (host RNG: the unsharded run draws the cond branch's posterior noise, then the uncond branch's — two consecutive
+                #  draws of the whole batch; every rank consumes both and uses its branch's, so the two groups' noises are
+                #  independent and later draws sit at the unsharded run's RNG position)
                 zb = ref.latent_z(both.view(-1, ld), ld, comm.branch, xt_all, ca, cb, autoencoder, dict(kw_b["gs_data"]),
-                                  views=(comm.rank * fl, fl)).contiguous()
+                                  views=(comm.rank * fl, fl), rng_part=(comm.branch, 2)).contiguous()
                 pair = torch.empty(2, zb.numel(), dtype=zb.dtype, device=zb.device)
                 comm.exchange_branches(pair, zb.view(-1))
-                ops.ddim_x0_step(pair[0].view_as(zb), pair[1].view_as(zb), xt, float(guide_scale), k["c_recip"], k["c_recipm1"], k["a_prev"])
+                upd(pair[0].view_as(zb), pair[1].view_as(zb))
                 return xt
             loc = eps_rows.reshape(2, -1).contiguous()                                  # [branch][local rows x ld]
             allr = torch.empty(comm.world, loc.numel(), dtype=loc.dtype, device=loc.device)
@@ -187,7 +207,7 @@ class DiffusionDDIM(object):
         else:
             z = [ref.latent_z(eps_rows, ld, br, xt_all, ca, cb, autoencoder, dict(kw["gs_data"]), views=views)
                  for br, kw in enumerate((cond_kwargs, uncond_kwargs))]
-        ops.ddim_x0_step(z[0], z[1], xt, float(guide_scale), k["c_recip"], k["c_recipm1"], k["a_prev"])
+        upd(z[0], z[1])
         return xt
 
     def _saturation_probe(self, unet, xt):
@@ -242,7 +262,7 @@ class DiffusionDDIM(object):
             unet.begin_sample()                                # new sample: step-invariant conditioning is re-evaluated
         for idx, step in enumerate(steps):
             if autoencoder is not None and idx in (20, 30, 40):      # LGM-refined steps (diffusion_ddim.py:254-256)
-                self.ddim_step_lgm(xt, int(step), unet, kc, ku, guide_scale, stride, autoencoder)
+                self.ddim_step_lgm(xt, int(step), unet, kc, ku, guide_scale, stride, autoencoder, clamp=clamp, eta=eta)
             else:
                 self.ddim_step_hip(xt, int(step), unet, kc, ku, guide_scale, stride, clamp=clamp, eta=eta)
             if idx == 0:

@@ -96,7 +96,12 @@ class GaussianRenderer:
         buf["total"].copy_(buf["offsets"][B * V * N - 1:], non_blocking=True)
         torch.cuda.current_stream(device).synchronize()
         n = int(buf["total"][0])
-        self.last_num_rendered, self.last_views = [n], B * V
+        # The scan and `num_rendered` are int32.  The caller bounds B * V * N * tiles below 2^32, so a total past 2^31 - 1 shows up as a
+        # NEGATIVE count (never as a small positive one): refuse it, and refuse totals whose key / value buffers (24 B per instance,
+        # x 1.25 head-room) would pass the memory budget — the caller then splits the views.
+        if n < 0 or n > self.max_batch_instances:
+            return False
+        self.last_num_rendered.append(n)
         if n > buf["cap"]:
             cap = max(int(n * 1.25), 1 << 16)
             sb, so = C.c_size_t(0), C.c_size_t(0)
@@ -113,7 +118,26 @@ class GaussianRenderer:
         p.ranges = buf["ranges"].data_ptr()
         p.out_color, p.out_alpha = images.data_ptr(), alphas.data_ptr()
         L.check(lib.vmv_gs_batch_render(C.byref(p), _stream_ptr()), "gs_batch_render")
-        self._keep = (g, views, vps)          # (referenced by the enqueued launches)
+        self._keep.append((g, views, vps))    # (referenced by the enqueued launches)
+        return True
+
+    def _render_views(self, gaussians, cam_view, cam_view_proj, bg, images, alphas):
+        """The batched pass over as many views at a time as its 32-bit instance count and the memory budget allow: all B * V at once when
+        they fit (the VideoMV shapes: 2 x 24 views, 21 M instances), else per sample, else halves of a sample's views; a single view that
+        still does not fit goes to the per-view entry points.  Chunks are independent renders: images are those of the one-pass call."""
+        B, V = cam_view.shape[:2]
+        N, tiles = gaussians.shape[1], ((self.size + 15) // 16) ** 2
+        if B * V * N * tiles < (1 << 32) and B * V * N < (1 << 31) and B * V <= 65535:
+            if self._render_batch(gaussians, cam_view, cam_view_proj, bg, images, alphas):
+                return True
+        if B > 1:
+            return all(self._render_views(gaussians[b:b + 1], cam_view[b:b + 1], cam_view_proj[b:b + 1], bg, images[b:b + 1], alphas[b:b + 1])
+                       for b in range(B))
+        if V > 1:
+            h = V // 2
+            return all(self._render_views(gaussians, cam_view[:, a:z], cam_view_proj[:, a:z], bg, images[:, a:z], alphas[:, a:z])
+                       for a, z in ((0, h), (h, V)))
+        return False
 
     @torch.no_grad()
     def render(self, gaussians, cam_view, cam_view_proj, cam_pos=None, bg_color=None, scale_modifier=1):
@@ -127,9 +151,11 @@ class GaussianRenderer:
         bg = [1.0, 1.0, 1.0] if bg_color is None else [float(v) for v in bg_color.reshape(-1)[:3]]
         images = torch.empty(B, V, 3, S, S, dtype=torch.float32, device=device)
         alphas = torch.empty(B, V, 1, S, S, dtype=torch.float32, device=device)
-        if os.environ.get("VMV_GS_BATCH", "1") != "0" and B * V * N < (1 << 31) and B * V <= 65535:
-            self._render_batch(gaussians, cam_view, cam_view_proj, bg, images, alphas)
-            return {"image": images, "alpha": alphas}
+        self.last_num_rendered, self.last_views, self._keep = [], B * V, []
+        self.max_batch_instances = min((1 << 31) - 1, int(os.environ.get("VMV_GS_BATCH_MAX_INSTANCES", str(1 << 28))))   # 2^28 x 30 B = 8 GB
+        if os.environ.get("VMV_GS_BATCH", "1") != "0":
+            if self._render_views(gaussians, cam_view, cam_view_proj, bg, images, alphas):
+                return {"image": images, "alpha": alphas}
         buf = self._buffers(N, device)
         self.last_num_rendered, self.last_views = [], B * V
         for b in range(B):

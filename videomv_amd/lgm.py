@@ -472,7 +472,8 @@ class LgmRefiner:
         return z[0], z[1]
 
     @torch.no_grad()
-    def latent_z(self, eps_rows, ld, branch, xt, c_recip, c_recipm1, autoencoder, gs_data, scale_factor=0.18215, views=None):
+    def latent_z(self, eps_rows, ld, branch, xt, c_recip, c_recipm1, autoencoder, gs_data, scale_factor=0.18215, views=None,
+                 rng_part=None):
         """x0 = c_recip * xt - c_recipm1 * pred  (eps-prediction: sqrt(1/a), sqrt(1/a - 1); v-prediction: sqrt(a), sqrt(1-a))."""
         _, Cc, F_, h, w = xt.shape
         idxs = [0, 6, 12, 18] if F_ == 24 else [i * F_ // 4 for i in range(4)]          # unet_t2v.py:409 (F = 24)
@@ -501,5 +502,6 @@ class LgmRefiner:
         if h != w:
             raise ValueError("the LGM branch renders square views")
         ops.lgm_render_to_vae(images.contiguous(), small)
-        z = autoencoder.encode_firsr_stage(small, scale_factor, of=of)                  # [T, C, h, w]
+        kw = {} if rng_part is None else dict(rng_part=rng_part)      # (a foreign autoencoder need not know the keyword)
+        z = autoencoder.encode_firsr_stage(small, scale_factor, of=of, **kw)            # [T, C, h, w]
         return z.reshape(1, T, z.shape[1], z.shape[2], z.shape[3]).permute(0, 2, 1, 3, 4).contiguous()

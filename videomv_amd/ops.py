@@ -582,9 +582,12 @@ def lgm_render_to_vae(images, out):
             "lgm_render_to_vae")
 
 
-def ddim_x0_step(x0_cond, x0_uncond, xt, guide, c_recip, c_recipm1, a_prev):
+def ddim_x0_step(x0_cond, x0_uncond, xt, guide, c_recip, c_recipm1, a_prev, clamp=None, sigma=0.0, noise=None):
+    if noise is not None:
+        assert noise.dtype == torch.float32 and noise.is_contiguous() and noise.numel() == xt.numel()
     L.check(L.load().vmv_ddim_x0_step(x0_cond.data_ptr(), x0_uncond.data_ptr(), xt.data_ptr(), xt.numel(), float(guide),
-                                      float(c_recip), float(c_recipm1), float(a_prev), _stream_ptr()), "ddim_x0_step")
+                                      float(c_recip), float(c_recipm1), float(a_prev), float(clamp or 0.0), float(sigma), _ptr(noise),
+                                      _stream_ptr()), "ddim_x0_step")
 
 
 def gaussian_activation(raw, ld, out, n, workspace):
