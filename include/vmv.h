@@ -76,6 +76,10 @@ typedef struct {
 
 #define VMV_EPI_NONE   0
 #define VMV_EPI_GEGLU  1   /* N counts x|gate pairs interleaved in 16-column blocks; writes N/2 columns: x*gelu_erf(gate) */
+#define VMV_EPI_TATTN  2   /* q | k | v projection + per-pixel TEMPORAL attention in one launch (gemm_tqa.hip; TemporalTransformer, util.py:1043-1089,
+                              230-268): rows are (sample, frame, pixel) with geometry F, P; W = [heads][q | k | v][64][ktot] (head-major,
+                              N = 192 * heads); out[m][64 h + d] = sum_f' softmax_f'(q_h(m) . k_h(m') * epi_scale) v_h(m')[d] over the F
+                              frames m' of row m's pixel; q, k, v never reach memory.  Ask vmv_gemm_tqa_ok() first.                       */
 #define VMV_ACT_NONE   0
 #define VMV_ACT_SILU   1
 #define VMV_ACT_GELU   2   /* exact (erf) GELU: nn.GELU() of the CLIP text tower's MLP */
@@ -141,6 +145,8 @@ typedef struct {
      * vmv_groupnorm_apply(silu = 1) would have stored, with the zero padding of frames -1 / F applied AFTER the norm (as Conv3d pads
      * the normalised tensor).  Ask vmv_gemm_tfr_ok() first.  gn_silu is ignored by the row-stationary kernel (must be 0 there).    */
     int32_t gn_silu;
+    /* VMV_EPI_TATTN: the softmax scale (1 / sqrt(head_dim) = 0.125); ignored by every other epilogue.  (ABI 10) */
+    float epi_scale;
 } VmvGemmParams;
 
 #define VMV_TILE_AUTO     0
@@ -180,7 +186,14 @@ typedef struct {
                                   output channels, A staged once through registers (optional GroupNorm + SiLU on the way, gn_table / gn_silu), the
                                   three taps as row-shifted views of one LDS tile; N % 320 == 0, C % 64 == 0 */
 
+#define VMV_TILE_TQA      28   /* q | k | v projection + temporal attention (gemm_tqa.hip, VMV_EPI_TATTN only): a wave keeps all F frames of 48 / F
+                                  pixels x K = 320 in registers, W streams head-major through the LDS ring, the head's 24 x 24 attention is finished
+                                  in registers; 48 % F == 0, N = 192 * heads <= 3840, optional folded LayerNorm (colsum + ln_eps) */
+
 int vmv_gemm(const VmvGemmParams* p, void* stream);
+/* 1 if the host should record ONE VMV_EPI_TATTN launch for *p (a fused q | k | v + temporal-attention GEMM, epilogue already set)
+ * instead of the q | k | v GEMM + vmv_attention pair: the fused kernel supports the shape and its grid fills the chip */
+int vmv_gemm_tqa_ok(const VmvGemmParams* p);
 /* 1 if vmv_gemm accepts *p (rowstat ignored) with in-loop LayerNorm statistics (VmvGemmParams.ln_eps), else 0 */
 int vmv_gemm_ln_inline_ok(const VmvGemmParams* p);
 /* 1 if vmv_gemm would run *p (tile = VMV_TILE_AUTO) on the row-stationary kernel, which takes the statistics of a folded

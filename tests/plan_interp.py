@@ -89,6 +89,13 @@ def gemm(p: L.GemmParams):
         acc = (acc - mean * _view(p.colsum, N, "f32")[None, :]) * rstd
     if p.bias:
         acc = acc + _view(p.bias, N, "f32")
+    if p.epilogue == L.EPI_TATTN:      # fused q | k | v (head-major W rows) + attention over the F frames of every (sample, pixel, head)
+        heads = N // 192
+        nb = M // (p.F * p.P)
+        qkv = acc.to(L.elem()).float().view(nb, p.F, p.P, heads, 3, 64)
+        q, k, v = (qkv[..., i, :].permute(0, 2, 3, 1, 4) for i in range(3))            # [nb, P, heads, F, 64]
+        att = torch.softmax((q @ k.transpose(-1, -2)) * p.epi_scale, dim=-1)
+        acc = (att @ v).permute(0, 3, 1, 2, 4).reshape(M, heads * 64)
     if p.epilogue == L.EPI_GEGLU:
         acc = acc.view(M, N // 32, 2, 16)
         x, g = acc[:, :, 0], acc[:, :, 1]

@@ -60,6 +60,42 @@ def test_recorded_plan_matches_oracle(monkeypatch):
     assert rel_l2(eps, eps_ref) < 2e-2, rel_l2(eps, eps_ref)
 
 
+def test_fused_qkv_temporal_attention_is_recorded_and_matches_oracle(monkeypatch):
+    """Round 6: a TemporalTransformer of a K = 320 level records ONE launch per attention — q | k | v projection + the attention over the
+    frames (VMV_EPI_TATTN, csrc/gemm_tqa.hip) with the head-major weight copies — instead of the GEMM + vmv_attention pair.  A one-level
+    dim-320 network (the full model's first level, 5 heads) through the interpreter: equal to the oracle at the plan tolerance, and to
+    the two-launch plan (VMV_TQA=0) to rounding."""
+    from videomv_amd import _lib as L
+    from videomv_amd.unet_engine import UNetEngine
+    plan_interp.install(monkeypatch)
+    monkeypatch.setenv("VMV_TQA_MIN_TILES", "1")       # (the library asks for >= 96 tiles before it prefers the fused form)
+    cfg = dict(CFG, dim=320, dim_mult=[1], num_heads=5, attn_scales=[1.0])
+    ocfg = UNetCfg(**{k: v for k, v in cfg.items() if k in {f.name for f in dataclasses.fields(UNetCfg)}})
+    sd = random_state_dict(unet_param_shapes(ocfg), 31)
+    B, F_, H, W, Lc = 2, 6, 4, 4, 5
+    x, t, y, cam = _inputs(B, F_, H, W, Lc, seed=8)
+    eps_ref = unet_forward(sd, ocfg, x, t, y, cam)
+
+    def run():
+        eng = UNetEngine(cfg, sd, B, F_, H, W, Lc, torch.device("cpu"), n_t=B)
+        eng.set_context(y); eng.set_camera(cam)
+        eng.forward_rows(x, t)
+        return eng, eng.eps_ncfhw()
+    eng, eps = run()
+    fused = [(lb, p_) for lb, (op, p_) in zip(eng.S.labels, eng.S.recorded) if op == L.OP_GEMM and p_.epilogue == L.EPI_TATTN]
+    n_tt = sum(1 for blk in eng.inp + [eng.mid] + eng.outb for k, _, _ in blk if k == "tt")
+    assert len(fused) == 2 * n_tt and all(lb.endswith("qkv+attn") for lb, _ in fused)
+    assert all(p_.F == F_ and p_.P == H * W and p_.N == 960 and abs(p_.epi_scale - 0.125) < 1e-9 and p_.colsum for _, p_ in fused)
+    # no temporal vmv_attention is left: the remaining attention launches are the spatial transformers' (Nq = H W)
+    assert all(p_.Nq == H * W for (op, p_) in eng.S.recorded if op == L.OP_ATTENTION)
+    assert rel_l2(eps, eps_ref) < 2e-2, rel_l2(eps, eps_ref)
+    monkeypatch.setenv("VMV_TQA", "0")
+    eng2, eps2 = run()
+    assert not any(op == L.OP_GEMM and p_.epilogue == L.EPI_TATTN for op, p_ in eng2.S.recorded)
+    assert eng2.S.nops >= eng.S.nops + 2 * n_tt        # (+ the LayerNorm statistics launch wherever the q | k | v GEMM is not row-stationary)
+    assert rel_l2(eps, eps2) < 5e-3, rel_l2(eps, eps2)
+
+
 def test_plan_replay_is_self_contained(monkeypatch):
     """the all-frame GroupNorms add into two alternating int64 accumulator buffers and each apply pass clears only the
     OTHER one, so after an odd number of such norms (or an aborted replay) the buffer norm 0 uses is dirty.  The plan's first

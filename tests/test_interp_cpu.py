@@ -111,6 +111,35 @@ def test_attention_maps_contract():
     close(o2, ref)
 
 
+def test_fused_qkv_temporal_attention_argument_block_equals_the_two_launch_form():
+    """VMV_EPI_TATTN (vmv.h, csrc/gemm_tqa.hip): ONE GEMM argument block with the head-major weight [head][q | k | v][64] (packing.
+    qkv_head_major), geometry (F, P) and the softmax scale against the plan's two launches — folded-LayerNorm q | k | v GEMM, then the
+    temporal attention through its index maps.  Same interpreter arithmetic on both sides: equal to rounding."""
+    from videomv_amd import packing as P
+    nb, F_, Pp, heads, K = 2, 6, 7, 3, 320
+    inner, M = 64 * heads, nb * F_ * Pp
+    x = (torch.randn(M, K, generator=g(3)) * 1.3 + 0.5).to(BF)
+    w = torch.randn(3 * inner, K, generator=g(4)) * K ** -0.5
+    gamma, beta = 1 + 0.2 * torch.randn(K, generator=g(5)), 0.2 * torch.randn(K, generator=g(6))
+    wf, bf, cs = P.fold_layernorm(w, None, gamma, beta)
+    wf, bf, cs = wf.contiguous(), bf.contiguous(), cs.contiguous()
+    qkv = torch.zeros(M, 3 * inner, dtype=BF)
+    I.gemm(ops.gemm_params(M, 3 * inner, ops.linear_segs([(x, K, K)]), wf, qkv, 3 * inner, bias=bf, colsum=cs, ln_eps=1e-5))
+    two = torch.zeros(M, inner, dtype=BF)
+    mt = lambda ld: ops.seq_map(F_ * Pp * ld, ld, Pp * ld, inner=Pp)
+    base = qkv.data_ptr()
+    I.attention(ops.attn_params(base, base + 2 * inner, base + 4 * inner, two, mt(3 * inner), mt(3 * inner), mt(3 * inner), mt(inner),
+                                nb * Pp, heads, F_, F_, 0.125))
+    whm, bhm, chm = (P.qkv_head_major(t).contiguous() for t in (wf, bf, cs))
+    # the permutation: row 192 h + 64 s + d of the head-major matrix is row s * inner + 64 h + d of [q | k | v]
+    assert torch.equal(whm[192 * 1 + 64 * 2 + 5], wf[2 * inner + 64 * 1 + 5]) and torch.equal(bhm[192 * 2 + 7], bf[64 * 2 + 7])
+    one = torch.full((M, inner + 8), 3.0, dtype=BF)
+    I.gemm(ops.gemm_params(M, 3 * inner, ops.linear_segs([(x, K, K)]), whm, one, inner + 8, bias=bhm, colsum=chm, ln_eps=1e-5,
+                           epilogue=L.EPI_TATTN, epi_scale=0.125, geom=ops.Geom(F=F_, P=Pp)))
+    close(one[:, :inner], two.float(), 2e-2)
+    assert bool((one[:, inner:].float() == 3.0).all())
+
+
 def test_ff_fused_argument_block_equals_the_two_gemm_form():
     """The fused FeedForward's argument block (interleaved W1, K-permuted W2: packing.ff_down_permute) through the interpreter
     against the two-GEMM form (LayerNorm-folded GEGLU GEMM with in-kernel statistics, then the down projection with the

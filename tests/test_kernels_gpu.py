@@ -952,6 +952,97 @@ def test_gemm_rs_layernorm(M, N, K, tile):
     assert torch.equal(outs[0], outs[1])
 
 
+def _tqa_case(nb, F_, Pp, heads, ln, seed=0):
+    """Fused q | k | v projection + per-pixel temporal attention (csrc/gemm_tqa.hip, VMV_EPI_TATTN): inputs + the torch reference
+    (LayerNorm -> q, k, v = Linear -> 16-bit -> softmax(q k^T / 8) v over the F frames of every (sample, pixel, head))."""
+    K, inner = 320, 64 * heads
+    M = nb * F_ * Pp
+    x = (rnd((M, K), seed + 1, 1.2).float() + 0.7 * torch.randn(M, 1, generator=g(seed + 9))).to(BF)
+    w = torch.randn(3 * inner, K, generator=g(seed + 2)) * (1.6 * K ** -0.5)        # (scores with a real spread: |q.k| / 8 ~ 2-3)
+    if ln:
+        gamma, beta = 1 + 0.2 * torch.randn(K, generator=g(seed + 4)), 0.2 * torch.randn(K, generator=g(seed + 5))
+        wf, bf, cs = P.fold_layernorm(w, None, gamma, beta)
+        xn = torch.nn.functional.layer_norm(x.float(), (K,), gamma, beta, 1e-5)
+        qkv = (xn @ w.t()).to(BF).float()
+    else:
+        wf, bf, cs = w.to(BF).float(), None, None
+        qkv = (x.float() @ wf.t()).to(BF).float()
+    q, k, v = (t.view(nb, F_, Pp, heads, 64).permute(0, 2, 3, 1, 4) for t in qkv.split(inner, dim=1))
+    att = torch.softmax((q @ k.transpose(-1, -2)) * 0.125, dim=-1)
+    ref = (att @ v).permute(0, 3, 1, 2, 4).reshape(M, inner)
+    hm = lambda t: None if t is None else P.qkv_head_major(t)
+    return x, hm(wf), hm(bf), hm(cs), ref, qkv
+
+
+@pytest.mark.parametrize("nb,F_,Pp,heads,ln", [(2, 24, 40, 5, True), (1, 24, 37, 5, True), (2, 24, 16, 2, False), (1, 12, 50, 5, True),
+                                               (2, 16, 21, 3, True), (1, 8, 100, 1, False), (1, 48, 9, 5, True), (3, 6, 33, 4, True),
+                                               (1, 24, 1, 5, True), (2, 24, 2560, 5, True)])
+def test_gemm_tqa_fused_qkv_temporal_attention(nb, F_, Pp, heads, ln):
+    """The fused launch against torch on the same 16-bit inputs: frames per pixel 24 (the band of fragment pairs), 12 / 6 (the same
+    band, 4 / 8 pixels per wave), 16 / 8 (the diagonal), 48 (all nine pairs); pixel counts that leave the last wave / block ragged
+    (37, 21, 1) and samples whose pixel ranges straddle a wave; 1-5 heads; with and without the folded LayerNorm; the last case is the
+    first level of the 24 x 40 x 64 plan (320 blocks).  Tolerance as test_attention (P rounded to 16 bits before P.V) on top of the
+    16-bit rounding of q, k, v."""
+    x, w, b, cs, ref, _ = _tqa_case(nb, F_, Pp, heads, ln)
+    M, inner = x.shape[0], 64 * heads
+    ldo = inner + 8                                           # (a padded output row stride: the pad columns must stay untouched)
+    out = torch.full((M, ldo), 7.0, dtype=BF, device="cuda")
+    xd, wd = x.cuda(), w.to(BF).cuda()
+    gp = ops.gemm_params(M, 3 * inner, ops.linear_segs([(xd, 320, 320)]), wd, out, ldo, bias=None if b is None else b.cuda(),
+                         colsum=None if cs is None else cs.cuda(), ln_eps=1e-5 if ln else 0.0, epilogue=L.EPI_TATTN, epi_scale=0.125,
+                         geom=ops.Geom(F=F_, P=Pp))
+    S = ops.Stream(record=False)
+    assert S.lib.vmv_gemm_pick_tile(C.byref(gp)) == L.TILE_TQA and S.lib.vmv_gemm_validate(C.byref(gp)) == 0
+    S.gemm(gp, "tqa")
+    torch.cuda.synchronize()
+    check(out[:, :inner], ref, tol_l2=8e-3, tol_max=3e-2)
+    assert bool((out[:, inner:].float() == 7.0).all())
+
+
+def test_gemm_tqa_equals_the_two_kernel_form():
+    """Same inputs through the plan's two-kernel form — row-stationary q | k | v GEMM (folded LayerNorm) -> attn_short_kernel — and
+    through the fused launch: both round q, k, v and P to 16 bits at the same points, so they agree far inside the tolerance either
+    holds against fp32 torch (the dot products run over a permuted channel order: not bitwise)."""
+    nb, F_, Pp, heads = 2, 24, 96, 5
+    x, w_hm, b_hm, cs_hm, ref, _ = _tqa_case(nb, F_, Pp, heads, True, seed=40)
+    M, inner = x.shape[0], 64 * heads
+    inv = torch.argsort(torch.arange(3 * inner).view(3, heads, 64).permute(1, 0, 2).reshape(-1))     # head-major -> [q | k | v]
+    w, b, cs = w_hm[inv], b_hm[inv], cs_hm[inv]
+    xd = x.cuda()
+    S = ops.Stream(record=False)
+    qkv = torch.zeros(M, 3 * inner, dtype=BF, device="cuda")
+    S.gemm(ops.gemm_params(M, 3 * inner, ops.linear_segs([(xd, 320, 320)]), w.to(BF).cuda(), qkv, 3 * inner, bias=b.cuda(), colsum=cs.cuda(),
+                           ln_eps=1e-5), "qkv")
+    two = torch.zeros(M, inner, dtype=BF, device="cuda")
+    mp = lambda ld: ops.seq_map(F_ * Pp * ld, ld, Pp * ld, inner=Pp)
+    base = qkv.data_ptr()
+    S.attention(ops.attn_params(base, base + 2 * inner, base + 4 * inner, two, mp(3 * inner), mp(3 * inner), mp(3 * inner), mp(inner),
+                                nb * Pp, heads, F_, F_, 0.125), "attn")
+    one = torch.zeros(M, inner, dtype=BF, device="cuda")
+    S.gemm(ops.gemm_params(M, 3 * inner, ops.linear_segs([(xd, 320, 320)]), w_hm.to(BF).cuda(), one, inner, bias=b_hm.cuda(), colsum=cs_hm.cuda(),
+                           ln_eps=1e-5, epilogue=L.EPI_TATTN, epi_scale=0.125, geom=ops.Geom(F=F_, P=Pp)), "tqa")
+    torch.cuda.synchronize()
+    check(one, two.float().cpu(), tol_l2=3e-3, tol_max=1.5e-2)
+    check(one, ref, tol_l2=8e-3, tol_max=3e-2)
+
+
+def test_gemm_tqa_eligibility():
+    """VMV_EPI_TATTN has one kernel: K = 320, 48 % F == 0, N = 192 * heads; anything else is VMV_EINVAL (never a silent fallback),
+    and vmv_gemm_tqa_ok asks for a grid that fills the chip."""
+    lib = ops.Stream(record=False).lib
+    x = torch.zeros(24 * 4096, 640, dtype=BF, device="cuda")
+    w = torch.zeros(960, 640, dtype=BF, device="cuda")
+    o = torch.zeros(24 * 4096, 320, dtype=BF, device="cuda")
+
+    def mk(K=320, F_=24, Pp=4096, N=960, scale=0.125, **kw):
+        return ops.gemm_params(F_ * Pp, N, ops.linear_segs([(x, K, K)]), w, o, 320, epilogue=L.EPI_TATTN, epi_scale=scale, geom=ops.Geom(F=F_, P=Pp), **kw)
+    assert lib.vmv_gemm_validate(C.byref(mk())) == 0 and lib.vmv_gemm_tqa_ok(C.byref(mk())) == 1
+    assert lib.vmv_gemm_tqa_ok(C.byref(mk(Pp=64))) == 0 and lib.vmv_gemm_validate(C.byref(mk(Pp=64))) == 0       # supported, not preferred
+    for bad in (mk(K=640), mk(F_=20), mk(N=900), mk(scale=0.0), mk(residual=o, ldr=320), mk(tile=L.TILE_RS), mk(ksplit=2, workspace=o)):
+        assert lib.vmv_gemm_validate(C.byref(bad)) != 0
+        assert lib.vmv_gemm_tqa_ok(C.byref(bad)) == 0
+
+
 def test_gemm_rs_eligibility():
     """What the row-stationary kernel refuses when forced (VMV_EINVAL), and what the default policy sends to it."""
     import ctypes as C

@@ -42,7 +42,7 @@ def lib_path() -> str:
 
 VMV_MAX_SEGS = 24
 SEG_LINEAR, SEG_SPATIAL, SEG_TEMPORAL = 0, 1, 2
-EPI_NONE, EPI_GEGLU = 0, 1
+EPI_NONE, EPI_GEGLU, EPI_TATTN = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 TILE_AUTO, TILE_128x128, TILE_128x160, TILE_128x64, TILE_64x64, TILE_256x128, TILE_256x160 = 0, 1, 2, 3, 4, 5, 6
 TILE_G128x128, TILE_G128x160, TILE_P256x128, TILE_P256x160, TILE_PP256x128, TILE_PP256x160 = 7, 8, 9, 10, 11, 12
@@ -50,7 +50,7 @@ TILE_Q128x128, TILE_Q96x160 = 13, 14
 TILE_S256x128, TILE_S192x160, TILE_S256x160 = 15, 16, 17
 TILE_A128x160, TILE_A128x128 = 18, 19
 TILE_X256x320, TILE_X256x256, TILE_X256x128 = 20, 21, 22
-TILE_RS, TILE_RS512, TILE_RS256, TILE_HALO, TILE_TFR = 23, 24, 25, 26, 27
+TILE_RS, TILE_RS512, TILE_RS256, TILE_HALO, TILE_TFR, TILE_TQA = 23, 24, 25, 26, 27, 28
 OP_GEMM, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTENTION, OP_SOFTMAX, OP_COPY, OP_GN_FUSED, OP_FF, OP_GN_TABLE, OP_COMM = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 COMM_ALL_TO_ALL, COMM_ALL_GATHER, COMM_ID_BYTES = 0, 1, 128
 ABI_VERSION = 10
@@ -76,7 +76,7 @@ class GemmParams(C.Structure):
                 ("ksplit", C.c_int32), ("workspace", C.c_void_p),
                 ("tile", C.c_int32), ("res_scale", C.c_float), ("rowstat", C.c_void_p), ("colsum", C.c_void_p),
                 ("ln_eps", C.c_float), ("wgroup_rows", C.c_int32), ("wgroup_stride", C.c_int64),
-                ("gn_table", C.c_void_p), ("gn_rows_per_stat", C.c_int32), ("gn_silu", C.c_int32)]
+                ("gn_table", C.c_void_p), ("gn_rows_per_stat", C.c_int32), ("gn_silu", C.c_int32), ("epi_scale", C.c_float)]
 
 
 class GroupNormParams(C.Structure):
@@ -166,6 +166,7 @@ SYMBOLS = {
     "vmv_gemm_ln_inline_ok": (C.c_int, [C.POINTER(GemmParams)]),
     "vmv_gemm_rs_ok": (C.c_int, [C.POINTER(GemmParams)]),
     "vmv_gemm_tfr_ok": (C.c_int, [C.POINTER(GemmParams)]),
+    "vmv_gemm_tqa_ok": (C.c_int, [C.POINTER(GemmParams)]),
     "vmv_has_experiments": (C.c_int, []),
     "vmv_ff_fused": (C.c_int, [C.POINTER(FfParams), _P]),
     "vmv_ff_fused_ok": (C.c_int, [C.POINTER(FfParams)]),

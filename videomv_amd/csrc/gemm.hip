@@ -40,6 +40,9 @@ bool vmv_gemm_rs_preferred(const VmvGemmParams& p);
 int vmv_gemm_tfr_launch(const VmvGemmParams& p, hipStream_t st);                              // gemm_tfr.hip
 bool vmv_gemm_tfr_supported(const VmvGemmParams& p);
 bool vmv_gemm_tfr_preferred(const VmvGemmParams& p);
+int vmv_gemm_tqa_launch(const VmvGemmParams& p, hipStream_t st);                              // gemm_tqa.hip
+bool vmv_gemm_tqa_supported(const VmvGemmParams& p);
+bool vmv_gemm_tqa_preferred(const VmvGemmParams& p);
 #if defined(VMV_EXPERIMENTS)
 bool vmv_gemm_astat_eligible(const VmvGemmParams& p);
 #else
@@ -332,6 +335,7 @@ int conv_halo_policy() {
 }
 
 int pick_tile(const VmvGemmParams& p, int total_steps) {
+    if (p.epilogue == VMV_EPI_TATTN) return VMV_TILE_TQA;      // fused q | k | v + temporal attention: one kernel (vmv_gemm checks eligibility)
     if (p.tile != VMV_TILE_AUTO) return p.tile;
     const int geglu = p.epilogue == VMV_EPI_GEGLU;
     // the short-K linears of the two large levels: rows resident in registers, W streamed, outputs per column pair (gemm_rs.hip)
@@ -445,6 +449,7 @@ int final_tile(const VmvGemmParams& p, int total_steps) {
 #endif
     if (picked == VMV_TILE_HALO) return vmv_conv_halo_supported(p) ? picked : VMV_EINVAL;
     if (picked == VMV_TILE_TFR) return vmv_gemm_tfr_supported(p) ? picked : VMV_EINVAL;
+    if (picked == VMV_TILE_TQA) return vmv_gemm_tqa_supported(p) && (p.tile == VMV_TILE_AUTO || p.tile == VMV_TILE_TQA) ? picked : VMV_EINVAL;
     const bool rs_tile = picked == VMV_TILE_RS || picked == VMV_TILE_RS512 || picked == VMV_TILE_RS256;
     if (rs_tile) return vmv_gemm_rs_supported(p) ? picked : VMV_EINVAL;      // (handles rowstat / colsum / grouped weights itself)
     if (p.gn_table) return VMV_EINVAL;                                       // (a forced tile that cannot fold the GroupNorm)
@@ -501,6 +506,11 @@ extern "C" int vmv_gemm_tfr_ok(const VmvGemmParams* pp) {
     return gemm_policy() >= 2 && vmv_gemm_tfr_preferred(*pp) ? 1 : 0;
 }
 
+extern "C" int vmv_gemm_tqa_ok(const VmvGemmParams* pp) {
+    if (!pp || pp->tile != VMV_TILE_AUTO || pp->nseg <= 0 || pp->nseg > VMV_MAX_SEGS) return 0;
+    return gemm_policy() >= 2 && vmv_gemm_tqa_preferred(*pp) ? 1 : 0;
+}
+
 extern "C" int vmv_gemm_pick_tile(const VmvGemmParams* pp) {
     if (!pp || pp->nseg <= 0 || pp->nseg > VMV_MAX_SEGS) return VMV_EINVAL;
     int total_steps = 0;
@@ -541,6 +551,8 @@ extern "C" int vmv_gemm(const VmvGemmParams* pp, void* stream) {
     }
     if (ksum != p.ktot) return VMV_EINVAL;
     if (p.epilogue == VMV_EPI_GEGLU && (p.N & 31)) return VMV_EINVAL;
+    if (p.epilogue < VMV_EPI_NONE || p.epilogue > VMV_EPI_TATTN) return VMV_EINVAL;
+    if (p.epilogue == VMV_EPI_TATTN && !vmv_gemm_tqa_supported(p)) return VMV_EINVAL;
     if (p.rowvec && (p.rowvec_div <= 0 || (p.rowvec_ld & 3) || !vmv_aligned16(p.rowvec))) return VMV_EINVAL;
     if (p.residual && ((p.ldr & 3) || (((uintptr_t)p.residual) & 7))) return VMV_EALIGN;
     if (p.ksplit > 1 && (!p.workspace || !vmv_aligned16(p.workspace))) return VMV_ENULL;
@@ -612,6 +624,10 @@ extern "C" int vmv_gemm(const VmvGemmParams* pp, void* stream) {
             break;
         case VMV_TILE_TFR:
             rc = vmv_gemm_tfr_launch(p, st);
+            if (rc == VMV_GLDS_UNSUPPORTED) return VMV_EINVAL;
+            break;
+        case VMV_TILE_TQA:
+            rc = vmv_gemm_tqa_launch(p, st);
             if (rc == VMV_GLDS_UNSUPPORTED) return VMV_EINVAL;
             break;
         case VMV_TILE_HALO:

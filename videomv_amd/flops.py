@@ -5,7 +5,10 @@ from . import _lib as L
 
 
 def gemm_flops(p) -> float:
-    return 2.0 * p.M * p.N * p.ktot
+    f = 2.0 * p.M * p.N * p.ktot
+    if p.epilogue == L.EPI_TATTN:      # fused q | k | v + temporal attention: + QK^T and PV of every (pixel, head): 4 * F * F * 64 each
+        f += 4.0 * p.M * p.F * 64 * (p.N // 192)
+    return f
 
 
 def gemm_bytes(p) -> float:
@@ -21,7 +24,7 @@ def gemm_bytes(p) -> float:
         if sg.mode == L.SEG_SPATIAL and p.OH > 0:
             rows = (p.M // (p.OH * p.OW)) * p.IH * p.IW
         b += 2.0 * rows * sg.k
-    n_out = p.N // 2 if p.epilogue == L.EPI_GEGLU else p.N
+    n_out = p.N // 2 if p.epilogue == L.EPI_GEGLU else (p.N // 3 if p.epilogue == L.EPI_TATTN else p.N)
     b += 2.0 * p.N * p.ktot
     b += (4.0 if p.out_fp32 else 2.0) * p.M * n_out
     if p.residual:

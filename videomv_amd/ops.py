@@ -59,7 +59,7 @@ class Geom:
 def gemm_params(M, N, segs: Sequence[Seg], W, out, ldo, bias=None, rowvec=None, rowvec_div=1, rowvec_ld=0,
                 residual=None, ldr=0, epilogue=L.EPI_NONE, act=L.ACT_NONE, out_fp32=False, geom: Optional[Geom] = None,
                 ksplit=0, workspace=None, tile=L.TILE_AUTO, res_scale=0.0, rowstat=None, colsum=None, ln_eps=0.0, wgroup_rows=0, wgroup_stride=0,
-                gn_table=None, gn_rows_per_stat=0, gn_silu=False) -> L.GemmParams:
+                gn_table=None, gn_rows_per_stat=0, gn_silu=False, epi_scale=0.0) -> L.GemmParams:
     p = L.GemmParams()
     p.M, p.N, p.nseg = int(M), int(N), len(segs)
     if len(segs) > L.VMV_MAX_SEGS:
@@ -82,6 +82,7 @@ def gemm_params(M, N, segs: Sequence[Seg], W, out, ldo, bias=None, rowvec=None, 
     p.wgroup_rows, p.wgroup_stride = int(wgroup_rows), int(wgroup_stride)
     p.gn_table, p.gn_rows_per_stat = _ptr(gn_table), int(gn_rows_per_stat)       # GroupNorm folded into the A rows (vmv.h; gemm_rs / gemm_tfr)
     p.gn_silu = 1 if gn_silu else 0
+    p.epi_scale = float(epi_scale)                         # VMV_EPI_TATTN: softmax scale of the fused temporal attention (gemm_tqa.hip)
     return p
 
 
@@ -222,7 +223,7 @@ def make_tuner(owner):
     dropped with one warning and the built-in policy stands, instead of VMV_EINVAL on the first replay.  `owner`
     provides .device (or .dev) and keeps the split-K slab (._splitk) and the hit count (.n_tuned)."""
     def tune(p):
-        if p.tile != L.TILE_AUTO or p.wgroup_rows:
+        if p.tile != L.TILE_AUTO or p.wgroup_rows or p.epilogue == L.EPI_TATTN:      # (the fused q|k|v + attention has ONE kernel)
             return
         ent = tuned_table().get(gemm_signature(p))
         from_rule = False

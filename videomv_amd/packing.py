@@ -114,3 +114,16 @@ def check_finite_weights(w: dict, what: str):
         names = [k for (k, t), good in zip([(k, t) for k, t in w.items() if torch.is_tensor(t) and t.is_floating_point() and t.is_cuda], ok.tolist()) if not good]
         raise FloatingPointError(f"{what}: packed weights hold inf / NaN ({', '.join(names[:5])}{' ...' if len(names) > 5 else ''}) — "
                                  f"values beyond the {L.elem_name()} range?" + (" Use hip_dtype: bf16 (VMV_DTYPE=bf16)." if L.elem_name() == "fp16" else ""))
+
+
+def qkv_head_major(t: torch.Tensor, head_dim: int = 64) -> torch.Tensor:
+    """Rows (or entries) of a fused [q | k | v] projection re-ordered head-major: [head][q | k | v][head_dim] — the order in which the
+    fused projection + temporal-attention kernel (csrc/gemm_tqa.hip, VMV_EPI_TATTN) streams the weight matrix: all of one head's
+    q, k and v rows arrive together and the head's attention is finished before the next head's rows.  Works on [3 C, K] matrices and
+    on [3 C] vectors (bias, colsum)."""
+    n3 = t.shape[0]
+    inner = n3 // 3
+    heads = inner // head_dim
+    assert n3 == 3 * heads * head_dim
+    idx = torch.arange(n3).view(3, heads, head_dim).permute(1, 0, 2).reshape(-1)
+    return t[idx.to(t.device)]

@@ -252,6 +252,9 @@ class UNetEngine:
         # VMV_TCONV_FOLD (default 1): the temporal conv block's GroupNorm -> SiLU -> (3,1,1) conv with the apply pass folded into the
         # frame-resident kernel's A path (_tconv_folded, csrc/gemm_tfr.hip) wherever that kernel's tiles fill the chip
         self.tconv_fold = os.environ.get("VMV_TCONV_FOLD", "1") != "0"
+        # VMV_TQA (default 1): the TemporalTransformers' q | k | v projection + attention over the frames as ONE launch (csrc/gemm_tqa.hip,
+        # VMV_EPI_TATTN) wherever the library serves the shape (K = 320: the first level) — q, k, v never reach memory
+        self.tqa = os.environ.get("VMV_TQA", "1") != "0"
         # VMV_FP_TEMPORAL (frame-parallel plans): "switch" (default) = the TemporalTransformer runs on the pixel-major shard between two
         # all-to-all layout switches; "kv_gather" = BASELINE's north-star form — frames stay sharded, ONE all-gather of [K | V] before
         # each temporal attention (B = 1 plans, i.e. the branch-pipelined / CFG-parallel modes; 16x the bytes of the switches)
@@ -323,7 +326,7 @@ class UNetEngine:
             w[key + ".ln.bias"] = P.pack_bias(bf, dev)
             w[key + ".ln.colsum"] = P.pack_bias(cs, dev)
 
-        def tblock(p):
+        def tblock(p, temporal=False):
             for a in ("attn1", "attn2"):
                 q = sd[f"{p}.{a}.to_q.weight"]
                 k = sd[f"{p}.{a}.to_k.weight"]
@@ -334,6 +337,11 @@ class UNetEngine:
                     if not self.fold_ln:
                         w[f"{p}.{a}.qkv"] = P.pack_linear(torch.cat([q, k, v], dim=0), dev)
                     folded(f"{p}.{a}.qkv", torch.cat([q, k, v], dim=0), None, f"{p}.{nk}")
+                    if temporal and self.tqa and q.shape[1] == 320 and q.shape[0] % 64 == 0:
+                        # head-major copies for the fused projection + temporal attention (csrc/gemm_tqa.hip: K = 320 levels)
+                        for sfx in ((".ln.weight", ".ln.bias", ".ln.colsum") if self.fold_ln else ("",)):
+                            src = w[f"{p}.{a}.qkv{sfx}"]
+                            w[f"{p}.{a}.qkv.hm{sfx}"] = P.qkv_head_major(src[: 3 * q.shape[0]]).contiguous()
                 else:                          # cross-attention: Q on tokens, fused KV on the context
                     if not self.fold_ln:
                         w[f"{p}.{a}.q"] = P.pack_linear(q, dev)
@@ -389,7 +397,7 @@ class UNetEngine:
                 elif kind in ("st", "tt"):
                     norm(f"{p}.norm")
                     lin(f"{p}.proj_in"); lin(f"{p}.proj_out")
-                    tblock(f"{p}.transformer_blocks.0")
+                    tblock(f"{p}.transformer_blocks.0", temporal=(kind == "tt"))
                 elif kind == "down":
                     w[f"{p}.weight"] = P.pack_conv3x3(sd[f"{p}.op.weight"], dev)
                     w[f"{p}.bias"] = P.pack_bias(sd[f"{p}.op.bias"], dev)
@@ -729,7 +737,41 @@ class UNetEngine:
         n_outer = B * hw if temporal else B * F
         Nq = F if temporal else hw
 
+        def fused_qkv_attn(tag, x: Act, normkey):
+            """q | k | v projection + the per-pixel attention over the frames in ONE launch (csrc/gemm_tqa.hip, VMV_EPI_TATTN): q, k, v
+            never reach memory.  Where the library serves the shape (K = 320, 48 % F == 0) and its grid fills the chip."""
+            hm = f"{p}.{tag}.qkv.hm"
+            if not (temporal and not kv_gather and self.tqa and (hm + (".ln.weight" if self.fold_ln else "")) in self.w):
+                return None
+            ao = self.act(T, inner)
+            geom = ops.Geom(F=F, P=hw)
+            if self.fold_ln:
+                gp = ops.gemm_params(T, 3 * inner, ops.linear_segs([(x.ptr, x.C, x.C)]), self.w[hm + ".ln.weight"], ao.ptr, ao.C,
+                                     bias=self.w[hm + ".ln.bias"], colsum=self.w[hm + ".ln.colsum"], ln_eps=1e-5,
+                                     epilogue=L.EPI_TATTN, epi_scale=scale, geom=geom)
+                ln = None
+            else:
+                ln = self._ln(f"{p}.{tag}.qkv.ln", x, f"{p}.{normkey}")
+                gp = ops.gemm_params(T, 3 * inner, ops.linear_segs([(ln.ptr, ln.C, ln.C)]), self.w[hm], ao.ptr, ao.C,
+                                     epilogue=L.EPI_TATTN, epi_scale=scale, geom=geom)
+            if not self.S.lib.vmv_gemm_tqa_ok(C.byref(gp)):
+                self.release(ao)
+                if ln is not None:
+                    self.release(ln)      # (recorded but unused LayerNorm launch: only on the non-folded debugging configuration)
+                return None
+            self.S.gemm(gp, f"{p}.{tag}.qkv+attn")
+            if ln is not None:
+                self.release(ln)
+            return ao
+
         def self_attn(tag, x: Act, normkey) -> Act:
+            ao = fused_qkv_attn(tag, x, normkey)
+            if ao is not None:
+                y = self.act(T, inner)
+                self._gemm(f"{p}.{tag}.out", T, inner, ops.linear_segs([(ao.ptr, ao.C, ao.C)]), f"{p}.{tag}.to_out.0.weight", y,
+                           bias=self.w[f"{p}.{tag}.to_out.0.bias"], residual=x.ptr, ldr=x.C)
+                self.release(ao)
+                return y
             qkv = self.act(T, 3 * inner)
             self._ln_linear(f"{p}.{tag}.qkv", x, f"{p}.{normkey}", 3 * inner, f"{p}.{tag}.qkv", qkv)
             ao = self.act(T, inner)
