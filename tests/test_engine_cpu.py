@@ -68,7 +68,7 @@ def test_fused_qkv_temporal_attention_is_recorded_and_matches_oracle(monkeypatch
     from videomv_amd import _lib as L
     from videomv_amd.unet_engine import UNetEngine
     plan_interp.install(monkeypatch)
-    monkeypatch.setenv("VMV_TQA_MIN_TILES", "1")       # (the library asks for >= 96 tiles before it prefers the fused form)
+    monkeypatch.setenv("VMV_TQA_MIN_ITEMS", "1")       # (the library asks for >= 128 (row tile, head) items before it prefers the fused form)
     cfg = dict(CFG, dim=320, dim_mult=[1], num_heads=5, attn_scales=[1.0])
     ocfg = UNetCfg(**{k: v for k, v in cfg.items() if k in {f.name for f in dataclasses.fields(UNetCfg)}})
     sd = random_state_dict(unet_param_shapes(ocfg), 31)

@@ -976,12 +976,13 @@ def _tqa_case(nb, F_, Pp, heads, ln, seed=0):
 
 @pytest.mark.parametrize("nb,F_,Pp,heads,ln", [(2, 24, 40, 5, True), (1, 24, 37, 5, True), (2, 24, 16, 2, False), (1, 12, 50, 5, True),
                                                (2, 16, 21, 3, True), (1, 8, 100, 1, False), (1, 48, 9, 5, True), (3, 6, 33, 4, True),
-                                               (1, 24, 1, 5, True), (2, 24, 2560, 5, True)])
+                                               (1, 24, 1, 5, True), (2, 24, 2560, 5, True), (2, 24, 600, 5, True), (3, 12, 1500, 2, False)])
 def test_gemm_tqa_fused_qkv_temporal_attention(nb, F_, Pp, heads, ln):
     """The fused launch against torch on the same 16-bit inputs: frames per pixel 24 (the band of fragment pairs), 12 / 6 (the same
     band, 4 / 8 pixels per wave), 16 / 8 (the diagonal), 48 (all nine pairs); pixel counts that leave the last wave / block ragged
     (37, 21, 1) and samples whose pixel ranges straddle a wave; 1-5 heads; with and without the folded LayerNorm; the last case is the
-    first level of the 24 x 40 x 64 plan (320 blocks).  Tolerance as test_attention (P rounded to 16 bits before P.V) on top of the
+    first level of the 24 x 40 x 64 plan (320 row tiles x 5 heads dealt to 256 persistent blocks: 6-7 items each, ranges that cross a
+    row-tile boundary re-load their rows), the two after it cross tile boundaries with 1-2 items per block.  Tolerance as test_attention (P rounded to 16 bits before P.V) on top of the
     16-bit rounding of q, k, v."""
     x, w, b, cs, ref, _ = _tqa_case(nb, F_, Pp, heads, ln)
     M, inner = x.shape[0], 64 * heads
@@ -1037,7 +1038,7 @@ def test_gemm_tqa_eligibility():
     def mk(K=320, F_=24, Pp=4096, N=960, scale=0.125, **kw):
         return ops.gemm_params(F_ * Pp, N, ops.linear_segs([(x, K, K)]), w, o, 320, epilogue=L.EPI_TATTN, epi_scale=scale, geom=ops.Geom(F=F_, P=Pp), **kw)
     assert lib.vmv_gemm_validate(C.byref(mk())) == 0 and lib.vmv_gemm_tqa_ok(C.byref(mk())) == 1
-    assert lib.vmv_gemm_tqa_ok(C.byref(mk(Pp=64))) == 0 and lib.vmv_gemm_validate(C.byref(mk(Pp=64))) == 0       # supported, not preferred
+    assert lib.vmv_gemm_tqa_ok(C.byref(mk(Pp=64))) == 0 and lib.vmv_gemm_validate(C.byref(mk(Pp=64))) == 0       # supported, not preferred (4 tiles x 5 heads)
     for bad in (mk(K=640), mk(F_=20), mk(N=900), mk(scale=0.0), mk(residual=o, ldr=320), mk(tile=L.TILE_RS), mk(ksplit=2, workspace=o)):
         assert lib.vmv_gemm_validate(C.byref(bad)) != 0
         assert lib.vmv_gemm_tqa_ok(C.byref(bad)) == 0

@@ -85,38 +85,49 @@ __global__ __launch_bounds__(512, 1) void gemm_tqa_kernel(const VmvGemmParams p,
     const int F = p.F, PX = p.P;
     const int PPW = TQ_ROWS / F;                                // pixels per wave
 
+    // ---- persistent (row tile, head) items (round 6, second form).  One block per CU; the items — ntiles x heads, tile-major — are dealt
+    //      out in contiguous, equally long ranges (lengths differ by at most one item), so 320 row tiles on 256 CUs cost 7 items per CU
+    //      instead of two whole tiles = 10 (24 x 40 x 64), and 128 row tiles cost 3 instead of 5 with half the chip idle (24 x 32 x 32).
+    //      A block re-loads its rows only when its range crosses a tile boundary (at most twice more); W keeps streaming through the
+    //      ring across items: chunk c of the block is section c % 3 (q, k, v) of head (i0 + c / 3) % heads.
+    const int nblk = gridDim.x;
     int logical;
     {
         const int bid = blockIdx.x;
-        const int q = ntiles >> 3, r = ntiles & 7;
+        const int q = nblk >> 3, r = nblk & 7;
         const int xcd = bid & 7, idx = bid >> 3;
         logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int gp0 = (logical * TQ_NW + wave) * PPW;             // first (sample, pixel) index of this wave
+    const long nitems = (long)ntiles * heads;
+    const int i0 = (int)(((long)logical * nitems) / nblk), i1 = (int)(((long)(logical + 1) * nitems) / nblk);
+    const int nit = i1 - i0;                                    // >= 1 (the grid never exceeds the item count)
 
     // ---- the wave's 48 tile rows: tile row tr = 16 i + frow -> pixel gp0 + tr / F, frame tr % F -> global row (b F + f) P + pp
     const VmvGemmSeg& sg = p.seg[0];
     const int lanecol = (fgrp & 1) * 16 + (fgrp >> 1) * 8;      // after the lane swaps: this lane's 8 consecutive columns of a 32-column pair
-    uint32_t avo[RT], ovo[RT];
+    uint32_t ovo[RT];
     int qlo[RT];                                                // first tile row of the pixel that owns tile row 16 i + frow
-#pragma unroll
-    for (int i = 0; i < RT; ++i) {
-        const int tr = 16 * i + frow;
-        const int px = tr / F, f = tr - px * F;
-        const int gp = gp0 + px;
-        const bool ok = gp < npix;
-        const int b = gp / PX, pp = gp - b * PX;
-        const long m = ((long)b * F + f) * PX + pp;
-        avo[i] = ok ? (uint32_t)((m * sg.ld + 8 * fgrp) * 2) : OOB;
-        ovo[i] = ok ? (uint32_t)((m * p.ldo + lanecol) * 2) : OOB;
-        qlo[i] = px * F;
-    }
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(sg.src), 0, (uint32_t)p.M * (uint32_t)sg.ld * 2u, SRD_FLAGS);
     u32x4_t a[RT][KS];
+    auto load_tile = [&](const int tile) __attribute__((always_inline)) {                      // the rows of row tile `tile` into the registers (rows outside the tensor: zeros)
+        const int gp0 = (tile * TQ_NW + wave) * PPW;            // first (sample, pixel) index of this wave
 #pragma unroll
-    for (int i = 0; i < RT; ++i)
+        for (int i = 0; i < RT; ++i) {
+            const int tr = 16 * i + frow;
+            const int px = tr / F, f = tr - px * F;
+            const int gp = gp0 + px;
+            const bool ok = gp < npix;
+            const int b = gp / PX, pp = gp - b * PX;
+            const long m = ((long)b * F + f) * PX + pp;
+            const uint32_t avo = ok ? (uint32_t)((m * sg.ld + 8 * fgrp) * 2) : OOB;
+            ovo[i] = ok ? (uint32_t)((m * p.ldo + lanecol) * 2) : OOB;
+            qlo[i] = px * F;
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) a[i][kk] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, avo[i] + (uint32_t)(kk * 64), 0, 0);
+            for (int kk = 0; kk < KS; ++kk) a[i][kk] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, avo + (uint32_t)(kk * 64), 0, 0);
+        }
+    };
+    int cur_tile = i0 / heads;
+    load_tile(cur_tile);
 
     // ---- bias strip (the folded LayerNorm's W beta, head-major like W), then the W ring (gemm_rs.hip: swizzle (r >> 1) & 7 on the SOURCE)
     float* bias_lds = reinterpret_cast<float*>(smem + TQ_STAGES * TQ_CHUNK);
@@ -128,7 +139,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tqa_kernel(const VmvGemmParams p,
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, (uint32_t)p.N * (uint32_t)p.ktot * 2u, SRD_FLAGS);
     auto issue_chunk = [&](int c, int slot) {
         unsigned char* base = smem + slot * TQ_CHUNK + wave * (P * 1024);
-        const uint32_t so = (uint32_t)(c * TQ_CROWS * p.ktot) * 2u;
+        const int it = c / 3, hc = (i0 + it) % heads;          // chunk c = section c % 3 of the head of item i0 + c / 3
+        const uint32_t so = (uint32_t)((3 * hc + (c - 3 * it)) * TQ_CROWS * p.ktot) * 2u;
         int ln = lane;
         asm volatile("" : "+v"(ln));                           // (recomputed per chunk instead of five more live registers: gemm_rs.hip)
 #pragma unroll
@@ -139,10 +151,11 @@ __global__ __launch_bounds__(512, 1) void gemm_tqa_kernel(const VmvGemmParams p,
             VMV_BLDS16(w_rsrc, base + q * 1024, (uint32_t)(r * p.ktot + (s ^ sw) * 8) * 2u, so);
         }
     };
-    const int NC = 3 * heads;
+    const int NC = 3 * nit;
     for (int c = 0; c < TQ_STAGES; ++c) issue_chunk(c, c);       // (NC >= 3 always)
 
     // ---- LayerNorm of the resident rows (two-pass, fp32; gemm_rs.hip): the plain product with W' = W diag(gamma) follows
+    auto layernorm_rows = [&]() __attribute__((always_inline)) {        // (called twice: out of line the rows would live in scratch)
     if constexpr (LN) {
         const float inv_k = 1.0f / (float)TQ_K;
 #pragma unroll
@@ -178,6 +191,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tqa_kernel(const VmvGemmParams p,
             }
         }
     }
+    };
+    layernorm_rows();
 
     constexpr uint32_t need = NEED;
     const float sc = p.epi_scale * 1.44269504088896341f;       // exp2 domain
@@ -249,7 +264,13 @@ __global__ __launch_bounds__(512, 1) void gemm_tqa_kernel(const VmvGemmParams p,
         return u32x4_t{pack_elem2(v0.x, v0.y), pack_elem2(v0.z, v0.w), pack_elem2(v1.x, v1.y), pack_elem2(v1.z, v1.w)};
     };
 
-    for (int h = 0; h < heads; ++h) {
+    for (int it = 0; it < nit; ++it) {
+        const int tile = (i0 + it) / heads, h = (i0 + it) - tile * heads;
+        if (tile != cur_tile) {         // the range crossed into the next row tile: new rows (every MFMA on the old ones has issued; the
+            cur_tile = tile;            // compiler's own waits cover the loads; the ring's DMAs in flight are untouched)
+            load_tile(tile);
+            layernorm_rows();
+        }
         // Chunk order q, k, v.  After k: S^T, mask, softmax -> the P^T fragments (14-18 registers) and 1 / l replace q and k (48); the v
         // chunk then multiplies each pair of 16-channel v tiles into the output as soon as the pair is projected.  (k, v, q with the
         // whole attention at the end keeps q, k AND v alive next to the projection's accumulators: 119 spilled registers.)
@@ -266,7 +287,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tqa_kernel(const VmvGemmParams p,
 #pragma unroll
                 for (int i = 0; i < RT; ++i) qf[i][pr] = pack_kq(c0[i] + b0, c1[i] + b1);
             }
-            chunk_end(h > 0 ? 2 * RT : 0);
+            chunk_end(it > 0 ? 2 * RT : 0);
         }
         {   // ---- chunk 3 h + 1: k rows of W
             const unsigned char* sbase = smem + slot * TQ_CHUNK;
@@ -354,6 +375,18 @@ __global__ __launch_bounds__(512, 1) void gemm_tqa_kernel(const VmvGemmParams p,
     }
 }
 
+int tqa_ncu() {          // CUs of whole XCDs (one block per CU; gemm_rs.hip ncu_whole_xcds)
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0, n = 0;
+        if (vmv_dry_run || hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        if (n < 8) n = 8;
+        if (vmv_dry_run) return n & ~7;      // (validation without a device must not cache the guess)
+        ncu = n & ~7;
+    }
+    return ncu;
+}
+
 int tqa_policy() {
     // VMV_GEMM_TQA (A/B experiments): 1 (default) = the engine records the fused launch where it is supported, 0 = the two-kernel form
     static int pol = -1;
@@ -378,13 +411,16 @@ bool vmv_gemm_tqa_supported(const VmvGemmParams& p) {
     return true;
 }
 
+// policy: taken when the (row tile, head) items give most of the chip a block (persistent blocks, one item or more each).  Measured
+// (tools/experiments/tqa_bench.py, profiles/r6_tqa_bench.log): 102 us against 167 us for the two launches at the first level of
+// 24 x 40 x 64, 46 against 71 at 24 x 32 x 32, 24 against 54 on rank 0 of 8 (40 row tiles x 5 heads = 200 items).
 bool vmv_gemm_tqa_preferred(const VmvGemmParams& p) {
     if (!tqa_policy() || !vmv_gemm_tqa_supported(p)) return false;
     const long npix = (long)(p.M / ((long)p.F * p.P)) * p.P;
     const long tiles = (npix + TQ_NW * (TQ_ROWS / p.F) - 1) / (TQ_NW * (TQ_ROWS / p.F));
-    static long min_tiles = -1;
-    if (min_tiles < 0) { const char* e = getenv("VMV_TQA_MIN_TILES"); min_tiles = e ? atol(e) : 96; }      // (tests / A/B experiments)
-    return tiles >= min_tiles;
+    static long min_items = -1;
+    if (min_items < 0) { const char* e = getenv("VMV_TQA_MIN_ITEMS"); min_items = e ? atol(e) : 128; }      // (tests / A/B experiments)
+    return tiles * (p.N / 192) >= min_items;
 }
 
 int vmv_gemm_tqa_launch(const VmvGemmParams& p, hipStream_t st) {
@@ -393,13 +429,15 @@ int vmv_gemm_tqa_launch(const VmvGemmParams& p, hipStream_t st) {
     const int ppb = TQ_NW * (TQ_ROWS / p.F);
     const int ntiles = (npix + ppb - 1) / ppb;
     const int heads = p.N / 192;
+    const long nitems = (long)ntiles * heads;
+    const int nblk = (int)(nitems < tqa_ncu() ? nitems : tqa_ncu());
     const uint32_t need = tq_need_mask(p.F);
     const bool ln = p.colsum != nullptr;
 #define TQ_LAUNCH(LNV, NEEDV)                                                                                                            \
     do {                                                                                                                                 \
         static std::atomic<unsigned long long> attr{0};                                                                                  \
         if (const int rc = vmv_lds_attr_once(attr, reinterpret_cast<const void*>(&gemm_tqa_kernel<LNV, NEEDV>), TQ_LDS)) return rc;      \
-        VMV_LAUNCH((gemm_tqa_kernel<LNV, NEEDV>), dim3(ntiles), dim3(TQ_NT), TQ_LDS, st, p, ntiles, heads, npix);                        \
+        VMV_LAUNCH((gemm_tqa_kernel<LNV, NEEDV>), dim3(nblk), dim3(TQ_NT), TQ_LDS, st, p, ntiles, heads, npix);                          \
     } while (0)
     if (need == TQ_BAND) { if (ln) TQ_LAUNCH(true, TQ_BAND); else TQ_LAUNCH(false, TQ_BAND); }
     else if (need == TQ_DIAG) { if (ln) TQ_LAUNCH(true, TQ_DIAG); else TQ_LAUNCH(false, TQ_DIAG); }
