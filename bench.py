@@ -129,6 +129,20 @@ def cpu_baseline(frames, cores, shape, threads=None, budget=None):
     return best if best else (None, threads, None)
 
 
+def kernel_sources_sha16():
+    """sha256 (first 16 hex digits) over the HIP sources the library is built from — what a committed counter measurement is tied to:
+    `roofline.traffic` comes from profiles/*_gemm_traffic.json (PMC passes cannot run inside the timed process) and is marked stale
+    when the kernels have changed since (no .git on the GPU box: the tree's own bytes are the reference)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "videomv_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def _device_count():
     """GPUs this process may use (VMV_BENCH_FAKE_DEVICES: the CPU test of the launcher pretends to have some)."""
     fake = os.environ.get("VMV_BENCH_FAKE_DEVICES")
@@ -354,18 +368,21 @@ def main(argv=None):
         ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
         # HBM bytes per launch of the same family from the committed PMC passes of this command (tools/gemm_traffic.py;
         # FETCH_SIZE doubled as the microarch guide prescribes for gfx950) — counters cannot be read from inside the run
-        traffic, traffic_src = None, None
-        tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_gemm_traffic.json") for r in (5, 4, 3)) if os.path.exists(q)), None)
+        traffic, traffic_src, traffic_stale = None, None, None
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_gemm_traffic.json") for r in (6, 5, 4, 3)) if os.path.exists(q)), None)
         if (H, W) == (40, 64) and args.frames == 24 and tpath:
             with open(tpath) as f:
                 tj = json.load(f)
             traffic = round(tj["bytes_per_launch"])
-            traffic_src = (f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
-                           f"separate runs, commit {tj.get('commit', '?')}, dtype {tj.get('dtype', '?')})")
+            # stale = the kernels were edited after the counters were read (last bundle's number on this run's line)
+            traffic_stale = tj.get("sources_sha16") != kernel_sources_sha16()
+            traffic_src = (f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, separate runs, "
+                           f"kernel sources {tj.get('sources_sha16', 'unrecorded')}, dtype {tj.get('dtype', '?')}; per-kernel table: "
+                           f"profiles/r6_gemm_traffic_by_kernel.tsv)" + (" — STALE: the kernel sources changed since" if traffic_stale else ""))
         roof = dict(bound="mfma", kernel="16-bit MFMA implicit-GEMM family (gemm_xglds_kernel / gemm_rs_kernel / gemm_glds_kernel / gemm_pglds_kernel / gemm_kernel: "
                     "conv3x3, temporal conv, linear)",
                     achieved=round(ach, 1), peak=PEAK_MFMA16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_MFMA16_TFLOPS, 4),
-                    traffic=traffic, traffic_source=traffic_src,
+                    traffic=traffic, traffic_source=traffic_src, traffic_stale=traffic_stale,
                     algorithmic_bytes_per_launch=round(sum(gemm_bytes(p) for op, p in rec if op == L.OP_GEMM) / gm["n"]),
                     launches=gm["n"], avg_launch_us=round(1000.0 * gm["ms"] / gm["n"], 2),
                     flop_per_launch=gm["flops"] / gm["n"], families=families, serial_forward_ms=round(tot_ms, 3))

@@ -168,7 +168,7 @@ def table(ops_path, fetch_dir, write_dir, out_tsv, out_family=None):
             f.write(f"# {k}\t{n}\t{c / n / 1e6:.2f}\n")
     if out_family:
         d = dict(kernel_family="16-bit MFMA implicit-GEMM launches of one forward (per-op replay, tools/traffic_by_op.py)", shape=meta["shape"],
-                 commit=os.environ.get("VMV_COMMIT", "unknown"), dtype=os.environ.get("VMV_DTYPE", "fp16"), launches=n_g,
+                 sources_sha16=__import__("bench").kernel_sources_sha16(), dtype=os.environ.get("VMV_DTYPE", "fp16"), launches=n_g,
                  bytes_per_launch=tot_c / n_g, algorithmic_bytes_per_launch=tot_a / n_g, ratio=tot_c / tot_a,
                  correction="FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request on wide reads), WRITE_SIZE as reported")
         with open(out_family, "w") as f:
