@@ -858,7 +858,8 @@ def test_gemm_astat_plain(M, N, K, geglu, bias, tile):
 # ------------------------------------------------------------------------------------------------- row-stationary GEMM
 RS_LIN = [(1000, 960, 320, L.TILE_RS512), (300, 320, 320, L.TILE_RS256), (70000, 320, 320, L.TILE_RS512), (513, 64, 320, L.TILE_RS256),
           (1000, 1920, 640, L.TILE_RS256), (513, 640, 640, L.TILE_RS256), (40000, 640, 640, L.TILE_RS), (70001, 960, 320, L.TILE_RS),
-          (2000, 2560, 320, L.TILE_RS512), (35000, 128, 640, L.TILE_RS256)]
+          (2000, 2560, 320, L.TILE_RS512), (35000, 128, 640, L.TILE_RS256),
+          (1000, 1536, 512, L.TILE_RS256), (61440, 512, 512, L.TILE_RS), (257, 320, 512, L.TILE_RS256)]      # K = 512: the init TemporalTransformer (round 6)
 
 
 @pytest.mark.parametrize("M,N,K,tile", RS_LIN)
@@ -890,7 +891,7 @@ def test_gemm_rs_linear(M, N, K, tile, bias, res):
     assert torch.equal(dev2["out"], dev["out"])
 
 
-@pytest.mark.parametrize("M,N,K,tile", [(1000, 2560, 320, L.TILE_RS512), (300, 128, 320, L.TILE_RS256), (70000, 2560, 320, L.TILE_RS),
+@pytest.mark.parametrize("M,N,K,tile", [(1000, 2560, 320, L.TILE_RS512), (300, 128, 320, L.TILE_RS256), (70000, 2560, 320, L.TILE_RS), (5000, 4096, 512, L.TILE_RS256),
                                          (700, 5120, 640, L.TILE_RS256), (33000, 1280, 640, L.TILE_RS)])
 @pytest.mark.parametrize("ln", [False, True])
 def test_gemm_rs_geglu_layernorm(M, N, K, tile, ln):
@@ -922,7 +923,7 @@ def test_gemm_rs_geglu_layernorm(M, N, K, tile, ln):
     check(out, a * torch.nn.functional.gelu(gate), tol_l2=6e-3, tol_max=2e-2)
 
 
-@pytest.mark.parametrize("M,N,K,tile", [(1000, 960, 320, L.TILE_RS512), (70000, 960, 320, L.TILE_RS), (61, 1920, 640, L.TILE_RS256),
+@pytest.mark.parametrize("M,N,K,tile", [(1000, 960, 320, L.TILE_RS512), (70000, 960, 320, L.TILE_RS), (61, 1920, 640, L.TILE_RS256), (3000, 1536, 512, L.TILE_RS256),
                                          (31000, 1920, 640, L.TILE_RS), (300, 320, 320, L.TILE_RS256)])
 def test_gemm_rs_layernorm(M, N, K, tile):
     """y = Linear(LayerNorm(x)) on the row-stationary kernel: statistics and normalisation from the resident rows (no rowstat;

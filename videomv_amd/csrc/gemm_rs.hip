@@ -1,5 +1,5 @@
 // gemm_rs.hip — ROW-STATIONARY implicit GEMM for the short-K linears of the transformer blocks (same contract as gemm.hip /
-// vmv.h; K = 320 / 640 = the channel counts of the UNet's two large levels).
+// vmv.h; K = 320 / 640 = the channel counts of the UNet's two large levels, and K = 512 = the init TemporalTransformer's 8 x 64 heads).
 //
 // Why: at K = C the tile kernels spend a tile's life outside their main loop.  A 256 x 128 tile of the K = 320 GEGLU is five
 // 64-deep chunks: per chunk the CU's LDS-DMA path moves 48 KB (A + W) for 1 k cycles of MFMAs, the epilogue is as long as
@@ -34,11 +34,11 @@ struct RsCfg {
     static constexpr int K = KS * 32;
     static constexpr int RB = K * 2;                           // bytes per W row
     static constexpr int SPR = RB / 16;                        // 16-byte slots per W row (40 / 80)
-    static constexpr int CHUNK_BYTES = 40960;
+    static constexpr int CHUNK_BYTES = KS == 16 ? 32768 : 40960;   // whole W rows: 64 x 640 B, 32 x 1280 B, 32 x 1024 B (K = 512: round 6)
     static constexpr int CROWS = CHUNK_BYTES / RB;             // W rows per chunk (64 / 32)
     static constexpr int G = CROWS / 16;                       // 16-row W tiles per chunk (4 / 2)
     static constexpr int STAGES = 3;
-    static constexpr int PIECES = CHUNK_BYTES / 1024 / NW;     // LDS-DMA wave-instructions per wave per chunk (5)
+    static constexpr int PIECES = CHUNK_BYTES / 1024 / NW;     // LDS-DMA wave-instructions per wave per chunk (5; 4 at K = 512)
     static constexpr int MAX_COLS = 5120;                      // W rows one block walks (bias strip: 20 KB)
     static constexpr int TAB_BYTES = 2 * 2 * K * 4;            // folded GroupNorm: (scale | shift)[K] fp32 of the two stat groups a block can touch
     static constexpr int LDS_BYTES = STAGES * CHUNK_BYTES + MAX_COLS * 4 + TAB_BYTES;
@@ -477,7 +477,7 @@ bool rs_plan(const VmvGemmParams& p, int force_rt, RsPlan& best, int ncu) {
     if (ns_env < 0) { const char* e = getenv("VMV_RS_NSPLIT"); ns_env = e ? atoi(e) : 0; }
     for (int rt = 4; rt >= 2; rt -= 2) {
         if (force_rt && rt != force_rt) continue;
-        if (K == 640 && rt != 2) continue;
+        if ((K == 640 || K == 512) && rt != 2) continue;
         const int bm = 128 * rt;
         const long tm = (p.M + bm - 1) / bm;
         for (int ns = 1; ns <= 8; ns *= 2) {
@@ -525,7 +525,7 @@ int launch_rs_mode(const VmvGemmParams& p, const RsPlan& pl, int mode, hipStream
 // needed and, with ln_eps given, ignored).
 bool vmv_gemm_rs_supported(const VmvGemmParams& p) {
     if (p.nseg != 1 || p.seg[0].mode != VMV_SEG_LINEAR || p.seg[0].k != p.ktot) return false;
-    if (p.ktot != 320 && p.ktot != 640) return false;
+    if (p.ktot != 320 && p.ktot != 640 && p.ktot != 512) return false;
     if (p.ksplit > 1 || p.out_fp32 || p.rowvec || p.act != VMV_ACT_NONE || p.wgroup_rows != 0) return false;
     if (p.N % 64) return false;
     const bool geglu = p.epilogue == VMV_EPI_GEGLU;
@@ -564,5 +564,6 @@ int vmv_gemm_rs_launch(const VmvGemmParams& p, int tile, hipStream_t st) {
     if (!rs_plan(p, force_rt, pl, ncu_whole_xcds())) return VMV_GLDS_UNSUPPORTED;
     const int mode = (p.epilogue == VMV_EPI_GEGLU ? RS_GEGLU : 0) | (p.colsum ? RS_LN : 0) | (p.residual ? RS_RES : 0) | (p.gn_table ? RS_GN : 0);
     if (p.ktot == 320) return pl.rt == 4 ? launch_rs_mode<4, 10>(p, pl, mode, st) : launch_rs_mode<2, 10>(p, pl, mode, st);
+    if (p.ktot == 512) return launch_rs_mode<2, 16>(p, pl, mode, st);      // (the init TemporalTransformer: 8 heads x 64 on a 320-channel level)
     return launch_rs_mode<2, 20>(p, pl, mode, st);
 }
