@@ -16,3 +16,5 @@ done
 cd $R
 python -m pytest tests/test_unet_gpu.py -x -q -k "golden or full_size_reference or tiny" > $O/r6_gn_unet_tests.log 2>&1; tail -2 $O/r6_gn_unet_tests.log
 python tools/experiments/rs512_bench.py > $O/r6_rs512_bench.log 2>&1; cat $O/r6_rs512_bench.log
+for e in "VMV_XGLDS_GM=1 VMV_GLDS_GM=1" "VMV_XGLDS_GM=-1"; do env $e python tools/experiments/groupm_bench.py; done > $O/r6_groupm_bench.log 2>&1; cat $O/r6_groupm_bench.log
+bash tools/experiments/run_env_ab2.sh "VMV_XGLDS_GM=1 VMV_GLDS_GM=1" "VMV_XGLDS_GM=-1" > $O/r6_groupm_step_ab.log 2>&1; cat $O/r6_groupm_step_ab.log

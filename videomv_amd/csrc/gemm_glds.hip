@@ -23,7 +23,7 @@ namespace {
 
 template <int WMW, int WN, int STAGES, int ablate, bool PP = false>
 __global__ __launch_bounds__(128 * WMW, WMW == 2 ? 2 : 1) void gemm_glds_kernel(const VmvGemmParams p, const int tiles_m, const int tiles_n,
-                                                              const int total_steps, const int steps_per_split) {
+                                                              const int total_steps, const int steps_per_split, const int gm) {
     VMV_KERNEL_ENTER();
     // ablate (experiments only, VMV_GEMM_ABLATE): 1 = skip the MFMAs + fragment reads, 2 = skip the LDS-DMA loads
     using Cfg = GlCfg<WMW, WN, STAGES>;
@@ -48,8 +48,17 @@ __global__ __launch_bounds__(128 * WMW, WMW == 2 ? 2 : 1) void gemm_glds_kernel(
         const int xcd = bid & 7, idx = bid >> 3;
         logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tile_n = logical % tiles_n;
-    const int tile_m = logical / tiles_n;
+    // grouped order (round 6; gemm_xglds.hip): gm row tiles x 32 / gm column tiles run together on an XCD, so its L2 serves each W
+    // slice to gm row tiles instead of one (gm = 1: the N tiles of one row tile adjacent, as before)
+    int tile_m, tile_n;
+    if (gm > 1) {
+        const int gsz = gm * tiles_n, g = logical / gsz, first = g * gm;
+        const int gmh = tiles_m - first < gm ? tiles_m - first : gm;
+        const int rem = logical - g * gsz;
+        tile_n = rem / gmh; tile_m = first + (rem - tile_n * gmh);
+    } else {
+        tile_n = logical % tiles_n; tile_m = logical / tiles_n;
+    }
     const int m0 = tile_m * GL_BM, n0 = tile_n * BN;
     const int split = blockIdx.y;
     const int step_begin = split * steps_per_split;
@@ -437,6 +446,23 @@ __global__ __launch_bounds__(128 * WMW, WMW == 2 ? 2 : 1) void gemm_glds_kernel(
     }
 }
 
+// rows of the tile group that shares W slices in an XCD's L2 (gemm_xglds.hip xglds_group_m; `conc` = blocks an XCD runs at once:
+// 32 CUs x 1 or 2 blocks).  VMV_GLDS_GM forces it (A/B; 1 = the round-5 order).
+int glds_group_m(int tiles_m, int tiles_n, int BM, int BN, int conc) {
+    static int env = -2;
+    if (env == -2) { const char* e = getenv("VMV_GLDS_GM"); env = e ? atoi(e) : -1; }
+    if (env >= 1) return env;
+    if (tiles_n < 2 || tiles_m < 2) return 1;
+    int best = 1, best_cost = BM + conc * BN;
+    for (int gm = 2; gm <= conc; gm *= 2) {
+        const int gn = (conc + gm - 1) / gm;
+        if (gn > tiles_n || gm > tiles_m) continue;
+        const int cost = gm * BM + gn * BN;
+        if (cost < best_cost) { best = gm; best_cost = cost; }
+    }
+    return best;
+}
+
 template <int WMW, int WN, int STAGES, bool PP = false>
 int launch_glds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
     using Cfg = GlCfg<WMW, WN, STAGES>;
@@ -449,12 +475,13 @@ int launch_glds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
     static int ablate = -1;
     if (ablate < 0) { const char* e = getenv("VMV_GEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
     dim3 grid(tiles_m * tiles_n, ks, 1);
+    const int gm = glds_group_m(tiles_m, tiles_n, Cfg::BM, Cfg::BN, WMW == 2 ? 64 : 32);
     auto go = [&](auto tag) -> int {
         constexpr int AB = decltype(tag)::value;
         static std::atomic<unsigned long long> attr_set{0};
         if (const int rc_attr = vmv_lds_attr_once(attr_set, reinterpret_cast<const void*>(&gemm_glds_kernel<WMW, WN, STAGES, AB, PP>), Cfg::LDS_BYTES)) return rc_attr;
         VMV_LAUNCH((gemm_glds_kernel<WMW, WN, STAGES, AB, PP>), grid, dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n,
-                           total_steps, sps);
+                           total_steps, sps, gm);
         return VMV_OK;
     };
     int rc;

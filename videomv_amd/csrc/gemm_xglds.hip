@@ -69,7 +69,7 @@ constexpr int XE_GEGLU = 1, XE_LN = 2;       // EPI bits
 // 256-row wide tiles on their own (the fourth UNet level, a frame-parallel rank's M / 8 rows) without falling back to 128-row tiles.
 template <int NH, int WH, int EPI = 0, bool SK = false>
 __global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams p, const int tiles_m, const int tiles_n, const int nsteps_arg,
-                                                            const int nsteps_total) {
+                                                            const int nsteps_total, const int gm) {
     VMV_KERNEL_ENTER();
     using Cfg = WgCfg<NH, WH>;
     constexpr int WM = Cfg::WM, WN = Cfg::WN, NW = Cfg::NW, BM = Cfg::BM, BN = Cfg::BN, S = Cfg::STAGES;
@@ -89,7 +89,21 @@ __global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams 
         const int xcd = bid & 7, idx = bid >> 3;
         logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int m0 = (logical / tiles_n) * BM, n0 = (logical % tiles_n) * BN;
+    // Round 6 — which tiles run TOGETHER on an XCD decides what its 4-MB L2 can share.  With the N tiles of one row tile adjacent, the
+    // 32 CUs of an XCD work on ONE row tile and 32 different W slices: A is shared, every W slice streams in from the fabric once PER
+    // ROW TILE (profiles/r6_gemm_traffic_by_kernel.tsv: the 7680 x 10240 x 1280 GEGLU fetches 834 MB for 46 MB of operands = W x 30 row
+    // tiles).  Grouped order (gm > 1): consecutive logical ids walk gm row tiles, then the next N tile — 32 concurrent blocks cover
+    // gm row tiles x 32 / gm column tiles, so a W slice is fetched once per gm row tiles and an A slice once per 32 / gm column tiles.
+    int tm_, tn_;
+    if (gm > 1) {
+        const int gsz = gm * tiles_n, g = logical / gsz, first = g * gm;
+        const int gmh = tiles_m - first < gm ? tiles_m - first : gm;
+        const int rem = logical - g * gsz;
+        tn_ = rem / gmh; tm_ = first + (rem - tn_ * gmh);
+    } else {
+        tm_ = logical / tiles_n; tn_ = logical - tm_ * tiles_n;
+    }
+    const int m0 = tm_ * BM, n0 = tn_ * BN;
 
     // ---- loader.  A wave instruction covers 16 rows x 64 B; lane -> (row in group = lane >> 2, physical 16-B slot = lane & 3).
     //      Row r keeps logical k-slot s at s ^ T[(r >> 2) & 3], T = {0, 2, 3, 1}: ds_read_b128 serves a wave in four groups
@@ -440,11 +454,29 @@ __global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams 
     }
 }
 
+// rows of the tile group that shares W slices in an XCD's L2 (kernel header): minimises the bytes 32 concurrent blocks pull in,
+// gm x BM + 32 / gm x BN per K chunk, with 32 / gm <= the N tiles there are; 1 = the round-5 order.  VMV_XGLDS_GM forces it (A/B).
+int xglds_group_m(int tiles_m, int tiles_n, int BM, int BN) {
+    static int env = -2;
+    if (env == -2) { const char* e = getenv("VMV_XGLDS_GM"); env = e ? atoi(e) : -1; }
+    if (env >= 1) return env;
+    if (tiles_n < 2 || tiles_m < 2) return 1;
+    int best = 1, best_cost = BM + 32 * BN;
+    for (int gm = 2; gm <= 32; gm *= 2) {
+        const int gn = (32 + gm - 1) / gm;
+        if (gn > tiles_n || gm > tiles_m) continue;
+        const int cost = gm * BM + gn * BN;
+        if (cost < best_cost) { best = gm; best_cost = cost; }
+    }
+    return best;
+}
+
 template <int NH, int WH, int EPI = 0>
 int launch_xglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
     using Cfg = WgCfg<NH, WH>;
     const int tiles_m = (p.M + Cfg::BM - 1) / Cfg::BM;
     const int tiles_n = (p.N + Cfg::BN - 1) / Cfg::BN;
+    const int gm = xglds_group_m(tiles_m, tiles_n, Cfg::BM, Cfg::BN);
     int nsteps = 0;                                          // chunks of WBK = 32 (total_steps counts the other kernels' 64)
     for (int i = 0; i < p.nseg; ++i) nsteps += (p.seg[i].k + WBK - 1) / WBK;
     (void)total_steps;
@@ -461,13 +493,13 @@ int launch_xglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
             static std::atomic<unsigned long long> attr_sk{0};
             if (const int rc_attr = vmv_lds_attr_once(attr_sk, reinterpret_cast<const void*>(&gemm_xglds_kernel<NH, WH, 0, true>), Cfg::LDS_BYTES)) return rc_attr;
             VMV_LAUNCH((gemm_xglds_kernel<NH, WH, 0, true>), dim3(tiles_m * tiles_n, p.ksplit), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n,
-                               sps, nsteps);
+                               sps, nsteps, gm);
             return vmv_launch_status();
         }
     }
     static std::atomic<unsigned long long> attr_set{0};
     if (const int rc_attr = vmv_lds_attr_once(attr_set, reinterpret_cast<const void*>(&gemm_xglds_kernel<NH, WH, EPI>), Cfg::LDS_BYTES)) return rc_attr;
-    VMV_LAUNCH((gemm_xglds_kernel<NH, WH, EPI>), dim3(tiles_m * tiles_n), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n, nsteps, nsteps);
+    VMV_LAUNCH((gemm_xglds_kernel<NH, WH, EPI>), dim3(tiles_m * tiles_n), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n, nsteps, nsteps, gm);
     return vmv_launch_status();
 }
 
