@@ -164,7 +164,7 @@ def launch_ranks(n, argv):
     code is the first non-zero one."""
     import subprocess
     have = _device_count()
-    if have < n:
+    if have < n and os.environ.get("VMV_BENCH_SHARE_GPU") != "1":
         raise SystemExit(f"--gpus {n} but only {have} GPU(s) are visible to this process")
     port = int(os.environ.get("MASTER_PORT") or _free_port())
     script = os.path.abspath(__file__)
@@ -235,11 +235,17 @@ def main(argv=None):
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     backend = os.environ.get("VMV_BENCH_PG_BACKEND", "nccl")          # nccl IS RCCL on ROCm; gloo only for the launcher's CPU test
-    if backend == "nccl":
+    # VMV_BENCH_SHARE_GPU=1 (with the gloo backend): every rank on device 0, collectives staged through the host (comm.FrameComm) — the
+    # whole N > 1 flow (launcher, replica timing, frame-parallel legs) smoke-tested on a ONE-GPU box; never a measurement
+    share_gpu = os.environ.get("VMV_BENCH_SHARE_GPU") == "1" and backend == "gloo"
+    if share_gpu:
+        local = 0
+    if backend == "nccl" or share_gpu:
         if _device_count() <= local:
             raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {_device_count()} GPU(s) visible")
         torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = dev if backend == "nccl" else torch.device("cpu")          # where the bench's own small collectives live
     dist, rccl_ranks = None, None
     if world > 1 or os.environ.get("VMV_BENCH_FORCE_PG") == "1":     # (forced at world 1 only to smoke-test the RCCL path)
         import torch.distributed as dist
@@ -311,7 +317,7 @@ def main(argv=None):
     fence()
     dt = time.perf_counter() - t0
     from videomv_amd.dist import max_over_ranks
-    dt = max_over_ranks(dt, dev)                 # the slowest rank defines the job time (no-op at N = 1)
+    dt = max_over_ranks(dt, cdev)                # the slowest rank defines the job time (no-op at N = 1)
     finite = bool(torch.isfinite(xt).all())
     steps_per_s = world * args.steps / dt
     ms_per_step = 1000.0 * dt / args.steps
@@ -441,7 +447,7 @@ def main(argv=None):
                "weights, zero-inits re-randomised)",
                "config": {"workload": f"t2v_infer.yaml UNetSD_T2VBase 1.413B, 24 views, latent {H}x{W}, 77 ctx tokens, "
                                       f"1 sample per GPU (cond+uncond batched)", "parallelism": f"replicas x{world}"},
-               "rccl_ranks": rccl_ranks, "launcher": launcher,
+               "rccl_ranks": rccl_ranks, "launcher": launcher, "pg_backend": (backend + (" (ranks share GPU 0: smoke test, not a measurement)" if share_gpu else "")) if dist is not None else None,
                "finite": finite, "roofline": roof, "reference_shape": ref_shape}
 
     # ---- frame-parallel leg: ONE sample over all ranks (strong scaling of a sample's latency)
@@ -487,7 +493,7 @@ def main(argv=None):
                     dif.ddim_step_hip(xs, steps[(args.warmup + i) % len(steps)], model, kc, ku, 9.0, stride)
                 fence()
                 dtf = time.perf_counter() - t0
-                tt = torch.tensor([dtf], device=dev)
+                tt = torch.tensor([dtf], device=cdev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 dtf = float(tt[0])
                 r = dict(steps_per_s=round(args.steps / dtf, 4), ms_per_step=round(1000.0 * dtf / args.steps, 3),

@@ -588,7 +588,7 @@ def test_tuned_table_matches_the_full_size_plans(monkeypatch):
     sigs = lambda e: {ops.gemm_signature(p) for op, p in e.S.recorded if op == L.OP_GEMM}
     # (round 5: the fill rule is the default and the table holds only what it does not reproduce — n_ruled counts the rule's launches)
     tot = lambda e: e.n_tuned + getattr(e, "n_ruled", 0)
-    assert e64.S.nops == 769 and tot(e64) >= 80 and tot(e32) >= 200 and tot(e8) >= 150, [(e.n_tuned, getattr(e, "n_ruled", 0)) for e in (e64, e32, e8)]
+    assert e64.S.nops == 766 and tot(e64) >= 80 and tot(e32) >= 200 and tot(e8) >= 150, [(e.n_tuned, getattr(e, "n_ruled", 0)) for e in (e64, e32, e8)]
     assert all(getattr(e, "n_stale", 0) == 0 for e in (e64, e32, e8))       # no entry of the packaged table is refused by the library
     for tag, eng in (("world1 40x64", e64), ("world1 32x32", e32), ("world8 rank0 B=2 40x64", e8)):
         mine = {k for k, v in tab.items() if v["plan"] == tag}

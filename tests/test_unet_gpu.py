@@ -25,7 +25,7 @@ pytestmark = pytest.mark.gpu
 from videomv_amd import _lib as _L  # noqa: E402
 FP16 = _L.elem_name() == "fp16"
 TOL_FWD, TOL_BLOCK, TOL_X0 = (1e-2, 5e-3, 2e-2) if FP16 else (3e-2, 3e-2, 6e-2)
-PLAN_LAUNCHES_40x64 = 769                # recorded launches of one [cond|uncond] forward (round 6: the 10 q|k|v + temporal-attention pairs of the first level's TemporalTransformers are ONE launch each, csrc/gemm_tqa.hip; shared CFG prefix, 67 one-launch GroupNorms — the 5 of the second level's spatial transformers became statistics + table for the GroupNorm fold into proj_in —, the accumulator-clearing copy; the 60 LayerNorm statistics launches of the two large levels went into gemm_rs; + 16 context K/V GEMMs once per sample) — DESIGN.md §5
+PLAN_LAUNCHES_40x64 = 766                # recorded launches of one [cond|uncond] forward (round 6: the init TemporalTransformer's K = 512 linears run row-stationary with in-kernel LayerNorm statistics (-3 launches); the 10 q|k|v + temporal-attention pairs of the first level's TemporalTransformers are ONE launch each, csrc/gemm_tqa.hip; shared CFG prefix, 67 one-launch GroupNorms — the 5 of the second level's spatial transformers became statistics + table for the GroupNorm fold into proj_in —, the accumulator-clearing copy; the 60 LayerNorm statistics launches of the two large levels went into gemm_rs; + 16 context K/V GEMMs once per sample) — DESIGN.md §5
 TOL_AUX = 5e-3 if FP16 else 2.5e-2          # VAE decode / encode, LGM Gaussians (not stated by §8d; same per-block bound)
 
 

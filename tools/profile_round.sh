@@ -3,7 +3,7 @@
 # separate PMC passes; summaries land in gpurun_out/ and are copied to profiles/ by hand.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
-RN=${RN:-r5}      # round tag of the output files; VMV_COMMIT (git hash of the submitted tree) is recorded in the traffic JSON
+RN=${RN:-r6}      # round tag of the output files; VMV_COMMIT (git hash of the submitted tree) is recorded in the traffic JSON
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py"
 P="--no-cpu-baseline --no-sample --no-op-profile --simulate-rank 0"
@@ -18,12 +18,19 @@ python tools/prof_summary.py $O/prof_fetch $O/${RN}_pmc_fetch.txt
 python tools/prof_summary.py $O/prof_write $O/${RN}_pmc_write.txt
 python tools/prof_summary.py $O/prof_mfma $O/${RN}_pmc_mfma.txt
 python tools/prof_summary.py $O/prof_lds $O/${RN}_pmc_lds.txt
-python tools/gemm_traffic.py $O/prof_fetch $O/prof_write $O/${RN}_gemm_traffic.json
+# HBM traffic per GEMM launch, attributed per (kernel, op kind, shape): the plan replayed op by op under the two counters (round 6;
+# tools/traffic_by_op.py — the family figure bench.py reports comes from the same passes)
+cd /tmp
+rocprofv3 --pmc FETCH_SIZE -f csv -d $O/tb_fetch -- python $R/tools/traffic_by_op.py run $O/${RN}_traffic_ops.json > $O/tb_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -f csv -d $O/tb_write -- python $R/tools/traffic_by_op.py run $O/${RN}_traffic_ops.json > $O/tb_write.log 2>&1
+cd $R
+python tools/traffic_by_op.py table $O/${RN}_traffic_ops.json $O/tb_fetch $O/tb_write $O/${RN}_gemm_traffic_by_kernel.tsv $O/${RN}_gemm_traffic.json
+rm -rf $O/tb_fetch $O/tb_write
 # the bench lines come last: roofline.traffic is read from profiles/${RN}_gemm_traffic.json, i.e. from THIS run's PMC passes
 cp $O/${RN}_gemm_traffic.json $R/profiles/${RN}_gemm_traffic.json
 cd /tmp
 $B > $O/${RN}_bench_40x64.json 2> $O/bench_full.err
-$B --latent 32x32 --no-cpu-baseline --no-sample --simulate-rank 0 > $O/${RN}_bench_32x32.json 2>> $O/bench_full.err
+$B --latent 32x32 --no-cpu-baseline --no-sample --simulate-rank 0 --dump-ops $O/${RN}_ops_32x32.tsv > $O/${RN}_bench_32x32.json 2>> $O/bench_full.err
 $B --no-cpu-baseline --no-sample --simulate-rank 8 --dump-ops $O/${RN}_ops_40x64.tsv --dump-ops-sim $O/${RN}_ops_sim_rank0of8.tsv > $O/${RN}_bench_sim8.json 2>> $O/bench_full.err
 for w in 2 4; do $B --no-cpu-baseline --no-sample --no-op-profile --simulate-rank $w > $O/${RN}_bench_sim$w.json 2>> $O/bench_full.err; done
 python tools/kernel_resources.py > $O/${RN}_kernel_resources.txt 2>/dev/null || true

@@ -3,8 +3,6 @@
 // wave-shuffle + LDS reductions; partial sums are written per chunk and reduced in a fixed order, or (long stat groups)
 // added to 64-bit fixed-point integer accumulators — either way results are bitwise reproducible run to run.
 #include "common.h"
-#include "gemm_glds_common.h"      // LDS-DMA helper (the one-launch GroupNorm stages its slab with it)
-#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -273,9 +271,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const VmvGroupNormParams 
 // + apply — at the small levels those are ~5-9 us of launch latency each for < 10 us of work.  Statistics are two-pass
 // (the data is on chip): mean first, then the squared deviations.  Fixed reduction order: bitwise reproducible.
 #ifndef VMV_GNF_UNROLL
-#define VMV_GNF_UNROLL 4      // (A/B, round 5: 8 / 16 loads in flight per lane measured 1.29 / 1.31 ms per step against 1.28: not the bound)
+#define VMV_GNF_UNROLL 4      // (A/B, round 5: 8 / 16 loads in flight per lane measured 1.29 / 1.31 ms per step against 1.28: not the bound.
+                              //  Round 6: the whole slab staged by LDS-DMA — EVERY load of the block in flight before the first wait, one
+                              //  memory round trip instead of seven dependent ones — measured the same again: 16.9 vs 17.4 us per launch in
+                              //  the kernel trace, 47.43 / 47.53 vs 47.54 / 47.35 ms per step (profiles/r6_gnf_dma_step_ab.log), so that form
+                              //  was removed.  A block is ONE wave per SIMD walking four dependent LDS passes: VALU / LDS latency, not memory.)
 #endif
-__global__ __launch_bounds__(256) void gn_fused_kernel(const VmvGroupNormParams p, const int CW, const int DMA) {
+__global__ __launch_bounds__(256) void gn_fused_kernel(const VmvGroupNormParams p, const int CW) {
     VMV_KERNEL_ENTER();
     extern __shared__ __attribute__((aligned(16))) float sh[];
     const int C = p.C0 + p.C1;
@@ -298,47 +300,6 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const VmvGroupNormParams 
     float* s_rstd = s_mean + 32;                                      // [32]
     const uint16_t* x0 = reinterpret_cast<const uint16_t*>(p.x);
     const uint16_t* x1 = reinterpret_cast<const uint16_t*>(p.x1);
-    // ---- pass 1: the slab into the stage, then column sums from the stage.
-    // Round 6: the slab goes global -> LDS by DMA (buffer_load ... lds, 16 B per lane, lane-linear destination): unit u = (row u / SW,
-    // slot u % SW) lands at stage[u] — the row-major image the later passes read — and EVERY load of the block is in flight before the
-    // first one is waited for.  The register-staged loop it replaces ran `rows / RPP` loads per lane in batches of four plus a tail of
-    // single loads: 7 dependent memory round trips for the 19 rows per lane of a 960-row group — most of the kernel's 16 us
-    // (profiles/r5_kernel_stats.txt), and deeper batches kept the tail (the round-5 A/B that saw no gain).  The DMA form needs the
-    // block's columns inside ONE source tensor and 32-bit byte offsets (DMA != 0, decided by the launcher); else the old loop runs.
-    if (DMA) {
-        const bool first = c0 < p.C0;
-        const uint16_t* base = first ? (x0 + c0) : (x1 + (c0 - p.C0));
-        const uint32_t ld2 = (uint32_t)(first ? p.ld : p.ld1) * 2u;
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(base), 0, vmvg::SRD_RECORDS, vmvg::SRD_FLAGS);
-        const int nunits = rows * SW;
-        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-        int r = tid / SW, cs = tid - r * SW;                        // unit tid; + 256 per instruction
-        const int dr = 256 / SW, dc = 256 - dr * SW;
-        unsigned char* dst = reinterpret_cast<unsigned char*>(stage) + wv * 1024;
-        for (int u0 = 0; u0 < nunits; u0 += 256) {
-            const uint32_t vo = (u0 + tid < nunits) ? (uint32_t)(row0 + r) * ld2 + (uint32_t)cs * 16u : vmvg::OOB;
-            if (u0 + wv * 64 < nunits) vmvg::blds16(rsrc, dst + (size_t)u0 * 16, vo, 0);      // (lanes past the slab write zeros behind the stage: into `red`, not yet in use)
-            r += dr; cs += dc;
-            if (cs >= SW) { cs -= SW; ++r; }
-        }
-        vmvg::wait_vmcnt<0>();
-        __syncthreads();
-        for (int cs2 = cl; cs2 < SW; cs2 += TPR) {
-            if (active) {
-                float s8[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) s8[e] = 0.f;
-                for (int rr = rl; rr < rows; rr += RPP) {
-                    float f[8];
-                    unpack8(stage[(size_t)rr * SW + cs2], f);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) s8[e] += f[e];
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) red[rl * CW + cs2 * 8 + e] = s8[e];
-            }
-        }
-    } else
     // ---- pass 1: stream in, stage, column sums
     for (int cs = cl; cs < SW; cs += TPR) {
         float s[8];
@@ -638,15 +599,8 @@ extern "C" int vmv_groupnorm_fused(const VmvGroupNormParams* pp, int32_t cols, v
     static std::atomic<unsigned long long> attr{0};
     if (const int rc_attr = vmv_lds_attr_once(attr, reinterpret_cast<const void*>(&gn_fused_kernel), 160 * 1024)) return rc_attr;
     if (shbytes > 160 * 1024) return VMV_ERANGE;
-    // LDS-DMA staging (kernel header): every block's columns inside one source tensor, 32-bit byte offsets, the zero lanes of the last
-    // wave-instruction inside the block's own LDS; VMV_GNF_DMA=0 keeps the register-staged loop (A/B)
-    static int dma_env = -1;
-    if (dma_env < 0) { const char* e = getenv("VMV_GNF_DMA"); dma_env = e ? atoi(e) : 1; }
-    const long maxld = p.C1 > 0 && p.ld1 > p.ld ? p.ld1 : p.ld;
-    const int dma = dma_env && (p.C1 == 0 || p.C0 % cols == 0) && (long)p.rows * maxld * 2 < (1L << 31) - 65536 &&
-                    (size_t)(RPP * cols) * sizeof(float) >= 1024;
     hipLaunchKernelGGL(gn_fused_kernel, dim3(C / cols, p.rows / p.rows_per_stat), dim3(256), shbytes,
-                       reinterpret_cast<hipStream_t>(stream), p, cols, dma);
+                       reinterpret_cast<hipStream_t>(stream), p, cols);
     return vmv_launch_status();
 }
 
