@@ -115,6 +115,66 @@ def _worker(rank, world, port, q):
         q.put(dict(rank=rank, error=traceback.format_exc()))
 
 
+def _tqa_fp_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        os.environ["VMV_TQA_MIN_ITEMS"] = "1"
+        torch.set_num_threads(2)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from tests import plan_interp
+        plan_interp.install(_Patch)
+        from oracle.weights import random_state_dict, unet_param_shapes
+        from oracle.unet_ref import UNetCfg
+        from videomv_amd import _lib as L
+        from videomv_amd.comm import FrameComm
+        from videomv_amd.unet_engine import UNetEngine
+        cfg = dict(CFG, dim=320, dim_mult=[1], num_heads=5, attn_scales=[1.0])
+        ocfg = UNetCfg(**{k: v for k, v in cfg.items() if k in {f.name for f in dataclasses.fields(UNetCfg)}})
+        sd = random_state_dict(unet_param_shapes(ocfg), 31)
+        B, F_, H, W, Lc = 2, 4, 4, 4, 5
+        g = torch.Generator().manual_seed(8)
+        x = torch.randn(1, 4, F_, H, W, generator=g)
+        t = torch.tensor([501])
+        y = torch.randn(B, Lc, 1024, generator=g)
+        cam = torch.randn(1, F_, 16, generator=g)
+        dev = torch.device("cpu")
+        ref = UNetEngine(cfg, sd, B, F_, H, W, Lc, dev, n_t=1)
+        ref.set_context(y); ref.set_camera(cam); ref.forward_rows(x, t)
+        comm = FrameComm()
+        fl = F_ // world
+        eng = UNetEngine(cfg, sd, B, F_, H, W, Lc, dev, n_t=1, comm=comm)
+        eng.set_context(y); eng.set_camera(cam)
+        eng.forward_rows(x[:, :, rank * fl:(rank + 1) * fl].contiguous(), t)
+        fused = [p_ for op, p_ in eng.S.recorded if op == L.OP_GEMM and p_.epilogue == L.EPI_TATTN]
+        q.put(dict(rank=rank, n_fused=len(fused), geom=sorted({(p_.F, p_.P, p_.M) for p_ in fused}),
+                   n_fused_ref=sum(1 for op, p_ in ref.S.recorded if op == L.OP_GEMM and p_.epilogue == L.EPI_TATTN),
+                   e_single=rel_l2(eng.eps_ncfhw(), ref.eps_ncfhw()[:, :, rank * fl:(rank + 1) * fl])))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put(dict(rank=rank, error=traceback.format_exc()))
+
+
+def test_fused_qkv_temporal_attention_on_the_pixel_major_shard_two_ranks():
+    """Round 6: under frame-parallel the TemporalTransformer runs on the pixel-major shard (all F frames of H W / R pixels), so the fused
+    q | k | v + temporal-attention launch (VMV_EPI_TATTN) is recorded there with P = H W / R and the GLOBAL frame count; a K = 320
+    one-level network on 2 gloo ranks against the single-rank plan (which records the same fused launches with P = H W)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tqa_fp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert "error" not in r, r["error"]
+        assert r["n_fused"] == r["n_fused_ref"] == 10 and r["geom"] == [(4, 8, 64)], r        # F = 4 global frames, 16 / 2 pixels, 2 x 4 x 8 rows
+        assert r["e_single"] < 3e-2, r
+
+
 def test_two_rank_frame_parallel_plan_matches_single_rank_and_oracle():
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")

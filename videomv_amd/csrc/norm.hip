@@ -3,6 +3,7 @@
 // wave-shuffle + LDS reductions; partial sums are written per chunk and reduced in a fixed order, or (long stat groups)
 // added to 64-bit fixed-point integer accumulators — either way results are bitwise reproducible run to run.
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -277,8 +278,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const VmvGroupNormParams 
                               //  the kernel trace, 47.43 / 47.53 vs 47.54 / 47.35 ms per step (profiles/r6_gnf_dma_step_ab.log), so that form
                               //  was removed.  A block is ONE wave per SIMD walking four dependent LDS passes: VALU / LDS latency, not memory.)
 #endif
-__global__ __launch_bounds__(256) void gn_fused_kernel(const VmvGroupNormParams p, const int CW) {
+__global__ __launch_bounds__(256) void gn_fused_kernel(const VmvGroupNormParams p, const int CW, const int stamp) {
     VMV_KERNEL_ENTER();
+    // stamp != 0 (VMV_GNF_STAMP=1, experiments): block (0, 0) writes s_memtime at its phase edges into p.partial (>= 8 x 8 bytes)
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(p.partial);
+    auto mark = [&](int i) { if (stamp && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) stamps[i] = __builtin_readcyclecounter(); };
+    mark(0);
     extern __shared__ __attribute__((aligned(16))) float sh[];
     const int C = p.C0 + p.C1;
     const int cpg = C >> 5;
@@ -339,6 +344,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const VmvGroupNormParams 
         }
     }
     __syncthreads();
+    mark(1);
     const float n = (float)rows * (float)cpg;
     // group totals in two parallel stages (fixed order): thread c < CW folds the RPP row lanes of column c, then one wave
     // per group sums the group's cpg columns with a shuffle tree
@@ -359,6 +365,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const VmvGroupNormParams 
         __syncthreads();
     };
     group_totals(s_mean, [&](float s) { return s / n; });
+    mark(2);
     // ---- pass 2 (from the stage): squared deviations from the group mean
     for (int cs = cl; cs < SW; cs += TPR) {
         if (active) {
@@ -376,7 +383,9 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const VmvGroupNormParams 
         }
     }
     __syncthreads();
+    mark(3);
     group_totals(s_rstd, [&](float q) { return rsqrtf(q / n + p.eps); });
+    mark(4);
     for (int c = tid; c < CW; c += 256) {
         const int g = c / cpg;
         const float sc = s_rstd[g] * p.gamma[c0 + c];
@@ -384,6 +393,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const VmvGroupNormParams 
         shift[c] = p.beta[c0 + c] - s_mean[g] * sc;
     }
     __syncthreads();
+    mark(5);
     // ---- apply from the stage
     uint16_t* y = reinterpret_cast<uint16_t*>(p.y);
     if (active) {
@@ -408,6 +418,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const VmvGroupNormParams 
             if (p.silu) run(std::true_type{}); else run(std::false_type{});
         }
     }
+    mark(6);
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
@@ -599,8 +610,10 @@ extern "C" int vmv_groupnorm_fused(const VmvGroupNormParams* pp, int32_t cols, v
     static std::atomic<unsigned long long> attr{0};
     if (const int rc_attr = vmv_lds_attr_once(attr, reinterpret_cast<const void*>(&gn_fused_kernel), 160 * 1024)) return rc_attr;
     if (shbytes > 160 * 1024) return VMV_ERANGE;
+    static int stamp_env = -1;
+    if (stamp_env < 0) { const char* e = getenv("VMV_GNF_STAMP"); stamp_env = e ? atoi(e) : 0; }
     hipLaunchKernelGGL(gn_fused_kernel, dim3(C / cols, p.rows / p.rows_per_stat), dim3(256), shbytes,
-                       reinterpret_cast<hipStream_t>(stream), p, cols);
+                       reinterpret_cast<hipStream_t>(stream), p, cols, stamp_env && pp->partial ? 1 : 0);
     return vmv_launch_status();
 }
 
