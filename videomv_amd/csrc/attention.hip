@@ -43,7 +43,7 @@ constexpr float NEG_BIG = -1.0e30f;
 // same kernel with D / 32 k-steps in S^T = K Q^T, D / 16 output tiles in O^T = V^T P^T and D / 8 16-byte slots per staged K row.
 // CAUSAL: keys j > query i masked out (own instantiation: the test costs <4, 4, 64> two spilled registers)
 template <int WPP, int QT, int D = 64, bool CAUSAL = false>
-__global__ __launch_bounds__(256, (QT == 1 ? 4 : 2)) void attn_kernel(const VmvAttnParams p, const int nproblems) {
+__global__ __launch_bounds__(256, 2) void attn_kernel(const VmvAttnParams p, const int nproblems) {
     VMV_KERNEL_ENTER();
     static_assert(D == 64 || ((D == 32 || D == 128) && WPP == 4), "head_dim 64, or 32 / 128 on the 4-waves-per-problem variant");
     constexpr int KK = D / 32, DT = D / 16, SLOTS = D / 8, SLOG = (D == 128) ? 4 : (D == 64) ? 3 : 2;
@@ -251,12 +251,11 @@ __global__ __launch_bounds__(256, (QT == 1 ? 4 : 2)) void attn_kernel(const VmvA
         }
         elem8_t pf[QT][2];
         const bool partial = key0 + 64 > p.Nk;                 // uniform
-        constexpr int QG = QT >= 2 ? 2 : 1;          // query tiles per S^T batch (QT = 1, round 6: the 64-query block of the short problems)
 #pragma unroll
-        for (int qp = 0; qp < QT / QG; ++qp) {
-            f32x4_t s[QG][4];
+        for (int qp = 0; qp < QT / 2; ++qp) {
+            f32x4_t s[2][4];
 #pragma unroll
-            for (int q2 = 0; q2 < QG; ++q2)
+            for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) s[q2][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -264,16 +263,16 @@ __global__ __launch_bounds__(256, (QT == 1 ? 4 : 2)) void attn_kernel(const VmvA
 #pragma unroll
                 for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-                    for (int q2 = 0; q2 < QG; ++q2)
-                        s[q2][t] = VMV_MFMA16(kf[t][kk], qf[QG * qp + q2][kk], s[q2][t], 0, 0, 0);
+                    for (int q2 = 0; q2 < 2; ++q2)
+                        s[q2][t] = VMV_MFMA16(kf[t][kk], qf[2 * qp + q2][kk], s[q2][t], 0, 0, 0);
             // ---- online softmax (per lane: query u, 16 keys of this tile).  The softmax VALU work, not the 32 MFMAs, bounds a
             //      tile (16 quarter-rate v_exp per query tile alone cost as much as the tile's MFMAs), so it is kept minimal:
             //      the running max is tracked on the RAW scores (scale > 0) and the scale is folded into one FMA per score,
             //      exp2((s - m) * sc) = exp2(fma(s, sc, -m * sc)); key masking runs only on a partial last tile; the
             //      accumulator rescale is skipped while no lane of the wave sees a new maximum.
     #pragma unroll
-            for (int q2 = 0; q2 < QG; ++q2) {
-                const int qt = QG * qp + q2;
+            for (int q2 = 0; q2 < 2; ++q2) {
+                const int qt = 2 * qp + q2;
                 if (partial || CAUSAL) {         // (causal: key <= query — the CLIP text tower; key 0 is visible to every query, so the
                                                  //  running max is real from the first tile on and masked scores exponentiate to 0)
                     const int qlim = CAUSAL ? q0 + qt * 16 + u : 0x7fffffff;
@@ -605,15 +604,12 @@ extern "C" int vmv_attention(const VmvAttnParams* pp, void* stream) {
         if (p.n_outer > 65535 || p.heads > 65535) return VMV_ERANGE;
         static int qt_env = -1;
         if (qt_env < 0) { const char* e = getenv("VMV_ATTN_QT"); qt_env = e ? atoi(e) : 0; }
+        // (round 6: 64-query blocks — QT = 1, 84 registers, four blocks per CU — for the short problems (Nk <= 192 or Nq <= 192: cross-
+        //  attention, third-level / middle self-attention) measured step-neutral: 47.88 / 47.91 vs 47.86 / 47.87 ms, attention family
+        //  4.16 / 4.13 vs 4.17 / 4.17 ms, profiles/r6_attn_q64_step_ab.log — not kept)
         // 256-query blocks when that still leaves >= 2 blocks per CU and the key loop is long enough to matter
         const long blocks256 = (long)((p.Nq + 255) / 256) * p.heads * p.n_outer;
         const bool big = qt_env == 4 || (qt_env == 0 && p.Nk >= 512 && blocks256 >= 512 && (p.Nq % 256 == 0 || p.Nq >= 2048));
-        // 64-query blocks (QT = 1, round 6) for the short problems: a 160-query sequence wastes 37 % of its second 128-query block
-        // (17 % of three 64-query ones), and with <= 3 key tiles a block is one short dependent chain — four of them per CU instead of two
-        static int q64_env = -1;
-        if (q64_env < 0) { const char* e = getenv("VMV_ATTN_Q64"); q64_env = e ? atoi(e) : 1; }
-        const bool small = !p.causal && !big && qt_env == 0 && q64_env && (p.Nk <= 192 || p.Nq <= 192);
-        if (small) { hipLaunchKernelGGL((attn_kernel<4, 1>), dim3((p.Nq + 63) / 64, p.heads, p.n_outer), dim3(256), VMV_ATTN_STAGES * 16384, st, p, 0); return vmv_launch_status(); }
         if (p.causal) hipLaunchKernelGGL((attn_kernel<4, 2, 64, true>), dim3((p.Nq + 127) / 128, p.heads, p.n_outer), dim3(256), VMV_ATTN_STAGES * 16384, st, p, 0);
         else if (big) hipLaunchKernelGGL((attn_kernel<4, 4>), dim3((p.Nq + 255) / 256, p.heads, p.n_outer), dim3(256), VMV_ATTN_STAGES * 16384, st, p, 0);
         else hipLaunchKernelGGL((attn_kernel<4, 2>), dim3((p.Nq + 127) / 128, p.heads, p.n_outer), dim3(256), VMV_ATTN_STAGES * 16384, st, p, 0);

@@ -346,22 +346,14 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const VmvGroupNormParams 
     __syncthreads();
     mark(1);
     const float n = (float)rows * (float)cpg;
+    // (round 6: folding the RPP row lanes with 256 / CW threads per column instead of one measured no gain — the phase is its four
+    //  barriers and the shuffle tree, 2 960 vs 2 672 ticks, profiles/r6_gnf_stamps_fold.log)
     // group totals in two parallel stages (fixed order): thread c < CW folds the RPP row lanes of column c, then one wave
     // per group sums the group's cpg columns with a shuffle tree
     auto group_totals = [&](float* dst, auto finish) {
-        // the RPP row lanes of a column are folded by NG = 256 / CW threads each taking every NG-th lane, then one thread per column folds
-        // the NG partials (round 6: one thread per column walking all 51 lanes was 11 % of a block's time twice over — r6_gnf_stamps.log)
-        const int NG = 256 / CW > 0 ? (256 / CW < RPP ? 256 / CW : RPP) : 1;
-        const int kq = tid / CW, cq = tid - kq * CW;
         float cs = 0.f;
-        if (kq < NG)
-            for (int r = kq; r < RPP; r += NG) cs += red[r * CW + cq];
-        __syncthreads();
-        if (kq < NG) red[kq * CW + cq] = cs;
-        __syncthreads();
-        cs = 0.f;
         if (tid < CW)
-            for (int k = 0; k < NG; ++k) cs += red[k * CW + tid];
+            for (int r = 0; r < RPP; ++r) cs += red[r * CW + tid];
         __syncthreads();
         if (tid < CW) red[tid] = cs;
         __syncthreads();
