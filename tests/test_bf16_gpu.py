@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SUBSET = ("test_unet_matches_reference_golden or test_unet_blocks_match_oracle or test_fused_cfg_ddim_loop_matches_oracle or "
           "test_full_size_architecture_parity_small_latent or test_gemm_linear_bias or test_gemm_geglu or test_gemm_rs_ or "
-          "test_gemm_conv3x3 or test_gemm_temporal_conv or test_gemm_tfr or test_gemm_layernorm_folded or test_attention or test_groupnorm or "
+          "test_gemm_conv3x3 or test_gemm_temporal_conv or test_gemm_tfr or test_gemm_tqa or test_gemm_layernorm_folded or test_attention or test_groupnorm or "
           "test_layernorm")
 
 
