@@ -47,7 +47,7 @@ class _DevView:
 
 def out_view(p):
     """The [M, ldo] output of a recorded GEMM as a tensor view (no copy)."""
-    n_out = p.N // 2 if p.epilogue == L.EPI_GEGLU else p.N
+    n_out = p.N // 2 if p.epilogue == L.EPI_GEGLU else (p.N // 3 if p.epilogue == L.EPI_TATTN else p.N)
     if p.out_fp32:
         t = torch.as_tensor(_DevView(p.out, p.M * p.ldo, "<f4"), device="cuda").view(p.M, p.ldo)
     else:
@@ -76,7 +76,7 @@ def tune_plan(eng, table, ws, tag, gains=(0.93, 0.90), verbose=True):
     torch.cuda.synchronize()
     seen = {}
     for (op, p), label in zip(eng.S.recorded, eng.S.labels):
-        if op != L.OP_GEMM or p.wgroup_rows:
+        if op != L.OP_GEMM or p.wgroup_rows or p.epilogue == L.EPI_TATTN:      # (the fused q|k|v + attention has one kernel: nothing to tune)
             continue
         sig = ops.gemm_signature(p)
         if sig in seen or sig in table["done"]:
