@@ -189,6 +189,9 @@ typedef struct {
 #define VMV_TILE_TQA      28   /* q | k | v projection + temporal attention (gemm_tqa.hip, VMV_EPI_TATTN only): a wave keeps all F frames of 48 / F
                                   pixels x K = 320 in registers, W streams head-major through the LDS ring, the head's 24 x 24 attention is finished
                                   in registers; 48 % F == 0, N = 192 * heads <= 3840, optional folded LayerNorm (colsum + ln_eps) */
+#define VMV_TILE_W256x256 29   /* wide-wave register-staged kernel (gemm_wreg.hip): 4 waves x 128 x 128 of a 256 x 256 tile, accumulators in AGPRs,
+                                  global -> registers -> LDS; one plain linear segment, K % 32 == 0.  EXPERIMENT (make EXPERIMENTS=1; forced tile only): correct,
+                                  0.69 x of the 8-wave wide tile — DESIGN.md 10 */
 
 int vmv_gemm(const VmvGemmParams* p, void* stream);
 /* 1 if the host should record ONE VMV_EPI_TATTN launch for *p (a fused q | k | v + temporal-attention GEMM, epilogue already set)

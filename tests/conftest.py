@@ -27,7 +27,8 @@ def pytest_collection_modifyitems(config, items):
             if "gpu" in item.keywords:
                 item.add_marker(skip)
         return
-    # kernel tests parametrised over the measured-and-rejected GEMM variants (wave-specialised, A-stationary) run only against a
+    # kernel tests parametrised over the measured-and-rejected GEMM variants (wave-specialised, A-stationary, round 6's wide-wave
+    # register-staged one) run only against a
     # library built with `make EXPERIMENTS=1`; the production library does not carry those kernels
     exp_tiles, has_exp = None, None
     for item in items:
@@ -36,7 +37,7 @@ def pytest_collection_modifyitems(config, items):
             continue
         if exp_tiles is None:
             from videomv_amd import _lib as L
-            exp_tiles = {L.TILE_S256x128, L.TILE_S192x160, L.TILE_S256x160, L.TILE_A128x160, L.TILE_A128x128}
+            exp_tiles = {L.TILE_S256x128, L.TILE_S192x160, L.TILE_S256x160, L.TILE_A128x160, L.TILE_A128x128, L.TILE_W256x256}
             has_exp = bool(L.load().vmv_has_experiments())
         if not has_exp and cs.params["tile"] in exp_tiles:
             item.add_marker(pytest.mark.skip(reason="experiment kernels not in this library (make EXPERIMENTS=1)"))

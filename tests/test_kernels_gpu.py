@@ -78,6 +78,7 @@ def run_gemm(build, case, out_keys=("out",), cpu_ref=True):
                                         (300, 320, 64, L.TILE_P256x160), (257, 128, 192, L.TILE_P256x128),
                                         (513, 200, 72, L.TILE_P256x128), (2000, 1280, 1280, L.TILE_P256x160),
                                         (70000, 320, 320, L.TILE_P256x160), (70000, 384, 128, L.TILE_P256x128),
+                                        (640, 640, 640, L.TILE_W256x256), (2000, 1280, 1280, L.TILE_W256x256), (300, 320, 320, L.TILE_W256x256), (257, 128, 192, L.TILE_W256x256), (7000, 3840, 1280, L.TILE_W256x256), (513, 200, 160, L.TILE_W256x256),
                                         (66000, 160, 64, L.TILE_P256x160),
                                         (640, 640, 640, L.TILE_PP256x128), (1000, 960, 320, L.TILE_PP256x160),
                                         (300, 320, 64, L.TILE_PP256x160), (257, 128, 192, L.TILE_PP256x128),
@@ -123,7 +124,7 @@ def test_gemm_fp32_out_rowvec_act_residual(tile):
     check(dev["out"], cpu["out"], tol_l2=1e-3, tol_max=2e-3)
 
 
-@pytest.mark.parametrize("tile", [0, L.TILE_256x128, L.TILE_G128x128, L.TILE_P256x128, L.TILE_PP256x128, L.TILE_Q128x128, L.TILE_S256x128, L.TILE_X256x256])
+@pytest.mark.parametrize("tile", [0, L.TILE_256x128, L.TILE_G128x128, L.TILE_P256x128, L.TILE_PP256x128, L.TILE_Q128x128, L.TILE_S256x128, L.TILE_X256x256, L.TILE_W256x256])
 def test_gemm_geglu(tile):
     M, I2, K = 200, 512, 128        # 2*I = 512 rows -> 256 outputs
     w = rnd((I2, K), 2, K ** -0.5)
@@ -746,7 +747,10 @@ def test_layernorm_stats_out(rows, Cc):
                                                (7680, 3840, 1280, False, L.TILE_X256x256), (7680, 10240, 1280, True, L.TILE_X256x256),
                                                (300, 512, 128, False, L.TILE_X256x256), (513, 768, 192, True, L.TILE_X256x256),
                                                (1000, 1000, 320, False, L.TILE_X256x256), (2001, 1280, 640, True, L.TILE_X256x256),
-                                               (7680, 3840, 1280, False, 0), (7680, 10240, 1280, True, 0)])
+                                               (7680, 3840, 1280, False, 0), (7680, 10240, 1280, True, 0),
+                                               # round 6: the wide-wave register-staged kernel (gemm_wreg.hip)
+                                               (7680, 3840, 1280, False, L.TILE_W256x256), (7680, 10240, 1280, True, L.TILE_W256x256), (513, 768, 192, True, L.TILE_W256x256),
+                                               (1000, 1000, 320, False, L.TILE_W256x256)])
 def test_gemm_layernorm_folded(M, N, K, geglu, tile):
     """y = Linear(LayerNorm(x)) as ONE GEMM on the raw rows (packing.fold_layernorm + rowstat / colsum epilogue) against
     the unfused definition, x with a large per-row offset (mean / sigma ~ 3) to exercise the cancellation."""

@@ -27,10 +27,14 @@ int vmv_gemm_xglds_epi_ok(const VmvGemmParams& p, int tile);                    
 #if defined(VMV_EXPERIMENTS)
 int vmv_gemm_sglds_launch(const VmvGemmParams& p, int total_steps, int tile, hipStream_t st);  // gemm_sglds.hip
 int vmv_gemm_astat_launch(const VmvGemmParams& p, int tile, hipStream_t st);                   // gemm_astat.hip
+int vmv_gemm_wreg_launch(const VmvGemmParams& p, hipStream_t st);                             // gemm_wreg.hip (round 6)
+bool vmv_gemm_wreg_supported(const VmvGemmParams& p);
 #else      // production build: the measured-and-rejected kernels are not in the library (make EXPERIMENTS=1)
 constexpr int VMV_NOT_BUILT = -101;
 static int vmv_gemm_sglds_launch(const VmvGemmParams&, int, int, hipStream_t) { return VMV_NOT_BUILT; }
 static int vmv_gemm_astat_launch(const VmvGemmParams&, int, hipStream_t) { return VMV_NOT_BUILT; }
+static int vmv_gemm_wreg_launch(const VmvGemmParams&, hipStream_t) { return VMV_NOT_BUILT; }
+static bool vmv_gemm_wreg_supported(const VmvGemmParams&) { return false; }
 #endif
 int vmv_gemm_rs_launch(const VmvGemmParams& p, int tile, hipStream_t st);                      // gemm_rs.hip
 bool vmv_gemm_rs_supported(const VmvGemmParams& p);
@@ -445,10 +449,11 @@ int final_tile(const VmvGemmParams& p, int total_steps) {
     int picked = pick_tile(p, total_steps);
 #if !defined(VMV_EXPERIMENTS)
     if (picked == VMV_TILE_S256x128 || picked == VMV_TILE_S192x160 || picked == VMV_TILE_S256x160 || picked == VMV_TILE_A128x160 ||
-        picked == VMV_TILE_A128x128) return VMV_EINVAL;
+        picked == VMV_TILE_A128x128 || picked == VMV_TILE_W256x256) return VMV_EINVAL;
 #endif
     if (picked == VMV_TILE_HALO) return vmv_conv_halo_supported(p) ? picked : VMV_EINVAL;
     if (picked == VMV_TILE_TFR) return vmv_gemm_tfr_supported(p) ? picked : VMV_EINVAL;
+    if (picked == VMV_TILE_W256x256) return vmv_gemm_wreg_supported(p) ? picked : VMV_EINVAL;
     if (picked == VMV_TILE_TQA) return vmv_gemm_tqa_supported(p) && (p.tile == VMV_TILE_AUTO || p.tile == VMV_TILE_TQA) ? picked : VMV_EINVAL;
     const bool rs_tile = picked == VMV_TILE_RS || picked == VMV_TILE_RS512 || picked == VMV_TILE_RS256;
     if (rs_tile) return vmv_gemm_rs_supported(p) ? picked : VMV_EINVAL;      // (handles rowstat / colsum / grouped weights itself)
@@ -624,6 +629,10 @@ extern "C" int vmv_gemm(const VmvGemmParams* pp, void* stream) {
             break;
         case VMV_TILE_TFR:
             rc = vmv_gemm_tfr_launch(p, st);
+            if (rc == VMV_GLDS_UNSUPPORTED) return VMV_EINVAL;
+            break;
+        case VMV_TILE_W256x256:
+            rc = vmv_gemm_wreg_launch(p, st);
             if (rc == VMV_GLDS_UNSUPPORTED) return VMV_EINVAL;
             break;
         case VMV_TILE_TQA:
