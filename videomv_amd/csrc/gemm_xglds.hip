@@ -56,11 +56,6 @@ struct WgCfg {
     static_assert(HALF_ROWS * (BN * 2 + 16) + XG_MAXG * BN * 4 + BN * 4 <= LDS_BYTES && LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
-struct WRow {        // gather state of one A row of the lane beyond its index m (recomputed: it lives beside 160 accumulators)
-    int nb;          // spatial: image base row (n * IH * IW); temporal: frame index
-    int yx;          // spatial: (oy << 16) | ox
-};
-
 constexpr int XE_GEGLU = 1, XE_LN = 2;       // EPI bits
 
 // SK (round 4): split-K — blockIdx.y owns `nsteps_arg` chunks of the K walk starting at blockIdx.y * nsteps_arg (the last split takes
@@ -69,7 +64,7 @@ constexpr int XE_GEGLU = 1, XE_LN = 2;       // EPI bits
 // 256-row wide tiles on their own (the fourth UNet level, a frame-parallel rank's M / 8 rows) without falling back to 128-row tiles.
 template <int NH, int WH, int EPI = 0, bool SK = false>
 __global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams p, const int tiles_m, const int tiles_n, const int nsteps_arg,
-                                                            const int nsteps_total, const int gm) {
+                                                            const int nsteps_total, const int gm, const int tapmajor) {
     VMV_KERNEL_ENTER();
     using Cfg = WgCfg<NH, WH>;
     constexpr int WM = Cfg::WM, WN = Cfg::WN, NW = Cfg::NW, BM = Cfg::BM, BN = Cfg::BN, S = Cfg::STAGES;
@@ -114,81 +109,132 @@ __global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams 
     //      lane (16 g + (lane >> 2)) the index is (lane >> 4) & 3.
     const int lrow = lane >> 2;
     const int lsw = (lane & 3) ^ ((0x78 >> (2 * ((lane >> 4) & 3))) & 3);
-    WRow rows[Cfg::NAI];
-#pragma unroll
-    for (int i = 0; i < Cfg::NAI; ++i) {
-        const int m = m0 + (i * NW + wave) * 16 + lrow;
-        WRow r;
-        r.nb = 0; r.yx = 0;
-        if (p.OH > 0) {
-            const int hw = p.OH * p.OW;
-            const int n = m / hw, rem = m - n * hw;
-            const int oy = rem / p.OW;
-            r.nb = n * p.IH * p.IW;
-            r.yx = (oy << 16) | (rem - oy * p.OW);
-        } else if (p.P > 0) {
-            r.nb = (m / p.P) % p.F;
-        }
-        rows[i] = r;
-    }
-    auto row_offset = [&](const VmvGemmSeg& sg, const WRow& r, const int m) -> int {       // element offset of the source row, or -1 (zero row)
-        if (m >= p.M) return -1;
-        if (sg.mode == VMV_SEG_LINEAR) return m * sg.ld;
-        if (sg.mode == VMV_SEG_SPATIAL) {
-            const int iy = (r.yx >> 16) * p.stride + sg.d0;
-            const int ix = (r.yx & 0xffff) * p.stride + sg.d1;
-            const int VH = p.IH << p.ups, VW = p.IW << p.ups;
-            if (iy < 0 || iy >= VH || ix < 0 || ix >= VW) return -1;
-            return (r.nb + (iy >> p.ups) * p.IW + (ix >> p.ups)) * sg.ld;
-        }
-        const int f = r.nb + sg.d0;
-        if (f < 0 || f >= p.F) return -1;
-        return (m + sg.d0 * p.P) * sg.ld;
-    };
     // weights: this lane's row of W group j is n0 + (j NW + wave) 16 + lrow — linear in j, so ONE offset register; rows >= N
     // fall outside the descriptor and read as zero
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, (uint32_t)p.N * (uint32_t)p.ktot * 2u, SRD_FLAGS);
     const uint32_t wvo0 = (uint32_t)((n0 + wave * 16 + lrow) * p.ktot + lsw * 8) * 2u;
     const uint32_t wstride = (uint32_t)(NW * 16 * p.ktot) * 2u;
 
-    int s = 0, kc = 0, koff = 0;
+    // ---- K walk: RUNS of segments, walked chunk-major (round 6).  A run is a maximal sequence of consecutive segments that differ only
+    //      in their tap — the nine of a 3 x 3 convolution, the three of a temporal one; every other segment (linear, strided /
+    //      up-sampling taps, everything under split-K) is a run of one.  Inside a run the walk takes the 32 channels of chunk c for EVERY
+    //      tap, then chunk c + 1.  The segment-major walk of rounds 2-5 re-read a tile's rows (6 image rows for 4) once per tap with all
+    //      the tile's other channels in between: 327 KB per tile and tap at the first level, x 32 CUs per XCD = 10 MB of reuse distance
+    //      against a 4-MB L2, so every tap came in over the fabric (profiles/r6_gemm_traffic_by_kernel.tsv: 1.4-2.2 GB fetched per
+    //      launch for 160-320 MB of operands).  Chunk-major the taps of a chunk touch 24 KB per tile: eight of nine hit the L2.  W needs
+    //      no repacking — its K order stays (tap, channel); the walk takes column offset tap * C + 32 c.
+    //      Per lane and A row: ONE byte offset (the row's tap-(0, 0) source position; for a run of one the tap's own position) and a
+    //      validity bit per tap (image / frame borders, rows >= M), computed once per run; per chunk one scalar delta and a select.  The
+    //      row's (image, y, x) is recomputed from m at every run start — two integer divisions per row once per source tensor — instead
+    //      of living in four registers beside 160 accumulators (the 256 x 320 form has none to spare; the asm below keeps the compiler
+    //      from hoisting the divisions out of the K loop and back into registers).
+    int s = 0, koff = 0;
+    int run_len = 1, run_t = 0, run_nch = 0, run_c = 0;
     int nsteps = nsteps_arg;
+    int skip0 = 0;
     if constexpr (SK) {           // fast-forward the K walk to this split's first chunk
         const int step_begin = (int)blockIdx.y * nsteps_arg;
         nsteps = nsteps_total - step_begin < nsteps_arg ? nsteps_total - step_begin : nsteps_arg;
         int skip = step_begin;
         while (s < p.nseg) {
             const int nch = (p.seg[s].k + WBK - 1) / WBK;
-            if (skip < nch) { kc = skip * WBK; break; }
+            if (skip < nch) { skip0 = skip; break; }
             skip -= nch; koff += p.seg[s].k; ++s;
         }
     }
+    static_assert(Cfg::NAI <= 2, "two 16-bit tap masks in one register");
     uint32_t avo[Cfg::NAI];
-    auto enter_segment = [&]() {
+    uint32_t rmask = 0;           // tap-validity bits of the lane's NAI rows, 16 per row
+    auto seg_same = [&](const VmvGemmSeg& a, const VmvGemmSeg& b) { return a.src == b.src && a.ld == b.ld && a.k == b.k && a.mode == b.mode; };
+    auto start_run = [&]() {
+        run_len = 1; run_t = 0; run_c = 0;
+        const VmvGemmSeg& s0 = p.seg[s];
+        run_nch = (s0.k + WBK - 1) / WBK;
+        const int mode = s0.mode, ld = s0.ld;
+        const bool tappable = (mode == VMV_SEG_SPATIAL && p.stride == 1 && p.ups == 0) || mode == VMV_SEG_TEMPORAL;
+        if (!SK && tapmajor && tappable)
+            while (s + run_len < p.nseg && run_len < 15 && seg_same(p.seg[s + run_len], s0)) ++run_len;
+        // (segment fields are read in wave-uniform control flow: inside per-row branches the compiler copied the whole kernel-argument
+        //  segment table to scratch to index it)
+        const bool single = run_len == 1;
+        rmask = 0;
 #pragma unroll
         for (int i = 0; i < Cfg::NAI; ++i) {
-            const int off = row_offset(p.seg[s], rows[i], m0 + (i * NW + wave) * 16 + lrow);
-            avo[i] = off >= 0 ? (uint32_t)(off + lsw * 8) * 2u : OOB;
+            int m = m0 + (i * NW + wave) * 16 + lrow;
+            asm volatile("" : "+v"(m));                 // not loop-invariant as far as the compiler can tell: see above
+            int nb = 0, oy = 0, ox = 0;                 // spatial: image base row n IH IW, output (y, x); temporal: nb = frame index
+            if (mode == VMV_SEG_SPATIAL) {
+                const int hw = p.OH * p.OW;
+                const int n = m / hw, rem = m - n * hw;
+                oy = rem / p.OW; ox = rem - oy * p.OW;
+                nb = n * p.IH * p.IW;
+            } else if (mode == VMV_SEG_TEMPORAL) {
+                nb = (m / p.P) % p.F;
+            }
+            const bool inm = m < p.M;
+            uint32_t mask = 0;
+            int base;
+            if (mode == VMV_SEG_LINEAR) {
+                base = m * ld; mask = inm ? 1u : 0u;
+            } else if (mode == VMV_SEG_SPATIAL) {
+                if (single) {                           // the tap's own position (strided / nearest-x2 gathers included)
+                    const int iy = oy * p.stride + s0.d0, ix = ox * p.stride + s0.d1;
+                    const int VH = p.IH << p.ups, VW = p.IW << p.ups;
+                    const bool ok = inm && iy >= 0 && iy < VH && ix >= 0 && ix < VW;
+                    base = ok ? (nb + (iy >> p.ups) * p.IW + (ix >> p.ups)) * ld : 0;
+                    mask = ok ? 1u : 0u;
+                } else {
+                    base = (nb + oy * p.IW + ox) * ld;
+                    for (int t = 0; t < run_len; ++t) {
+                        const int iy = oy + p.seg[s + t].d0, ix = ox + p.seg[s + t].d1;
+                        if (inm && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) mask |= 1u << t;
+                    }
+                }
+            } else {
+                if (single) {
+                    const int f = nb + s0.d0;
+                    const bool ok = inm && f >= 0 && f < p.F;
+                    base = ok ? (m + s0.d0 * p.P) * ld : 0;
+                    mask = ok ? 1u : 0u;
+                } else {
+                    base = m * ld;
+                    for (int t = 0; t < run_len; ++t) {
+                        const int f = nb + p.seg[s + t].d0;
+                        if (inm && f >= 0 && f < p.F) mask |= 1u << t;
+                    }
+                }
+            }
+            avo[i] = (uint32_t)(base + lsw * 8) * 2u;
+            rmask |= mask << (16 * i);
         }
     };
-    enter_segment();
+    start_run();
+    if constexpr (SK) run_c = skip0;
     auto issue = [&](int stage) {           // LDS-DMA one chunk into ring slot `stage`, then advance the K walk
-        const VmvGemmSeg& sg = p.seg[s];
-        const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(sg.src), 0, SRD_RECORDS, SRD_FLAGS);
-        const bool kvalid = (kc + WBK) <= sg.k || (kc + lsw * 8) < sg.k;      // k tail of a segment: zero fill
         unsigned char* abase = smem + stage * Cfg::STAGE_BYTES + wave * 1024;
         unsigned char* wbase = smem + stage * Cfg::STAGE_BYTES + Cfg::A_BYTES + wave * 1024;
-        const uint32_t a_so = (uint32_t)kc * 2u, w_so = (uint32_t)(koff + kc) * 2u;
+        const VmvGemmSeg& sg = p.seg[s + run_t];
+        const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(sg.src), 0, SRD_RECORDS, SRD_FLAGS);
+        const int kc = run_c * WBK;
+        const bool kvalid = (kc + WBK) <= sg.k || (kc + lsw * 8) < sg.k;      // k tail of a segment: zero fill
+        // the tap's distance from the run's base position, elements, wave-uniform.  It may be negative: it goes into the 32-bit lane
+        // offset (a valid tap's sum is a non-negative offset inside the tensor), not into the unsigned scalar offset
+        int delta = 0;
+        if (run_len > 1) delta = sg.mode == VMV_SEG_SPATIAL ? (sg.d0 * p.IW + sg.d1) * sg.ld : sg.d0 * p.P * sg.ld;
+        const uint32_t a_so = (uint32_t)kc * 2u, w_so = (uint32_t)(koff + run_t * sg.k + kc) * 2u, d2 = (uint32_t)(delta * 2);
 #pragma unroll
-        for (int i = 0; i < Cfg::NAI; ++i) VMV_BLDS16(a_rsrc, abase + i * (NW * 1024), kvalid ? avo[i] : OOB, a_so);
+        for (int i = 0; i < Cfg::NAI; ++i)
+            VMV_BLDS16(a_rsrc, abase + i * (NW * 1024), (kvalid && ((rmask >> (16 * i + run_t)) & 1u)) ? avo[i] + d2 : OOB, a_so);
 #pragma unroll
         for (int j = 0; j < Cfg::NWI; ++j) VMV_BLDS16(w_rsrc, wbase + j * (NW * 1024), kvalid ? wvo0 + (uint32_t)j * wstride : OOB, w_so);
         if (Cfg::NWX > 0 && wave < Cfg::NWX)
             VMV_BLDS16(w_rsrc, wbase + Cfg::NWI * (NW * 1024), kvalid ? wvo0 + (uint32_t)Cfg::NWI * wstride : OOB, w_so);
-        kc += WBK;
-        if (kc >= sg.k) {
-            koff += sg.k; ++s; kc = 0;
-            if (s < p.nseg) enter_segment();
+        if (++run_t == run_len) {
+            run_t = 0;
+            if (++run_c == run_nch) {
+                koff += run_len * sg.k; s += run_len;
+                if (s < p.nseg) start_run();
+            }
         }
     };
 
@@ -471,6 +517,12 @@ int xglds_group_m(int tiles_m, int tiles_n, int BM, int BN) {
     return best;
 }
 
+int xglds_tapmajor() {        // VMV_XGLDS_TAPMAJOR (A/B): 1 = tap-interleaved K walk of the convolutions (kernel header), 0 = segment-major
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VMV_XGLDS_TAPMAJOR"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
 template <int NH, int WH, int EPI = 0>
 int launch_xglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
     using Cfg = WgCfg<NH, WH>;
@@ -493,13 +545,13 @@ int launch_xglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
             static std::atomic<unsigned long long> attr_sk{0};
             if (const int rc_attr = vmv_lds_attr_once(attr_sk, reinterpret_cast<const void*>(&gemm_xglds_kernel<NH, WH, 0, true>), Cfg::LDS_BYTES)) return rc_attr;
             VMV_LAUNCH((gemm_xglds_kernel<NH, WH, 0, true>), dim3(tiles_m * tiles_n, p.ksplit), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n,
-                               sps, nsteps, gm);
+                               sps, nsteps, gm, 0);
             return vmv_launch_status();
         }
     }
     static std::atomic<unsigned long long> attr_set{0};
     if (const int rc_attr = vmv_lds_attr_once(attr_set, reinterpret_cast<const void*>(&gemm_xglds_kernel<NH, WH, EPI>), Cfg::LDS_BYTES)) return rc_attr;
-    VMV_LAUNCH((gemm_xglds_kernel<NH, WH, EPI>), dim3(tiles_m * tiles_n), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n, nsteps, nsteps, gm);
+    VMV_LAUNCH((gemm_xglds_kernel<NH, WH, EPI>), dim3(tiles_m * tiles_n), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n, nsteps, nsteps, gm, xglds_tapmajor());
     return vmv_launch_status();
 }
 
