@@ -23,7 +23,7 @@ namespace {
 
 template <int WMW, int WN, int STAGES, int ablate, bool PP = false>
 __global__ __launch_bounds__(128 * WMW, WMW == 2 ? 2 : 1) void gemm_glds_kernel(const VmvGemmParams p, const int tiles_m, const int tiles_n,
-                                                              const int total_steps, const int steps_per_split, const int gm) {
+                                                              const int total_steps, const int steps_per_split, const int gm, const int tapmajor) {
     VMV_KERNEL_ENTER();
     // ablate (experiments only, VMV_GEMM_ABLATE): 1 = skip the MFMAs + fragment reads, 2 = skip the LDS-DMA loads
     using Cfg = GlCfg<WMW, WN, STAGES>;
@@ -71,23 +71,6 @@ __global__ __launch_bounds__(128 * WMW, WMW == 2 ? 2 : 1) void gemm_glds_kernel(
     const int lrow = lane >> 3;
     const int lsw = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);    // logical 16-B slot this lane fetches
 
-    RowInfo rinfo[Cfg::NAI];
-#pragma unroll
-    for (int i = 0; i < Cfg::NAI; ++i) {
-        const int m = m0 + (i * NW + wave) * 8 + lrow;
-        RowInfo r;
-        r.m = (m < p.M) ? m : -1;
-        r.nb = 0; r.oy = 0; r.ox = 0; r.fr = 0;
-        if (p.OH > 0) {
-            const int hw = p.OH * p.OW;
-            const int n = m / hw, rem = m - n * hw;
-            r.nb = n * p.IH * p.IW;
-            r.oy = rem / p.OW;
-            r.ox = rem - r.oy * p.OW;
-        }
-        if (p.P > 0) r.fr = (m / p.P) % p.F;
-        rinfo[i] = r;
-    }
     uint32_t wvo[Cfg::NWI];                       // per-lane byte offset of its weight row (+ its k-slot) or OOB
     int wgrp[Cfg::NWI];
 #pragma unroll
@@ -102,50 +85,129 @@ __global__ __launch_bounds__(128 * WMW, WMW == 2 ? 2 : 1) void gemm_glds_kernel(
     }
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, SRD_RECORDS, SRD_FLAGS);
 
-    // ---- K-walk state (runs two chunks ahead of the MFMAs)
-    int s = 0, kc = 0, koff = 0;
-    {
-        int skip = step_begin;
-        while (s < p.nseg) {
-            const int nch = (p.seg[s].k + BK - 1) / BK;
-            if (skip < nch) { kc = skip * BK; break; }
-            skip -= nch; koff += p.seg[s].k; ++s;
-        }
-    }
-    uint32_t avo[Cfg::NAI];                       // per-lane byte offset of its gathered source row (+ k-slot) or OOB
-    auto enter_segment = [&]() {
+    // ---- K-walk state (runs two chunks ahead of the MFMAs).  The walk is RUN-wise (round 6, as gemm_xglds.hip): consecutive segments
+    //      that differ only in their tap (the 9 of a 3 x 3 convolution, the 3 of a temporal one) form a run and are walked chunk-major —
+    //      the 64 channels of chunk c for every tap, then chunk c + 1 — so the taps of a chunk re-read the tile's rows out of the L2
+    //      instead of the fabric; W keeps its (tap, channel) K order and is read at column tap * C + 64 c.  Everything else (linear,
+    //      strided / up-sampling taps) is a run of one.  Per lane and A row: one byte offset (the row's tap-(0, 0) position; for a run
+    //      of one the tap's own position) and a validity bit per tap, computed once per run from m (no per-row state is kept).
+    int s = 0, koff = 0;
+    int run_len = 1, run_t = 0, run_nch = 0, run_c = 0;
+    auto seg_same = [&](const VmvGemmSeg& a, const VmvGemmSeg& b) { return a.src == b.src && a.ld == b.ld && a.k == b.k && a.mode == b.mode; };
+    auto detect_run = [&]() {               // run_len / run_nch of the run that starts at segment s
+        const VmvGemmSeg& s0 = p.seg[s];
+        run_len = 1;
+        run_nch = (s0.k + BK - 1) / BK;
+        const bool tappable = (s0.mode == VMV_SEG_SPATIAL && p.stride == 1 && p.ups == 0) || s0.mode == VMV_SEG_TEMPORAL;
+        if (tapmajor && tappable)
+            while (s + run_len < p.nseg && run_len < 15 && seg_same(p.seg[s + run_len], s0)) ++run_len;
+    };
+    static_assert(Cfg::NAI == 4, "four 16-bit tap masks in two registers");
+    uint32_t avo[Cfg::NAI];                       // per-lane byte offset of its gathered source row (+ k-slot)
+    uint32_t rmask[2] = {0u, 0u};                 // tap-validity bits of the lane's four rows, 16 per row
+    auto setup_rows = [&]() {
+        const VmvGemmSeg& s0 = p.seg[s];
+        const int mode = s0.mode, ld = s0.ld;
+        const bool single = run_len == 1;
+        rmask[0] = 0u; rmask[1] = 0u;
 #pragma unroll
         for (int i = 0; i < Cfg::NAI; ++i) {
-            const int off = seg_row_offset(p, p.seg[s], rinfo[i]);
-            avo[i] = off >= 0 ? (uint32_t)(off + lsw * 8) * 2u : OOB;
+            int m = m0 + (i * NW + wave) * 8 + lrow;
+            asm volatile("" : "+v"(m));             // keeps the divisions below out of the K loop's live registers
+            const bool inm = m < p.M;
+            int nb = 0, oy = 0, ox = 0;             // spatial: image base row n IH IW, output (y, x); temporal: nb = frame index
+            if (mode == VMV_SEG_SPATIAL) {
+                const int hw = p.OH * p.OW;
+                const int n = m / hw, rem = m - n * hw;
+                oy = rem / p.OW; ox = rem - oy * p.OW;
+                nb = n * p.IH * p.IW;
+            } else if (mode == VMV_SEG_TEMPORAL) {
+                nb = (m / p.P) % p.F;
+            }
+            uint32_t mask = 0;
+            int base;
+            if (mode == VMV_SEG_LINEAR) {
+                base = m * ld; mask = inm ? 1u : 0u;
+            } else if (mode == VMV_SEG_SPATIAL) {
+                if (single) {
+                    const int iy = oy * p.stride + s0.d0, ix = ox * p.stride + s0.d1;
+                    const int VH = p.IH << p.ups, VW = p.IW << p.ups;
+                    const bool ok = inm && iy >= 0 && iy < VH && ix >= 0 && ix < VW;
+                    base = ok ? (nb + (iy >> p.ups) * p.IW + (ix >> p.ups)) * ld : 0;
+                    mask = ok ? 1u : 0u;
+                } else {
+                    base = (nb + oy * p.IW + ox) * ld;
+                    for (int t = 0; t < run_len; ++t) {
+                        const int iy = oy + p.seg[s + t].d0, ix = ox + p.seg[s + t].d1;
+                        if (inm && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) mask |= 1u << t;
+                    }
+                }
+            } else {
+                if (single) {
+                    const int f = nb + s0.d0;
+                    const bool ok = inm && f >= 0 && f < p.F;
+                    base = ok ? (m + s0.d0 * p.P) * ld : 0;
+                    mask = ok ? 1u : 0u;
+                } else {
+                    base = m * ld;
+                    for (int t = 0; t < run_len; ++t) {
+                        const int f = nb + p.seg[s + t].d0;
+                        if (inm && f >= 0 && f < p.F) mask |= 1u << t;
+                    }
+                }
+            }
+            avo[i] = (uint32_t)(base + lsw * 8) * 2u;
+            rmask[i >> 1] |= mask << (16 * (i & 1));
         }
     };
-    if (s < p.nseg && nsteps > 0) enter_segment();
+    {       // fast-forward to this split's first chunk (split-K: chunks are counted in walk order)
+        int skip = step_begin;
+        while (s < p.nseg) {
+            detect_run();
+            const int total = run_nch * run_len;
+            if (skip < total) { run_c = skip / run_len; run_t = skip - run_c * run_len; break; }
+            skip -= total; koff += run_len * p.seg[s].k; s += run_len;
+        }
+    }
+    if (s < p.nseg && nsteps > 0) setup_rows();
+    auto advance = [&](const int segk) {    // the K walk moves one chunk on
+        if (++run_t == run_len) {
+            run_t = 0;
+            if (++run_c == run_nch) {
+                koff += run_len * segk; s += run_len; run_c = 0;
+                if (s < p.nseg) { detect_run(); setup_rows(); }
+            }
+        }
+    };
+    // what one chunk's loads need besides the lane offsets: the segment's descriptor, the scalar offsets, the tap's distance from the
+    // run's base position (elements x 2, wave-uniform; may be negative: it is added to the 32-bit lane offset, a valid tap's sum is a
+    // non-negative offset inside the tensor) and the k-tail flag
+    struct ChunkArgs { __amdgpu_buffer_rsrc_t a_rsrc; uint32_t a_so, w_so, d2; bool kvalid; int tapbit; int segk; };
+    auto chunk_args = [&](const bool more) -> ChunkArgs {
+        const VmvGemmSeg& sg = p.seg[more ? s + run_t : 0];
+        ChunkArgs c;
+        c.a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(sg.src), 0, SRD_RECORDS, SRD_FLAGS);
+        const int kc = run_c * BK;
+        c.kvalid = (kc + BK) <= sg.k || (kc + lsw * 8) < sg.k;      // k tail of a segment: zero fill
+        int delta = 0;
+        if (run_len > 1) delta = sg.mode == VMV_SEG_SPATIAL ? (sg.d0 * p.IW + sg.d1) * sg.ld : sg.d0 * p.P * sg.ld;
+        c.a_so = (uint32_t)kc * 2u; c.w_so = (uint32_t)(koff + run_t * sg.k + kc) * 2u; c.d2 = (uint32_t)(delta * 2);
+        c.tapbit = run_t; c.segk = sg.k;
+        return c;
+    };
+    auto a_off = [&](const ChunkArgs& c, const int i) -> uint32_t {
+        return (c.kvalid && ((rmask[i >> 1] >> (16 * (i & 1) + c.tapbit)) & 1u)) ? avo[i] + c.d2 : OOB;
+    };
 
     auto issue = [&](int stage) {           // LDS-DMA one chunk into ring slot `stage`, then advance the walk
-        const VmvGemmSeg& sg = p.seg[s];
-        const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(sg.src), 0, SRD_RECORDS, SRD_FLAGS);
-        const bool ktail = (kc + BK) > sg.k;                    // uniform: only the last chunk of a segment with k % 64 != 0
-        const bool kvalid = (kc + lsw * 8) < sg.k;
+        const ChunkArgs c = chunk_args(true);
         unsigned char* abase = smem + stage * Cfg::STAGE_BYTES + wave * 1024;
         unsigned char* wbase = smem + stage * Cfg::STAGE_BYTES + Cfg::A_BYTES;
-        const uint32_t a_so = (uint32_t)kc * 2u, w_so = (uint32_t)(koff + kc) * 2u;
-        if (!ktail) {
 #pragma unroll
-            for (int i = 0; i < Cfg::NAI; ++i) VMV_BLDS16(a_rsrc, abase + i * (NW * 1024), avo[i], a_so);
+        for (int i = 0; i < Cfg::NAI; ++i) VMV_BLDS16(c.a_rsrc, abase + i * (NW * 1024), a_off(c, i), c.a_so);
 #pragma unroll
-            for (int j = 0; j < Cfg::NWI; ++j) VMV_BLDS16(w_rsrc, wbase + wgrp[j] * 1024, wvo[j], w_so);
-        } else {
-#pragma unroll
-            for (int i = 0; i < Cfg::NAI; ++i) VMV_BLDS16(a_rsrc, abase + i * (NW * 1024), kvalid ? avo[i] : OOB, a_so);
-#pragma unroll
-            for (int j = 0; j < Cfg::NWI; ++j) VMV_BLDS16(w_rsrc, wbase + wgrp[j] * 1024, kvalid ? wvo[j] : OOB, w_so);
-        }
-        kc += BK;
-        if (kc >= sg.k) {
-            koff += sg.k; ++s; kc = 0;
-            if (s < p.nseg) enter_segment();
-        }
+        for (int j = 0; j < Cfg::NWI; ++j) VMV_BLDS16(w_rsrc, wbase + wgrp[j] * 1024, c.kvalid ? wvo[j] : OOB, c.w_so);
+        advance(c.segk);
     };
 
     f32x4_t acc[WN][WM];
@@ -217,12 +279,9 @@ __global__ __launch_bounds__(128 * WMW, WMW == 2 ? 2 : 1) void gemm_glds_kernel(
                 int s2 = st + 2; if (s2 >= 3) s2 -= 3;
                 const bool more = issued < nsteps;
                 {
-                    const VmvGemmSeg& sg = p.seg[more ? s : 0];
-                    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(sg.src), 0, SRD_RECORDS, SRD_FLAGS);
-                    const bool kvalid = !((kc + BK) > sg.k) || (kc + lsw * 8) < sg.k;      // k tail of a segment: zero fill
+                    const ChunkArgs c = chunk_args(more);
                     unsigned char* abase = smem + s2 * Cfg::STAGE_BYTES + wave * 1024;
                     unsigned char* wbase = smem + s2 * Cfg::STAGE_BYTES + Cfg::A_BYTES;
-                    const uint32_t a_so = (uint32_t)kc * 2u, w_so = (uint32_t)(koff + kc) * 2u;
                     const u32x4_t* fa = reinterpret_cast<const u32x4_t*>(smem + st * Cfg::STAGE_BYTES) + (wave_m * 64 + frow) * 8;
                     const u32x4_t* fw = reinterpret_cast<const u32x4_t*>(smem + st * Cfg::STAGE_BYTES + Cfg::A_BYTES) +
                                         (wave_n * 16 * WN + frow) * 8;
@@ -238,8 +297,8 @@ __global__ __launch_bounds__(128 * WMW, WMW == 2 ? 2 : 1) void gemm_glds_kernel(
 #pragma unroll
                     for (int k = 0; k < Cfg::LPT; ++k) {
                         if (more && ablate != 2) {
-                            if (k < Cfg::NAI) VMV_BLDS16(a_rsrc, abase + k * (NW * 1024), kvalid ? avo[k] : OOB, a_so);
-                            else VMV_BLDS16(w_rsrc, wbase + wgrp[k - Cfg::NAI] * 1024, kvalid ? wvo[k - Cfg::NAI] : OOB, w_so);
+                            if (k < Cfg::NAI) VMV_BLDS16(c.a_rsrc, abase + k * (NW * 1024), a_off(c, k < Cfg::NAI ? k : 0), c.a_so);
+                            else VMV_BLDS16(w_rsrc, wbase + wgrp[k - Cfg::NAI] * 1024, c.kvalid ? wvo[k - Cfg::NAI] : OOB, c.w_so);
                         }
                         const int upto = (NRD * (k + 1)) / Cfg::LPT;
                         if constexpr (ablate != 1) {
@@ -250,14 +309,7 @@ __global__ __launch_bounds__(128 * WMW, WMW == 2 ? 2 : 1) void gemm_glds_kernel(
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     stamp(t, 1);
-                    if (more) {                                // advance the K walk
-                        kc += BK;
-                        if (kc >= sg.k) {
-                            koff += sg.k; ++s; kc = 0;
-                            if (s < p.nseg) enter_segment();
-                        }
-                        ++issued;
-                    }
+                    if (more) { advance(c.segk); ++issued; }
                 }
                 stamp(t, 2);
                 if (grp == 1) { if (more) wait_vmcnt<Cfg::LPT>(); else wait_vmcnt<0>(); }
@@ -446,6 +498,17 @@ __global__ __launch_bounds__(128 * WMW, WMW == 2 ? 2 : 1) void gemm_glds_kernel(
     }
 }
 
+// VMV_GLDS_TAPMAJOR: 1 = run-wise K walk of the convolutions (kernel), 0 = segment-major.  DEFAULT 0: measured on one box the run-wise
+// walk cuts this kernel's convolution fetches 5.2 x -> 3.8 x of the algorithmic bytes (what is left is W, streamed once into each of the
+// 8 L2s: 240 tiles = one round) but its convolutions run 1-4 % slower (L3 tconv 314 -> 303 TFLOP/s, conv L2 1018 -> 1008) and the step
+// +0.25 ms (48.05 / 48.20 vs 47.87 / 47.89 with both kernels' walks off; gemm_xglds's alone: -0.08 ms) — profiles/r6_tap2_*.log,
+// profiles/r6b_gemm_traffic_by_kernel.tsv.  The fetches it saves come out of the Infinity Cache, not HBM, and were not the bound.
+int glds_tapmajor() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VMV_GLDS_TAPMAJOR"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
 // rows of the tile group that shares W slices in an XCD's L2 (gemm_xglds.hip xglds_group_m; `conc` = blocks an XCD runs at once:
 // 32 CUs x 1 or 2 blocks).  VMV_GLDS_GM forces it (A/B; 1 = the round-5 order).
 int glds_group_m(int tiles_m, int tiles_n, int BM, int BN, int conc) {
@@ -481,7 +544,7 @@ int launch_glds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
         static std::atomic<unsigned long long> attr_set{0};
         if (const int rc_attr = vmv_lds_attr_once(attr_set, reinterpret_cast<const void*>(&gemm_glds_kernel<WMW, WN, STAGES, AB, PP>), Cfg::LDS_BYTES)) return rc_attr;
         VMV_LAUNCH((gemm_glds_kernel<WMW, WN, STAGES, AB, PP>), grid, dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n,
-                           total_steps, sps, gm);
+                           total_steps, sps, gm, glds_tapmajor());
         return VMV_OK;
     };
     int rc;
