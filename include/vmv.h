@@ -471,12 +471,17 @@ int vmv_gs_render(const VmvGsParams* p, void* stream);
 
 /* The same rasteriser for ALL views of a call in one pass (the LGM branch renders 24 views of each CFG branch's Gaussians per refined
  * step, core/gs.py:41-83 loops `for b in range(B): for v in range(V):` around the extension): "view" vv = b * V + v uses sample b's
- * Gaussians and the vv-th camera.  ONE preprocess launch over (view, Gaussian), ONE inclusive scan over the B * V * N tile counts, ONE
- * 64-bit radix sort of every instance with key = (vv * tiles + tile) << 32 | depth bits, one ranges and one blend launch (grid =
- * tiles x views; a tile without instances writes the background) — 6 launches and ONE host read of the instance total per call instead
- * of 6 launches and one host round trip per view.  Per-(view, Gaussian) arrays hold B * V * N entries; keys / vals num_rendered.
- * Same arithmetic as the per-view entry points (shared device code): the images are bit-identical.
- *   vmv_gs_batch_key_bits(n_views, size)       -> significant key bits (32 depth + ceil(log2(n_views * tiles)))
+ * Gaussians and the vv-th camera.  ONE preprocess launch over (view, Gaussian); the B * V * N records are ranked by (view, depth) with a
+ * stable 64-bit radix sort (1.6 M pairs at the VideoMV size) and their tile counts scanned in rank order, so the instances are emitted
+ * depth-ordered per view; ONE radix sort of every instance on its 32-bit (view, tile) id vv * tiles + tile ALONE (round 6: two 8-bit
+ * passes over 8-byte pairs at 24 views instead of six over 12-byte pairs with the depth in the key) — stable, so a tile's instances
+ * stay in (depth, Gaussian index) order, the order the per-view entry points' 64-bit (tile, depth) sort produces — one ranges and one
+ * blend launch (grid = tiles x views; a tile without instances writes the background): ONE host read of the instance total per call
+ * instead of one host round trip per view.  Per-(view, Gaussian) arrays hold B * V * N entries; keys / vals num_rendered (keys: the
+ * 32-bit ids use the first half of the 8 bytes per instance).  scan_temp is the preprocess workspace (ranking buffers + primitive
+ * temporaries, sized by vmv_gs_batch_workspace_bytes) and must stay untouched between _preprocess and _render; `offsets` is the scan
+ * in RANK order (offsets[B*V*N - 1] = num_rendered).  Shared blend code, same order: the images are bit-identical to the per-view path.
+ *   vmv_gs_batch_key_bits(n_views, size)       -> 32 + ceil(log2(n_views * tiles)) (ABI-stable; the sort uses the low part)
  *   vmv_gs_batch_workspace_bytes(n_view_gaussians, n_instances, key_bits, &scan, &sort)
  *   vmv_gs_batch_preprocess -> offsets[B*V*N - 1] = num_rendered (host reads it, sizes keys / vals / sort_temp), vmv_gs_batch_render. */
 typedef struct {

@@ -17,6 +17,17 @@
 //                          of 256 (xy, conic+opacity, colour), every thread blends its pixel front to back with the
 //                          1/255 alpha cut, the 0.99 clamp and the T < 1e-4 stop; block-wide early exit
 // Memory: everything per Gaussian is 48 B, per instance 12 B; the render pass reads each instance once per tile.
+//
+// The BATCHED pass (vmv_gs_batch_*, round 6) keeps the depth out of the big sort.  The V x N (view, Gaussian) records are first sorted by
+// (view, depth bits) — a 64-bit-key radix sort of 1.6 M pairs, stable, so equal depths stay in Gaussian-index order — and the instances
+// are emitted in THAT order; the instance sort then runs on the 32-bit (view, tile) id alone — two 8-bit radix passes over 8-byte pairs
+// for 24 views x 1024 tiles instead of six over 12-byte pairs — and, being stable, leaves every tile's instances ordered by (depth,
+// Gaussian index): exactly the order of the per-view path's 64-bit (tile, depth) stable sort (a tile holds a Gaussian at most once),
+// so both paths blend the same sequence and give the same bits (tests/test_gs_gpu.py::test_batched_pass_equals_the_per_view_loop).
+// The duplicate pass is block-cooperative: the offsets of 256 depth-ranked Gaussians in LDS, one thread per INSTANCE slot (owner by
+// binary search), so the key / value stores are coalesced (the one-thread-per-Gaussian loop wrote ~20 scattered runs per thread:
+// 0.67 ms for 32 M instances, now 0.10).  Measured and rejected on the way: the tile-id sort followed by a per-tile bitonic sort of
+// (depth, index) keys in the blend block's LDS — correct, but 2.8 ms of sorting for 24 576 tiles (profiles/r6_gs_*).
 #include "common.h"
 #include <cstring>
 #include <rocprim/device/device_scan.hpp>
@@ -122,33 +133,98 @@ __global__ __launch_bounds__(256) void gs_preprocess_batch_kernel(const VmvGsBat
     gs_project(p.gaussians + ((long)(vv / p.V) * p.N + i) * 14, s_m, s_m + 16, p.size, p.tan_half_fov, out, (long)vv * p.N + i);
 }
 
-__global__ __launch_bounds__(256) void gs_duplicate_batch_kernel(const VmvGsBatchParams p) {
-    const int vv = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.N) return;
-    const long o = (long)vv * p.N + i;
-    if (p.tiles_touched[o] == 0) return;
-    uint32_t off = o == 0 ? 0u : p.offsets[o - 1];
-    const int* rc = p.rect + 4L * o;
+// Preprocess workspace of the batched pass, carved out of VmvGsBatchParams.scan_temp (vmv_gs_batch_workspace_bytes sizes it): the
+// depth-ranking sort's key / value buffers, the tile counts in rank order, rocprim's temporaries.  `perm[r]` = index o = vv * N + i of the
+// (view, Gaussian) record with rank r in (view, depth, Gaussian index) order.
+struct GsBatchWs {
+    uint64_t* dkeys; uint64_t* dkeys_sorted;
+    uint32_t* perm_in; uint32_t* perm;
+    uint32_t* touched_ranked;
+    void* prim; size_t prim_bytes;
+};
+inline size_t gs_align(size_t v) { return (v + 255) & ~(size_t)255; }
+inline size_t gs_batch_ws_fixed_bytes(size_t vn) { return 2 * gs_align(vn * 8) + 3 * gs_align(vn * 4); }
+inline GsBatchWs gs_batch_ws(void* base, size_t bytes, size_t vn) {
+    unsigned char* q = reinterpret_cast<unsigned char*>(base);
+    GsBatchWs w;
+    w.dkeys = reinterpret_cast<uint64_t*>(q); q += gs_align(vn * 8);
+    w.dkeys_sorted = reinterpret_cast<uint64_t*>(q); q += gs_align(vn * 8);
+    w.perm_in = reinterpret_cast<uint32_t*>(q); q += gs_align(vn * 4);
+    w.perm = reinterpret_cast<uint32_t*>(q); q += gs_align(vn * 4);
+    w.touched_ranked = reinterpret_cast<uint32_t*>(q); q += gs_align(vn * 4);
+    w.prim = q;
+    const size_t fixed = gs_batch_ws_fixed_bytes(vn);
+    w.prim_bytes = bytes > fixed ? bytes - fixed : 0;
+    return w;
+}
+
+// key of the depth-ranking sort: (view << 32) | depth bits (depth > 0.2: the bit pattern orders like the float); records that touch no
+// tile sort last in their view (their depth was never written)
+__global__ __launch_bounds__(256) void gs_depth_keys_batch_kernel(const VmvGsBatchParams p, uint64_t* __restrict__ dkeys, uint32_t* __restrict__ perm_in) {
+    const long o = (long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= (long)p.B * p.V * p.N) return;
+    const uint32_t vv = (uint32_t)(o / p.N);
+    const uint32_t d = p.tiles_touched[o] ? __float_as_uint(p.depth[o]) : 0xffffffffu;
+    dkeys[o] = ((uint64_t)vv << 32) | d;
+    perm_in[o] = (uint32_t)o;
+}
+__global__ __launch_bounds__(256) void gs_rank_counts_batch_kernel(const VmvGsBatchParams p, const uint32_t* __restrict__ perm, uint32_t* __restrict__ touched_ranked) {
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= (long)p.B * p.V * p.N) return;
+    touched_ranked[r] = p.tiles_touched[perm[r]];
+}
+
+// Block-cooperative duplicate: the block owns 256 consecutive RANKS (records in (view, depth) order); their inclusive offsets and
+// rectangles sit in LDS, and thread j of every 256-slot round writes instance slot j of the block's contiguous output range — its owner
+// found by binary search over the LDS offsets — so keys and values are stored coalesced.  Key = the 32-bit (view, tile) id; instance k of
+// a Gaussian is tile (y0 + k / w, x0 + k % w), the enumeration order of the per-view kernel.
+__global__ __launch_bounds__(256) void gs_duplicate_batch_kernel(const VmvGsBatchParams p, const uint32_t* __restrict__ perm) {
+    __shared__ uint32_t s_off[256];          // inclusive offsets relative to the block's base
+    __shared__ uint32_t s_tile[256];         // (view, tile) id of the rectangle's first tile
+    __shared__ int s_w[256];                 // rectangle width in tiles
+    __shared__ uint32_t s_gi[256];           // Gaussian index inside its sample
+    const long total = (long)p.B * p.V * p.N;
+    const long r0 = (long)blockIdx.x * 256, r = r0 + threadIdx.x;
+    const uint32_t base = r0 == 0 ? 0u : p.offsets[r0 - 1];
     const int grid = (p.size + GS_TILE - 1) / GS_TILE;
-    const uint32_t tile0 = (uint32_t)vv * (uint32_t)(grid * grid);
-    const uint32_t dbits = __float_as_uint(p.depth[o]);           // depth > 0.2: the bit pattern orders like the float
-    for (int y = rc[1]; y < rc[3]; ++y)
-        for (int x = rc[0]; x < rc[2]; ++x) {
-            if (off >= (uint32_t)p.num_rendered) return;
-            p.keys[off] = ((uint64_t)(tile0 + (uint32_t)(y * grid + x)) << 32) | dbits;      // (view, tile) major, depth minor
-            p.vals[off] = (uint32_t)i;                                                       // Gaussian index inside its sample
-            ++off;
-        }
+    uint32_t off_incl = 0;
+    if (r < total) {
+        off_incl = p.offsets[r];
+        const long o = perm[r];
+        const int* rc = p.rect + 4L * o;
+        const int vv = (int)(o / p.N);
+        const bool any = p.tiles_touched[o] != 0;
+        s_tile[threadIdx.x] = any ? (uint32_t)vv * (uint32_t)(grid * grid) + (uint32_t)(rc[1] * grid + rc[0]) : 0u;
+        s_w[threadIdx.x] = any ? rc[2] - rc[0] : 1;
+        s_gi[threadIdx.x] = (uint32_t)(o - (long)vv * p.N);
+    }
+    const long last = (r0 + 255 < total ? r0 + 255 : total - 1);
+    s_off[threadIdx.x] = (r < total ? off_incl : p.offsets[last]) - base;
+    __syncthreads();
+    const uint32_t nblk = s_off[255];
+    const uint32_t lim = (uint32_t)p.num_rendered;
+    uint32_t* keys32 = reinterpret_cast<uint32_t*>(p.keys);
+    for (uint32_t j = threadIdx.x; j < nblk; j += 256) {
+        int lo = 0, hi = 255;                // smallest t with s_off[t] > j
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_off[mid] > j) hi = mid; else lo = mid + 1; }
+        const uint32_t k = j - (lo == 0 ? 0u : s_off[lo - 1]);
+        const int w = s_w[lo];
+        const uint32_t ky = k / (uint32_t)w, kx = k - ky * (uint32_t)w;
+        const uint32_t dst = base + j;
+        if (dst >= lim) break;
+        keys32[dst] = s_tile[lo] + ky * (uint32_t)grid + kx;
+        p.vals[dst] = s_gi[lo];
+    }
 }
 
 __global__ __launch_bounds__(256) void gs_ranges_batch_kernel(const VmvGsBatchParams p) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.num_rendered) return;
-    const uint32_t t = (uint32_t)(p.keys_sorted[i] >> 32);
+    const uint32_t* ks = reinterpret_cast<const uint32_t*>(p.keys_sorted);
+    const uint32_t t = ks[i];
     if (i == 0) p.ranges[2 * t] = 0;
     else {
-        const uint32_t tp = (uint32_t)(p.keys_sorted[i - 1] >> 32);
+        const uint32_t tp = ks[i - 1];
         if (tp != t) { p.ranges[2 * tp + 1] = (uint32_t)i; p.ranges[2 * t] = (uint32_t)i; }
     }
     if (i == p.num_rendered - 1) p.ranges[2 * t + 1] = (uint32_t)p.num_rendered;
@@ -183,42 +259,61 @@ __global__ __launch_bounds__(256) void gs_ranges_kernel(const VmvGsParams p) {
 }
 
 // One 16 x 16 tile of one view: blend the tile's sorted instances [lo, hi) front to back.  Arrays are the view's own (already offset).
+// `order(j)` = Gaussian index of the tile's j-th instance in blend order, j in [lo, hi).
+// Round 6: the inner loop is branch-free per lane and wave-uniform in its control flow.  The divergent form (three nested `continue` /
+// `break` tests) spent as many scalar mask instructions as vector ones — 35 + 35 per Gaussian and wave in the ISA — on a kernel that is
+// VALU-bound (8 G pixel x Gaussian evaluations per 24 views; it was priced against HBM before, wrongly).  Now the exponent is taken in
+// base 2 with the conic pre-scaled by -0.5 log2(e) when the Gaussian is staged (one v_exp_f32 instead of expf's range reduction), a
+// WAVE skips a Gaussian none of its 64 pixels can see (conservative pre-test on p2 + log2(opacity), before the exponential), the
+// per-lane tests are selects, and the loop leaves when every lane of the wave is done.  Same rule as before per pixel: skip power > 0,
+// alpha = min(0.99, opacity e^power), skip alpha < 1/255, stop BEFORE the Gaussian that would take T below 1e-4.
+template <typename Order>
 VMV_DEV void gs_blend_tile(const int size, const float* __restrict__ bg, const uint32_t lo, const uint32_t hi,
-                           const uint32_t* __restrict__ vals_sorted, const float* __restrict__ xy, const float* __restrict__ conic_opacity,
+                           const Order order, const float* __restrict__ xy, const float* __restrict__ conic_opacity,
                            const float* __restrict__ gaussians, float* __restrict__ out_color, float* __restrict__ out_alpha) {
-    __shared__ float s_xy[256][2];
-    __shared__ float s_co[256][4];
-    __shared__ float s_rgb[256][3];
+    __shared__ f32x4_t s_g0[256];            // x, y, A = -0.5 log2e a, B = -log2e b
+    __shared__ f32x4_t s_g1[256];            // C = -0.5 log2e c, log2(opacity), opacity, red
+    __shared__ f32x2_t s_g2[256];            // green, blue
     __shared__ int s_done;
     const int px = blockIdx.x * GS_TILE + (threadIdx.x & 15), py = blockIdx.y * GS_TILE + (threadIdx.x >> 4);
     const bool inside = px < size && py < size;
+    const float fx = (float)px, fy = (float)py;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Wt = 0.f;
     bool done = !inside;
+    constexpr float LOG2E = 1.4426950408889634f;
+    constexpr float CULL = -7.9943534f - 0.02f;      // log2(1 / 255) with a margin: the exact alpha test follows for what passes
     for (uint32_t base = lo; base < hi; base += 256) {
         if (threadIdx.x == 0) s_done = 0;
         __syncthreads();
         const uint32_t j = base + threadIdx.x;
         if (j < hi) {
-            const uint32_t gi = vals_sorted[j];
-            s_xy[threadIdx.x][0] = xy[2 * gi]; s_xy[threadIdx.x][1] = xy[2 * gi + 1];
+            const uint32_t gi = order(j);
             const float* co = conic_opacity + 4L * gi;
-            s_co[threadIdx.x][0] = co[0]; s_co[threadIdx.x][1] = co[1]; s_co[threadIdx.x][2] = co[2]; s_co[threadIdx.x][3] = co[3];
             const float* g = gaussians + 14L * gi + 11;
-            s_rgb[threadIdx.x][0] = g[0]; s_rgb[threadIdx.x][1] = g[1]; s_rgb[threadIdx.x][2] = g[2];
+            const float o = co[3];
+            s_g0[threadIdx.x] = f32x4_t{xy[2 * gi], xy[2 * gi + 1], -0.5f * LOG2E * co[0], -LOG2E * co[1]};
+            s_g1[threadIdx.x] = f32x4_t{-0.5f * LOG2E * co[2], o > 0.f ? __builtin_amdgcn_logf(o) : -1e30f, o, g[0]};
+            s_g2[threadIdx.x] = f32x2_t{g[1], g[2]};
         }
         __syncthreads();
         const int n = (int)min(256u, hi - base);
-        for (int k = 0; k < n && !done; ++k) {
-            const float dx = s_xy[k][0] - (float)px, dy = s_xy[k][1] - (float)py;
-            const float power = -0.5f * (s_co[k][0] * dx * dx + s_co[k][2] * dy * dy) - s_co[k][1] * dx * dy;
-            if (power > 0.0f) continue;
-            const float alpha = fminf(0.99f, s_co[k][3] * expf(power));
-            if (alpha < 1.0f / 255.0f) continue;
+        for (int k = 0; k < n; ++k) {
+            const f32x4_t g0 = s_g0[k], g1 = s_g1[k];
+            const float dx = g0.x - fx, dy = g0.y - fy;
+            const float p2 = g0.z * dx * dx + g1.x * dy * dy + g0.w * dx * dy;        // log2 of the Gaussian's falloff at this pixel
+            const bool maybe = !done && p2 <= 0.0f && p2 + g1.y >= CULL;
+            if (__builtin_amdgcn_ballot_w64(maybe) == 0) continue;                    // nobody in the wave sees it
+            const float alpha = fminf(0.99f, g1.z * __builtin_amdgcn_exp2f(p2));
+            const bool valid = maybe && alpha >= 1.0f / 255.0f;
             const float tT = T * (1.0f - alpha);
-            if (tT < 1e-4f) { done = true; break; }
-            const float w = alpha * T;
-            C0 += s_rgb[k][0] * w; C1 += s_rgb[k][1] * w; C2 += s_rgb[k][2] * w; Wt += w;
-            T = tT;
+            const bool stop = valid && tT < 1e-4f;
+            done = done || stop;
+            const bool apply = valid && !stop;
+            const float w = apply ? alpha * T : 0.0f;
+            const f32x2_t g2 = s_g2[k];
+            C0 += g1.w * w; C1 += g2.x * w; C2 += g2.y * w; Wt += w;
+            T = apply ? tT : T;
+            if (__builtin_amdgcn_ballot_w64(!done) == 0) break;                       // the whole wave is saturated
         }
         if (!done) s_done = 1;                 // somebody still needs more Gaussians
         __syncthreads();
@@ -238,8 +333,9 @@ VMV_DEV void gs_blend_tile(const int size, const float* __restrict__ bg, const u
 __global__ __launch_bounds__(256) void gs_render_kernel(const VmvGsParams p) {
     const int grid = (p.size + GS_TILE - 1) / GS_TILE;
     const int tile = blockIdx.y * grid + blockIdx.x;
-    gs_blend_tile(p.size, p.bg, p.ranges[2 * tile], p.ranges[2 * tile + 1], p.vals_sorted, p.xy, p.conic_opacity, p.gaussians,
-                  p.out_color, p.out_alpha);
+    const uint32_t* vs = p.vals_sorted;
+    gs_blend_tile(p.size, p.bg, p.ranges[2 * tile], p.ranges[2 * tile + 1], [vs](const uint32_t j) { return vs[j]; }, p.xy, p.conic_opacity,
+                  p.gaussians, p.out_color, p.out_alpha);
 }
 
 __global__ __launch_bounds__(256) void gs_render_batch_kernel(const VmvGsBatchParams p) {
@@ -248,8 +344,10 @@ __global__ __launch_bounds__(256) void gs_render_batch_kernel(const VmvGsBatchPa
     const long tile = (long)vv * grid * grid + blockIdx.y * grid + blockIdx.x;
     const long hw = (long)p.size * p.size, vo = (long)vv * p.N;
     // (a view without instances has ranges 0 / 0 from the memset: the tile writes the background)
-    gs_blend_tile(p.size, p.bg, p.ranges[2 * tile], p.ranges[2 * tile + 1], p.vals_sorted, p.xy + 2 * vo, p.conic_opacity + 4 * vo,
-                  p.gaussians + (long)(vv / p.V) * p.N * 14, p.out_color + 3 * hw * vv, p.out_alpha ? p.out_alpha + hw * vv : nullptr);
+    const uint32_t* vs = p.vals_sorted;
+    gs_blend_tile(p.size, p.bg, p.ranges[2 * tile], p.ranges[2 * tile + 1], [vs](const uint32_t j) { return vs[j]; }, p.xy + 2 * vo,
+                  p.conic_opacity + 4 * vo, p.gaussians + (long)(vv / p.V) * p.N * 14, p.out_color + 3 * hw * vv,
+                  p.out_alpha ? p.out_alpha + hw * vv : nullptr);
 }
 
 int gs_check(const VmvGsParams& p) {
@@ -328,10 +426,15 @@ extern "C" int vmv_gs_batch_workspace_bytes(int n_view_gaussians, int n_instance
     if (!scan_bytes || !sort_bytes || n_view_gaussians <= 0 || n_instances < 0 || key_bits < 1 || key_bits > 64) return VMV_EINVAL;
     uint32_t* a = nullptr;
     uint64_t* k = nullptr;
-    hipError_t e = rocprim::inclusive_scan(nullptr, *scan_bytes, a, a, (size_t)n_view_gaussians, rocprim::plus<uint32_t>(), (hipStream_t)0);
+    // scan_temp = the preprocess workspace (GsBatchWs): the depth-ranking sort's buffers + the larger of the two primitives' temporaries
+    size_t scan_prim = 0, rank_prim = 0;
+    hipError_t e = rocprim::inclusive_scan(nullptr, scan_prim, a, a, (size_t)n_view_gaussians, rocprim::plus<uint32_t>(), (hipStream_t)0);
     if (e != hipSuccess) return (int)e;
-    e = rocprim::radix_sort_pairs(nullptr, *sort_bytes, k, k, a, a, (size_t)(n_instances > 0 ? n_instances : 1), 0u, (unsigned)key_bits,
-                                  (hipStream_t)0);
+    e = rocprim::radix_sort_pairs(nullptr, rank_prim, k, k, a, a, (size_t)n_view_gaussians, 0u, 64u, (hipStream_t)0);
+    if (e != hipSuccess) return (int)e;
+    *scan_bytes = gs_batch_ws_fixed_bytes((size_t)n_view_gaussians) + gs_align(scan_prim > rank_prim ? scan_prim : rank_prim);
+    e = rocprim::radix_sort_pairs(nullptr, *sort_bytes, a, a, a, a, (size_t)(n_instances > 0 ? n_instances : 1), 0u,
+                                  (unsigned)(key_bits > 32 ? key_bits - 32 : key_bits), (hipStream_t)0);      // 32-bit (view, tile) keys
     return e == hipSuccess ? VMV_OK : (int)e;
 }
 
@@ -349,10 +452,23 @@ extern "C" int vmv_gs_batch_preprocess(const VmvGsBatchParams* pp, void* stream)
     int rc = gs_batch_check(p);
     if (rc != VMV_OK) return rc;
     if (!p.scan_temp) return VMV_ENULL;
+    const size_t vn = (size_t)p.B * p.V * p.N;
+    if (!vmv_aligned16(p.scan_temp)) return VMV_EALIGN;
+    if (p.scan_temp_bytes <= gs_batch_ws_fixed_bytes(vn)) return VMV_ERANGE;
+    const GsBatchWs w = gs_batch_ws(p.scan_temp, p.scan_temp_bytes, vn);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const unsigned nb = (unsigned)((vn + 255) / 256);
     hipLaunchKernelGGL(gs_preprocess_batch_kernel, dim3((p.N + 255) / 256, p.B * p.V), dim3(256), 0, st, p);
-    size_t bytes = p.scan_temp_bytes;
-    hipError_t e = rocprim::inclusive_scan(p.scan_temp, bytes, p.tiles_touched, p.offsets, (size_t)p.B * p.V * p.N, rocprim::plus<uint32_t>(), st);
+    // rank the records of every view by depth (stable: equal depths keep their Gaussian-index order), count tiles in rank order, scan
+    hipLaunchKernelGGL(gs_depth_keys_batch_kernel, dim3(nb), dim3(256), 0, st, p, w.dkeys, w.perm_in);
+    int vbits = 1;
+    while ((1L << vbits) < (long)p.B * p.V) ++vbits;
+    size_t bytes = w.prim_bytes;
+    hipError_t e = rocprim::radix_sort_pairs(w.prim, bytes, w.dkeys, w.dkeys_sorted, w.perm_in, w.perm, vn, 0u, (unsigned)(32 + vbits), st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(gs_rank_counts_batch_kernel, dim3(nb), dim3(256), 0, st, p, w.perm, w.touched_ranked);
+    bytes = w.prim_bytes;
+    e = rocprim::inclusive_scan(w.prim, bytes, w.touched_ranked, p.offsets, vn, rocprim::plus<uint32_t>(), st);
     if (e != hipSuccess) return (int)e;
     return vmv_launch_status();
 }
@@ -371,10 +487,13 @@ extern "C" int vmv_gs_batch_render(const VmvGsBatchParams* pp, void* stream) {
     if (e != hipSuccess) return (int)e;
     if (p.num_rendered > 0) {
         if (!p.keys || !p.keys_sorted || !p.vals || !p.vals_sorted || !p.sort_temp) return VMV_ENULL;
-        hipLaunchKernelGGL(gs_duplicate_batch_kernel, dim3((p.N + 255) / 256, VV), dim3(256), 0, st, p);
+        if (!p.scan_temp || p.scan_temp_bytes <= gs_batch_ws_fixed_bytes((size_t)VV * p.N)) return VMV_ENULL;      // perm[] of _preprocess
+        const GsBatchWs w = gs_batch_ws(p.scan_temp, p.scan_temp_bytes, (size_t)VV * p.N);
+        hipLaunchKernelGGL(gs_duplicate_batch_kernel, dim3((unsigned)(((long)VV * p.N + 255) / 256)), dim3(256), 0, st, p, (const uint32_t*)w.perm);
         size_t bytes = p.sort_temp_bytes;
-        e = rocprim::radix_sort_pairs(p.sort_temp, bytes, p.keys, p.keys_sorted, p.vals, p.vals_sorted, (size_t)p.num_rendered,
-                                      0u, (unsigned)vmv_gs_batch_key_bits(VV, p.size), st);
+        // (view, tile) ids only: keys are the first 4 n bytes of the 8 n-byte key buffers (header comment)
+        e = rocprim::radix_sort_pairs(p.sort_temp, bytes, reinterpret_cast<uint32_t*>(p.keys), reinterpret_cast<uint32_t*>(p.keys_sorted),
+                                      p.vals, p.vals_sorted, (size_t)p.num_rendered, 0u, (unsigned)(vmv_gs_batch_key_bits(VV, p.size) - 32), st);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(gs_ranges_batch_kernel, dim3((p.num_rendered + 255) / 256), dim3(256), 0, st, p);
     }
