@@ -718,9 +718,13 @@ def main(argv=None):
                                      ms_per_view=round(1000 * t_r / nview, 4), algorithmic_bytes=int(by),
                                      achieved_gb_s=round(by / t_r / 1e9, 1), peak_gb_s=8000.0, frac=round(by / t_r / 8e12, 4),
                                      per_view_loop_ms_per_24_views=round(1000 * t_pv, 3), host_syncs_per_call=1,
-                                     note="wall time of GaussianRenderer.render: ONE batched pass over all views (one preprocess / scan / radix sort / "
-                                          "ranges / blend launch, one host read of the instance total); per_view_loop = round 4's loop with a host "
-                                          "round trip per view, same run; rocprim radix sort passes are traffic on top of the algorithmic bytes")
+                                     bound="valu (the blend: ~8 G pixel x Gaussian evaluations per 24 views at 13-30 vector instructions each is "
+                                           "56 % of the GPU time in profiles/r6_gs_kernel_stats_after.txt; the HBM figure is kept for continuity, it is "
+                                           "not what limits the pass)",
+                                     note="wall time of GaussianRenderer.render: ONE batched pass over all views (preprocess, per-view depth ranking, "
+                                          "scan, ONE host read of the instance total, coalesced duplicate, 2-pass radix sort on the 32-bit tile id, "
+                                          "ranges, branch-free blend — round 6); per_view_loop = round 4's loop with a host round trip per view and "
+                                          "the 64-bit (tile, depth) sort, same run, same bits")
         except Exception as e:
             lgm["rasteriser"] = {"error": f"{type(e).__name__}: {e}"}
     if lgm is not None:
