@@ -498,15 +498,17 @@ __global__ __launch_bounds__(128 * WMW, WMW == 2 ? 2 : 1) void gemm_glds_kernel(
     }
 }
 
-// VMV_GLDS_TAPMAJOR: 1 = run-wise K walk of the convolutions (kernel), 0 = segment-major.  DEFAULT 0: measured on one box the run-wise
-// walk cuts this kernel's convolution fetches 5.2 x -> 3.8 x of the algorithmic bytes (what is left is W, streamed once into each of the
-// 8 L2s: 240 tiles = one round) but its convolutions run 1-4 % slower (L3 tconv 314 -> 303 TFLOP/s, conv L2 1018 -> 1008) and the step
-// +0.25 ms (48.05 / 48.20 vs 47.87 / 47.89 with both kernels' walks off; gemm_xglds's alone: -0.08 ms) — profiles/r6_tap2_*.log,
-// profiles/r6b_gemm_traffic_by_kernel.tsv.  The fetches it saves come out of the Infinity Cache, not HBM, and were not the bound.
-int glds_tapmajor() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("VMV_GLDS_TAPMAJOR"); v = e ? atoi(e) : 0; }
-    return v;
+// Run-wise K walk of the convolutions (kernel): on for M >= 16384 rows, off below; VMV_GLDS_TAPMAJOR = 0 / 1 forces it (A/B).
+// Measured on one box: the walk cuts this kernel's convolution fetches 5.2 x -> 3.8 x of the algorithmic bytes at the UNet's third /
+// fourth level (what is left is W, streamed once into each of the 8 L2s: 240 tiles = one round), but those convolutions (M = 7680 /
+// 1920) run 1-4 % slower (L3 tconv 314 -> 303 TFLOP/s, conv L2 1018 -> 1008) and the step +0.25 ms (48.05 / 48.20 vs 47.87 / 47.89;
+// profiles/r6_tap2_*.log, r6b_gemm_traffic_by_kernel.tsv): there the fetches it saves come out of the Infinity Cache and were not
+// the bound.  Where A is the whole traffic — the VAE's 128-channel convolutions over 1.6-3.1 M rows (W = 295 KB) — it pays: encoder
+// first level 570 -> 672 / 503 -> 585 TFLOP/s, 48-view encode 22.4 -> 20.6 ms, decode 7.7 -> 7.4 (profiles/r6_lgm_step_bench*.log).
+int glds_tapmajor(const VmvGemmParams& p) {
+    static int v = -2;
+    if (v == -2) { const char* e = getenv("VMV_GLDS_TAPMAJOR"); v = e ? atoi(e) : -1; }
+    return v >= 0 ? v : (p.M >= 16384 ? 1 : 0);
 }
 
 // rows of the tile group that shares W slices in an XCD's L2 (gemm_xglds.hip xglds_group_m; `conc` = blocks an XCD runs at once:
@@ -544,7 +546,7 @@ int launch_glds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
         static std::atomic<unsigned long long> attr_set{0};
         if (const int rc_attr = vmv_lds_attr_once(attr_set, reinterpret_cast<const void*>(&gemm_glds_kernel<WMW, WN, STAGES, AB, PP>), Cfg::LDS_BYTES)) return rc_attr;
         VMV_LAUNCH((gemm_glds_kernel<WMW, WN, STAGES, AB, PP>), grid, dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n,
-                           total_steps, sps, gm, glds_tapmajor());
+                           total_steps, sps, gm, glds_tapmajor(p));
         return VMV_OK;
     };
     int rc;
