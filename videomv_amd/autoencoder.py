@@ -419,19 +419,41 @@ class DiagonalGaussianDistribution(object):
             if not (0 <= first and first + self.n <= total):
                 raise ValueError("posterior sample slice outside its batch")
             draws = [torch.randn(total, self.zc, self.h, self.w) for _ in range(k)]
-            noise = draws[i][first:first + self.n].to(device=self.device)
+            noise = self._to_device(draws[i][first:first + self.n].contiguous())
         elif of is not None:
             total, first = int(of[0]), int(of[1])
             if not (0 <= first and first + per <= total):
                 raise ValueError("posterior sample slice outside its batch")
-            noise = torch.cat([torch.randn(total, self.zc, self.h, self.w)[first:first + per] for _ in range(nparts)]).to(device=self.device)
+            noise = self._to_device(torch.cat([torch.randn(total, self.zc, self.h, self.w)[first:first + per] for _ in range(nparts)]))
         elif nparts > 1:
-            noise = torch.cat([torch.randn(per, self.zc, self.h, self.w) for _ in range(nparts)]).to(device=self.device)
+            noise = self._to_device(torch.cat([torch.randn(per, self.zc, self.h, self.w) for _ in range(nparts)]))
         else:
-            noise = torch.randn(self.n, self.zc, self.h, self.w).to(device=self.device)
+            noise = self._to_device(torch.randn(self.n, self.zc, self.h, self.w))
         z = torch.empty(self.n, self.zc, self.h, self.w, dtype=torch.float32, device=self.device)
         ops.posterior_sample(self.moment_rows, 2 * self.zc, noise.contiguous(), z, scale)
         return z
+
+    _pinned = {}      # (shape, device) -> (pinned host buffer, event recorded after the last upload from it)
+
+    def _to_device(self, host_noise):
+        """Host-RNG noise -> device WITHOUT blocking the host on the stream: `.to(device)` of a pageable tensor waits for everything
+        queued before it — here the whole encoder — and the launch that needs the noise then leaves the host late (round 6: 0.5-14 ms
+        of idle GPU per LGM-refined step in the kernel trace, tools/experiments/lgm_gaps.py).  The draw goes through a pinned buffer
+        and an asynchronous copy; the buffer is reused once the event after its last upload has passed."""
+        if not str(self.device).startswith("cuda"):
+            return host_noise.to(device=self.device)
+        key = (tuple(host_noise.shape), str(self.device))
+        ent = DiagonalGaussianDistribution._pinned.get(key)
+        if ent is None:
+            ent = [torch.empty(host_noise.shape, dtype=torch.float32).pin_memory(), None]
+            DiagonalGaussianDistribution._pinned[key] = ent
+        if ent[1] is not None:
+            ent[1].synchronize()
+        ent[0].copy_(host_noise)
+        dev = ent[0].to(device=self.device, non_blocking=True)
+        ent[1] = torch.cuda.Event()
+        ent[1].record(torch.cuda.current_stream(self.device))
+        return dev
 
 
 @AUTO_ENCODER.register_class()

@@ -264,16 +264,17 @@ __global__ __launch_bounds__(256) void gs_ranges_kernel(const VmvGsParams p) {
 // `break` tests) spent as many scalar mask instructions as vector ones — 35 + 35 per Gaussian and wave in the ISA — on a kernel that is
 // VALU-bound (8 G pixel x Gaussian evaluations per 24 views; it was priced against HBM before, wrongly).  Now the exponent is taken in
 // base 2 with the conic pre-scaled by -0.5 log2(e) when the Gaussian is staged (one v_exp_f32 instead of expf's range reduction), a
-// WAVE skips a Gaussian none of its 64 pixels can see (conservative pre-test on p2 + log2(opacity), before the exponential), the
+// WAVE skips a PAIR of Gaussians none of its 64 pixels can see (conservative pre-test on p2 + log2(opacity), before the exponential;
+// the pair's exponents are packed fp32 operations), the
 // per-lane tests are selects, and the loop leaves when every lane of the wave is done.  Same rule as before per pixel: skip power > 0,
 // alpha = min(0.99, opacity e^power), skip alpha < 1/255, stop BEFORE the Gaussian that would take T below 1e-4.
 template <typename Order>
 VMV_DEV void gs_blend_tile(const int size, const float* __restrict__ bg, const uint32_t lo, const uint32_t hi,
                            const Order order, const float* __restrict__ xy, const float* __restrict__ conic_opacity,
                            const float* __restrict__ gaussians, float* __restrict__ out_color, float* __restrict__ out_alpha) {
-    __shared__ f32x4_t s_g0[256];            // x, y, A = -0.5 log2e a, B = -log2e b
-    __shared__ f32x4_t s_g1[256];            // C = -0.5 log2e c, log2(opacity), opacity, red
-    __shared__ f32x2_t s_g2[256];            // green, blue
+    // staged Gaussians, one array per field (+ 2 pad entries): the loop takes them TWO at a time, a field pair is one ds_read_b64 and
+    // the falloff exponents of the pair are packed fp32 operations (v_pk_*: 8 for two Gaussians where the one-at-a-time form issued 16)
+    __shared__ __attribute__((aligned(16))) float s_x[258], s_y[258], s_A[258], s_B[258], s_C[258], s_l[258], s_o[258], s_r[258], s_g[258], s_b[258];
     __shared__ int s_done;
     const int px = blockIdx.x * GS_TILE + (threadIdx.x & 15), py = blockIdx.y * GS_TILE + (threadIdx.x >> 4);
     const bool inside = px < size && py < size;
@@ -291,29 +292,41 @@ VMV_DEV void gs_blend_tile(const int size, const float* __restrict__ bg, const u
             const float* co = conic_opacity + 4L * gi;
             const float* g = gaussians + 14L * gi + 11;
             const float o = co[3];
-            s_g0[threadIdx.x] = f32x4_t{xy[2 * gi], xy[2 * gi + 1], -0.5f * LOG2E * co[0], -LOG2E * co[1]};
-            s_g1[threadIdx.x] = f32x4_t{-0.5f * LOG2E * co[2], o > 0.f ? __builtin_amdgcn_logf(o) : -1e30f, o, g[0]};
-            s_g2[threadIdx.x] = f32x2_t{g[1], g[2]};
+            s_x[threadIdx.x] = xy[2 * gi]; s_y[threadIdx.x] = xy[2 * gi + 1];
+            s_A[threadIdx.x] = -0.5f * LOG2E * co[0]; s_B[threadIdx.x] = -LOG2E * co[1]; s_C[threadIdx.x] = -0.5f * LOG2E * co[2];
+            s_l[threadIdx.x] = o > 0.f ? __builtin_amdgcn_logf(o) : -1e30f;      // v_log_f32: log2
+            s_o[threadIdx.x] = o;
+            s_r[threadIdx.x] = g[0]; s_g[threadIdx.x] = g[1]; s_b[threadIdx.x] = g[2];
+        } else {                               // pad: a Gaussian nobody sees (the pair of an odd tail)
+            s_x[threadIdx.x] = 0.f; s_y[threadIdx.x] = 0.f; s_A[threadIdx.x] = 0.f; s_B[threadIdx.x] = 0.f; s_C[threadIdx.x] = 0.f;
+            s_l[threadIdx.x] = -1e30f; s_o[threadIdx.x] = 0.f;
+            s_r[threadIdx.x] = 0.f; s_g[threadIdx.x] = 0.f; s_b[threadIdx.x] = 0.f;      // (weight 0 x stale LDS could be 0 x NaN)
         }
         __syncthreads();
         const int n = (int)min(256u, hi - base);
-        for (int k = 0; k < n; ++k) {
-            const f32x4_t g0 = s_g0[k], g1 = s_g1[k];
-            const float dx = g0.x - fx, dy = g0.y - fy;
-            const float p2 = g0.z * dx * dx + g1.x * dy * dy + g0.w * dx * dy;        // log2 of the Gaussian's falloff at this pixel
-            const bool maybe = !done && p2 <= 0.0f && p2 + g1.y >= CULL;
-            if (__builtin_amdgcn_ballot_w64(maybe) == 0) continue;                    // nobody in the wave sees it
-            const float alpha = fminf(0.99f, g1.z * __builtin_amdgcn_exp2f(p2));
-            const bool valid = maybe && alpha >= 1.0f / 255.0f;
+        // one Gaussian against this lane's pixel (p2 = log2 of its falloff there, already known to pass the pre-test in some lane)
+        auto blend_one = [&](const int k, const float p2, const bool maybe) {
+            const float alpha = fminf(0.99f, s_o[k] * __builtin_amdgcn_exp2f(p2));
+            const bool valid = maybe && !done && alpha >= 1.0f / 255.0f;
             const float tT = T * (1.0f - alpha);
             const bool stop = valid && tT < 1e-4f;
             done = done || stop;
             const bool apply = valid && !stop;
             const float w = apply ? alpha * T : 0.0f;
-            const f32x2_t g2 = s_g2[k];
-            C0 += g1.w * w; C1 += g2.x * w; C2 += g2.y * w; Wt += w;
+            C0 += s_r[k] * w; C1 += s_g[k] * w; C2 += s_b[k] * w; Wt += w;
             T = apply ? tT : T;
-            if (__builtin_amdgcn_ballot_w64(!done) == 0) break;                       // the whole wave is saturated
+        };
+        const f32x2_t fx2 = {fx, fx}, fy2 = {fy, fy};
+        for (int k = 0; k < n; k += 2) {       // (entry n of an odd n is a pad or, in a full batch, never read: n = 256 is even)
+            const f32x2_t dx = *reinterpret_cast<const f32x2_t*>(s_x + k) - fx2, dy = *reinterpret_cast<const f32x2_t*>(s_y + k) - fy2;
+            const f32x2_t p2 = *reinterpret_cast<const f32x2_t*>(s_A + k) * dx * dx + *reinterpret_cast<const f32x2_t*>(s_C + k) * dy * dy +
+                               *reinterpret_cast<const f32x2_t*>(s_B + k) * dx * dy;
+            const f32x2_t pre = p2 + *reinterpret_cast<const f32x2_t*>(s_l + k);
+            const bool m0 = p2.x <= 0.0f && pre.x >= CULL, m1 = p2.y <= 0.0f && pre.y >= CULL;
+            if (__builtin_amdgcn_ballot_w64(!done && (m0 || m1)) == 0) continue;      // nobody in the wave sees either
+            blend_one(k, p2.x, m0);
+            blend_one(k + 1, p2.y, m1);
+            if (__builtin_amdgcn_ballot_w64(!done) == 0) break;                        // the whole wave is saturated
         }
         if (!done) s_done = 1;                 // somebody still needs more Gaussians
         __syncthreads();

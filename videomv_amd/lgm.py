@@ -413,6 +413,7 @@ class LgmRefiner:
         self.opt, self.device, self.bg_color = opt, device, float(bg_color)
         self.engine = LgmEngine(opt, lgm_state, opt.input_size, opt.input_size, device)
         self._engine2 = None                  # two samples per plan (both CFG branches at once), same packed weights
+        self._dev_cache = {}                  # device copies of gs_data's per-sample constants (_dev_const)
         self._lgm_state = lgm_state
         self.renderer = GaussianRenderer(opt.output_size, opt.fovy, opt.znear, opt.zfar)
         S = opt.input_size
@@ -429,6 +430,19 @@ class LgmRefiner:
         return hd_ok and os.environ.get("VMV_LGM_BATCHED", "1") != "0"
 
     @torch.no_grad()
+    def _dev_const(self, gs_data, name, make):
+        """Device copy of one of gs_data's per-sample constants (rays of the key views, cameras), made once per tensor instead of once
+        per refined step: a blocking `.to(device)` of a host tensor drains the stream, and the launches after it leave the host late."""
+        src = gs_data["input"] if name == "rays" else gs_data[name]
+        if src.is_cuda and name != "rays":
+            return src
+        key = (name, src.data_ptr(), tuple(src.shape), src._version)
+        hit = self._dev_cache.get(name)
+        if hit is None or hit[0] != key:
+            hit = (key, make(), src)           # (src kept alive: its address is the key)
+            self._dev_cache[name] = hit
+        return hit[1]
+
     def latent_z_pair(self, eps_rows, ld, xt, c_recip, c_recipm1, autoencoder, gs_data, scale_factor=0.18215, views=None):
         """latent_z of BOTH CFG branches (rows blocks 0 and 1 of ``eps_rows``) with every stage batched over the two: one VAE
         decode of 8 views, one LGM plan of two samples, 2 x 24 renders, one VAE encode of 48 views.  Same arithmetic per image as
@@ -448,14 +462,15 @@ class LgmRefiner:
         if self._engine2 is None:
             self._engine2 = LgmEngine(self.opt, self._lgm_state, S, S, self.device, batch=2, packed=self.engine.wt)
             self.inp2 = torch.zeros(2 * self.opt.num_frames, 9, S, S, dtype=torch.float32, device=self.device)
-        rays = gs_data["input"][0, idxs].to(self.device, torch.float32).contiguous()
+        rays = self._dev_const(gs_data, "rays", lambda: gs_data["input"][0, idxs].to(self.device, torch.float32).contiguous())
         decoded = decoded.contiguous()
         for br in range(2):
             ops.lgm_pack_input(decoded[br * V:(br + 1) * V], rays, self.inp2[br * V:(br + 1) * V])
         gaussians = self._engine2.forward_gaussians(self.inp2).view(2, -1, 14)
         self.last_gaussians = gaussians[0]          # (profiling handle: bench.py times the rasteriser alone on these)
         bg = torch.full((3,), self.bg_color, dtype=torch.float32, device=self.device)
-        cv, cvp = gs_data["cam_view"].to(self.device), gs_data["cam_view_proj"].to(self.device)
+        cv = self._dev_const(gs_data, "cam_view", lambda: gs_data["cam_view"].to(self.device))
+        cvp = self._dev_const(gs_data, "cam_view_proj", lambda: gs_data["cam_view_proj"].to(self.device))
         if h != w:
             raise ValueError("the LGM branch renders square views")
         of = None
@@ -484,12 +499,13 @@ class LgmRefiner:
         S = self.opt.input_size
         if decoded.shape[-1] != S or decoded.shape[-2] != S:
             raise ValueError(f"LGM expects {S}x{S} decoded views (latent {S // 8}x{S // 8}), got {tuple(decoded.shape[-2:])}")
-        rays = gs_data["input"][0, idxs].to(self.device, torch.float32).contiguous()
+        rays = self._dev_const(gs_data, "rays", lambda: gs_data["input"][0, idxs].to(self.device, torch.float32).contiguous())
         ops.lgm_pack_input(decoded.contiguous(), rays, self.inp)
         gaussians = self.engine.forward_gaussians(self.inp)
         self.last_gaussians = gaussians
         bg = torch.full((3,), self.bg_color, dtype=torch.float32, device=self.device)   # LGM.infer bg_color_factor
-        cv, cvp, of = gs_data["cam_view"].to(self.device), gs_data["cam_view_proj"].to(self.device), None
+        cv = self._dev_const(gs_data, "cam_view", lambda: gs_data["cam_view"].to(self.device))
+        cvp, of = self._dev_const(gs_data, "cam_view_proj", lambda: gs_data["cam_view_proj"].to(self.device)), None
         if views is not None:      # (frame-parallel: this rank's views only — see latent_z_pair)
             f0, cnt = int(views[0]), int(views[1])
             cv, cvp, of = cv[:, f0:f0 + cnt].contiguous(), cvp[:, f0:f0 + cnt].contiguous(), (cv.shape[1], f0)
