@@ -30,7 +30,7 @@ extern "C" {
 #define VMV_ERANGE       -4   /* size outside what the kernel supports */
 #define VMV_ECOMM        -5   /* an RCCL call of vmv_comm_* failed */
 
-#define VMV_ABI_VERSION   10
+#define VMV_ABI_VERSION   11
 int vmv_abi_version(void);
 /* The 16-bit storage / MFMA operand type ("elem") this build of the library computes in.  The same sources are
  * compiled once per type: libvmv_hip_f16.so (VMV_ELEM_F16: IEEE fp16 — the default; the reference's own half mode,
@@ -192,6 +192,10 @@ typedef struct {
 #define VMV_TILE_W256x256 29   /* wide-wave register-staged kernel (gemm_wreg.hip): 4 waves x 128 x 128 of a 256 x 256 tile, accumulators in AGPRs,
                                   global -> registers -> LDS; one plain linear segment, K % 32 == 0.  EXPERIMENT (make EXPERIMENTS=1; forced tile only): correct,
                                   0.69 x of the 8-wave wide tile — DESIGN.md 10 */
+
+#define VMV_TILE_X512x128 30   /* (ABI 11) gemm_xglds.hip with an 8 x 1 wave grid: 512 x 128 tile of 64 x 128 wave tiles — the N = 128 convolutions over
+                                  millions of rows (the VAE's first level), where every 64 x 64-wave-tile kernel sits at 670 TFLOP/s; plain
+                                  epilogue, no split-K */
 
 int vmv_gemm(const VmvGemmParams* p, void* stream);
 /* 1 if the host should record ONE VMV_EPI_TATTN launch for *p (a fused q | k | v + temporal-attention GEMM, epilogue already set)

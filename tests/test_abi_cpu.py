@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
-    assert lib.vmv_abi_version() == L.ABI_VERSION == 10
+    assert lib.vmv_abi_version() == L.ABI_VERSION == 11
 
 
 def test_struct_layouts_match_c():
@@ -115,7 +115,10 @@ def test_gemm_tile_policy(monkeypatch):
     # VAE decoder at 24 frames of 320 x 512: 512- / 256-channel levels on 256 x 256 wide tiles, the 128-channel level on 256 x 128
     assert pick(24 * 80 * 128, 512, ops.conv3x3_segs([(X, 512, 512)]), ops.Geom(OH=80, OW=128, IH=80, IW=128)) == L.TILE_X256x256
     assert pick(24 * 160 * 256, 256, ops.conv3x3_segs([(X, 256, 256)]), ops.Geom(OH=160, OW=256, IH=160, IW=256)) == L.TILE_X256x256
-    assert pick(24 * 320 * 512, 128, ops.conv3x3_segs([(X, 128, 128)]), ops.Geom(OH=320, OW=512, IH=320, IW=512)) == L.TILE_256x128
+    # round 6: the VAE's 128-channel first level (N = 128, millions of rows) on the 8 x 1 wave grid's 512 x 128 tile
+    assert pick(24 * 320 * 512, 128, ops.conv3x3_segs([(X, 128, 128)]), ops.Geom(OH=320, OW=512, IH=320, IW=512)) == L.TILE_X512x128
+    assert pick(4 * 256 * 256, 128, ops.conv3x3_segs([(X, 128, 128)]), ops.Geom(OH=256, OW=256, IH=256, IW=256)) == L.TILE_X512x128
+    assert pick(24 * 320 * 512, 128, lin(128)) != L.TILE_X512x128              # plain rows keep their kernel
     # split-K shapes of the smallest level stay on the 128-row LDS-DMA kernel; a forced tile is returned as is
     assert pick(M3, 1280, ops.conv3x3_segs([(X, 1280, 1280)]), ops.Geom(OH=5, OW=8, IH=5, IW=8), ksplit=8, workspace=X) == L.TILE_G128x160
     assert pick(M0, 320, lin(320), tile=L.TILE_128x64) == L.TILE_128x64

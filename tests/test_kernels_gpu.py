@@ -143,7 +143,7 @@ def test_gemm_geglu(tile):
 
 
 @pytest.mark.parametrize("tile", [0, L.TILE_256x128, L.TILE_G128x128, L.TILE_P256x128, L.TILE_PP256x128, L.TILE_Q128x128, L.TILE_S256x128, L.TILE_S192x160, L.TILE_S256x160,
-                                  L.TILE_X256x320, L.TILE_X256x256, L.TILE_X256x128])
+                                  L.TILE_X256x320, L.TILE_X256x256, L.TILE_X256x128, L.TILE_X512x128])
 @pytest.mark.parametrize("stride,ups,two_src,skip", [(1, 0, False, False), (2, 0, False, False), (1, 1, False, False),
                                                      (1, 0, True, True)])
 def test_gemm_conv3x3(stride, ups, two_src, skip, tile):
@@ -282,7 +282,8 @@ def test_conv_halo_few_output_channels(n, H, W, Cin, N, fp32, ldo):
     assert float((old["out"].float()[:, :N] - dev["out"].float()[:, :N]).abs().max().cpu()) <= (2e-3 if fp32 else 2e-2) * float(ref.abs().max())
 
 
-@pytest.mark.parametrize("tile", [L.TILE_S256x128, L.TILE_S192x160, L.TILE_S256x160, L.TILE_256x160, L.TILE_X256x320, L.TILE_X256x256, L.TILE_X256x128])
+@pytest.mark.parametrize("tile", [L.TILE_S256x128, L.TILE_S192x160, L.TILE_S256x160, L.TILE_256x160, L.TILE_X256x320, L.TILE_X256x256, L.TILE_X256x128,
+                                  L.TILE_X512x128])
 def test_gemm_conv3x3_many_tiles(tile):
     """>= 2 tiles per persistent block (M = 2*24*40*64/2 rows), residual + per-image row vector, two sources + 1x1 skip."""
     n, IH, IW, C0, C1, N = 24, 40, 64, 64, 32, 320
@@ -307,7 +308,7 @@ def test_gemm_conv3x3_many_tiles(tile):
     check(dev["out"], ref.permute(0, 2, 3, 1).reshape(M, N))
 
 
-@pytest.mark.parametrize("tile", [L.TILE_S256x128, L.TILE_S192x160, L.TILE_S256x160, L.TILE_X256x320, L.TILE_X256x256])
+@pytest.mark.parametrize("tile", [L.TILE_S256x128, L.TILE_S192x160, L.TILE_S256x160, L.TILE_X256x320, L.TILE_X256x256, L.TILE_X512x128])
 def test_gemm_temporal_conv_many_tiles(tile):
     Bn, F_, Pp, Cc = 2, 24, 1280, 320
     M = Bn * F_ * Pp

@@ -28,7 +28,7 @@ from . import _lib as L
 from . import ops
 
 TILES = [L.TILE_128x128, L.TILE_128x160, L.TILE_128x64, L.TILE_64x64, L.TILE_256x128, L.TILE_256x160, L.TILE_G128x128, L.TILE_G128x160,
-         L.TILE_P256x128, L.TILE_P256x160, L.TILE_Q128x128, L.TILE_Q96x160, L.TILE_X256x320, L.TILE_X256x256, L.TILE_X256x128,
+         L.TILE_P256x128, L.TILE_P256x160, L.TILE_Q128x128, L.TILE_Q96x160, L.TILE_X256x320, L.TILE_X256x256, L.TILE_X256x128, L.TILE_X512x128,
          L.TILE_RS, L.TILE_RS256, L.TILE_RS512]
 KSPLITS = [2, 3, 4, 6, 8, 12, 16]
 WS_CAP = 512 << 20

@@ -316,6 +316,12 @@ int tile_override(int which) {
     return ov[which];
 }
 
+int x512_policy() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VMV_GEMM_X512"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
 int xglds_policy() {
     // VMV_GEMM_XGLDS (A/B experiments): 1 (default) = the wide-tile kernel (gemm_xglds.hip: 256 x 320 tiles, 64 x 160 wave tiles,
     // four-stage ring of 32-deep chunks) takes the long-K GATHERED GEMMs — 3x3 convolutions, temporal convolutions — whose
@@ -363,6 +369,15 @@ int pick_tile(const VmvGemmParams& p, int total_steps) {
         const long rounds_x = (tm * (p.N / bx) + 255) / 256, rounds_g = (tm * (p.N / (bx / 2)) + 255) / 256;
         // (plain rows too once the reduction is long: FF-down of the second level, K = 2560 — 937 -> 1008 TFLOP/s)
         if ((any_gather || total_steps >= 32) && 20 * rounds_x <= 11 * rounds_g) return bx == 320 ? VMV_TILE_X256x320 : VMV_TILE_X256x256;
+    }
+    // Round 6: N = 128 convolutions over >= 2 rounds of 512-row tiles (the VAE's first level: 1.6-3.9 M rows x 128 channels) — every
+    // kernel with 64 x 64 wave tiles runs them at ~670 TFLOP/s (0.5 fragment reads per MFMA); the 8 x 1 wave grid's 64 x 128 wave tiles
+    // (gemm_xglds.hip WNV = 1) read 0.375.  VMV_GEMM_X512=0 keeps the old choice (A/B).
+    if (gemm_policy() >= 2 && xglds_policy() && x512_policy() && !geglu && p.ksplit <= 1 && !p.rowstat && !vmv_gemm_ln_inline(p) && p.N == 128 &&
+        total_steps >= 12 && p.wgroup_rows == 0 && !p.out_fp32 && (long)p.M >= 2L * 256 * 512) {
+        bool any_gather = false;
+        for (int i = 0; i < p.nseg; ++i) any_gather = any_gather || p.seg[i].mode != VMV_SEG_LINEAR;
+        if (any_gather) return VMV_TILE_X512x128;
     }
     // Round 4: the transformer linears of the K = 1280 level that carry a folded LayerNorm (rowstat) and / or GEGLU — qkv, q, GEGLU of
     // the third level and the middle block — on the wide tile's 256 x 256 form (gemm_xglds.hip EPI): 780-870 -> ~1000 TFLOP/s.  Taken
@@ -467,7 +482,7 @@ int final_tile(const VmvGemmParams& p, int total_steps) {
                         picked == VMV_TILE_G128x128 || picked == VMV_TILE_P256x128;
         if (p.tile != VMV_TILE_AUTO) {
             if (!ok) return VMV_EINVAL;
-        } else if (picked == VMV_TILE_P256x160 || picked == VMV_TILE_X256x320 || picked == VMV_TILE_X256x256) picked = VMV_TILE_P256x128;
+        } else if (picked == VMV_TILE_P256x160 || picked == VMV_TILE_X256x320 || picked == VMV_TILE_X256x256 || picked == VMV_TILE_X512x128) picked = VMV_TILE_P256x128;
         else if (picked == VMV_TILE_256x160) picked = VMV_TILE_256x128;
         else if (!ok) picked = VMV_TILE_G128x128;
     }
@@ -614,6 +629,7 @@ extern "C" int vmv_gemm(const VmvGemmParams* pp, void* stream) {
         case VMV_TILE_X256x320:
         case VMV_TILE_X256x256:
         case VMV_TILE_X256x128:
+        case VMV_TILE_X512x128:
             rc = vmv_gemm_xglds_launch(p, total_steps, picked, st);
             if (rc == VMV_GLDS_UNSUPPORTED && (p.rowstat || p.epilogue == VMV_EPI_GEGLU)) {      // the fused epilogues' other home
                 if (p.tile != VMV_TILE_AUTO) return VMV_EINVAL;

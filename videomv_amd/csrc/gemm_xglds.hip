@@ -34,11 +34,15 @@ namespace {
 #endif
 constexpr int WBK = 32;                 // this kernel's K chunk: ONE k-step of v_mfma_f32_16x16x32 (see above)
 
-template <int NH, int WH>
+// WNV = waves along N: 2 (the 4 x 2 wave grid of the 256-row tiles) or 1 (round 6: 8 x 1 — a 512 x 128 tile of 64 x 128 wave tiles for
+// the N = 128 convolutions of the VAE's first level, whose 64 x 64 wave tiles in every other kernel read 0.5 fragments per MFMA and
+// sit at 670 TFLOP/s whatever the tile: 0.375 here)
+template <int NH, int WH, int WNV = 2>
 struct WgCfg {
     static constexpr int WM = 4, WN = NH * WH;              // 16-row / 16-column MFMA tiles per wave
-    static constexpr int NW = 8, NT = 512;                  // 4 waves along M x 2 along N
-    static constexpr int BM = 64 * WM, BN = 32 * WN;
+    static constexpr int NW = 8, NT = 512;                  // WMV waves along M x WNV along N
+    static constexpr int WMV = NW / WNV;
+    static constexpr int BM = 16 * WM * WMV, BN = 16 * WN * WNV;
     static constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64;         // rows of 32 elements = 64 B
     static constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
 #ifndef VMV_XGLDS_STAGES
@@ -46,13 +50,14 @@ struct WgCfg {
 #endif
     static constexpr int STAGES = VMV_XGLDS_STAGES;
     static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
-    static constexpr int NAI = BM / (16 * NW);              // A wave-instructions per wave per chunk (16 rows x 64 B each) = 2
+    static constexpr int NAI = BM / (16 * NW);              // A wave-instructions per wave per chunk (16 rows x 64 B each) = 2 (4 at BM = 512)
     static constexpr int WGROUPS = BN / 16;                 // 16-row groups of W per chunk (20 at BN = 320)
     static constexpr int NWI = WGROUPS / NW;                // W wave-instructions of EVERY wave per chunk ...
     static constexpr int NWX = WGROUPS % NW;                // ... and one more for the waves < NWX
     static constexpr int LPT = NAI + NWI;                   // loads per lane per chunk (waves < NWX: LPT + 1)
-    static constexpr int HALF_ROWS = 128;                   // epilogue staging: half a tile at a time
+    static constexpr int HALF_ROWS = 128;                   // epilogue staging: 128 rows (two wave rows) at a time
     static constexpr int XG_MAXG = 8;                       // row groups (rowvec rows) one tile's rows may span
+    static_assert(WNV == 1 || WNV == 2, "wave grid");
     static_assert(HALF_ROWS * (BN * 2 + 16) + XG_MAXG * BN * 4 + BN * 4 <= LDS_BYTES && LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
@@ -62,18 +67,18 @@ constexpr int XE_GEGLU = 1, XE_LN = 2;       // EPI bits
 // what is left; the launcher keeps every split even and >= STAGES) and writes its raw fp32 accumulators to slab blockIdx.y of
 // p.workspace; gemm_splitk_reduce (gemm.hip) sums the slabs and runs the epilogue.  For the grids that cannot fill the chip with
 // 256-row wide tiles on their own (the fourth UNet level, a frame-parallel rank's M / 8 rows) without falling back to 128-row tiles.
-template <int NH, int WH, int EPI = 0, bool SK = false>
+template <int NH, int WH, int EPI = 0, bool SK = false, int WNV = 2>
 __global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams p, const int tiles_m, const int tiles_n, const int nsteps_arg,
                                                             const int nsteps_total, const int gm, const int tapmajor) {
     VMV_KERNEL_ENTER();
-    using Cfg = WgCfg<NH, WH>;
+    using Cfg = WgCfg<NH, WH, WNV>;
     constexpr int WM = Cfg::WM, WN = Cfg::WN, NW = Cfg::NW, BM = Cfg::BM, BN = Cfg::BN, S = Cfg::STAGES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int wave_m = WNV == 2 ? wave >> 1 : wave, wave_n = WNV == 2 ? wave & 1 : 0;
 
     // ---- XCD-aware tile mapping (bijective, as gemm_glds.hip)
     const int nblk = tiles_m * tiles_n;
@@ -142,9 +147,8 @@ __global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams 
             skip -= nch; koff += p.seg[s].k; ++s;
         }
     }
-    static_assert(Cfg::NAI <= 2, "two 16-bit tap masks in one register");
     uint32_t avo[Cfg::NAI];
-    uint32_t rmask = 0;           // tap-validity bits of the lane's NAI rows, 16 per row
+    uint32_t rmask[(Cfg::NAI + 1) / 2];      // tap-validity bits of the lane's NAI rows, 16 per row, two rows per register
     auto seg_same = [&](const VmvGemmSeg& a, const VmvGemmSeg& b) { return a.src == b.src && a.ld == b.ld && a.k == b.k && a.mode == b.mode; };
     auto start_run = [&]() {
         run_len = 1; run_t = 0; run_c = 0;
@@ -157,56 +161,71 @@ __global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams 
         // (segment fields are read in wave-uniform control flow: inside per-row branches the compiler copied the whole kernel-argument
         //  segment table to scratch to index it)
         const bool single = run_len == 1;
-        rmask = 0;
+        // (the segment table is read in wave-uniform code only — tap loop outside, rows inside: indexed from inside the per-row code the
+        //  compiler copies the whole kernel-argument table to scratch)
+        int nb[Cfg::NAI], oy[Cfg::NAI], ox[Cfg::NAI];      // spatial: image base row n IH IW, output (y, x); temporal: nb = frame index
+        uint32_t mask[Cfg::NAI];
+        bool inm[Cfg::NAI];
 #pragma unroll
         for (int i = 0; i < Cfg::NAI; ++i) {
             int m = m0 + (i * NW + wave) * 16 + lrow;
             asm volatile("" : "+v"(m));                 // not loop-invariant as far as the compiler can tell: see above
-            int nb = 0, oy = 0, ox = 0;                 // spatial: image base row n IH IW, output (y, x); temporal: nb = frame index
+            nb[i] = 0; oy[i] = 0; ox[i] = 0; mask[i] = 0;
             if (mode == VMV_SEG_SPATIAL) {
                 const int hw = p.OH * p.OW;
                 const int n = m / hw, rem = m - n * hw;
-                oy = rem / p.OW; ox = rem - oy * p.OW;
-                nb = n * p.IH * p.IW;
+                oy[i] = rem / p.OW; ox[i] = rem - oy[i] * p.OW;
+                nb[i] = n * p.IH * p.IW;
             } else if (mode == VMV_SEG_TEMPORAL) {
-                nb = (m / p.P) % p.F;
+                nb[i] = (m / p.P) % p.F;
             }
-            const bool inm = m < p.M;
-            uint32_t mask = 0;
+            inm[i] = m < p.M;
             int base;
             if (mode == VMV_SEG_LINEAR) {
-                base = m * ld; mask = inm ? 1u : 0u;
+                base = m * ld; mask[i] = inm[i] ? 1u : 0u;
             } else if (mode == VMV_SEG_SPATIAL) {
                 if (single) {                           // the tap's own position (strided / nearest-x2 gathers included)
-                    const int iy = oy * p.stride + s0.d0, ix = ox * p.stride + s0.d1;
+                    const int iy = oy[i] * p.stride + s0.d0, ix = ox[i] * p.stride + s0.d1;
                     const int VH = p.IH << p.ups, VW = p.IW << p.ups;
-                    const bool ok = inm && iy >= 0 && iy < VH && ix >= 0 && ix < VW;
-                    base = ok ? (nb + (iy >> p.ups) * p.IW + (ix >> p.ups)) * ld : 0;
-                    mask = ok ? 1u : 0u;
+                    const bool ok = inm[i] && iy >= 0 && iy < VH && ix >= 0 && ix < VW;
+                    base = ok ? (nb[i] + (iy >> p.ups) * p.IW + (ix >> p.ups)) * ld : 0;
+                    mask[i] = ok ? 1u : 0u;
                 } else {
-                    base = (nb + oy * p.IW + ox) * ld;
-                    for (int t = 0; t < run_len; ++t) {
-                        const int iy = oy + p.seg[s + t].d0, ix = ox + p.seg[s + t].d1;
-                        if (inm && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) mask |= 1u << t;
-                    }
+                    base = (nb[i] + oy[i] * p.IW + ox[i]) * ld;
                 }
             } else {
                 if (single) {
-                    const int f = nb + s0.d0;
-                    const bool ok = inm && f >= 0 && f < p.F;
+                    const int f = nb[i] + s0.d0;
+                    const bool ok = inm[i] && f >= 0 && f < p.F;
                     base = ok ? (m + s0.d0 * p.P) * ld : 0;
-                    mask = ok ? 1u : 0u;
+                    mask[i] = ok ? 1u : 0u;
                 } else {
                     base = m * ld;
-                    for (int t = 0; t < run_len; ++t) {
-                        const int f = nb + p.seg[s + t].d0;
-                        if (inm && f >= 0 && f < p.F) mask |= 1u << t;
-                    }
                 }
             }
             avo[i] = (uint32_t)(base + lsw * 8) * 2u;
-            rmask |= mask << (16 * i);
         }
+        if (!single) {
+            for (int t = 0; t < run_len; ++t) {
+                const int d0 = p.seg[s + t].d0, d1 = p.seg[s + t].d1;
+#pragma unroll
+                for (int i = 0; i < Cfg::NAI; ++i) {
+                    bool ok;
+                    if (mode == VMV_SEG_SPATIAL) {
+                        const int iy = oy[i] + d0, ix = ox[i] + d1;
+                        ok = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+                    } else {
+                        const int f = nb[i] + d0;
+                        ok = f >= 0 && f < p.F;
+                    }
+                    if (ok && inm[i]) mask[i] |= 1u << t;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < (Cfg::NAI + 1) / 2; ++i) rmask[i] = 0;
+#pragma unroll
+        for (int i = 0; i < Cfg::NAI; ++i) rmask[i >> 1] |= mask[i] << (16 * (i & 1));
     };
     start_run();
     if constexpr (SK) run_c = skip0;
@@ -224,7 +243,7 @@ __global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams 
         const uint32_t a_so = (uint32_t)kc * 2u, w_so = (uint32_t)(koff + run_t * sg.k + kc) * 2u, d2 = (uint32_t)(delta * 2);
 #pragma unroll
         for (int i = 0; i < Cfg::NAI; ++i)
-            VMV_BLDS16(a_rsrc, abase + i * (NW * 1024), (kvalid && ((rmask >> (16 * i + run_t)) & 1u)) ? avo[i] + d2 : OOB, a_so);
+            VMV_BLDS16(a_rsrc, abase + i * (NW * 1024), (kvalid && ((rmask[i >> 1] >> (16 * (i & 1) + run_t)) & 1u)) ? avo[i] + d2 : OOB, a_so);
 #pragma unroll
         for (int j = 0; j < Cfg::NWI; ++j) VMV_BLDS16(w_rsrc, wbase + j * (NW * 1024), kvalid ? wvo0 + (uint32_t)j * wstride : OOB, w_so);
         if (Cfg::NWX > 0 && wave < Cfg::NWX)
@@ -436,7 +455,7 @@ __global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams 
         return __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, (m < p.M && n < No) ? (uint32_t)(m * p.ldr + n) * 2u : OOB, 0, 0);
     };
 #pragma unroll 1
-    for (int hh = 0; hh < 2; ++hh) {
+    for (int hh = 0; hh < BM / Cfg::HALF_ROWS; ++hh) {
         u32x4_t rr[RD];
         if (resp) {
 #pragma unroll
@@ -523,9 +542,9 @@ int xglds_tapmajor() {        // VMV_XGLDS_TAPMAJOR (A/B): 1 = tap-interleaved K
     return v;
 }
 
-template <int NH, int WH, int EPI = 0>
+template <int NH, int WH, int EPI = 0, int WNV = 2>
 int launch_xglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
-    using Cfg = WgCfg<NH, WH>;
+    using Cfg = WgCfg<NH, WH, WNV>;
     const int tiles_m = (p.M + Cfg::BM - 1) / Cfg::BM;
     const int tiles_n = (p.N + Cfg::BN - 1) / Cfg::BN;
     const int gm = xglds_group_m(tiles_m, tiles_n, Cfg::BM, Cfg::BN);
@@ -535,7 +554,7 @@ int launch_xglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
     if (nsteps < Cfg::STAGES || (nsteps & 1)) return VMV_GLDS_UNSUPPORTED;
     if (p.rowvec && (Cfg::BM - 1) / p.rowvec_div + 2 > Cfg::XG_MAXG) return VMV_GLDS_UNSUPPORTED;      // column vectors staged per row group
     if (p.ksplit > 1) {
-        if constexpr (EPI != 0) return VMV_GLDS_UNSUPPORTED;
+        if constexpr (EPI != 0 || WNV != 2) return VMV_GLDS_UNSUPPORTED;
         else {
             // even chunk counts per split (the loop body is two chunks), every split >= STAGES chunks, no empty split
             int sps = (nsteps + p.ksplit - 1) / p.ksplit;
@@ -550,8 +569,8 @@ int launch_xglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
         }
     }
     static std::atomic<unsigned long long> attr_set{0};
-    if (const int rc_attr = vmv_lds_attr_once(attr_set, reinterpret_cast<const void*>(&gemm_xglds_kernel<NH, WH, EPI>), Cfg::LDS_BYTES)) return rc_attr;
-    VMV_LAUNCH((gemm_xglds_kernel<NH, WH, EPI>), dim3(tiles_m * tiles_n), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n, nsteps, nsteps, gm, xglds_tapmajor());
+    if (const int rc_attr = vmv_lds_attr_once(attr_set, reinterpret_cast<const void*>(&gemm_xglds_kernel<NH, WH, EPI, false, WNV>), Cfg::LDS_BYTES)) return rc_attr;
+    VMV_LAUNCH((gemm_xglds_kernel<NH, WH, EPI, false, WNV>), dim3(tiles_m * tiles_n), dim3(Cfg::NT), Cfg::LDS_BYTES, st, p, tiles_m, tiles_n, nsteps, nsteps, gm, xglds_tapmajor());
     return vmv_launch_status();
 }
 
@@ -561,7 +580,7 @@ int launch_xglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
 int vmv_gemm_xglds_epi_ok(const VmvGemmParams& p, int tile) {
     const bool geglu = p.epilogue == VMV_EPI_GEGLU, lnf = p.rowstat != nullptr;
     if (!geglu && !lnf) return 1;
-    if (tile != VMV_TILE_X256x256) return 0;                 // the fused epilogues exist for 64 x 128 wave tiles only
+    if (tile != VMV_TILE_X256x256) return 0;                 // the fused epilogues exist for the 256 x 256 tile only
     if (lnf && !p.colsum) return 0;
     if (geglu && ((p.N & 31) || p.residual || p.act != VMV_ACT_NONE)) return 0;      // whole x | gate pairs; no residual (as the other kernels)
     return 1;
@@ -590,5 +609,6 @@ int vmv_gemm_xglds_launch(const VmvGemmParams& p, int total_steps, int tile, hip
     if (tile == VMV_TILE_X256x320) return launch_xglds<2, 5>(p, total_steps, st);
     if (tile == VMV_TILE_X256x256) return launch_xglds<2, 4>(p, total_steps, st);
     if (tile == VMV_TILE_X256x128) return launch_xglds<1, 4>(p, total_steps, st);
+    if (tile == VMV_TILE_X512x128) return launch_xglds<2, 4, 0, 1>(p, total_steps, st);
     return VMV_EINVAL;
 }
