@@ -196,6 +196,9 @@ typedef struct {
 #define VMV_TILE_X512x128 30   /* (ABI 11) gemm_xglds.hip with an 8 x 1 wave grid: 512 x 128 tile of 64 x 128 wave tiles — the N = 128 convolutions over
                                   millions of rows (the VAE's first level), where every 64 x 64-wave-tile kernel sits at 670 TFLOP/s; plain
                                   epilogue, no split-K */
+#define VMV_TILE_Y256x128 31   /* (ABI 11) gemm_xglds.hip in 256-thread blocks: 4 x 1 waves of 64 x 128, 256 x 128 tile, three-stage ring, TWO blocks per CU
+                                  (one's fill / epilogue under the other's main loop); plain, folded-LayerNorm and GEGLU epilogues; no split-K.  EXPERIMENT
+                                  (make EXPERIMENTS=1; forced tile only): correct, 0.62-0.92 x of the one-block forms — DESIGN.md 10 */
 
 int vmv_gemm(const VmvGemmParams* p, void* stream);
 /* 1 if the host should record ONE VMV_EPI_TATTN launch for *p (a fused q | k | v + temporal-attention GEMM, epilogue already set)

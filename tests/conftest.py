@@ -37,7 +37,7 @@ def pytest_collection_modifyitems(config, items):
             continue
         if exp_tiles is None:
             from videomv_amd import _lib as L
-            exp_tiles = {L.TILE_S256x128, L.TILE_S192x160, L.TILE_S256x160, L.TILE_A128x160, L.TILE_A128x128, L.TILE_W256x256}
+            exp_tiles = {L.TILE_S256x128, L.TILE_S192x160, L.TILE_S256x160, L.TILE_A128x160, L.TILE_A128x128, L.TILE_W256x256, L.TILE_Y256x128}
             has_exp = bool(L.load().vmv_has_experiments())
         if not has_exp and cs.params["tile"] in exp_tiles:
             item.add_marker(pytest.mark.skip(reason="experiment kernels not in this library (make EXPERIMENTS=1)"))

@@ -100,7 +100,10 @@ def run_gemm(build, case, out_keys=("out",), cpu_ref=True):
                                         (2000, 1280, 1280, L.TILE_X256x320), (70000, 320, 320, L.TILE_X256x320), (513, 200, 192, L.TILE_X256x320),
                                         (640, 640, 640, L.TILE_X256x256), (257, 256, 192, L.TILE_X256x256), (2000, 1280, 1280, L.TILE_X256x256),
                                         (66000, 512, 128, L.TILE_X256x256), (640, 640, 640, L.TILE_X256x128), (257, 128, 192, L.TILE_X256x128),
-                                        (70000, 384, 128, L.TILE_X256x128)])
+                                        (70000, 384, 128, L.TILE_X256x128),
+                                        # round 6: 256-thread blocks, two per CU (gemm_xglds.hip WNV = 4)
+                                        (640, 640, 640, L.TILE_Y256x128), (257, 128, 192, L.TILE_Y256x128), (2000, 1280, 1280, L.TILE_Y256x128),
+                                        (70000, 384, 128, L.TILE_Y256x128)])
 def test_gemm_linear_bias(M, N, K, tile):
     c = Case(a=rnd((M, K), 1), w=rnd((N, K), 2, K ** -0.5), b=torch.randn(N, generator=g(3)), out=torch.zeros(M, N, dtype=BF))
 
@@ -124,7 +127,7 @@ def test_gemm_fp32_out_rowvec_act_residual(tile):
     check(dev["out"], cpu["out"], tol_l2=1e-3, tol_max=2e-3)
 
 
-@pytest.mark.parametrize("tile", [0, L.TILE_256x128, L.TILE_G128x128, L.TILE_P256x128, L.TILE_PP256x128, L.TILE_Q128x128, L.TILE_S256x128, L.TILE_X256x256, L.TILE_W256x256])
+@pytest.mark.parametrize("tile", [0, L.TILE_256x128, L.TILE_G128x128, L.TILE_P256x128, L.TILE_PP256x128, L.TILE_Q128x128, L.TILE_S256x128, L.TILE_X256x256, L.TILE_W256x256, L.TILE_Y256x128])
 def test_gemm_geglu(tile):
     M, I2, K = 200, 512, 128        # 2*I = 512 rows -> 256 outputs
     w = rnd((I2, K), 2, K ** -0.5)
@@ -143,7 +146,7 @@ def test_gemm_geglu(tile):
 
 
 @pytest.mark.parametrize("tile", [0, L.TILE_256x128, L.TILE_G128x128, L.TILE_P256x128, L.TILE_PP256x128, L.TILE_Q128x128, L.TILE_S256x128, L.TILE_S192x160, L.TILE_S256x160,
-                                  L.TILE_X256x320, L.TILE_X256x256, L.TILE_X256x128, L.TILE_X512x128])
+                                  L.TILE_X256x320, L.TILE_X256x256, L.TILE_X256x128, L.TILE_X512x128, L.TILE_Y256x128])
 @pytest.mark.parametrize("stride,ups,two_src,skip", [(1, 0, False, False), (2, 0, False, False), (1, 1, False, False),
                                                      (1, 0, True, True)])
 def test_gemm_conv3x3(stride, ups, two_src, skip, tile):
@@ -749,6 +752,10 @@ def test_layernorm_stats_out(rows, Cc):
                                                (300, 512, 128, False, L.TILE_X256x256), (513, 768, 192, True, L.TILE_X256x256),
                                                (1000, 1000, 320, False, L.TILE_X256x256), (2001, 1280, 640, True, L.TILE_X256x256),
                                                (7680, 3840, 1280, False, 0), (7680, 10240, 1280, True, 0),
+                                               # round 6: the same epilogues in 256-thread blocks, two per CU (gemm_xglds.hip WNV = 4)
+                                               (7680, 3840, 1280, False, L.TILE_Y256x128), (7680, 10240, 1280, True, L.TILE_Y256x128),
+                                               (300, 512, 128, False, L.TILE_Y256x128), (513, 768, 192, True, L.TILE_Y256x128),
+                                               (1000, 1000, 320, False, L.TILE_Y256x128), (2001, 1280, 640, True, L.TILE_Y256x128),
                                                # round 6: the wide-wave register-staged kernel (gemm_wreg.hip)
                                                (7680, 3840, 1280, False, L.TILE_W256x256), (7680, 10240, 1280, True, L.TILE_W256x256), (513, 768, 192, True, L.TILE_W256x256),
                                                (1000, 1000, 320, False, L.TILE_W256x256)])

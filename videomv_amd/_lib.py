@@ -50,7 +50,7 @@ TILE_Q128x128, TILE_Q96x160 = 13, 14
 TILE_S256x128, TILE_S192x160, TILE_S256x160 = 15, 16, 17
 TILE_A128x160, TILE_A128x128 = 18, 19
 TILE_X256x320, TILE_X256x256, TILE_X256x128 = 20, 21, 22
-TILE_RS, TILE_RS512, TILE_RS256, TILE_HALO, TILE_TFR, TILE_TQA, TILE_W256x256, TILE_X512x128 = 23, 24, 25, 26, 27, 28, 29, 30
+TILE_RS, TILE_RS512, TILE_RS256, TILE_HALO, TILE_TFR, TILE_TQA, TILE_W256x256, TILE_X512x128, TILE_Y256x128 = 23, 24, 25, 26, 27, 28, 29, 30, 31
 OP_GEMM, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTENTION, OP_SOFTMAX, OP_COPY, OP_GN_FUSED, OP_FF, OP_GN_TABLE, OP_COMM = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 COMM_ALL_TO_ALL, COMM_ALL_GATHER, COMM_ID_BYTES = 0, 1, 128
 ABI_VERSION = 11

@@ -464,7 +464,7 @@ int final_tile(const VmvGemmParams& p, int total_steps) {
     int picked = pick_tile(p, total_steps);
 #if !defined(VMV_EXPERIMENTS)
     if (picked == VMV_TILE_S256x128 || picked == VMV_TILE_S192x160 || picked == VMV_TILE_S256x160 || picked == VMV_TILE_A128x160 ||
-        picked == VMV_TILE_A128x128 || picked == VMV_TILE_W256x256) return VMV_EINVAL;
+        picked == VMV_TILE_A128x128 || picked == VMV_TILE_W256x256 || picked == VMV_TILE_Y256x128) return VMV_EINVAL;
 #endif
     if (picked == VMV_TILE_HALO) return vmv_conv_halo_supported(p) ? picked : VMV_EINVAL;
     if (picked == VMV_TILE_TFR) return vmv_gemm_tfr_supported(p) ? picked : VMV_EINVAL;
@@ -486,7 +486,7 @@ int final_tile(const VmvGemmParams& p, int total_steps) {
         else if (picked == VMV_TILE_256x160) picked = VMV_TILE_256x128;
         else if (!ok) picked = VMV_TILE_G128x128;
     }
-    if (p.rowstat && !(picked == VMV_TILE_X256x256 && vmv_gemm_xglds_epi_ok(p, picked)) && picked != VMV_TILE_A128x160 && picked != VMV_TILE_A128x128 && picked != VMV_TILE_P256x128 && picked != VMV_TILE_P256x160 && picked != VMV_TILE_Q128x128 &&
+    if (p.rowstat && !((picked == VMV_TILE_X256x256 || picked == VMV_TILE_Y256x128) && vmv_gemm_xglds_epi_ok(p, picked)) && picked != VMV_TILE_A128x160 && picked != VMV_TILE_A128x128 && picked != VMV_TILE_P256x128 && picked != VMV_TILE_P256x160 && picked != VMV_TILE_Q128x128 &&
         picked != VMV_TILE_Q96x160 && picked != VMV_TILE_128x128 && picked != VMV_TILE_128x160 && picked != VMV_TILE_128x64 &&
         picked != VMV_TILE_64x64)
         picked = (p.epilogue != VMV_EPI_GEGLU && p.N % 160 == 0) ? VMV_TILE_P256x160 : VMV_TILE_P256x128;
@@ -630,6 +630,7 @@ extern "C" int vmv_gemm(const VmvGemmParams* pp, void* stream) {
         case VMV_TILE_X256x256:
         case VMV_TILE_X256x128:
         case VMV_TILE_X512x128:
+        case VMV_TILE_Y256x128:
             rc = vmv_gemm_xglds_launch(p, total_steps, picked, st);
             if (rc == VMV_GLDS_UNSUPPORTED && (p.rowstat || p.epilogue == VMV_EPI_GEGLU)) {      // the fused epilogues' other home
                 if (p.tile != VMV_TILE_AUTO) return VMV_EINVAL;

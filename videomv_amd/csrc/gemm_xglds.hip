@@ -34,21 +34,28 @@ namespace {
 #endif
 constexpr int WBK = 32;                 // this kernel's K chunk: ONE k-step of v_mfma_f32_16x16x32 (see above)
 
-// WNV = waves along N: 2 (the 4 x 2 wave grid of the 256-row tiles) or 1 (round 6: 8 x 1 — a 512 x 128 tile of 64 x 128 wave tiles for
-// the N = 128 convolutions of the VAE's first level, whose 64 x 64 wave tiles in every other kernel read 0.5 fragments per MFMA and
-// sit at 670 TFLOP/s whatever the tile: 0.375 here)
+// WNV = the wave grid: 2 = 4 x 2 waves (the 256-row tiles); 1 = 8 x 1 (round 6: a 512 x 128 tile of 64 x 128 wave tiles for the N = 128
+// convolutions of the VAE's first level, whose 64 x 64 wave tiles in every other kernel read 0.5 fragments per MFMA and sit at
+// 670 TFLOP/s whatever the tile: 0.375 here); 4 = 4 x 1 waves in a 256-THREAD block, 256 x 128 tile, three-stage ring (72 KB) and TWO
+// blocks per CU (round 6 experiment for the K = 1280 linears: still 2 waves per SIMD and 64 x 128 wave tiles, but the two blocks of a CU
+// are independent, so one's fill / epilogue runs under the other's main loop — the 14.7 us per 47.6-us tile the one-block form exposes.
+// MEASURED: correct, and slower everywhere — qkv L2 644 vs 754 TFLOP/s, GEGLU L2 756 vs 818, FF-down L2 608 vs 977: a 256 x 128 block
+// moves 50 % more LDS-DMA bytes per flop than the 256 x 256 one and its steady state is DMA-bound at ~620 TFLOP/s; built with
+// EXPERIMENTS=1 only, profiles/r6_y256_bench.log).
 template <int NH, int WH, int WNV = 2>
 struct WgCfg {
     static constexpr int WM = 4, WN = NH * WH;              // 16-row / 16-column MFMA tiles per wave
-    static constexpr int NW = 8, NT = 512;                  // WMV waves along M x WNV along N
-    static constexpr int WMV = NW / WNV;
-    static constexpr int BM = 16 * WM * WMV, BN = 16 * WN * WNV;
+    static constexpr int NW = WNV == 4 ? 4 : 8, NT = 64 * NW;          // waves per block: WMV along M x WNW along N
+    static constexpr int WNW = WNV == 2 ? 2 : 1;
+    static constexpr int WMV = NW / WNW;
+    static constexpr int BPC = WNV == 4 ? 2 : 1;            // blocks per CU
+    static constexpr int BM = 16 * WM * WMV, BN = 16 * WN * WNW;
     static constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64;         // rows of 32 elements = 64 B
     static constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
 #ifndef VMV_XGLDS_STAGES
 #define VMV_XGLDS_STAGES 4      // (experiments: 3 = the depth a persistent form with per-wave epilogue slabs could afford)
 #endif
-    static constexpr int STAGES = VMV_XGLDS_STAGES;
+    static constexpr int STAGES = WNV == 4 ? 3 : VMV_XGLDS_STAGES;
     static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
     static constexpr int NAI = BM / (16 * NW);              // A wave-instructions per wave per chunk (16 rows x 64 B each) = 2 (4 at BM = 512)
     static constexpr int WGROUPS = BN / 16;                 // 16-row groups of W per chunk (20 at BN = 320)
@@ -57,8 +64,8 @@ struct WgCfg {
     static constexpr int LPT = NAI + NWI;                   // loads per lane per chunk (waves < NWX: LPT + 1)
     static constexpr int HALF_ROWS = 128;                   // epilogue staging: 128 rows (two wave rows) at a time
     static constexpr int XG_MAXG = 8;                       // row groups (rowvec rows) one tile's rows may span
-    static_assert(WNV == 1 || WNV == 2, "wave grid");
-    static_assert(HALF_ROWS * (BN * 2 + 16) + XG_MAXG * BN * 4 + BN * 4 <= LDS_BYTES && LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(WNV == 1 || WNV == 2 || WNV == 4, "wave grid");
+    static_assert(HALF_ROWS * (BN * 2 + 16) + XG_MAXG * BN * 4 + BN * 4 <= LDS_BYTES && BPC * LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
 constexpr int XE_GEGLU = 1, XE_LN = 2;       // EPI bits
@@ -68,7 +75,7 @@ constexpr int XE_GEGLU = 1, XE_LN = 2;       // EPI bits
 // p.workspace; gemm_splitk_reduce (gemm.hip) sums the slabs and runs the epilogue.  For the grids that cannot fill the chip with
 // 256-row wide tiles on their own (the fourth UNet level, a frame-parallel rank's M / 8 rows) without falling back to 128-row tiles.
 template <int NH, int WH, int EPI = 0, bool SK = false, int WNV = 2>
-__global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams p, const int tiles_m, const int tiles_n, const int nsteps_arg,
+__global__ __launch_bounds__(WNV == 4 ? 256 : 512, WNV == 4 ? 2 : 1) void gemm_xglds_kernel(const VmvGemmParams p, const int tiles_m, const int tiles_n, const int nsteps_arg,
                                                             const int nsteps_total, const int gm, const int tapmajor) {
     VMV_KERNEL_ENTER();
     using Cfg = WgCfg<NH, WH, WNV>;
@@ -521,14 +528,14 @@ __global__ __launch_bounds__(512, 1) void gemm_xglds_kernel(const VmvGemmParams 
 
 // rows of the tile group that shares W slices in an XCD's L2 (kernel header): minimises the bytes 32 concurrent blocks pull in,
 // gm x BM + 32 / gm x BN per K chunk, with 32 / gm <= the N tiles there are; 1 = the round-5 order.  VMV_XGLDS_GM forces it (A/B).
-int xglds_group_m(int tiles_m, int tiles_n, int BM, int BN) {
+int xglds_group_m(int tiles_m, int tiles_n, int BM, int BN, int conc = 32) {
     static int env = -2;
     if (env == -2) { const char* e = getenv("VMV_XGLDS_GM"); env = e ? atoi(e) : -1; }
     if (env >= 1) return env;
     if (tiles_n < 2 || tiles_m < 2) return 1;
-    int best = 1, best_cost = BM + 32 * BN;
-    for (int gm = 2; gm <= 32; gm *= 2) {
-        const int gn = (32 + gm - 1) / gm;
+    int best = 1, best_cost = BM + conc * BN;          // conc = blocks an XCD runs at once (32 CUs x blocks per CU)
+    for (int gm = 2; gm <= conc; gm *= 2) {
+        const int gn = (conc + gm - 1) / gm;
         if (gn > tiles_n || gm > tiles_m) continue;
         const int cost = gm * BM + gn * BN;
         if (cost < best_cost) { best = gm; best_cost = cost; }
@@ -547,7 +554,7 @@ int launch_xglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
     using Cfg = WgCfg<NH, WH, WNV>;
     const int tiles_m = (p.M + Cfg::BM - 1) / Cfg::BM;
     const int tiles_n = (p.N + Cfg::BN - 1) / Cfg::BN;
-    const int gm = xglds_group_m(tiles_m, tiles_n, Cfg::BM, Cfg::BN);
+    const int gm = xglds_group_m(tiles_m, tiles_n, Cfg::BM, Cfg::BN, 32 * Cfg::BPC);
     int nsteps = 0;                                          // chunks of WBK = 32 (total_steps counts the other kernels' 64)
     for (int i = 0; i < p.nseg; ++i) nsteps += (p.seg[i].k + WBK - 1) / WBK;
     (void)total_steps;
@@ -580,7 +587,7 @@ int launch_xglds(const VmvGemmParams& p, int total_steps, hipStream_t st) {
 int vmv_gemm_xglds_epi_ok(const VmvGemmParams& p, int tile) {
     const bool geglu = p.epilogue == VMV_EPI_GEGLU, lnf = p.rowstat != nullptr;
     if (!geglu && !lnf) return 1;
-    if (tile != VMV_TILE_X256x256) return 0;                 // the fused epilogues exist for the 256 x 256 tile only
+    if (tile != VMV_TILE_X256x256 && tile != VMV_TILE_Y256x128) return 0;      // the fused epilogues exist for 64 x 128 wave tiles only
     if (lnf && !p.colsum) return 0;
     if (geglu && ((p.N & 31) || p.residual || p.act != VMV_ACT_NONE)) return 0;      // whole x | gate pairs; no residual (as the other kernels)
     return 1;
@@ -601,6 +608,16 @@ int vmv_gemm_xglds_launch(const VmvGemmParams& p, int total_steps, int tile, hip
     const int No = geglu ? p.N / 2 : p.N;
     if (p.ksplit <= 1 && (p.out_fp32 || (p.ldo & 7) || (No & 7) || !vmv_aligned16(p.out) ||
                           (p.residual && ((p.ldr & 7) || !vmv_aligned16(p.residual))))) return VMV_GLDS_UNSUPPORTED;   // staged epilogue only
+    if (tile == VMV_TILE_Y256x128) {          // 4-wave blocks, two per CU (WgCfg WNV = 4): measured and rejected, experiment builds only
+#if defined(VMV_EXPERIMENTS)
+        if (geglu && lnf) return launch_xglds<2, 4, XE_GEGLU | XE_LN, 4>(p, total_steps, st);
+        if (geglu) return launch_xglds<2, 4, XE_GEGLU, 4>(p, total_steps, st);
+        if (lnf) return launch_xglds<2, 4, XE_LN, 4>(p, total_steps, st);
+        return launch_xglds<2, 4, 0, 4>(p, total_steps, st);
+#else
+        return VMV_GLDS_UNSUPPORTED;
+#endif
+    }
     if (geglu || lnf) {
         if (geglu && lnf) return launch_xglds<2, 4, XE_GEGLU | XE_LN>(p, total_steps, st);
         if (geglu) return launch_xglds<2, 4, XE_GEGLU>(p, total_steps, st);
