@@ -196,6 +196,61 @@ def launch_ranks(n, argv):
     return rc
 
 
+def run_fp_children(args, rank, world, local_launcher, port, dry_run=False):
+    """The frame-parallel leg (BASELINE configs[2]) of an N > 1 run in CHILD processes, one per rank, with a process group of their own.
+
+    Why: that leg is the one part of the bench no round could run on real peers (in-plan RCCL all-to-all / all-gather at world > 1 has
+    only met gloo, a simulated rank and world-1 RCCL), and a GPU fault or a native abort there would take the rank — and under
+    torch.distributed.run every rank — down BEFORE the replica line (`value`, the scaling curve's point) is printed.  In children the
+    worst case is `frame_parallel: {error}` beside an intact headline.  Each child is this script again with --fp-inprocess and the
+    same RANK / LOCAL_RANK / WORLD_SIZE, a fresh MASTER_PORT (`port`, agreed by the parents) and without the TORCHELASTIC_* variables
+    (the agent's store serves the parents' port only).  Returns the dict for the line's `frame_parallel` (rank 0) or None."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+               VMV_BENCH_LAUNCHER=f"frame-parallel child of {local_launcher}")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--latent", args.latent, "--frames", str(args.frames), "--fp-inprocess", "--frame-parallel-budget", str(args.frame_parallel_budget),
+           "--no-cpu-baseline", "--no-op-profile", "--no-sample", "--no-lgm", "--no-i2vgen", "--simulate-rank", "0"]
+    if dry_run:
+        cmd.append("--pg-dry-run")
+    limit = 60.0 if dry_run else args.frame_parallel_budget + 240.0      # (the child's own watchdog fires at the budget; + start-up)
+    out, err = "", None
+    p_ = subprocess.Popen(cmd, env=env, cwd=os.getcwd(), stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True)
+    try:
+        out, _ = p_.communicate(timeout=limit)
+        if p_.returncode != 0:
+            err = f"child exited with code {p_.returncode}"
+    except subprocess.TimeoutExpired:
+        p_.kill()                                 # (exact PID)
+        try:
+            out, _ = p_.communicate(timeout=20)
+        except Exception:
+            out = ""
+        err = f"child did not finish inside {limit:.0f} s"
+    if rank != 0:
+        return None
+    line = next((l for l in (out or "").splitlines()[::-1] if l.startswith("{")), None)
+    dj = None
+    if line:
+        try:
+            dj = json.loads(line)
+        except Exception:
+            dj = None
+    if dry_run:
+        return dict(dj or {}, **({"error": err} if err else {}))
+    fp = (dj or {}).get("frame_parallel")
+    if not isinstance(fp, dict):
+        fp = dict(error=err or "the child printed no frame_parallel object")
+    elif err and "error" not in fp:
+        fp["error"] = err
+    fp["isolation"] = "child processes with their own process group (a fault in this leg cannot cost the replica line)"
+    if dj and "rccl_ranks" in dj:
+        fp["child_rccl_ranks"] = dj["rccl_ranks"]
+    return fp
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
@@ -209,6 +264,8 @@ def main(argv=None):
     ap.add_argument("--dump-ops", type=str, default="", help="write the per-launch timing table to this file")
     ap.add_argument("--no-frame-parallel", action="store_true", help="N > 1: skip the frame-parallel (one sample over all GPUs) leg")
     ap.add_argument("--frame-parallel-budget", type=float, default=300.0, help="seconds before the watchdog abandons that leg")
+    ap.add_argument("--fp-inprocess", action="store_true", help="N > 1: run the frame-parallel leg inside the rank processes themselves (what the "
+                    "leg's child processes do); default: in one child process per rank, so that a fault there cannot cost the replica line")
     ap.add_argument("--no-lgm", action="store_true", help="skip the LGM-refined sample (BASELINE configs[4])")
     ap.add_argument("--no-sample", action="store_true", help="skip the (untimed-region) full 50-step + VAE-decode sample")
     ap.add_argument("--simulate-rank", type=int, default=8, metavar="W", help="N = 1 only: also build rank 0's plan of a W-GPU frame-parallel run "
@@ -262,10 +319,18 @@ def main(argv=None):
             raise SystemExit(f"process group of {world} ranks counted {rccl_ranks}")
     launcher = os.environ.get("VMV_BENCH_LAUNCHER") or ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
                                                         ("none (single process)" if world == 1 else "external"))
+    def agreed_port():
+        """A free port picked by rank 0 and handed to every rank through the parents' own process group (for the children's group)."""
+        pt = torch.tensor([_free_port() if rank == 0 else 0], dtype=torch.int32, device=cdev)
+        dist.all_reduce(pt)
+        return int(pt[0])
+
+    fp_children = dist is not None and world > 1 and args.frames % world == 0 and not args.no_frame_parallel and not args.fp_inprocess
     if args.pg_dry_run:
+        fp_child = run_fp_children(args, rank, world, launcher, agreed_port(), dry_run=True) if fp_children else None
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "rccl_ranks": rccl_ranks, "pg_backend": backend if dist is not None else None,
-                              "launcher": launcher, "steps": args.steps, "warmup": args.warmup}), flush=True)
+                              "launcher": launcher, "steps": args.steps, "warmup": args.warmup, "fp_child": fp_child}), flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -452,7 +517,12 @@ def main(argv=None):
 
     # ---- frame-parallel leg: ONE sample over all ranks (strong scaling of a sample's latency)
     fpar = None
-    if dist is not None and args.frames % world == 0 and not args.no_frame_parallel:
+    if fp_children:
+        # default at N > 1: the leg runs in one child process per rank (run_fp_children: a fault there cannot cost the line below)
+        fence()
+        fpar = run_fp_children(args, rank, world, launcher, agreed_port())
+        fence()
+    elif dist is not None and args.frames % world == 0 and not args.no_frame_parallel:
         import threading
         done = threading.Event()
         state = {"stage": "init"}

@@ -29,6 +29,39 @@ def test_bench_gpus_n_spawns_n_ranks_and_counts_them(n):
     assert len(lines) == 1, r.stdout                      # ONE JSON line, rank 0's
     j = json.loads(lines[0])
     assert j["n_gpus"] == n and j["rccl_ranks"] == n and j["launcher"] == "self-spawned" and j["steps"] == 3 and j["warmup"] == 1
+    # the frame-parallel leg's CHILD processes (one per rank, a process group of their own on a port the parents agreed on) met too
+    c = j["fp_child"]
+    assert c and "error" not in c and c["n_gpus"] == n and c["rccl_ranks"] == n and c["launcher"] == "frame-parallel child of self-spawned"
+
+
+def test_frame_parallel_children_rendezvous_under_torch_distributed_run():
+    """The driver's own form — `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` — with the frame-parallel leg in
+    child processes: the children must not inherit the elastic agent's store (TORCHELASTIC_USE_AGENT_STORE points at the PARENTS' port;
+    a child that kept it would wait for ever on a port nobody serves).  --pg-dry-run, gloo: no GPU needed."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, VMV_BENCH_FAKE_DEVICES="2", VMV_BENCH_PG_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--pg-dry-run"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["launcher"] == "torch.distributed.run"
+    c = j["fp_child"]
+    assert c and "error" not in c and c["rccl_ranks"] == 2 and c["launcher"] == "frame-parallel child of torch.distributed.run"
+
+
+def test_no_frame_parallel_spawns_no_children():
+    r = _run(["--gpus", "2", "--pg-dry-run", "--no-frame-parallel"], dict(VMV_BENCH_FAKE_DEVICES="2", VMV_BENCH_PG_BACKEND="gloo"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["fp_child"] is None and j["rccl_ranks"] == 2
 
 
 def test_bench_gpus_n_refuses_when_fewer_devices_are_visible():

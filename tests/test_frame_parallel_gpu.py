@@ -277,3 +277,5 @@ def test_bench_gpus_2_end_to_end_on_one_gpu():
     fp = d["frame_parallel"]
     assert fp and "error" not in fp, fp
     assert fp["views_per_gpu"] == 2 and fp["single_plan"]["finite"] and fp["branch_pipelined"]["finite"] and fp["cfg_x_frame"]["finite"]
+    # (the leg ran in one child process per rank with a process group of its own: a fault there cannot cost the replica line)
+    assert fp["child_rccl_ranks"] == 2 and "child processes" in fp["isolation"]
