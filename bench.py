@@ -266,6 +266,7 @@ def main(argv=None):
     ap.add_argument("--frame-parallel-budget", type=float, default=300.0, help="seconds before the watchdog abandons that leg")
     ap.add_argument("--fp-inprocess", action="store_true", help="N > 1: run the frame-parallel leg inside the rank processes themselves (what the "
                     "leg's child processes do); default: in one child process per rank, so that a fault there cannot cost the replica line")
+    ap.add_argument("--no-prompt-batch", action="store_true", help="skip the two-prompts-per-plan throughput leg")
     ap.add_argument("--no-lgm", action="store_true", help="skip the LGM-refined sample (BASELINE configs[4])")
     ap.add_argument("--no-sample", action="store_true", help="skip the (untimed-region) full 50-step + VAE-decode sample")
     ap.add_argument("--simulate-rank", type=int, default=8, metavar="W", help="N = 1 only: also build rank 0's plan of a W-GPU frame-parallel run "
@@ -504,6 +505,39 @@ def main(argv=None):
         except Exception as e:
             ref_shape = dict(ref_shape or {}, error=f"{type(e).__name__}: {e}")
 
+    # ---- two prompts per plan (round 6): the reference denoises one prompt at a time; its sampler API admits noise [b, 4, F, h, w].  One
+    #      sample's small levels do not fill 256 CUs, so b = 2 prompts in ONE plan of B = 4 row blocks (pair-major, fused CFG + DDIM update
+    #      per sample: unet_t2v._forward_cfg_rows_batched) raise per-GPU throughput.  An extra object: `value` stays the 1-sample step.
+    pbatch = None
+    if rank == 0 and world == 1 and not args.no_op_profile and not args.no_prompt_batch:
+        def time_batch(h, w, nb, n=8):
+            x = torch.randn(nb, 4, args.frames, h, w, generator=g, device=dev)
+            yb = torch.randn(nb, 77, 1024, generator=g, device=dev)
+            kc_b, ku_b = dict(y=yb, camera_data=cam), dict(y=y0, camera_data=cam)
+            for i in range(2):
+                dif.ddim_step_hip(x, steps[i], model, kc_b, ku_b, 9.0, stride)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n):
+                dif.ddim_step_hip(x, steps[(2 + i) % len(steps)], model, kc_b, ku_b, 9.0, stride)
+            torch.cuda.synchronize()
+            return 1000.0 * (time.perf_counter() - t0) / n, bool(torch.isfinite(x).all())
+        try:
+            pbatch = dict(prompts=2, note="b = 2 prompts per plan (B = 4 row blocks, pair-major; CFG prefix shared per prompt), same kernels and tile rule; "
+                                          "sample_steps_per_s = 2 / batched step; `value` above is the 1-prompt step")
+            for (h, w) in ([(H, W)] + ([(32, 32)] if (H, W) == (40, 64) else [])):
+                ms1, _ = time_batch(h, w, 1)
+                ms2, fin2 = time_batch(h, w, 2)
+                d = dict(ms_per_step_1_prompt=round(ms1, 3), ms_per_step_2_prompts=round(ms2, 3), sample_steps_per_s=round(2000.0 / ms2, 3),
+                         throughput_vs_1_prompt=round(2.0 * ms1 / ms2, 4), finite=fin2)
+                if STEP_TFLOP.get((h, w)):
+                    d["whole_step_frac_of_peak"] = round(2.0 * STEP_TFLOP[(h, w)] / (ms2 * 1e-3) / PEAK_MFMA16_TFLOPS, 4)
+                pbatch[f"{args.frames}x{h}x{w}"] = d
+                for k_ in [k for k in getattr(model, "_engines", {}) if k[0] == 4]:      # (free the B = 4 engines' buffers)
+                    model._engines.pop(k_, None)
+        except Exception as e:
+            pbatch = dict(pbatch or {}, error=f"{type(e).__name__}: {e}")
+
     def headline():
         return {"metric": "denoise-steps/sec, t2v %dx%dx%d (latent %dx%dx%d), CFG 9.0, 50-step DDIM schedule" % (8 * H, 8 * W, args.frames, args.frames, H, W),
                "value": round(steps_per_s, 4), "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps,
@@ -513,7 +547,7 @@ def main(argv=None):
                "config": {"workload": f"t2v_infer.yaml UNetSD_T2VBase 1.413B, 24 views, latent {H}x{W}, 77 ctx tokens, "
                                       f"1 sample per GPU (cond+uncond batched)", "parallelism": f"replicas x{world}"},
                "rccl_ranks": rccl_ranks, "launcher": launcher, "pg_backend": (backend + (" (ranks share GPU 0: smoke test, not a measurement)" if share_gpu else "")) if dist is not None else None,
-               "finite": finite, "roofline": roof, "reference_shape": ref_shape}
+               "finite": finite, "roofline": roof, "reference_shape": ref_shape, "prompt_batch": pbatch}
 
     # ---- frame-parallel leg: ONE sample over all ranks (strong scaling of a sample's latency)
     fpar = None

@@ -391,6 +391,85 @@ def test_cfg_conditioning_cache_follows_the_tensors(monkeypatch):
     assert rel_l2(mine_u, e_u) < 2e-3
 
 
+def test_batched_prompts_in_one_cfg_plan_equal_the_single_prompt_passes(monkeypatch):
+    """b = 2 prompts of one denoising step in ONE plan of B = 4 row blocks, pair-major [c_0 | u_0 | c_1 | u_1] (round 6: the small
+    levels of one sample do not fill the chip; the reference's sampler API admits noise [b, 4, F, h, w], diffusion_ddim.py:247-260).
+    Every sample's eps rows and its fused CFG + DDIM update must equal the single-prompt pass of that sample: shared uncond text and
+    camera ([1, ...]), per-sample cond text; then per-sample cameras on both branches."""
+    plan_interp.install(monkeypatch)
+    from videomv_amd.registry import MODEL, DIFFUSION
+    import videomv_amd.unet_t2v  # noqa: F401
+    import videomv_amd.diffusion_ddim  # noqa: F401
+    ocfg = UNetCfg(**{k: v for k, v in CFG.items() if k in {f.name for f in dataclasses.fields(UNetCfg)}})
+    sd = random_state_dict(unet_param_shapes(ocfg), 5)
+    m = MODEL.build(dict(type="UNetSD_T2VBase", y_dim=1024, **CFG)).eval()
+    m.load_state_dict(sd, strict=True)
+    F_, H, W, Lc = 2, 8, 8, 5
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 4, F_, H, W, generator=g)
+    t1, t2 = torch.tensor([501]), torch.tensor([501, 501])
+    yc = torch.randn(2, Lc, 1024, generator=g)
+    y0 = torch.randn(1, Lc, 1024, generator=g)
+    cam = torch.randn(1, F_, 16, generator=g)
+    T = F_ * H * W
+    singles = [m.forward_cfg_rows(x[s:s + 1], t1, dict(y=yc[s:s + 1], camera_data=cam), dict(y=y0, camera_data=cam))[1].clone() for s in range(2)]
+    eng, rows = m.forward_cfg_rows(x, t2, dict(y=yc, camera_data=cam), dict(y=y0, camera_data=cam))
+    assert eng.B == 4 and rows.shape[0] == 4 * T
+    # one camera set => the CFG prefix is recorded on ONE row block per prompt (2 of the 4) and replicated pairwise, as in the 1-prompt pass
+    from videomv_amd import _lib as L
+    assert eng.share_prefix and eng.Bp == 2
+    gm = [p.M for op, p in eng.S.recorded if op == L.OP_GEMM]
+    assert gm.count(2 * T) >= 10 and sum(1 for l in eng.S.labels if ".share." in l or l.startswith("share.")) == 3
+    to_ncfhw = lambda r: r[:, :4].reshape(F_, H * W, 4).permute(2, 0, 1).reshape(1, 4, F_, H, W)
+    for s in range(2):
+        # (16-bit storage rounding: the single-prompt pass records its CFG prefix once on one branch's rows, the B = 4 plan does not)
+        assert rel_l2(rows[2 * s * T:(2 * s + 2) * T, :4], singles[s][:, :4]) < 3e-3, s
+        for br, yy in enumerate((yc[s:s + 1], y0)):                          # and each row block against the fp32 oracle of its own (x, y)
+            ref = unet_forward(sd, ocfg, x[s:s + 1], t1, yy, cam)
+            blk = rows[(2 * s + br) * T:(2 * s + br + 1) * T]
+            assert rel_l2(to_ncfhw(blk), ref) < 1e-2, (s, br)
+    assert rel_l2(rows[:2 * T, :4], rows[2 * T:, :4]) > 0.05                 # (the two prompts do differ)
+    # the whole fused step, per sample on its row offset: against the reference-structured update (DiffusionDDIM.ddim_sample) fed the SAME
+    # eps rows (guidance 9 would amplify the storage-rounding difference between two plans: compare the update, not the plans, here)
+    dif = DIFFUSION.build(dict(type="DiffusionDDIM", schedule="linear_sd", schedule_param=dict(num_timesteps=1000, init_beta=0.00085, last_beta=0.0120),
+                               mean_type="eps", var_type="fixed_small"))
+    kc, ku = dict(y=yc, camera_data=cam), dict(y=y0, camera_data=cam)
+    xb, x0b = x.clone(), torch.empty_like(x)
+    dif.ddim_step_hip(xb, 501, m, kc, ku, 9.0, 500, x0_out=x0b, clamp=1.5)
+    for s in range(2):
+        fake = lambda xt, ts, br=0, s=s: to_ncfhw(rows[(2 * s + br) * T:(2 * s + br + 1) * T])
+        want, want0 = dif.ddim_sample(x[s:s + 1], torch.tensor([501]), fake, None, [dict(br=0), dict(br=1)], 1.5, None, None, 9.0, 2, 0.0)
+        assert rel_l2(xb[s:s + 1], want) < 1e-5 and rel_l2(x0b[s:s + 1], want0) < 1e-5, s
+    assert float(x0b.abs().max()) <= 1.5 and rel_l2(xb[:1], xb[1:]) > 0.05
+    # stochastic step: sample s gets ITS slice of the one randn_like(x_t) the batch draws
+    xe, x0e = x.clone(), torch.empty_like(x)
+    torch.manual_seed(3)
+    dif.ddim_step_hip(xe, 501, m, kc, ku, 9.0, 500, x0_out=x0e, clamp=1.5, eta=0.7)
+    torch.manual_seed(3)
+    noise = torch.randn_like(x)
+    k = dif.step_scalars(501, 500)
+    sg = dif.ddim_sigma(501, 500, 0.7)
+    eps_hat = (k["c_recip"] * x - x0e) / k["c_recipm1"]
+    want = (k["a_prev"] ** 0.5) * x0e + ((1 - k["a_prev"] - sg * sg) ** 0.5) * eps_hat + sg * noise
+    assert torch.equal(x0e, x0b) and rel_l2(xe, want) < 1e-5 and sg > 0
+    # per-sample cameras, different on the two branches
+    cams_c, cams_u = torch.randn(2, F_, 16, generator=g), torch.randn(2, F_, 16, generator=g)
+    eng_c, rows_c = m.forward_cfg_rows(x, t2, dict(y=yc, camera_data=cams_c), dict(y=y0, camera_data=cams_u))
+    assert not eng_c.share_prefix and eng_c is not eng
+    for s in range(2):
+        one = m.forward_cfg_rows(x[s:s + 1], t1, dict(y=yc[s:s + 1], camera_data=cams_c[s:s + 1]), dict(y=y0, camera_data=cams_u[s:s + 1]))[1]
+        assert rel_l2(rows_c[2 * s * T:(2 * s + 2) * T, :4], one[:, :4]) < 3e-3, s
+    # samples never see each other (all-frame GroupNorm statistics, attention batches, context K / V are per row block): another prompt
+    # and latent in slot 1 leaves slot 0's rows BIT-identical
+    r_a = m.forward_cfg_rows(x, t2, dict(y=yc, camera_data=cam), dict(y=y0, camera_data=cam))[1].clone()
+    x_b, y_b = x.clone(), yc.clone()
+    x_b[1], y_b[1] = 3.0 * torch.randn(4, F_, H, W, generator=g), torch.randn(Lc, 1024, generator=g)
+    r_b = m.forward_cfg_rows(x_b, t2, dict(y=y_b, camera_data=cam), dict(y=y0, camera_data=cam))[1]
+    assert torch.equal(r_a[:2 * T], r_b[:2 * T]) and rel_l2(r_a[2 * T:], r_b[2 * T:]) > 0.1
+    with pytest.raises(ValueError):
+        m.forward_cfg_rows(x, t2, dict(y=torch.randn(3, Lc, 1024), camera_data=cam), dict(y=y0, camera_data=cam))
+
+
 def test_shared_cfg_prefix_and_hoisted_context_kv(monkeypatch):
     """B = 2 CFG pair: (a) everything before the first cross-attention is recorded once on one branch's rows and
     replicated (share_prefix) — same eps as the plain B = 2 plan and as the oracle, fewer rows in the prefix GEMMs;

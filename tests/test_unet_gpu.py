@@ -126,6 +126,44 @@ def test_fused_cfg_ddim_loop_matches_oracle():
     print("fused-vs-oracle", e, "generic-vs-oracle", e_gen_ref, "generic-vs-fused", e_gen)
 
 
+def test_two_prompts_batched_in_one_fused_loop_match_oracle(monkeypatch):
+    """noise [2, 4, F, h, w] + model_kwargs y [2, L, D]: ddim_sample_loop takes the FUSED path with ONE plan of B = 4 row blocks
+    (round 6: the small levels of one sample do not fill 256 CUs) — every sample against the oracle loop of ITS prompt at the stated x0
+    tolerance and against the single-prompt fused loop; samples do not see each other (slot 0 bit-identical whatever sits in slot 1)."""
+    from videomv_amd.registry import DIFFUSION
+    cfg = dict(in_dim=4, dim=64, context_dim=1024, out_dim=4, dim_mult=[1, 2], num_heads=2, head_dim=64,
+               num_res_blocks=1, attn_scales=[1.0, 0.5])
+    ocfg = UNetCfg(**cfg)
+    sd = random_state_dict(unet_param_shapes(ocfg), 31)
+    m = build_model(cfg, sd).cuda()
+    dif = DIFFUSION.build(dict(type="DiffusionDDIM", schedule="linear_sd",
+                               schedule_param=dict(num_timesteps=1000, init_beta=0.00085, last_beta=0.012,
+                                                   zero_terminal_snr=False),
+                               mean_type="eps", var_type="fixed_small"))
+    gen = torch.Generator().manual_seed(12)
+    noise = torch.randn(2, 4, 4, 8, 8, generator=gen)
+    y, y0 = torch.randn(2, 7, 1024, generator=gen), torch.randn(1, 7, 1024, generator=gen)
+    cam = torch.randn(1, 4, 16, generator=gen)
+    calls = []
+    orig = type(m).forward_cfg_rows
+    monkeypatch.setattr(type(m), "forward_cfg_rows", lambda self, xt, *a: (calls.append(xt.shape[0]), orig(self, xt, *a))[1])
+    kw = [dict(y=y.cuda(), camera_data=cam), dict(y=y0.cuda(), camera_data=cam)]
+    x_hip = dif.ddim_sample_loop(noise=noise.cuda(), model=m, model_kwargs=kw, guide_scale=9.0, ddim_timesteps=3, eta=0.0)
+    assert calls == [2] * len(dif.ddim_steps(3)) and x_hip.shape == noise.shape            # fused, both prompts in every call
+    tb = DDIMTables(betas_for("linear_sd"))
+    fwd = lambda xt, t, y, camera_data: unet_forward(sd, ocfg, xt, t, y, camera_data)
+    for s in range(2):
+        x_ref = ddim_sample_loop(noise[s:s + 1].clone(), fwd, tb, [dict(y=y[s:s + 1], camera_data=cam), dict(y=y0, camera_data=cam)], 9.0, ddim_timesteps=3)
+        x_one = dif.ddim_sample_loop(noise=noise[s:s + 1].cuda(), model=m, guide_scale=9.0, ddim_timesteps=3, eta=0.0,
+                                     model_kwargs=[dict(y=y[s:s + 1].cuda(), camera_data=cam), dict(y=y0.cuda(), camera_data=cam)])
+        e, e_one = rel_l2(x_hip[s:s + 1], x_ref), rel_l2(x_hip[s:s + 1], x_one.cpu())
+        assert e < TOL_X0 and e_one < TOL_X0, (s, e, e_one)
+    n2, y2 = noise.clone(), y.clone()
+    n2[1], y2[1] = 2.0 * torch.randn(4, 4, 8, 8, generator=gen), torch.randn(7, 1024, generator=gen)
+    x_b = dif.ddim_sample_loop(noise=n2.cuda(), model=m, model_kwargs=[dict(y=y2.cuda(), camera_data=cam), kw[1]], guide_scale=9.0, ddim_timesteps=3, eta=0.0)
+    assert torch.equal(x_b[0], x_hip[0]) and rel_l2(x_b[1], x_hip[1].cpu()) > 0.1
+
+
 def test_fused_step_with_clamp_and_eta_matches_oracle(monkeypatch):
     """The sampler options that ride in the fused update (round 5: they used to raise): `clamp` on x0 and stochastic DDIM (`eta > 0`:
     sigma_t, the shortened direction term, + sigma * noise) on the HIP path against the oracle loop, which is itself pinned to the imported

@@ -1,0 +1,11 @@
+#!/bin/bash
+# round 6, 18th GPU call: two prompts per plan with the CFG prefix shared per prompt — UNet / frame-parallel GPU tests, bench leg
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out
+cd $R; mkdir -p $O
+timeout 1500 python -m pytest tests/test_unet_gpu.py -x -q > $O/r6_pbatch2_tests.log 2>&1; tail -5 $O/r6_pbatch2_tests.log
+timeout 600 python bench.py --no-cpu-baseline --no-sample --simulate-rank 0 > $O/r6_pbatch2_bench.json 2> $O/r6_pbatch2_bench.err
+python -c "
+import json
+d=json.loads([l for l in open('$O/r6_pbatch2_bench.json') if l.startswith('{')][-1])
+print(d['ms_per_step'], json.dumps(d['prompt_batch'], indent=1)); print(d['reference_shape'])"
+tail -3 $O/r6_pbatch2_bench.err

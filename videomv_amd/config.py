@@ -63,6 +63,7 @@ def default_cfg() -> AttrDict:
     c.cfg_parallel = False            # with frame_parallel: 2 x N/2 — one CFG branch per half of the ranks (comm.CfgFrameComm)
     c.hip_dtype = ''                  # 16-bit storage / MFMA operand type of the HIP kernels: '' (VMV_DTYPE or fp16) | fp16 | bf16
     c.num_views = None                # None -> max_frames
+    c.prompt_batch = 1                # t2v entrance: prompts denoised per plan (1 = the reference's one prompt at a time; 2 fills the small levels)
     return c
 
 

@@ -134,8 +134,18 @@ class DiffusionDDIM(object):
         sigma = self.ddim_sigma(int(step), stride, eta)
         # (the reference draws randn_like(xt) every step, eta = 0 included; only a stochastic step needs it here)
         noise = self._step_noise(xt, unet) if sigma > 0.0 else None
-        ops.cfg_ddim_step(eps_rows, eng.out_pad, xt, float(guide_scale), v_pred=(self.mean_type == 'v'),
-                          x0_out=x0_out, clamp=clamp, sigma=sigma, noise=noise, **self.step_scalars(int(step), stride))
+        k = self.step_scalars(int(step), stride)
+        if xt.shape[0] == 1:
+            ops.cfg_ddim_step(eps_rows, eng.out_pad, xt, float(guide_scale), v_pred=(self.mean_type == 'v'),
+                              x0_out=x0_out, clamp=clamp, sigma=sigma, noise=noise, **k)
+            return xt
+        # b > 1 prompts in one plan: row blocks are pair-major [c_0 | u_0 | c_1 | u_1 ...] (unet_t2v._forward_cfg_rows_batched), so sample s's
+        # pair starts 2 s F h w rows in and the single-sample kernel applies to it unchanged
+        per = 2 * xt.shape[2] * xt.shape[3] * xt.shape[4]
+        for s in range(xt.shape[0]):
+            ops.cfg_ddim_step(eps_rows[s * per:(s + 1) * per], eng.out_pad, xt[s:s + 1], float(guide_scale), v_pred=(self.mean_type == 'v'),
+                              x0_out=None if x0_out is None else x0_out[s:s + 1], clamp=clamp, sigma=sigma,
+                              noise=None if noise is None else noise[s:s + 1], **k)
         return xt
 
     def _same_gs_data(self, ga, gb) -> bool:
@@ -234,8 +244,9 @@ class DiffusionDDIM(object):
         unet = _unwrap(model)
         fused = (hasattr(unet, "forward_cfg_rows") and guide_scale is not None and isinstance(model_kwargs, list)
                  and len(model_kwargs) == 2 and percentile is None
-                 and condition_fn is None and b == 1 and self.mean_type in ('eps', 'v')
-                 and noise.is_cuda)
+                 and condition_fn is None and self.mean_type in ('eps', 'v') and noise.is_cuda
+                 and (b == 1 or (getattr(unet, "cfg_batch_ok", False) and autoencoder is None
+                                 and getattr(unet, "frame_comm", None) is None)))
         # (clamp and eta > 0 ride in the fused update kernel; percentile clipping needs a quantile of the whole x0 and classifier
         #  guidance a foreign callable — both take the generic two-forward path below, as does any foreign model)
         if not fused:

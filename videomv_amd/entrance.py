@@ -137,22 +137,25 @@ def worker(gpu, cfg, cfg_update):
     F = int(cfg.num_views or cfg.max_frames)
     lat_h, lat_w = int(cfg.resolution[1] / cfg.scale), int(cfg.resolution[0] / cfg.scale)
     outputs = []
-    for idx, caption in enumerate(test_list):
-        if caption.startswith('#') or caption == "":
-            logging.info(f'Skip {caption!r}')
-            continue
-        if '3d asset' not in caption:
-            caption = caption + ", 3d asset"
-        logging.info(f"[{idx}]/[{len(test_list)}] Begin to sample {caption} ...")
-        elevation, camera_dist = 15, 2.0
+    # `prompt_batch: b` (not a reference key; default 1 = the reference's one prompt at a time, :152-214): b prompts are denoised in ONE
+    # plan per step (noise [b, 4, F, h, w], y [b, 77, 1024] — the shapes the reference's sampler API admits, diffusion_ddim.py:247-260).
+    # One sample's small levels do not fill 256 CUs: 2 prompts per plan = +22 % samples/s at 256 px, +6 % at 320 x 512.
+    # Noises are drawn per prompt in list order, so every sample starts from the noise the unbatched run gives it.  The LGM-refined
+    # second loop and frame-parallel sampling keep one prompt per plan.
+    pbatch = 1 if (use_lgm or fpar) else max(1, int(cfg.get('prompt_batch', 1) or 1))
+    elevation, camera_dist = 15, 2.0
+
+    def run_group(group):
         camera_data = entrance_camera_data(F, elevation=elevation, camera_distance=camera_dist)
-        _, _, y_words = clip_encoder(text=[caption])
-        noise = torch.randn([1, 4, F, lat_h, lat_w]).to(device)
-        x0, video = sample_views(model, diffusion, autoencoder, noise, y_words.to(device), zero_y_negative.to(device),
-                                 camera_data, guide_scale=cfg.guide_scale, ddim_timesteps=int(cfg.ddim_timesteps),
-                                 decoder_bs=int(cfg.decoder_bs), scale_factor=cfg.scale_factor)
+        ys = [clip_encoder(text=[cap])[2] for _, cap in group]
+        noises = [torch.randn([1, 4, F, lat_h, lat_w]) for _ in group]
+        y_words, noise = torch.cat(ys, dim=0), torch.cat(noises, dim=0).to(device)
+        y_neg = zero_y_negative.to(device).expand(len(group), -1, -1).contiguous()      # (the reference's forward wants y of the noise's batch)
+        x0_all, video_all = sample_views(model, diffusion, autoencoder, noise, y_words.to(device), y_neg,
+                                         camera_data, guide_scale=cfg.guide_scale, ddim_timesteps=int(cfg.ddim_timesteps),
+                                         decoder_bs=int(cfg.decoder_bs), scale_factor=cfg.scale_factor)
         x0_gs = video_gs = None
-        if use_lgm:       # second, LGM-refined loop from the SAME noise (inference_text2video_entrance.py:267-279,302-311)
+        if use_lgm:       # second, LGM-refined loop from the SAME noise (inference_text2video_entrance.py:267-279,302-311); one prompt
             from .lgm import prepare_gs_data
             from .pipeline import decode_views
             gs_data = prepare_gs_data(camera_data, model.lgm_opt)
@@ -162,19 +165,36 @@ def worker(gpu, cfg, cfg_update):
                                                guide_scale=cfg.guide_scale, ddim_timesteps=int(cfg.ddim_timesteps), eta=0.0)
             video_gs = decode_views(autoencoder, x0_gs, int(cfg.decoder_bs), cfg.scale_factor)
         if fpar and cfg.rank != 0:          # every rank holds the gathered views; rank 0 writes them
+            return
+        for s, (idx, caption) in enumerate(group):
+            x0, video = x0_all[s:s + 1], video_all[s:s + 1]
+            cap_name = re.sub(r'[^\w\s]', '', caption).replace(' ', '_')
+            stem = f'rank_{cfg.world_size:02d}_{cfg.rank:02d}_{idx:04d}_{cap_name}_{int(elevation):02d}_{camera_dist:.02f}'
+            path = osp.join(cfg.log_dir, stem + '.pt')
+            torch.save({'latent': x0.cpu(), 'video': video.cpu(), 'caption': caption}, path)
+            _save_contact_sheet(video.cpu(), osp.join(cfg.log_dir, stem + '.png'), cfg.mean, cfg.std)
+            _save_frames_safe(osp.join(cfg.log_dir, stem + '.mp4'), video, cfg)          # the reference's <name>.mp4 + frame PNGs
+            if video_gs is not None:                     # the reference's second file: <name>_gs
+                torch.save({'latent': x0_gs.cpu(), 'video': video_gs.cpu(), 'caption': caption}, osp.join(cfg.log_dir, stem + '_gs.pt'))
+                _save_contact_sheet(video_gs.cpu(), osp.join(cfg.log_dir, stem + '_gs.png'), cfg.mean, cfg.std)
+                _save_frames_safe(osp.join(cfg.log_dir, stem + '_gs.mp4'), video_gs, cfg)
+            logging.info('Save views to %s' % path)
+            outputs.append(path)
+
+    pending = []
+    for idx, caption in enumerate(test_list):
+        if caption.startswith('#') or caption == "":
+            logging.info(f'Skip {caption!r}')
             continue
-        cap_name = re.sub(r'[^\w\s]', '', caption).replace(' ', '_')
-        stem = f'rank_{cfg.world_size:02d}_{cfg.rank:02d}_{idx:04d}_{cap_name}_{int(elevation):02d}_{camera_dist:.02f}'
-        path = osp.join(cfg.log_dir, stem + '.pt')
-        torch.save({'latent': x0.cpu(), 'video': video.cpu(), 'caption': caption}, path)
-        _save_contact_sheet(video.cpu(), osp.join(cfg.log_dir, stem + '.png'), cfg.mean, cfg.std)
-        _save_frames_safe(osp.join(cfg.log_dir, stem + '.mp4'), video, cfg)          # the reference's <name>.mp4 + frame PNGs
-        if video_gs is not None:                     # the reference's second file: <name>_gs
-            torch.save({'latent': x0_gs.cpu(), 'video': video_gs.cpu(), 'caption': caption}, osp.join(cfg.log_dir, stem + '_gs.pt'))
-            _save_contact_sheet(video_gs.cpu(), osp.join(cfg.log_dir, stem + '_gs.png'), cfg.mean, cfg.std)
-            _save_frames_safe(osp.join(cfg.log_dir, stem + '_gs.mp4'), video_gs, cfg)
-        logging.info('Save views to %s' % path)
-        outputs.append(path)
+        if '3d asset' not in caption:
+            caption = caption + ", 3d asset"
+        logging.info(f"[{idx}]/[{len(test_list)}] Begin to sample {caption} ...")
+        pending.append((idx, caption))
+        if len(pending) == pbatch:
+            run_group(pending)
+            pending = []
+    if pending:
+        run_group(pending)
     logging.info('Congratulations! The inference is completed!')
     if on_gpu:
         torch.cuda.synchronize()

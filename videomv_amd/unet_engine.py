@@ -204,7 +204,10 @@ class UNetEngine:
         # before the first cross-attention (init conv + TemporalTransformer, the first ResBlock, the first SpatialTransformer up
         # to and including its self-attention) sees identical inputs in both branches: it is recorded once on
         # B = 1 rows and its three live tensors are replicated (3 copies instead of ~1.1 TFLOP per step at 40x64)
-        self.share_prefix = bool(share_prefix) and B == 2 and n_t == 1 and comm is None
+        # (round 6: B = 2 b row blocks of b prompts, PAIR-major [c_0 | u_0 | c_1 | u_1 ...]: the prefix is recorded on b row blocks, one per
+        #  prompt, and replicated pairwise — unet_t2v._forward_cfg_rows_batched)
+        self.share_prefix = bool(share_prefix) and B >= 2 and B % 2 == 0 and n_t == 1 and comm is None
+        self.Bp = B // 2 if self.share_prefix else B        # row blocks while the shared prefix is recorded
         self.comm = comm
         self.R = comm.world if comm is not None else 1
         self.rk = comm.rank if comm is not None else 0
@@ -665,10 +668,10 @@ class UNetEngine:
         return y
 
     def _replicate(self, x: Act, label) -> Act:
-        """[T, C] (one branch) -> [2 T, C]: both CFG branches start from the shared prefix's tensor."""
+        """[Bp][T, C] (one row block per prompt) -> [Bp][2][T, C]: both CFG branches of every prompt start from the shared prefix's tensor."""
         y = self.act(2 * x.rows, x.C)
-        n16 = x.rows * x.C // 8
-        self.S.copy(ops.copy_params(x.ptr, y.ptr, 2, 1, 1, n16, 0, 0), label)
+        n16 = x.rows * x.C // 8 // self.Bp
+        self.S.copy(ops.copy_params(x.ptr, y.ptr, self.Bp, 2, 1, n16, n16, 0), label)
         return y
 
     # ------------------------------------------------------------------ blocks
@@ -877,7 +880,7 @@ class UNetEngine:
                        bias=self.w[f"{p}.proj_in.bias"])
             self.release(n0)
         if cut:
-            assert not temporal and self.B == 1
+            assert not temporal and self.B == self.Bp
             a1 = self._tblock(f"{p}.transformer_blocks.0", a, m["heads"], temporal, h, w, cross_ctx=True, phase="pre")
             self.release(a)
             self.B = self.B_ctx                        # ---- the branches diverge here (cross-attention on their own text)
@@ -960,7 +963,7 @@ class UNetEngine:
         x = None
         share = self.share_prefix and len(self.inp) > 1 and any(k == "st" for k, _, _ in self.inp[1])
         if share:
-            self.B = 1           # record the shared prefix on one branch's rows; _transformer(cut) switches back
+            self.B = self.Bp     # record the shared prefix on one branch's rows (per prompt); _transformer(cut) switches back
         for bi, blk in enumerate(self.inp):
             x, h, w = self._run_block(blk, [x] if x is not None else [], h, w)
             if share and bi == 0:            # block 0's output is also a decoder skip: both branches need their copy
@@ -1081,12 +1084,23 @@ class UNetEngine:
         self.run_plan()
         return self.eps_rows
 
-    def prepare_rows(self, x: torch.Tensor, t: torch.Tensor):
-        """Everything of forward_rows before the plan: latent -> rows, timestep, embeddings."""
+    def prepare_rows(self, x: torch.Tensor, t: torch.Tensor, pair_major: bool = False):
+        """Everything of forward_rows before the plan: latent -> rows, timestep, embeddings.  ``pair_major``: the B // nb copies of
+        every sample are ADJACENT row blocks ([x_0 | x_0 | x_1 | x_1]: the batched CFG pass, unet_t2v._forward_cfg_rows_batched)
+        instead of the default tiling ([x_0 | x_1 | x_0 | x_1])."""
         nb = x.shape[0]
         # only the latent's own channels are written: channels >= x.shape[1] hold zeros (T2V) or the step-invariant
         # image `concat` of the I2VGen front-end (unet_i2vgen.py:383)
-        ops.latent_to_rows_keep(x.contiguous(), self.x_rows, self.cin_pad, self.B // nb)
+        if pair_major and nb > 1:
+            x, rep = x.contiguous(), self.B // nb
+            per = rep * self.F * self.H * self.W
+            if self.share_prefix:        # the input conv belongs to the shared prefix: it reads one row block per prompt, [x_0 | x_1 ...]
+                ops.latent_to_rows_keep(x, self.x_rows[:nb * self.F * self.H * self.W], self.cin_pad, 1)
+            else:
+                for s in range(nb):
+                    ops.latent_to_rows_keep(x[s:s + 1], self.x_rows[s * per:(s + 1) * per], self.cin_pad, rep)
+        else:
+            ops.latent_to_rows_keep(x.contiguous(), self.x_rows, self.cin_pad, self.B // nb)
         self.t_dev.copy_(t.to(torch.float32).reshape(-1)[: self.n_t])
         self._embeddings()
 

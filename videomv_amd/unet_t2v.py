@@ -276,9 +276,11 @@ class UNetSD_T2VBase(nn.Module, LgmMixin):
         camera_data = cond_kwargs.get("camera_data", None)
         cam_u = uncond_kwargs.get("camera_data", None)
         b, c, f, h, w = xt.shape
-        if b != 1:
-            raise ValueError("forward_cfg_rows handles one sample (the reference's noise is [1,4,F,h,w])")
         dev = xt.device
+        if b != 1:
+            if self.frame_comm is not None:
+                raise ValueError("forward_cfg_rows over a frame-parallel group handles one sample (the reference's noise is [1,4,F,h,w])")
+            return self._forward_cfg_rows_batched(xt, t, cond_kwargs, uncond_kwargs)
         if self.frame_comm is not None:
             if hasattr(self.frame_comm, "exchange_branches"):          # comm.CfgFrameComm: one branch per rank group
                 return self._forward_cfg_rows_cfgpar(xt, t, cond_kwargs, uncond_kwargs)
@@ -303,6 +305,56 @@ class UNetSD_T2VBase(nn.Module, LgmMixin):
                 same_for_both_branches("fps", fps, uncond_kwargs.get("fps"))
             eng.set_fps(fps)
         return eng, eng.forward_rows(xt.float(), t.to(dev))
+
+    cfg_batch_ok = True       # DiffusionDDIM.ddim_sample_loop: noise [b > 1, ...] may take the fused path (_forward_cfg_rows_batched)
+
+    @torch.no_grad()
+    def _forward_cfg_rows_batched(self, xt, t, cond_kwargs, uncond_kwargs):
+        """b > 1 samples (prompts) of one denoising step in ONE plan of B = 2 b row blocks, PAIR-major [c_0 | u_0 | c_1 | u_1 | ...]
+        so that every sample's (cond, uncond) eps rows sit like the single-sample pass's and the fused CFG + DDIM update runs per
+        sample on a row offset.  No reference counterpart in the entrance (it denoises one prompt at a time,
+        inference_text2video_entrance.py:152-214) but the reference's sampler API admits it: noise [b, 4, F, h, w] with
+        model_kwargs y [b, L, D] (diffusion_ddim.py:247-260, p_mean_variance :149-160).  Why: the small levels of one sample do
+        not fill 256 CUs (a 24 x 32 x 32 step is 0.75 / 0.19 / 0.05 / 0.01 rounds of 256-row tiles at the four levels); two prompts in one plan
+        measure 41.6 ms against 2 x 25.3 at that shape and 95.1 against 2 x 50.2 at 24 x 40 x 64 (profiles/r6_batch_fill.log).
+        y [1, L, D] / camera_data [1, F, 16] are shared by all samples; with ONE camera set the CFG prefix (everything before the first
+        cross-attention) is recorded on one row block per prompt and replicated pairwise, as in the 1-prompt pass."""
+        y_c, y_u = cond_kwargs["y"], uncond_kwargs["y"]
+        cam_c, cam_u = cond_kwargs.get("camera_data", None), uncond_kwargs.get("camera_data", None)
+        b, c, f, h, w = xt.shape
+        dev = xt.device
+        # one camera set [1, F, 16] for every row block (the entrance's orbit) => the CFG prefix is shared per prompt, as in the 1-prompt pass
+        one_cam = (not self.use_camera_condition) or (cam_c is None and cam_u is None) or (
+            cam_c is not None and cam_u is not None and cam_c.numel() == f * cam_c.shape[-1] and self._cameras_agree(cam_c, cam_u))
+        eng = self.engine_for(2 * b, f, h, w, y_c.shape[1], dev, n_t=1, share_prefix=one_cam)
+        cache = eng.__dict__.setdefault("_cond", CondCache())
+        if not cache.hit(y_c, y_u, cam_c, cam_u, cond_kwargs.get("fps")):
+            def per_sample(v, what):
+                v = v.to(dev).float()
+                v = v.reshape(-1, *v.shape[-2:])
+                if v.shape[0] not in (1, b):
+                    raise ValueError(f"{what} has batch {v.shape[0]}, expected 1 or {b}")
+                return v.expand(b, *v.shape[1:])
+            ctx = torch.stack([per_sample(y_c, "cond y"), per_sample(y_u, "uncond y")], dim=1)          # [b, 2, L, D]: pair-major
+            eng.set_context(ctx.reshape(2 * b, *ctx.shape[2:]).contiguous())
+            cam = None
+            if self.use_camera_condition and (cam_c is not None or cam_u is not None):
+                if cam_c is None or cam_u is None:
+                    raise NotImplementedError("camera_data on only one CFG branch is not supported by the fused pass")
+                cc, cu = cam_c.to(dev).float(), cam_u.to(dev).float()
+                cc, cu = cc.reshape(-1, f, cc.shape[-1]), cu.reshape(-1, f, cu.shape[-1])
+                if cc.shape[0] == 1 and cu.shape[0] == 1 and torch.equal(cc, cu):
+                    cam = cc                                                                  # one camera set for every row block
+                else:
+                    cam = torch.stack([per_sample(cc, "cond camera_data"), per_sample(cu, "uncond camera_data")], dim=1).reshape(2 * b, f, -1)
+            eng.set_camera(cam)
+            fps = cond_kwargs.get("fps") if self.use_fps_condition else None
+            if self.use_fps_condition:
+                same_for_both_branches("fps", fps, uncond_kwargs.get("fps"))
+            eng.set_fps(fps)
+        eng.prepare_rows(xt.float(), t.to(dev), pair_major=True)
+        eng.run_plan()
+        return eng, eng.eps_rows
 
     def _cameras_agree(self, cam_c, cam_u) -> bool:
         """Do the two CFG branches carry the same camera_data (=> shared-prefix engine)?  The comparison is a device-to-host
