@@ -523,18 +523,21 @@ def main(argv=None):
             torch.cuda.synchronize()
             return 1000.0 * (time.perf_counter() - t0) / n, bool(torch.isfinite(x).all())
         try:
-            pbatch = dict(prompts=2, note="b = 2 prompts per plan (B = 4 row blocks, pair-major; CFG prefix shared per prompt), same kernels and tile rule; "
-                                          "sample_steps_per_s = 2 / batched step; `value` above is the 1-prompt step")
+            pbatch = dict(note="b prompts per plan (B = 2 b row blocks, pair-major; CFG prefix shared per prompt), same kernels and tile rule; "
+                               "sample_steps_per_s = b / batched step; `value` above is the 1-prompt step; the t2v entrance's key: prompt_batch")
             for (h, w) in ([(H, W)] + ([(32, 32)] if (H, W) == (40, 64) else [])):
                 ms1, _ = time_batch(h, w, 1)
-                ms2, fin2 = time_batch(h, w, 2)
-                d = dict(ms_per_step_1_prompt=round(ms1, 3), ms_per_step_2_prompts=round(ms2, 3), sample_steps_per_s=round(2000.0 / ms2, 3),
-                         throughput_vs_1_prompt=round(2.0 * ms1 / ms2, 4), finite=fin2)
-                if STEP_TFLOP.get((h, w)):
-                    d["whole_step_frac_of_peak"] = round(2.0 * STEP_TFLOP[(h, w)] / (ms2 * 1e-3) / PEAK_MFMA16_TFLOPS, 4)
+                d = dict(ms_per_step_1_prompt=round(ms1, 3))
+                for nb in ((2, 4) if h * w <= 1024 else (2,)):
+                    msb, finb = time_batch(h, w, nb)
+                    q = dict(ms_per_batched_step=round(msb, 3), sample_steps_per_s=round(1000.0 * nb / msb, 3),
+                             throughput_vs_1_prompt=round(nb * ms1 / msb, 4), finite=finb)
+                    if STEP_TFLOP.get((h, w)):
+                        q["whole_step_frac_of_peak"] = round(nb * STEP_TFLOP[(h, w)] / (msb * 1e-3) / PEAK_MFMA16_TFLOPS, 4)
+                    d[f"prompts_{nb}"] = q
+                    for k_ in [k for k in getattr(model, "_engines", {}) if k[0] > 2]:      # (free the B > 2 engines' buffers)
+                        model._engines.pop(k_, None)
                 pbatch[f"{args.frames}x{h}x{w}"] = d
-                for k_ in [k for k in getattr(model, "_engines", {}) if k[0] == 4]:      # (free the B = 4 engines' buffers)
-                    model._engines.pop(k_, None)
         except Exception as e:
             pbatch = dict(pbatch or {}, error=f"{type(e).__name__}: {e}")
 
@@ -689,6 +692,25 @@ def main(argv=None):
         sample = dict(seconds=round(t3 - t1, 4), ddim50_seconds=round(t2 - t1, 4), vae_decode24_seconds=round(t3 - t2, 4),
                       samples_per_s=round(1.0 / (t3 - t1), 5), video_shape=list(vid.shape),
                       finite=bool(torch.isfinite(vid).all() and torch.isfinite(x0_lat).all()))
+        if not args.no_prompt_batch:       # the same, two prompts per plan (the entrance's `prompt_batch: 2`): 2 samples per pass
+            try:
+                n2 = torch.randn(2, 4, args.frames, H, W, generator=g, device=dev)
+                y2 = torch.randn(2, 77, 1024, generator=g, device=dev)
+                y02 = y0.expand(2, -1, -1).contiguous()
+                sample_views(model, dif, vae, n2, y2, y02, cam, guide_scale=9.0, ddim_timesteps=2, decode=False)      # (records the B = 4 plan)
+                torch.cuda.synchronize()
+                t4 = time.perf_counter()
+                x0_2, vid2 = sample_views(model, dif, vae, n2, y2, y02, cam, guide_scale=9.0, ddim_timesteps=50, decoder_bs=4)
+                torch.cuda.synchronize()
+                t5 = time.perf_counter()
+                sample["two_prompts_per_plan"] = dict(seconds_for_2_samples=round(t5 - t4, 4), samples_per_s=round(2.0 / (t5 - t4), 5),
+                                                      vs_one_prompt=round(2.0 * (t3 - t1) / (t5 - t4), 4), video_shape=list(vid2.shape),
+                                                      finite=bool(torch.isfinite(vid2).all() and torch.isfinite(x0_2).all()))
+                del x0_2, vid2
+                for k_ in [k for k in getattr(model, "_engines", {}) if k[0] == 4]:
+                    model._engines.pop(k_, None)
+            except Exception as e:
+                sample["two_prompts_per_plan"] = dict(error=f"{type(e).__name__}: {e}")
 
     # ---- the once-per-prompt conditioning upstream of the loop: open_clip ViT-H/14 text (2 prompts: caption + negative) and image
     #      towers on the same kernels (clip_embedder.py:187-201); full-size, random-init on the device

@@ -36,8 +36,12 @@ def decode_views(autoencoder, x0, decoder_bs=4, scale_factor=0.18215):
     # (per-frame GroupNorm / attention) and the MI355X has 288 GB: it takes every frame in ONE plan when the top level
     # stays within the kernels' 32-bit row offsets (<= 4 M output pixels) — 6x fewer launches, fuller tile grids at the
     # low-resolution levels; the images are the same up to fp32 summation order inside a GEMM tile.
-    if getattr(autoencoder, "frame_independent", False) and b * f * 64 * h * w <= (1 << 22):
-        decoder_bs = max(decoder_bs, b * f)
+    # (b > 1 samples — `prompt_batch` — : the largest divisor of b * f that fits, e.g. one 24-frame plan per sample at 320 x 512)
+    if getattr(autoencoder, "frame_independent", False):
+        cap = (1 << 22) // (64 * h * w)
+        fit = [d for d in range(1, b * f + 1) if (b * f) % d == 0 and d <= cap]
+        if fit:
+            decoder_bs = max(decoder_bs, fit[-1])
     outs = []
     for i in range(0, b * f, decoder_bs):
         outs.append(autoencoder.decode(z[i:i + decoder_bs].contiguous()))
