@@ -969,6 +969,35 @@ def main(argv=None):
                         simr["serial_forward_ms"] = round(simr["serial_forward_ms"], 3)
                 except Exception as e:
                     simr["modes"][tag] = {"error": f"{type(e).__name__}: {e}"}
+            # b prompts per plan ON the simulated rank (round 6): a rank's 1 / W share of ONE sample is launch-bound (~1 100 dependent launches
+            # of ~15 us for 1 / W of the FLOPs); with b prompts in the plan the launches stay and their rows grow b-fold.  Single-plan mode.
+            if not args.no_prompt_batch:
+                simr["prompts_per_plan"] = {}
+                for nb in (2, 4, 8):
+                    try:
+                        os.environ["VMV_FP_PIPELINE"], os.environ["VMV_GRAPH"] = "0", "0"
+                        model.set_frame_parallel(SimComm(Wn, 0))
+                        xb = torch.randn(nb, 4, fl, H, W, generator=g, device=dev)
+                        kcb = dict(y=torch.randn(nb, 77, 1024, generator=g, device=dev), camera_data=cam)
+                        for i in range(2):
+                            dif.ddim_step_hip(xb, steps[i % len(steps)], model, kcb, kw_u, 9.0, stride)
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        for i in range(args.steps):
+                            dif.ddim_step_hip(xb, steps[(2 + i) % len(steps)], model, kcb, kw_u, 9.0, stride)
+                        torch.cuda.synchronize()
+                        tb = (time.perf_counter() - t1) / args.steps
+                        q_ = dict(gpu_ms_per_batched_step=round(1000 * tb, 3), gpu_ms_per_sample_step=round(1000 * tb / nb, 3),
+                                  group_sample_steps_per_s_no_wire=round(nb / tb, 2), replicas_sample_steps_per_s=round(Wn * steps_per_s, 2),
+                                  finite=bool(torch.isfinite(xb).all()))
+                        if step_tflop:
+                            q_["frac_of_peak_if_all_ranks_equal"] = round(nb * step_tflop / Wn / tb / PEAK_MFMA16_TFLOPS, 4)
+                        simr["prompts_per_plan"][str(nb)] = q_
+                    except Exception as e:
+                        simr["prompts_per_plan"][str(nb)] = {"error": f"{type(e).__name__}: {e}"}
+                    finally:
+                        for k_ in [k for k in getattr(model, "_engines", {}) if k[0] > 2]:
+                            model._engines.pop(k_, None)
             best = min((v["gpu_ms_per_step"], k) for k, v in simr["modes"].items() if "gpu_ms_per_step" in v)
             simr["best_mode"], simr["best_gpu_ms_per_step"] = best[1], best[0]
             simr["projected_speedup_vs_1gpu_no_wire"] = round(ms_per_step / best[0], 2)

@@ -200,6 +200,89 @@ def test_two_rank_frame_parallel_plan_matches_single_rank_and_oracle():
         assert pp["copies"][0] == pp["copies"][1] == pp["a2a_b2"] and pp["copies_b2"] == 2 * pp["a2a_b2"], pp
 
 
+def _pb_fp_worker(rank, world, port, q):
+    """Two prompts per plan OVER a frame-parallel group (round 6): every rank denoises its frames of BOTH samples in one plan of B = 4
+    row blocks (pair-major), so a rank's GEMMs see twice the rows of its 1 / world share."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        torch.set_num_threads(2)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from tests import plan_interp
+        plan_interp.install(_Patch)
+        from oracle.unet_ref import UNetCfg, unet_forward
+        from oracle.weights import random_state_dict, unet_param_shapes
+        from videomv_amd.comm import FrameComm
+        from videomv_amd.registry import MODEL, DIFFUSION
+        from videomv_amd.unet_t2v import gather_frames
+        import videomv_amd  # noqa: F401
+        ocfg = UNetCfg(**{k: v for k, v in CFG.items() if k in {f.name for f in dataclasses.fields(UNetCfg)}})
+        sd = random_state_dict(unet_param_shapes(ocfg), 99)
+        F_, H, W, L = 4, 8, 8, 5
+        g = torch.Generator().manual_seed(6)
+        x = torch.randn(2, 4, F_, H, W, generator=g)
+        yc, y0 = torch.randn(2, L, 1024, generator=g), torch.randn(1, L, 1024, generator=g)
+        cam = torch.randn(1, F_, 16, generator=g)
+        m = MODEL.build(dict(type="UNetSD_T2VBase", **{k: v for k, v in CFG.items()}))
+        m.load_state_dict(sd, strict=False)
+        dif = DIFFUSION.build(dict(type="DiffusionDDIM", schedule="linear_sd",
+                                   schedule_param=dict(num_timesteps=1000, init_beta=0.00085, last_beta=0.0120),
+                                   mean_type="eps", var_type="fixed_small"))
+        kc, ku = dict(y=yc, camera_data=cam), dict(y=y0, camera_data=cam)
+        t2 = torch.tensor([501, 501])
+        # unsharded: both prompts in one plan
+        _, rows_full = m.forward_cfg_rows(x, t2, kc, ku)
+        rows_full = rows_full.clone()
+        x_full = x.clone()
+        dif.ddim_step_hip(x_full, 501, m, kc, ku, 9.0, 500)
+        # sharded
+        comm = FrameComm()
+        m.set_frame_parallel(comm)
+        fl = F_ // world
+        sl = slice(rank * fl, (rank + 1) * fl)
+        eng, rows = m.forward_cfg_rows(x[:, :, sl].contiguous(), t2, kc, ku)
+        T, Tl = F_ * H * W, fl * H * W
+        out = dict(rank=rank, B=eng.B, Fl=eng.F, n_breaks=len(eng.breaks), errs=[], e_full=[])
+        for s_ in range(2):
+            for br, yy in enumerate((yc[s_:s_ + 1], y0)):
+                blk = rows[(2 * s_ + br) * Tl:(2 * s_ + br + 1) * Tl, :4].reshape(fl, H * W, 4).permute(2, 0, 1).reshape(1, 4, fl, H, W)
+                ref = unet_forward(sd, ocfg, x[s_:s_ + 1], torch.tensor([501]), yy, cam)[:, :, sl]
+                full = rows_full[(2 * s_ + br) * T:(2 * s_ + br + 1) * T, :4].reshape(F_, H * W, 4).permute(2, 0, 1).reshape(1, 4, F_, H, W)[:, :, sl]
+                out["errs"].append(rel_l2(blk, ref))
+                out["e_full"].append(rel_l2(blk, full))
+        xs = x[:, :, sl].clone().contiguous()
+        dif.ddim_step_hip(xs, 501, m, kc, ku, 9.0, 500)
+        out["e_ddim"] = rel_l2(gather_frames(comm, xs), x_full)
+        # the whole loop through the sampler API: fused path, gathered at the end
+        xl = dif.ddim_sample_loop(noise=x.clone(), model=m, model_kwargs=[kc, ku], guide_scale=9.0, ddim_timesteps=2, eta=0.0)
+        out["loop_shape"] = tuple(xl.shape)
+        m.set_frame_parallel(None)
+        q.put(out)
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put(dict(error=traceback.format_exc()))
+
+
+def test_two_prompts_per_plan_over_a_frame_parallel_group_two_ranks():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pb_fp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert "error" not in r, r["error"]
+    for r in res:
+        assert r["B"] == 4 and r["Fl"] == 2 and r["n_breaks"] > 0, r
+        assert max(r["errs"]) < 2e-2 and max(r["e_full"]) < 3e-2, r              # each (sample, branch) block: oracle / unsharded plan
+        assert r["e_ddim"] < 6e-2 and r["loop_shape"] == (2, 4, 4, 8, 8), r
+
+
 def _entrance_worker(rank, world, port, tmp, q):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),

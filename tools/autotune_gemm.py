@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--merge", action="store_true", help="keep the entries already in --out for signatures not measured now")
     ap.add_argument("--min-gain", type=float, default=0.93, help="keep a candidate only if its time <= this fraction of the policy's (launches < 120 us)")
     ap.add_argument("--min-gain-big", type=float, default=0.90, help="the same for launches >= 120 us (burst timings overstate dense kernels)")
+    ap.add_argument("--prompts", type=int, default=1, help="world 1: tune the plan of this many prompts per step (B = 2 x prompts row blocks, "
+                    "unet_t2v._forward_cfg_rows_batched — the entrance's prompt_batch)")
     ap.add_argument("--lgm", action="store_true", help="also tune the VAE decoder / encoder and LGM U-Net plans (one LGM-refined step at 24x32x32 + the 24-frame decode)")
     a = ap.parse_args()
     H, W = (int(v) for v in a.latent.split("x"))
@@ -97,8 +99,13 @@ def main():
             continue
         if w == 1:
             model.set_frame_parallel(None)
-            eng, _ = model.forward_cfg_rows(noise, t, kc, ku)
-            tune_plan(eng, table, ws, f"world1 {H}x{W}", (a.min_gain, a.min_gain_big))
+            if a.prompts > 1:
+                nz = torch.randn(a.prompts, 4, a.frames, H, W, generator=g, device=dev)
+                yb = torch.randn(a.prompts, 77, 1024, generator=g, device=dev)
+                eng, _ = model.forward_cfg_rows(nz, t.expand(a.prompts), dict(y=yb, camera_data=cam), ku)
+            else:
+                eng, _ = model.forward_cfg_rows(noise, t, kc, ku)
+            tune_plan(eng, table, ws, f"world1 {H}x{W}" + (f" prompts{a.prompts}" if a.prompts > 1 else ""), (a.min_gain, a.min_gain_big))
             save()
             continue
         if a.frames % w:

@@ -246,7 +246,7 @@ class DiffusionDDIM(object):
                  and len(model_kwargs) == 2 and percentile is None
                  and condition_fn is None and self.mean_type in ('eps', 'v') and noise.is_cuda
                  and (b == 1 or (getattr(unet, "cfg_batch_ok", False) and autoencoder is None
-                                 and getattr(unet, "frame_comm", None) is None)))
+                                 and not hasattr(getattr(unet, "frame_comm", None), "exchange_branches"))))
         # (clamp and eta > 0 ride in the fused update kernel; percentile clipping needs a quantile of the whole x0 and classifier
         #  guidance a foreign callable — both take the generic two-forward path below, as does any foreign model)
         if not fused:

@@ -245,6 +245,8 @@ class UNetSD_T2VBase(nn.Module, LgmMixin):
             y = self.zero_y.repeat(b, 1, 1)[:, :1, :]
         # the reference relies on DDP's scatter to move CPU kwargs: do it ourselves
         y = y.to(dev)
+        if y.shape[0] == 1 and b > 1:        # (one text for the whole batch, e.g. the negative prompt: the reference wants it repeated by the caller)
+            y = y.expand(b, -1, -1)
         if camera_data is not None:
             camera_data = camera_data.to(dev)
         eng = self.engine_for(b, f, h, w, y.shape[1], dev, n_t=b)
@@ -278,8 +280,8 @@ class UNetSD_T2VBase(nn.Module, LgmMixin):
         b, c, f, h, w = xt.shape
         dev = xt.device
         if b != 1:
-            if self.frame_comm is not None:
-                raise ValueError("forward_cfg_rows over a frame-parallel group handles one sample (the reference's noise is [1,4,F,h,w])")
+            if self.frame_comm is not None and hasattr(self.frame_comm, "exchange_branches"):
+                raise ValueError("forward_cfg_rows over a CFG-parallel group handles one sample (the reference's noise is [1,4,F,h,w])")
             return self._forward_cfg_rows_batched(xt, t, cond_kwargs, uncond_kwargs)
         if self.frame_comm is not None:
             if hasattr(self.frame_comm, "exchange_branches"):          # comm.CfgFrameComm: one branch per rank group
@@ -323,6 +325,8 @@ class UNetSD_T2VBase(nn.Module, LgmMixin):
         cam_c, cam_u = cond_kwargs.get("camera_data", None), uncond_kwargs.get("camera_data", None)
         b, c, f, h, w = xt.shape
         dev = xt.device
+        if self.frame_comm is not None:       # frame-parallel (plain FrameComm, single plan): xt holds this rank's frames of all b samples;
+            f = f * self.frame_comm.world     # a rank's GEMMs see b times the rows of its 1 / world share (comm engines never share a prefix)
         # one camera set [1, F, 16] for every row block (the entrance's orbit) => the CFG prefix is shared per prompt, as in the 1-prompt pass
         one_cam = (not self.use_camera_condition) or (cam_c is None and cam_u is None) or (
             cam_c is not None and cam_u is not None and cam_c.numel() == f * cam_c.shape[-1] and self._cameras_agree(cam_c, cam_u))
