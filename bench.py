@@ -662,6 +662,33 @@ def main(argv=None):
                 fpar["kv_gather_temporal"] = dict(error=f"{type(e).__name__}: {e}")
             finally:
                 os.environ.pop("VMV_FP_TEMPORAL", None)
+            # b prompts per plan over the group (round 6): the ranks' launch-bound 1 / W shares get b times the rows.  Single plan,
+            # plain FrameComm; per-sample latency = the batched step, group throughput = b / batched step.  Last, inside its own try.
+            state["partial"] = dict(fpar)
+            if not args.no_prompt_batch:
+                try:
+                    os.environ["VMV_FP_PIPELINE"] = "0"
+                    model.set_frame_parallel(comm)
+                    fpar["prompts_per_plan"] = {}
+                    for nb in (2, 4):
+                        state["stage"] = f"prompts-{nb}:warmup"
+                        xb = torch.randn(nb, 4, args.frames, H, W, generator=gs, device=dev)[:, :, rank * fl:(rank + 1) * fl].contiguous()
+                        kcb = dict(y=torch.randn(nb, 77, 1024, generator=gs, device=dev), camera_data=cams)
+                        for i in range(max(1, args.warmup)):
+                            dif.ddim_step_hip(xb, steps[i % len(steps)], model, kcb, ku, 9.0, stride)
+                        fence()
+                        state["stage"] = f"prompts-{nb}:timed"
+                        t0 = time.perf_counter()
+                        for i in range(args.steps):
+                            dif.ddim_step_hip(xb, steps[(args.warmup + i) % len(steps)], model, kcb, ku, 9.0, stride)
+                        fence()
+                        tt = torch.tensor([time.perf_counter() - t0], device=cdev)
+                        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                        tb = float(tt[0]) / args.steps
+                        fpar["prompts_per_plan"][str(nb)] = dict(ms_per_batched_step=round(1000 * tb, 3), ms_per_sample_step=round(1000 * tb / nb, 3),
+                                                                 group_sample_steps_per_s=round(nb / tb, 3), finite=bool(torch.isfinite(xb).all()))
+                except Exception as e:
+                    fpar["prompts_per_plan"] = dict(fpar.get("prompts_per_plan") or {}, error=f"{type(e).__name__}: {e}")
         except Exception as e:      # the headline (replicas) line must survive any problem in this leg
             fpar = dict(state.get("partial") or {}, error=f"{type(e).__name__}: {e}")
         finally:

@@ -279,3 +279,6 @@ def test_bench_gpus_2_end_to_end_on_one_gpu():
     assert fp["views_per_gpu"] == 2 and fp["single_plan"]["finite"] and fp["branch_pipelined"]["finite"] and fp["cfg_x_frame"]["finite"]
     # (the leg ran in one child process per rank with a process group of its own: a fault there cannot cost the replica line)
     assert fp["child_rccl_ranks"] == 2 and "child processes" in fp["isolation"]
+    # b prompts per plan over the group: every rank its frames of all b samples in one plan
+    pp = fp["prompts_per_plan"]
+    assert "error" not in pp and pp["2"]["finite"] and pp["4"]["finite"], pp
