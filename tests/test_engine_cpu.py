@@ -255,6 +255,44 @@ def test_i2vgen_plan_matches_reference_golden(monkeypatch, golden_dir):
     assert rel_l2(out, g["out"]) < 2.5e-2, rel_l2(out, g["out"])
 
 
+def test_i2vgen_two_images_per_plan_equal_the_single_image_passes(monkeypatch, golden_dir):
+    """UNetSD_I2VGen, b = 2 input images of one denoising step in ONE plan of B = 4 row blocks (pair-major; round 6): every sample's
+    (cond, uncond) eps rows equal the single-image fused pass of that sample (per-sample y / image / local_image, shared black image and
+    negative text on the uncond branch), and slot 0 is bit-identical whatever sits in slot 1."""
+    plan_interp.install(monkeypatch)
+    from videomv_amd.registry import MODEL
+    g, c, sd = _i2v_setup(golden_dir)
+    m = MODEL.build(dict(type="UNetSD_I2VGen", y_dim=1024, use_camera_condition=True, concat_dim=4, **c)).eval()
+    m.load_state_dict(sd, strict=True)
+    gen = torch.Generator().manual_seed(4)
+    x1 = g["x"][:1]
+    _, _, F_, H, W = x1.shape
+    T = F_ * H * W
+    x = torch.cat([x1, torch.randn(x1.shape, generator=gen)], dim=0)
+    y = torch.cat([g["y"][:1], torch.randn(g["y"][:1].shape, generator=gen)], dim=0)
+    img = torch.cat([g["image"][:1], torch.randn(g["image"][:1].shape, generator=gen)], dim=0)
+    li = torch.cat([g["local_image"][:1], torch.randn(g["local_image"][:1].shape, generator=gen)], dim=0)
+    y0, img0 = torch.randn(g["y"][:1].shape, generator=gen), torch.zeros_like(g["image"][:1])
+    fps, cam = g["fps"][:1], g["camera_data"][:1]
+    t1, t2 = g["t"][:1], g["t"][:1].repeat(2)
+    kw = lambda s: (dict(y=y[s:s + 1], image=img[s:s + 1], local_image=li[s:s + 1], fps=fps, camera_data=cam),
+                    dict(y=y0, image=img0, local_image=li[s:s + 1], fps=fps, camera_data=cam))
+    singles = [m.forward_cfg_rows(x[s:s + 1], t1, *kw(s))[1].clone() for s in range(2)]
+    kc, ku = dict(y=y, image=img, local_image=li, fps=fps, camera_data=cam), dict(y=y0, image=img0, local_image=li, fps=fps, camera_data=cam)
+    eng, rows = m.forward_cfg_rows(x, t2, kc, ku)
+    rows = rows.clone()
+    assert eng.B == 4 and rows.shape[0] == 4 * T
+    for s in range(2):      # (16-bit storage rounding: the single pass shares its CFG prefix, the B = 4 plan does not)
+        assert rel_l2(rows[2 * s * T:(2 * s + 2) * T, :4], singles[s][:, :4]) < 5e-3, s
+    assert rel_l2(rows[:2 * T, :4], rows[2 * T:, :4]) > 0.05
+    x_b, y_b, li_b, img_b = x.clone(), y.clone(), li.clone(), img.clone()
+    x_b[1], y_b[1] = 2.0 * torch.randn(x1.shape[1:], generator=gen), torch.randn(y.shape[1:], generator=gen)
+    li_b[1], img_b[1] = torch.randn(li.shape[1:], generator=gen), torch.randn(img.shape[1:], generator=gen)
+    m.begin_sample()
+    r_b = m.forward_cfg_rows(x_b, t2, dict(kc, y=y_b, image=img_b, local_image=li_b), dict(ku, local_image=li_b))[1]
+    assert torch.equal(r_b[:2 * T], rows[:2 * T]) and rel_l2(r_b[2 * T:], rows[2 * T:]) > 0.1
+
+
 def test_vae_encoder_plan_matches_reference_golden(monkeypatch, golden_dir):
     """VAE encoder plan (asymmetric-pad stride-2 convs, quant_conv, posterior sampling kernel) on the CPU interpreter vs
     the moments captured from the imported reference (non-square 64x72 image)."""

@@ -111,9 +111,10 @@ class I2VFrontEnd:
         ctx[:, Ly + 64:].copy_(img_tok.view(B, self.num_tokens, -1))
         ld = eng.cin_pad
         for b in range(B):
-            if b > 0 and torch.equal(local_images[b], local_images[0]):      # CFG pair: same conditioning image
-                eng.x_rows.view(B, -1, ld)[b, :, 4:8].copy_(eng.x_rows.view(B, -1, ld)[0, :, 4:8])
-                ctx[b, Ly:Ly + 64].copy_(ctx[0, Ly:Ly + 64])
+            same = next((q for q in ((0, b - 1) if b > 0 else ()) if torch.equal(local_images[b], local_images[q])), None)
+            if same is not None:                                             # CFG pair (block 0, or the previous block of a pair-major batch): same conditioning image
+                eng.x_rows.view(B, -1, ld)[b, :, 4:8].copy_(eng.x_rows.view(B, -1, ld)[same, :, 4:8])
+                ctx[b, Ly:Ly + 64].copy_(ctx[same, Ly:Ly + 64])
                 continue
             li = local_images[b:b + 1].float()
             seq = torch.empty(1, 4, F, h, w, dtype=torch.float32, device=dev)                 # :333-335
@@ -244,12 +245,12 @@ class UNetSD_I2VGen(nn.Module, LgmMixin):
         """cond / uncond branches in one pass; image conditioning is evaluated once per sample (cached on the tensors'
         identity).  kwargs as in inference_i2vgen_entrance.py:267-269: y, image, local_image, fps, camera_data."""
         b, c, f, h, w = xt.shape
-        if b != 1:
-            raise ValueError("forward_cfg_rows handles one sample")
         dev = xt.device
         kc, ku = cond_kwargs, uncond_kwargs
         if ku.get("image") is None:
             raise NotImplementedError("uncond branch without image tokens (use_zero_infer=False) has a shorter context")
+        if b != 1:
+            return self._forward_cfg_rows_batched(xt, t, kc, ku)
         L_ctx = kc["y"].shape[1] + 64 + self.num_tokens
         # (local_image / fps / camera are checked to be the same for both branches below: the CFG pair shares its prefix)
         eng, front = self._get(2, f, h, w, L_ctx, dev, n_t=1, share_prefix=True)
@@ -266,6 +267,45 @@ class UNetSD_I2VGen(nn.Module, LgmMixin):
             cam = kc.get("camera_data")
             eng.set_camera(cam.to(dev) if (cam is not None and self.use_camera_condition) else None)
         return eng, eng.forward_rows(xt.float(), t.to(dev))
+
+    cfg_batch_ok = True       # DiffusionDDIM.ddim_sample_loop: noise [b > 1, ...] may take the fused path
+
+    @torch.no_grad()
+    def _forward_cfg_rows_batched(self, xt, t, kc, ku):
+        """b > 1 input images of one denoising step in ONE plan of B = 2 b row blocks, pair-major [c_0 | u_0 | c_1 | u_1 ...] (round 6; as
+        unet_t2v._forward_cfg_rows_batched — the reference's sampler API admits the batch, inference_i2vgen_entrance.py:267-270 feeds it
+        one image at a time).  Per-sample: y, image, local_image; shared ([1, ...]) or per-sample: the uncond branch's y / image,
+        camera_data; fps is one value.  The CFG prefix is not shared here: the front-end lays every row block's image channels out in place."""
+        b, c, f, h, w = xt.shape
+        dev = xt.device
+        L_ctx = kc["y"].shape[1] + 64 + self.num_tokens
+        eng, front = self._get(2 * b, f, h, w, L_ctx, dev, n_t=1, share_prefix=False)
+        cache = eng.__dict__.setdefault("_cond", CondCache())
+        if not cache.hit(kc["y"], ku["y"], kc["image"], ku["image"], kc["local_image"], kc["fps"], kc.get("camera_data"),
+                         ku.get("local_image"), ku.get("fps"), ku.get("camera_data")):
+            same_for_both_branches("local_image", kc.get("local_image"), ku.get("local_image"))
+            same_for_both_branches("fps", kc.get("fps"), ku.get("fps"))
+            same_for_both_branches("camera_data", kc.get("camera_data"), ku.get("camera_data"))
+
+            def per_sample(v, what):
+                v = v.to(dev).float()
+                if v.shape[0] not in (1, b):
+                    raise ValueError(f"{what} has batch {v.shape[0]}, expected 1 or {b}")
+                return v.expand(b, *v.shape[1:])
+            pair = lambda a_, b_: torch.stack([a_, b_], dim=1).reshape(2 * b, *a_.shape[1:]).contiguous()       # pair-major row blocks
+            li = per_sample(self._first_frame(kc["local_image"]), "local_image")
+            front.run(eng, pair(li, li), pair(per_sample(kc["y"], "cond y"), per_sample(ku["y"], "uncond y")),
+                      pair(per_sample(kc["image"], "cond image"), per_sample(ku["image"], "uncond image")), kc["fps"][:1])
+            cam = kc.get("camera_data")
+            if cam is not None and self.use_camera_condition:
+                cam = cam.to(dev).float().reshape(-1, f, cam.shape[-1])
+                cam = cam if cam.shape[0] == 1 else pair(per_sample(cam, "camera_data"), per_sample(cam, "camera_data"))
+            else:
+                cam = None
+            eng.set_camera(cam)
+        eng.prepare_rows(xt.float(), t.to(dev), pair_major=True)
+        eng.run_plan()
+        return eng, eng.eps_rows
 
     def begin_sample(self):
         """Drop the per-sample conditioning caches (called by the sampler at the start of every ddim_sample_loop)."""
