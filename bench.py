@@ -923,6 +923,27 @@ def main(argv=None):
                 tf = STEP_TFLOP.get((hh, ww))
                 if tf:       # (the T2V trunk's algorithmic FLOPs: the 8-channel input conv and the 68 extra context tokens add < 1 %)
                     r["whole_step"] = dict(algorithmic_tflop=tf, achieved=round(tf / t_i, 1), frac=round(tf / t_i / PEAK_MFMA16_TFLOPS, 4))
+                if not args.no_prompt_batch:       # two input images per plan (round 6: B = 4 row blocks, pair-major; unet_i2vgen._forward_cfg_rows_batched)
+                    try:
+                        xb = torch.randn(2, 4, args.frames, hh, ww, generator=gi, device=dev)
+                        lib = torch.randn(2, 4, hh, ww, generator=gi, device=dev).unsqueeze(2).repeat_interleave(args.frames, dim=2)
+                        yb, imb = torch.randn(2, 77, 1024, generator=gi, device=dev), torch.randn(2, 1, 1024, generator=gi, device=dev)
+                        kcb = dict(y=yb, image=imb, local_image=lib, fps=fps, camera_data=cam)
+                        kub = dict(y=y0, image=img0, local_image=lib, fps=fps, camera_data=cam)
+                        for i in range(2):
+                            dif_v.ddim_step_hip(xb, steps_v[1 + i], m_i, kcb, kub, 6.0, stride)
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        for i in range(args.steps):
+                            dif_v.ddim_step_hip(xb, steps_v[(3 + i) % 49 + 1], m_i, kcb, kub, 6.0, stride)
+                        torch.cuda.synchronize()
+                        t_b = (time.perf_counter() - t1) / args.steps
+                        r["two_images_per_plan"] = dict(ms_per_batched_step=round(1000 * t_b, 3), sample_steps_per_s=round(2.0 / t_b, 3),
+                                                        throughput_vs_1_image=round(2.0 * t_i / t_b, 4), finite=bool(torch.isfinite(xb).all()))
+                        for k_ in [k for k in getattr(m_i, "_engines", {}) if k[0] > 2]:
+                            m_i._engines.pop(k_, None)
+                    except Exception as e:
+                        r["two_images_per_plan"] = dict(error=f"{type(e).__name__}: {e}")
                 i2v["shapes"][f"{args.frames}x{hh}x{ww}"] = r
             del m_i
             torch.cuda.empty_cache()

@@ -281,8 +281,8 @@ def test_i2vgen_two_images_per_plan_equal_the_single_image_passes(monkeypatch, g
     kc, ku = dict(y=y, image=img, local_image=li, fps=fps, camera_data=cam), dict(y=y0, image=img0, local_image=li, fps=fps, camera_data=cam)
     eng, rows = m.forward_cfg_rows(x, t2, kc, ku)
     rows = rows.clone()
-    assert eng.B == 4 and rows.shape[0] == 4 * T
-    for s in range(2):      # (16-bit storage rounding: the single pass shares its CFG prefix, the B = 4 plan does not)
+    assert eng.B == 4 and rows.shape[0] == 4 * T and eng.share_prefix and eng.Bp == 2      # one camera set: the CFG prefix is shared per sample
+    for s in range(2):      # (16-bit storage rounding between plans of different row counts)
         assert rel_l2(rows[2 * s * T:(2 * s + 2) * T, :4], singles[s][:, :4]) < 5e-3, s
     assert rel_l2(rows[:2 * T, :4], rows[2 * T:, :4]) > 0.05
     x_b, y_b, li_b, img_b = x.clone(), y.clone(), li.clone(), img.clone()

@@ -136,6 +136,49 @@ def test_i2vgen_entrance_plumbing(monkeypatch, tmp_path):
     assert torch.isfinite(blob["video"]).all()
 
 
+def test_i2vgen_entrance_prompt_batch_equals_one_image_at_a_time(monkeypatch, tmp_path):
+    """`prompt_batch: 2` on the image-to-multi-view entrance: two input images per plan — the same files, every sample equal to the
+    one-image-at-a-time run's (posterior draw of the VAE encode and noise drawn per image in list order)."""
+    import numpy as np
+    from PIL import Image
+    plan_interp.install(monkeypatch)
+    from videomv_amd.config import Config
+    from videomv_amd.registry import INFER_ENGINE
+    import videomv_amd.entrance  # noqa: F401
+    paths = []
+    for i, col in enumerate(((200, 60, 30, 255), (20, 160, 220, 255), (90, 200, 40, 255))):
+        rgba = np.zeros((80, 96, 4), dtype=np.uint8)
+        rgba[10 + 8 * i:60, 20 + 6 * i:70] = col
+        pth = tmp_path / f"obj{i}.png"
+        Image.fromarray(rgba, "RGBA").save(pth)
+        paths.append(str(pth))
+    lst = tmp_path / "images.txt"
+    lst.write_text("\n".join(paths) + "\n")
+    monkeypatch.setattr(torch, "randn_like", lambda x, **kw: torch.zeros_like(x))      # (see the t2v test above: per-step draws off the global RNG)
+    blobs = {}
+    for pb in (1, 2):
+        argv = ["--cfg", "configs/i2vgen_xl_infer.yaml", "--debug", "device", "cpu", "allow_random_init", "True", "prompt_batch", str(pb),
+                "num_views", "2", "ddim_timesteps", "2", "test_list_path", str(lst), "log_dir", str(tmp_path / f"out{pb}"),
+                "UNet.num_heads", "2", "UNet.num_res_blocks", "1", "UNet.dim_mult", "[1, 2]", "UNet.use_lgm_refine", "False",
+                "test_model", "none.pth"]
+        cu = Config(load=True, argv=argv)
+        cu.cfg_dict["UNet"]["dim"] = 64
+        cu.cfg_dict["UNet"]["attn_scales"] = [1.0, 0.5]
+        cu.cfg_dict["resolution"] = [64, 64]
+        cu.cfg_dict["auto_encoder"] = {"type": "AutoencoderKL", "embed_dim": 4, "pretrained": "none.pth",
+                                       "ddconfig": {"double_z": True, "z_channels": 4, "resolution": 64, "in_channels": 3,
+                                                    "out_ch": 3, "ch": 32, "ch_mult": [1, 2, 4, 4], "num_res_blocks": 2,
+                                                    "attn_resolutions": [], "dropout": 0.0}}
+        cfg = INFER_ENGINE.build(dict(type=cu.TASK_TYPE), cfg_update=cu.cfg_dict)
+        files = sorted(f for f in os.listdir(cfg.log_dir) if f.endswith(".pt"))
+        assert len(files) == 3 and len(cfg.outputs) == 3
+        blobs[pb] = [torch.load(os.path.join(cfg.log_dir, f)) for f in files]
+    for one, two in zip(blobs[1], blobs[2]):
+        assert one["image"] == two["image"] and one["latent"].shape == two["latent"].shape == (1, 4, 2, 8, 8)
+        e = float((one["latent"] - two["latent"]).norm() / one["latent"].norm())
+        assert e < 2e-2 and torch.isfinite(two["video"]).all(), e
+
+
 def test_entrance_lgm_refined_loop(monkeypatch, tmp_path):
     """BASELINE configs[4] plumbing (use_lgm_refine=True, the YAML default): the second, LGM-refined DDIM loop — at step
     index 20 each CFG branch's eps goes x0 -> 4 decoded views -> LGM Gaussians -> 4 renders (oracle rasteriser on CPU) ->

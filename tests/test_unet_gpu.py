@@ -397,6 +397,53 @@ def test_i2vgen_matches_reference_golden_and_vpred_loop(golden_dir):
     assert e2 < TOL_X0, e2
 
 
+def test_i2vgen_two_images_batched_in_one_fused_loop_match_oracle(golden_dir, monkeypatch):
+    """UNetSD_I2VGen with noise [2, 4, F, h, w] (round 6): the v-prediction loop takes the FUSED path with ONE plan of B = 4 row blocks;
+    every sample against the oracle loop of ITS (text, image, local image) at the stated x0 tolerance and against the single-image
+    fused loop."""
+    from videomv_amd.registry import MODEL, DIFFUSION
+    from oracle.unet_i2v_ref import i2v_param_shapes, unet_i2v_forward
+    path = os.path.join(golden_dir, "unet_i2v_tiny.safetensors")
+    with safe_open(path, "pt") as f:
+        meta = f.metadata()
+    c = json.loads(meta["cfg"])
+    cfg = UNetCfg(**c)
+    shapes = dict(unet_param_shapes(UNetCfg(**dict(c, in_dim=8))))
+    shapes.update(i2v_param_shapes(cfg))
+    sd = random_state_dict({k: shapes[k] for k in sorted(shapes)}, int(meta["seed"]))
+    m = MODEL.build(dict(type="UNetSD_I2VGen", y_dim=1024, use_camera_condition=True, concat_dim=4, **c))
+    m.load_state_dict(sd, strict=True)
+    m = m.eval().cuda()
+    dif = DIFFUSION.build(dict(type="DiffusionDDIM", schedule="cosine",
+                               schedule_param=dict(num_timesteps=1000, cosine_s=0.008, zero_terminal_snr=True),
+                               mean_type="v", var_type="fixed_small"))
+    gen = torch.Generator().manual_seed(7)
+    noise = torch.randn(2, 4, 3, 8, 8, generator=gen)
+    y, y0 = torch.randn(2, 5, 1024, generator=gen), torch.randn(1, 5, 1024, generator=gen)
+    img, img0 = torch.randn(2, 1, 1024, generator=gen), torch.zeros(1, 1, 1024)
+    li = torch.randn(2, 4, 8, 8, generator=gen)
+    cam = torch.randn(1, 3, 16, generator=gen)
+    fps = torch.tensor([8])
+    li5 = li.unsqueeze(2).repeat_interleave(3, dim=2)
+    calls = []
+    orig = type(m).forward_cfg_rows
+    monkeypatch.setattr(type(m), "forward_cfg_rows", lambda self, xt, *a: (calls.append(xt.shape[0]), orig(self, xt, *a))[1])
+    kw = [dict(y=y.cuda(), image=img.cuda(), local_image=li5.cuda(), fps=fps.cuda(), camera_data=cam),
+          dict(y=y0.cuda(), image=img0.cuda(), local_image=li5.cuda(), fps=fps.cuda(), camera_data=cam)]
+    x_hip = dif.ddim_sample_loop(noise=noise.cuda(), model=m, model_kwargs=kw, guide_scale=6.0, ddim_timesteps=4, eta=0.0)
+    assert calls == [2] * len(dif.ddim_steps(4)) and torch.isfinite(x_hip).all()
+    tb = DDIMTables(betas_for("cosine", zero_terminal_snr=True))
+    for s in range(2):
+        model = lambda xt, t, y, image, s=s: unet_i2v_forward(sd, cfg, xt, t, y, image, li[s:s + 1], fps, cam)
+        x_ref = ddim_sample_loop(noise[s:s + 1].clone(), model, tb, [dict(y=y[s:s + 1], image=img[s:s + 1]), dict(y=y0, image=img0)], 6.0,
+                                 ddim_timesteps=4, mean_type="v")
+        kw1 = [dict(y=y[s:s + 1].cuda(), image=img[s:s + 1].cuda(), local_image=li5[s:s + 1].cuda(), fps=fps.cuda(), camera_data=cam),
+               dict(y=y0.cuda(), image=img0.cuda(), local_image=li5[s:s + 1].cuda(), fps=fps.cuda(), camera_data=cam)]
+        x_one = dif.ddim_sample_loop(noise=noise[s:s + 1].cuda(), model=m, model_kwargs=kw1, guide_scale=6.0, ddim_timesteps=4, eta=0.0)
+        e, e_one = rel_l2(x_hip[s:s + 1], x_ref), rel_l2(x_hip[s:s + 1], x_one.cpu())
+        assert e < TOL_X0 and e_one < TOL_X0, (s, e, e_one)
+
+
 def test_full_size_architecture_parity_small_latent():
     """The REAL architecture (dim 320, 1.413 B parameters, 28 blocks, heads 5/10/20) on a small latent (24 x 8 x 8) vs the
     fp32 oracle on the host: measures how the bf16 storage error accumulates over the full depth.

@@ -275,11 +275,16 @@ class UNetSD_I2VGen(nn.Module, LgmMixin):
         """b > 1 input images of one denoising step in ONE plan of B = 2 b row blocks, pair-major [c_0 | u_0 | c_1 | u_1 ...] (round 6; as
         unet_t2v._forward_cfg_rows_batched — the reference's sampler API admits the batch, inference_i2vgen_entrance.py:267-270 feeds it
         one image at a time).  Per-sample: y, image, local_image; shared ([1, ...]) or per-sample: the uncond branch's y / image,
-        camera_data; fps is one value.  The CFG prefix is not shared here: the front-end lays every row block's image channels out in place."""
+        camera_data; fps is one value.  With one camera set the CFG prefix is shared per sample (the front-end's image channels of sample s are
+        moved to row block s, which the prefix reads)."""
         b, c, f, h, w = xt.shape
         dev = xt.device
         L_ctx = kc["y"].shape[1] + 64 + self.num_tokens
-        eng, front = self._get(2 * b, f, h, w, L_ctx, dev, n_t=1, share_prefix=False)
+        cam_in = kc.get("camera_data")
+        one_cam = (not self.use_camera_condition) or cam_in is None or cam_in.numel() == f * cam_in.shape[-1]
+        # (local_image / fps / camera are checked to be the same for both branches below; with ONE camera set the CFG prefix is recorded
+        #  on one row block per sample and replicated pairwise, as in the single-image pass)
+        eng, front = self._get(2 * b, f, h, w, L_ctx, dev, n_t=1, share_prefix=one_cam)
         cache = eng.__dict__.setdefault("_cond", CondCache())
         if not cache.hit(kc["y"], ku["y"], kc["image"], ku["image"], kc["local_image"], kc["fps"], kc.get("camera_data"),
                          ku.get("local_image"), ku.get("fps"), ku.get("camera_data")):
@@ -296,6 +301,12 @@ class UNetSD_I2VGen(nn.Module, LgmMixin):
             li = per_sample(self._first_frame(kc["local_image"]), "local_image")
             front.run(eng, pair(li, li), pair(per_sample(kc["y"], "cond y"), per_sample(ku["y"], "uncond y")),
                       pair(per_sample(kc["image"], "cond image"), per_sample(ku["image"], "uncond image")), kc["fps"][:1])
+            if eng.share_prefix:
+                # the shared prefix reads ONE row block per sample, [s_0 | s_1 ...]: move sample s's image channels from its pair's first
+                # block (2 s) to block s (ascending: a source 2 s is never an earlier destination)
+                xr = eng.x_rows.view(2 * b, -1, eng.cin_pad)
+                for s_ in range(1, b):
+                    xr[s_, :, 4:8].copy_(xr[2 * s_, :, 4:8])
             cam = kc.get("camera_data")
             if cam is not None and self.use_camera_condition:
                 cam = cam.to(dev).float().reshape(-1, f, cam.shape[-1])
