@@ -331,6 +331,31 @@ def test_inference_py_entry_on_gpu(tmp_path):
     assert any(f.endswith(".png") for f in os.listdir(outdir))
 
 
+def test_inference_py_prompt_batch_on_gpu(tmp_path):
+    """`prompt_batch 2` through inference.py on the GPU: three prompts -> a group of two (ONE plan of B = 4 row blocks per step) and a group
+    of one; the same three files as the one-prompt-at-a-time run, every sample within the x0 tolerance of it (noises are drawn per prompt
+    in list order and the fused path draws nothing else at eta = 0)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prompts = tmp_path / "p.txt"
+    prompts.write_text("a wooden chair\na red teapot\n# skipped\na small robot\n")
+    blobs = {}
+    for pb in (1, 2):
+        cmd = [sys.executable, "inference.py", "--cfg", "configs/t2v_infer.yaml", "--debug", "allow_random_init", "True", "prompt_batch", str(pb),
+               "num_views", "4", "ddim_timesteps", "2", "test_list_path", str(prompts), "log_dir", str(tmp_path / f"out{pb}"),
+               "UNet.num_res_blocks", "1", "UNet.dim_mult", "[1, 2]", "UNet.use_lgm_refine", "False", "test_model", "none.pth"]
+        r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outdir = tmp_path / f"out{pb}" / "p"
+        pts = sorted(f for f in os.listdir(outdir) if f.endswith(".pt"))
+        assert [f.split("_")[3] for f in pts] == ["0000", "0001", "0003"], pts
+        blobs[pb] = [torch.load(os.path.join(outdir, f)) for f in pts]
+    for one, two in zip(blobs[1], blobs[2]):
+        assert one["caption"] == two["caption"] and two["latent"].shape == (1, 4, 4, 32, 32) and two["video"].shape == (1, 3, 4, 256, 256)
+        assert torch.isfinite(two["video"]).all() and rel_l2(two["latent"], one["latent"]) < TOL_X0, rel_l2(two["latent"], one["latent"])
+
+
 def test_inference_py_i2vgen_entry_on_gpu(tmp_path):
     """`python inference.py --cfg configs/i2vgen_xl_infer.yaml ...` (BASELINE configs[3]) on the GPU: image -> HIP VAE
     encode -> UNetSD_I2VGen v-prediction DDIM -> HIP VAE decode (random weights, 4 views, 4 steps, full 256x256 image)."""
