@@ -646,6 +646,101 @@ def test_lgm_fused_step_equals_reference_structured_step(monkeypatch, batched):
     print("LGM fused step vs reference-structured, batched =", batched, rel_l2(xa, xb.cpu()))
 
 
+def test_lgm_refined_loop_with_two_prompts_per_plan(monkeypatch):
+    """The LGM-refined second loop with noise [2, ...] (round 6): plain steps run as ONE plan of B = 4 row blocks, the refined steps
+    (indices 20 / 30 / 40 of 50; here a 21-step schedule reaches index 20) sample by sample on the 1-prompt plan with that sample's
+    kwargs.  Every sample must equal the single-prompt LGM loop of its prompt given the same posterior noise — the host RNG is
+    re-seeded so that sample s's refined step draws what its single run draws."""
+    from videomv_amd.registry import MODEL, DIFFUSION, AUTO_ENCODER
+    from videomv_amd.lgm import prepare_gs_data
+    from videomv_amd.camera import entrance_camera_data
+    cfg = dict(in_dim=4, dim=64, y_dim=1024, context_dim=1024, out_dim=4, dim_mult=[1], num_heads=2, head_dim=64,
+               num_res_blocks=1, attn_scales=[1.0], use_camera_condition=True, use_lgm_refine=True,
+               lgm_opt=dict(down_channels=(32, 64), down_attention=(False, True), mid_attention=True, up_channels=(64, 32),
+                            up_attention=(True, False), num_heads=2, input_size=64, splat_size=64, output_size=128))
+    torch.manual_seed(0)
+    m = MODEL.build(dict(type="UNetSD_T2VBase", **cfg)).cuda().eval()
+    for n_, p_ in m.named_parameters():
+        if p_.abs().max() == 0:
+            p_.data.normal_(0, 0.02)
+    m._invalidate()
+    dd = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 4, 4],
+              num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    vae = AUTO_ENCODER.build(dict(type="AutoencoderKL", ddconfig=dd, embed_dim=4)).cuda()
+    dif = DIFFUSION.build(dict(type="DiffusionDDIM", schedule="linear_sd",
+                               schedule_param=dict(num_timesteps=1000, init_beta=0.00085, last_beta=0.012,
+                                                   zero_terminal_snr=False), mean_type="eps", var_type="fixed_small"))
+    gen = torch.Generator().manual_seed(13)
+    F_ = 4
+    noise = torch.randn(2, 4, F_, 8, 8, generator=gen).cuda()
+    y, y0 = torch.randn(2, 7, 1024, generator=gen).cuda(), torch.randn(1, 7, 1024, generator=gen).cuda()
+    cam = entrance_camera_data(F_, elevation=15, camera_distance=2.0)
+    gs_data = prepare_gs_data(cam, m.lgm_opt)
+    lgm_calls, plain_calls = [], []
+    o_lgm, o_hip = type(dif).ddim_step_lgm, type(dif).ddim_step_hip
+
+    def spy_lgm(self, xt, *a, **k):
+        lgm_calls.append(xt.shape[0])
+        torch.manual_seed(100 + (len(lgm_calls) - 1) % 2 if mode["b"] == 2 else 100 + mode["s"])      # the posterior noise of THIS sample's refined step
+        return o_lgm(self, xt, *a, **k)
+    monkeypatch.setattr(type(dif), "ddim_step_lgm", spy_lgm)
+    monkeypatch.setattr(type(dif), "ddim_step_hip", lambda self, xt, *a, **k: (plain_calls.append(xt.shape[0]), o_hip(self, xt, *a, **k))[1])
+    mode = dict(b=2, s=0)
+    kw = [dict(y=y, camera_data=cam, gs_data=gs_data), dict(y=y0, camera_data=cam, gs_data=gs_data)]
+    x2 = dif.ddim_sample_loop(noise=noise, model=m, autoencoder=vae, model_kwargs=kw, guide_scale=9.0, ddim_timesteps=21, eta=0.0)
+    n_plain = len(dif.ddim_steps(21)) - 1                                                        # (the reference's stride rule: 22 steps, index 20 refined)
+    assert lgm_calls == [1, 1] and plain_calls == [2] * n_plain and torch.isfinite(x2).all()     # batched plain steps, ONE refined step per sample
+    for s in range(2):
+        lgm_calls.clear(); plain_calls.clear()
+        mode.update(b=1, s=s)
+        kw1 = [dict(y=y[s:s + 1], camera_data=cam, gs_data=gs_data), dict(y=y0, camera_data=cam, gs_data=gs_data)]
+        x1 = dif.ddim_sample_loop(noise=noise[s:s + 1], model=m, autoencoder=vae, model_kwargs=kw1, guide_scale=9.0, ddim_timesteps=21, eta=0.0)
+        assert lgm_calls == [1] and plain_calls == [1] * n_plain
+        e = rel_l2(x2[s:s + 1], x1.cpu())
+        assert e < 3 * TOL_X0, (s, e)            # 21 CFG-9 steps on two plans of different row counts (the 4-step loops are held to TOL_X0)
+
+
+def test_entrance_lgm_refined_loop_with_prompt_batch_on_gpu(tmp_path):
+    """The t2v entrance with the YAML default use_lgm_refine=True AND prompt_batch 2 on the GPU (tiny LGM through the `lgm_opt` hook, 21
+    steps so that the refined index 20 exists): both loops are batched, every prompt gets its plain and its `_gs` file, finite, and the
+    refined loop changed the trajectory."""
+    from videomv_amd.config import Config
+    from videomv_amd.registry import INFER_ENGINE
+    import videomv_amd.entrance  # noqa: F401
+    prompts = tmp_path / "prompts.txt"
+    prompts.write_text("a wooden chair\na red teapot\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        argv = ["--cfg", "configs/t2v_infer.yaml", "--debug", "allow_random_init", "True", "num_views", "4", "prompt_batch", "2",
+                "ddim_timesteps", "21", "test_list_path", str(prompts), "log_dir", str(tmp_path / "out"),
+                "UNet.num_heads", "2", "UNet.num_res_blocks", "1", "UNet.dim_mult", "[1]", "test_model", "none.pth"]
+        cu = Config(load=True, argv=argv)
+        assert cu.cfg_dict["UNet"]["use_lgm_refine"] is True
+        cu.cfg_dict["UNet"]["dim"] = 64
+        cu.cfg_dict["UNet"]["attn_scales"] = [1.0]
+        cu.cfg_dict["resolution"] = [64, 64]
+        cu.cfg_dict["lgm_opt"] = dict(down_channels=(32, 64), down_attention=(False, True), mid_attention=True,
+                                      up_channels=(64, 32), up_attention=(True, False), num_heads=2, input_size=64,
+                                      splat_size=64, output_size=128)
+        cu.cfg_dict["auto_encoder"] = {"type": "AutoencoderKL", "embed_dim": 4, "pretrained": "none.pth",
+                                       "ddconfig": {"double_z": True, "z_channels": 4, "resolution": 64, "in_channels": 3,
+                                                    "out_ch": 3, "ch": 32, "ch_mult": [1, 2, 4, 4], "num_res_blocks": 2,
+                                                    "attn_resolutions": [], "dropout": 0.0}}
+        cfg = INFER_ENGINE.build(dict(type=cu.TASK_TYPE), cfg_update=cu.cfg_dict)
+    finally:
+        os.chdir(cwd)
+    outs = sorted(f for f in os.listdir(cfg.log_dir) if f.endswith(".pt"))
+    assert len(outs) == 4 and outs[1].endswith("_gs.pt") and outs[3].endswith("_gs.pt"), outs
+    for i in (0, 2):
+        plain, gs = (torch.load(os.path.join(cfg.log_dir, f)) for f in outs[i:i + 2])
+        assert gs["caption"] == plain["caption"] and gs["latent"].shape == plain["latent"].shape == (1, 4, 4, 8, 8)
+        assert torch.isfinite(gs["video"]).all() and torch.isfinite(plain["video"]).all()
+        assert not torch.allclose(gs["latent"], plain["latent"])
+    assert not torch.allclose(torch.load(os.path.join(cfg.log_dir, outs[0]))["latent"], torch.load(os.path.join(cfg.log_dir, outs[2]))["latent"])
+
+
 def test_full_size_config1_properties():
     """BASELINE configs[1] at its REAL size through the sampler API: full architecture (1.413 B parameters), latent
     24 x 40 x 64 (320 x 512 px), cond + uncond batched, CFG 9, 2 DDIM steps.  The fp32 oracle cannot run this shape in a

@@ -66,6 +66,16 @@ def comm_of(unet):
     return getattr(unet, "frame_comm", None)
 
 
+def _kw_of_sample(kw: dict, s: int, b: int) -> dict:
+    """model_kwargs of sample s of a batch of b: tensors whose leading dimension is the batch are sliced (y [b, L, D], per-sample
+    camera_data [b, F, 16]), everything else (shared [1, ...] tensors, gs_data dicts, fps) is passed on as it is."""
+    out = {}
+    for k, v in kw.items():
+        per_sample = k in ("y", "image", "local_image", "camera_data") and torch.is_tensor(v) and v.ndim >= 3 and v.shape[0] == b and b > 1
+        out[k] = v[s:s + 1] if per_sample else v
+    return out
+
+
 @DIFFUSION.register_class()
 class DiffusionDDIM(object):
     def __init__(self, schedule='linear_sd', schedule_param={}, mean_type='eps', var_type='learned_range',
@@ -245,8 +255,9 @@ class DiffusionDDIM(object):
         fused = (hasattr(unet, "forward_cfg_rows") and guide_scale is not None and isinstance(model_kwargs, list)
                  and len(model_kwargs) == 2 and percentile is None
                  and condition_fn is None and self.mean_type in ('eps', 'v') and noise.is_cuda
-                 and (b == 1 or (getattr(unet, "cfg_batch_ok", False) and autoencoder is None
-                                 and not hasattr(getattr(unet, "frame_comm", None), "exchange_branches"))))
+                 and (b == 1 or (getattr(unet, "cfg_batch_ok", False)
+                                 and not hasattr(getattr(unet, "frame_comm", None), "exchange_branches")
+                                 and (autoencoder is None or getattr(unet, "frame_comm", None) is None))))
         # (clamp and eta > 0 ride in the fused update kernel; percentile clipping needs a quantile of the whole x0 and classifier
         #  guidance a foreign callable — both take the generic two-forward path below, as does any foreign model)
         if not fused:
@@ -273,7 +284,14 @@ class DiffusionDDIM(object):
             unet.begin_sample()                                # new sample: step-invariant conditioning is re-evaluated
         for idx, step in enumerate(steps):
             if autoencoder is not None and idx in (20, 30, 40):      # LGM-refined steps (diffusion_ddim.py:254-256)
-                self.ddim_step_lgm(xt, int(step), unet, kc, ku, guide_scale, stride, autoencoder, clamp=clamp, eta=eta)
+                if b == 1:
+                    self.ddim_step_lgm(xt, int(step), unet, kc, ku, guide_scale, stride, autoencoder, clamp=clamp, eta=eta)
+                else:
+                    # b prompts per plan: the 47 plain steps run batched, the 3 refined ones sample by sample on the 1-prompt plan (the
+                    # LGM branch decodes / renders / re-encodes per sample anyway: 2 x 24 views of 65 536 Gaussians each)
+                    for s_ in range(b):
+                        self.ddim_step_lgm(xt[s_:s_ + 1], int(step), unet, _kw_of_sample(kc, s_, b), _kw_of_sample(ku, s_, b), guide_scale,
+                                           stride, autoencoder, clamp=clamp, eta=eta)
             else:
                 self.ddim_step_hip(xt, int(step), unet, kc, ku, guide_scale, stride, clamp=clamp, eta=eta)
             if idx == 0:

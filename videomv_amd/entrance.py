@@ -140,9 +140,11 @@ def worker(gpu, cfg, cfg_update):
     # `prompt_batch: b` (not a reference key; default 1 = the reference's one prompt at a time, :152-214): b prompts are denoised in ONE
     # plan per step (noise [b, 4, F, h, w], y [b, 77, 1024] — the shapes the reference's sampler API admits, diffusion_ddim.py:247-260).
     # One sample's small levels do not fill 256 CUs: 2 prompts per plan = +22 % samples/s at 256 px, +6 % at 320 x 512.
-    # Noises are drawn per prompt in list order, so every sample starts from the noise the unbatched run gives it.  The LGM-refined
-    # second loop and frame-parallel sampling keep one prompt per plan.
-    pbatch = 1 if (use_lgm or fpar) else max(1, int(cfg.get('prompt_batch', 1) or 1))
+    # Noises are drawn per prompt in list order, so every sample starts from the noise the unbatched run gives it (without the LGM-refined
+    # loop; with it the refined steps' posterior draws sit between two prompts' noises in the unbatched run, so the noises — not their
+    # distribution — differ).  The LGM-refined second loop is batched too: its 47 plain steps in one plan, the 3 refined ones sample by
+    # sample (diffusion_ddim.ddim_sample_loop).  Frame-parallel sampling keeps one prompt per plan here.
+    pbatch = 1 if (fpar or (use_lgm and not on_gpu)) else max(1, int(cfg.get('prompt_batch', 1) or 1))      # (the fused LGM steps are GPU-only)
     elevation, camera_dist = 15, 2.0
 
     def run_group(group):
@@ -154,20 +156,21 @@ def worker(gpu, cfg, cfg_update):
         x0_all, video_all = sample_views(model, diffusion, autoencoder, noise, y_words.to(device), y_neg,
                                          camera_data, guide_scale=cfg.guide_scale, ddim_timesteps=int(cfg.ddim_timesteps),
                                          decoder_bs=int(cfg.decoder_bs), scale_factor=cfg.scale_factor)
-        x0_gs = video_gs = None
-        if use_lgm:       # second, LGM-refined loop from the SAME noise (inference_text2video_entrance.py:267-279,302-311); one prompt
+        x0_gs_all = video_gs_all = None
+        if use_lgm:       # second, LGM-refined loop from the SAME noise (inference_text2video_entrance.py:267-279,302-311)
             from .lgm import prepare_gs_data
             from .pipeline import decode_views
             gs_data = prepare_gs_data(camera_data, model.lgm_opt)
             kw = [dict(y=y_words.to(device), camera_data=camera_data, gs_data=gs_data),
-                  dict(y=zero_y_negative.to(device), camera_data=camera_data, gs_data=gs_data)]
-            x0_gs = diffusion.ddim_sample_loop(noise=noise, model=model, autoencoder=autoencoder, model_kwargs=kw,
-                                               guide_scale=cfg.guide_scale, ddim_timesteps=int(cfg.ddim_timesteps), eta=0.0)
-            video_gs = decode_views(autoencoder, x0_gs, int(cfg.decoder_bs), cfg.scale_factor)
+                  dict(y=y_neg, camera_data=camera_data, gs_data=gs_data)]
+            x0_gs_all = diffusion.ddim_sample_loop(noise=noise, model=model, autoencoder=autoencoder, model_kwargs=kw,
+                                                   guide_scale=cfg.guide_scale, ddim_timesteps=int(cfg.ddim_timesteps), eta=0.0)
+            video_gs_all = decode_views(autoencoder, x0_gs_all, int(cfg.decoder_bs), cfg.scale_factor)
         if fpar and cfg.rank != 0:          # every rank holds the gathered views; rank 0 writes them
             return
         for s, (idx, caption) in enumerate(group):
             x0, video = x0_all[s:s + 1], video_all[s:s + 1]
+            x0_gs, video_gs = (None, None) if video_gs_all is None else (x0_gs_all[s:s + 1], video_gs_all[s:s + 1])
             cap_name = re.sub(r'[^\w\s]', '', caption).replace(' ', '_')
             stem = f'rank_{cfg.world_size:02d}_{cfg.rank:02d}_{idx:04d}_{cap_name}_{int(elevation):02d}_{camera_dist:.02f}'
             path = osp.join(cfg.log_dir, stem + '.pt')
@@ -288,8 +291,9 @@ def worker_i2v(gpu, cfg, cfg_update):
     outputs = []
     # `prompt_batch: b` (not a reference key; default 1 = the reference's one image at a time, inference_i2vgen_entrance.py:215-300): b input
     # images are denoised in ONE plan per step (unet_i2vgen._forward_cfg_rows_batched): +23 % samples/s at 256 px, +7 % at 320 x 512 with
-    # b = 2.  Noises are drawn per image in list order; the LGM-refined second loop keeps one image per plan.
-    pbatch = 1 if use_lgm else max(1, int(cfg.get('prompt_batch', 1) or 1))
+    # b = 2.  Noises are drawn per image in list order; the LGM-refined second loop is batched too (47 plain steps in one plan, the 3
+    # refined ones sample by sample: diffusion_ddim.ddim_sample_loop).
+    pbatch = 1 if (use_lgm and not on_gpu) else max(1, int(cfg.get('prompt_batch', 1) or 1))
 
     def run_group(group):
         ys, vis, locs, noises = [], [], [], []
@@ -314,16 +318,17 @@ def worker_i2v(gpu, cfg, cfg_update):
                                             ddim_timesteps=int(cfg.ddim_timesteps), eta=0.0)
         from .pipeline import decode_views
         video_all = decode_views(autoencoder, x0_all, int(cfg.decoder_bs), cfg.scale_factor)
-        x0_gs = video_gs = None
-        if use_lgm:       # second, LGM-refined loop from the same noise (inference_i2vgen_entrance.py:281-292); one image per plan
+        x0_gs_all = video_gs_all = None
+        if use_lgm:       # second, LGM-refined loop from the same noise (inference_i2vgen_entrance.py:281-292)
             from .lgm import prepare_gs_data
             gs_data = prepare_gs_data(camera_data, model.lgm_opt)
             kw_gs = [dict(k, gs_data=gs_data) for k in kw]
-            x0_gs = diffusion.ddim_sample_loop(noise=noise, model=model, autoencoder=autoencoder, model_kwargs=kw_gs,
-                                               guide_scale=cfg.guide_scale, ddim_timesteps=int(cfg.ddim_timesteps), eta=0.0)
-            video_gs = decode_views(autoencoder, x0_gs, int(cfg.decoder_bs), cfg.scale_factor)
+            x0_gs_all = diffusion.ddim_sample_loop(noise=noise, model=model, autoencoder=autoencoder, model_kwargs=kw_gs,
+                                                   guide_scale=cfg.guide_scale, ddim_timesteps=int(cfg.ddim_timesteps), eta=0.0)
+            video_gs_all = decode_views(autoencoder, x0_gs_all, int(cfg.decoder_bs), cfg.scale_factor)
         for s_, (idx, line, _) in enumerate(group):
             x0, video = x0_all[s_:s_ + 1], video_all[s_:s_ + 1]
+            x0_gs, video_gs = (None, None) if video_gs_all is None else (x0_gs_all[s_:s_ + 1], video_gs_all[s_:s_ + 1])
             stem = f'rank_{cfg.world_size:02d}_{cfg.rank:02d}_{idx:04d}_{osp.basename(line).split(".")[0]}_{int(elevation):02d}_{camera_dist:.02f}'
             path = osp.join(cfg.log_dir, stem + '.pt')
             torch.save({'latent': x0.cpu(), 'video': video.cpu(), 'image': line}, path)
