@@ -535,6 +535,14 @@ def main(argv=None):
                     if STEP_TFLOP.get((h, w)):
                         q["whole_step_frac_of_peak"] = round(nb * STEP_TFLOP[(h, w)] / (msb * 1e-3) / PEAK_MFMA16_TFLOPS, 4)
                     d[f"prompts_{nb}"] = q
+                    if (h, w) == (32, 32) and nb == 2:
+                        # where the gain comes from: the per-family table of the B = 4 plan beside the B = 2 plan's at the same shape
+                        try:
+                            fam4, _ = profile_plan(model.engine_for(4, args.frames, h, w, 77, dev, n_t=1, share_prefix=True))
+                            fam2, _ = profile_plan(model.engine_for(2, args.frames, h, w, 77, dev, n_t=1, share_prefix=True))
+                            q["families"], q["families_1_prompt"] = fam_table(fam4)[0], fam_table(fam2)[0]
+                        except Exception as e:
+                            q["families"] = dict(error=f"{type(e).__name__}: {e}")
                     for k_ in [k for k in getattr(model, "_engines", {}) if k[0] > 2]:      # (free the B > 2 engines' buffers)
                         model._engines.pop(k_, None)
                 pbatch[f"{args.frames}x{h}x{w}"] = d
