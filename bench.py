@@ -215,7 +215,7 @@ def run_fp_children(args, rank, world, local_launcher, port, dry_run=False):
            "--no-cpu-baseline", "--no-op-profile", "--no-sample", "--no-lgm", "--no-i2vgen", "--simulate-rank", "0"]
     if dry_run:
         cmd.append("--pg-dry-run")
-    limit = 60.0 if dry_run else args.frame_parallel_budget + 240.0      # (the child's own watchdog fires at the budget; + start-up)
+    limit = 60.0 if dry_run else args.frame_parallel_budget + 150.0      # (the child's own watchdog fires at the budget; + start-up: imports, model build, headline warm-up)
     out, err = "", None
     p_ = subprocess.Popen(cmd, env=env, cwd=os.getcwd(), stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True)
     try:
@@ -263,7 +263,8 @@ def main(argv=None):
     ap.add_argument("--no-op-profile", action="store_true")
     ap.add_argument("--dump-ops", type=str, default="", help="write the per-launch timing table to this file")
     ap.add_argument("--no-frame-parallel", action="store_true", help="N > 1: skip the frame-parallel (one sample over all GPUs) leg")
-    ap.add_argument("--frame-parallel-budget", type=float, default=300.0, help="seconds before the watchdog abandons that leg")
+    ap.add_argument("--frame-parallel-budget", type=float, default=150.0, help="seconds before the watchdog abandons that leg (a healthy leg "
+                    "takes 30-40 s at 8 ranks: seven sub-legs of ~12 steps + their plan builds)")
     ap.add_argument("--fp-inprocess", action="store_true", help="N > 1: run the frame-parallel leg inside the rank processes themselves (what the "
                     "leg's child processes do); default: in one child process per rank, so that a fault there cannot cost the replica line")
     ap.add_argument("--no-prompt-batch", action="store_true", help="skip the two-prompts-per-plan throughput leg")
