@@ -844,6 +844,22 @@ def main(argv=None):
                    lgm_refined_step_in_loop_ms=round(1000 * (t_loop - 47 * t_plain) / 3, 2),
                    instances_per_view=int(sum(ref_l.renderer.last_num_rendered) / max(1, getattr(ref_l.renderer, "last_views", 0) or len(ref_l.renderer.last_num_rendered))),
                    finite=bool(torch.isfinite(x0_l).all()))
+        if not args.no_prompt_batch:      # the same refined loop with two prompts per plan (the YAML default use_lgm_refine + `prompt_batch: 2`):
+            try:                          # 47 plain steps batched, the 3 refined ones sample by sample
+                n2l = torch.randn(2, 4, 24, 32, 32, generator=gl, device=dev)
+                kw2 = [dict(y=torch.randn(2, 77, 1024, generator=gl, device=dev), camera_data=cam_l, gs_data=gs_data),
+                       dict(y=y0.expand(2, -1, -1).contiguous(), camera_data=cam_l, gs_data=gs_data)]
+                dif.ddim_sample_loop(noise=n2l, model=model_l, model_kwargs=kw2[:1] + [dict(kw2[1])], guide_scale=9.0, ddim_timesteps=2, eta=0.0)   # (records the B = 4 plan)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                x0_2l = dif.ddim_sample_loop(noise=n2l, model=model_l, autoencoder=vae, model_kwargs=kw2, guide_scale=9.0, ddim_timesteps=50, eta=0.0)
+                torch.cuda.synchronize()
+                t2l = time.perf_counter() - t1
+                lgm["two_prompts_per_plan"] = dict(ddim50_lgm_seconds_for_2_samples=round(t2l, 4), samples_per_s=round(2.0 / t2l, 4),
+                                                   vs_one_prompt=round(2.0 * t_loop / t2l, 4), finite=bool(torch.isfinite(x0_2l).all()))
+                del x0_2l
+            except Exception as e:
+                lgm["two_prompts_per_plan"] = dict(error=f"{type(e).__name__}: {e}")
         del model_l
 
     # ---- the rasteriser alone on the last refined step's Gaussians (BASELINE configs[4]'s only new kernel family): HBM-bound,
