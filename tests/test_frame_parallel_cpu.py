@@ -283,20 +283,22 @@ def test_two_prompts_per_plan_over_a_frame_parallel_group_two_ranks():
         assert r["e_ddim"] < 6e-2 and r["loop_shape"] == (2, 4, 4, 8, 8), r
 
 
-def _entrance_worker(rank, world, port, tmp, q):
+def _entrance_worker(rank, world, port, tmp, q, prompt_batch=1):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                           LOCAL_RANK=str(rank))
         torch.set_num_threads(2)
         from tests import plan_interp
         plan_interp.install(_Patch)
+        if prompt_batch is not None and prompt_batch != 1 or os.environ.get("VMV_TEST_NO_STEP_DRAWS") == "1":
+            torch.randn_like = lambda x, **kw: torch.zeros_like(x)      # (CPU path: per-step draws at eta = 0 off the global RNG, see test_entrance_cpu)
         from videomv_amd.config import Config
         from videomv_amd.registry import INFER_ENGINE
         import videomv_amd.entrance  # noqa: F401
         argv = ["--cfg", "configs/t2v_infer.yaml", "device", "cpu", "allow_random_init", "True", "num_views", "4",
                 "ddim_timesteps", "2", "test_list_path", os.path.join(tmp, "prompts.txt"), "log_dir", os.path.join(tmp, f"out{world}"),
                 "UNet.num_heads", "2", "UNet.num_res_blocks", "1", "UNet.dim_mult", "[1, 2]", "test_model", "none.pth",
-                "UNet.use_lgm_refine", "False", "frame_parallel", "True"]
+                "UNet.use_lgm_refine", "False", "frame_parallel", "True", "prompt_batch", str(prompt_batch or 1)]
         cu = Config(load=True, argv=argv)
         cu.cfg_dict["UNet"]["dim"] = 64
         cu.cfg_dict["UNet"]["attn_scales"] = [1.0, 0.5]
@@ -337,6 +339,33 @@ def test_entrance_frame_parallel_two_ranks_matches_one_rank(tmp_path):
     assert torch.isfinite(b["video"]).all()
     assert rel_l2(b["latent"], a["latent"]) < 8e-2, rel_l2(b["latent"], a["latent"])
     assert rel_l2(b["video"], a["video"]) < 8e-2, rel_l2(b["video"], a["video"])
+
+
+def test_entrance_frame_parallel_with_prompt_batch_two_ranks(tmp_path):
+    """`frame_parallel True` + `prompt_batch 2` through the t2v entrance: 2 gloo ranks, each denoising its 2 views of BOTH prompts in one
+    pass, write the samples one rank writes one prompt at a time (same noises: drawn per prompt in list order)."""
+    (tmp_path / "prompts.txt").write_text("a wooden chair\na red teapot\n")
+    ctx = mp.get_context("spawn")
+    results = {}
+    for world, pb in ((1, None), (2, 2)):
+        q, port = ctx.Queue(), _free_port()
+        if pb is None:
+            os.environ["VMV_TEST_NO_STEP_DRAWS"] = "1"
+        procs = [ctx.Process(target=_entrance_worker, args=(r, world, port, str(tmp_path), q, pb)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=900) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+        os.environ.pop("VMV_TEST_NO_STEP_DRAWS", None)
+        for r in res:
+            assert "error" not in r, r["error"]
+        results[world] = {r["rank"]: r["outputs"] for r in res}
+    assert len(results[1][0]) == 2 and len(results[2][0]) == 2 and results[2][1] == []
+    for fa, fb in zip(sorted(results[1][0]), sorted(results[2][0])):
+        a, b = torch.load(fa), torch.load(fb)
+        assert a["caption"] == b["caption"] and a["video"].shape == b["video"].shape
+        assert torch.isfinite(b["video"]).all() and rel_l2(b["video"], a["video"]) < 8e-2, rel_l2(b["video"], a["video"])
 
 
 def _cfgpar_worker(rank, world, port, q):

@@ -143,8 +143,11 @@ def worker(gpu, cfg, cfg_update):
     # Noises are drawn per prompt in list order, so every sample starts from the noise the unbatched run gives it (without the LGM-refined
     # loop; with it the refined steps' posterior draws sit between two prompts' noises in the unbatched run, so the noises — not their
     # distribution — differ).  The LGM-refined second loop is batched too: its 47 plain steps in one plan, the 3 refined ones sample by
-    # sample (diffusion_ddim.ddim_sample_loop).  Frame-parallel sampling keeps one prompt per plan here.
-    pbatch = 1 if (fpar or (use_lgm and not on_gpu)) else max(1, int(cfg.get('prompt_batch', 1) or 1))      # (the fused LGM steps are GPU-only)
+    # sample (diffusion_ddim.ddim_sample_loop).  Over a frame-parallel group (plain `frame_parallel`, no LGM loop) every rank denoises its
+    # frames of all b prompts in one plan.
+    # (the fused LGM steps are GPU-only; over a frame-parallel group: plain FrameComm without the LGM loop — DESIGN 8)
+    one_only = (use_lgm and (not on_gpu or fpar)) or (fpar and bool(cfg.get('cfg_parallel', False)))
+    pbatch = 1 if one_only else max(1, int(cfg.get('prompt_batch', 1) or 1))
     elevation, camera_dist = 15, 2.0
 
     def run_group(group):
