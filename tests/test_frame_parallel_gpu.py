@@ -254,8 +254,9 @@ def test_simulated_rank_and_graph_replay_on_the_gpu(monkeypatch):
         assert torch.equal(eng.eps_ncfhw(), e1)
 
 
-def test_bench_gpus_2_end_to_end_on_one_gpu():
-    """`python bench.py --gpus 2` with no launcher around it, END TO END on real kernels (round 6): bench.py starts the two
+@pytest.mark.parametrize("n", [2, 4])
+def test_bench_gpus_2_end_to_end_on_one_gpu(n):
+    """`python bench.py --gpus 2` (and 4: CFG x frame as 2 groups x 2 shards, all-to-all over 4 chunks) with no launcher around it, END TO END on real kernels (round 6): bench.py starts the two
     ranks itself; here both share GPU 0 and the process group is gloo with host-staged collectives (VMV_BENCH_SHARE_GPU=1 — a smoke
     test of the N > 1 flow, never a measurement): the one JSON line says n_gpus = 2, the communicator counted 2 ranks, the replica value
     covers both ranks' steps, and the frame-parallel legs (single plan, branch-pipelined, CFG x frame) ran to finite latents."""
@@ -266,19 +267,19 @@ def test_bench_gpus_2_end_to_end_on_one_gpu():
     env = dict(os.environ, VMV_BENCH_PG_BACKEND="gloo", VMV_BENCH_SHARE_GPU="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--latent", "16x16", "--frames", "4",
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--latent", "16x16", "--frames", "4",
                         "--no-cpu-baseline", "--no-op-profile", "--frame-parallel-budget", "600"], cwd=root, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["launcher"] == "self-spawned" and d["finite"] and d["scaling"] == "weak"
-    assert abs(d["value"] - 2 * 2 / (d["ms_per_step"] * 2 / 1000.0)) < 1e-2 * d["value"]          # value = N x K steps / max-over-ranks time
+    assert d["n_gpus"] == n and d["rccl_ranks"] == n and d["launcher"] == "self-spawned" and d["finite"] and d["scaling"] == "weak"
+    assert abs(d["value"] - n * 2 / (d["ms_per_step"] * 2 / 1000.0)) < 1e-2 * d["value"]          # value = N x K steps / max-over-ranks time
     fp = d["frame_parallel"]
     assert fp and "error" not in fp, fp
-    assert fp["views_per_gpu"] == 2 and fp["single_plan"]["finite"] and fp["branch_pipelined"]["finite"] and fp["cfg_x_frame"]["finite"]
+    assert fp["views_per_gpu"] == 4 // n and fp["single_plan"]["finite"] and fp["branch_pipelined"]["finite"] and fp["cfg_x_frame"]["finite"]
     # (the leg ran in one child process per rank with a process group of its own: a fault there cannot cost the replica line)
-    assert fp["child_rccl_ranks"] == 2 and "child processes" in fp["isolation"]
+    assert fp["child_rccl_ranks"] == n and "child processes" in fp["isolation"]
     # b prompts per plan over the group: every rank its frames of all b samples in one plan
     pp = fp["prompts_per_plan"]
     assert "error" not in pp and pp["2"]["finite"] and pp["4"]["finite"], pp
